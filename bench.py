@@ -1,0 +1,224 @@
+#!/usr/bin/env python
+"""bench.py — LR-patches/sec of one full training iteration on the hot path (BASELINE.json metric).
+
+Workload at N GPUs (weak scaling, one process per GPU, RCCL all-reduce of the flat grad arena):
+BASELINE.json configs[1] = "esrgan RRDB x4, paired 64^2 LR synthetic, L1 only, batch=16" per GPU:
+`feed_data` (inputs already resident in HBM) + `optimize_parameters` (RRDBNet fwd + L1 + bwd +
+grad-clip + AdamW + EMA) through the same `image` model plugin a neosr TOML would build.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0.  Extra objects:
+  roofline     — dominant conv kernel class: algorithmic FLOPs / HIP-event time of its launches,
+                 measured in a dedicated profiled pass of the same K steps (events on the launch
+                 stream, collected inside libneosr_amd), against the dense fp32 MFMA peak.
+  cpu_baseline — the CPU oracle (oracle/neosr_oracle.py, a pure-PyTorch port of the same
+                 iteration) timed on this host's cores on a bounded sample (rank 0, N=1 only).
+"""
+
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X dense fp32 MFMA = fp32 vector peak (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0
+# SURVEY §8(d) / BASELINE.md §3: esrgan fwd+bwd per LR patch
+GFLOP_PER_PATCH = 440.56
+ALGO_MB_PER_PATCH = 2852.8
+
+
+def make_opt(batch: int, world: int, rank: int, arch: str) -> dict:
+    nets = {
+        "esrgan": {"type": "esrgan"},
+        "esrgan_small": {"type": "esrgan", "num_block": 2, "num_feat": 32, "num_grow_ch": 16},
+        "compact": {"type": "compact"},
+    }
+    return {
+        "name": f"bench_{arch}", "model_type": "image", "scale": 4, "manual_seed": 1024,
+        "is_train": True, "dist": world > 1, "rank": rank, "world_size": world, "num_gpu": world,
+        "datasets": {"train": {"type": "paired", "patch_size": 64, "batch_size": batch,
+                               "phase": "train", "scale": 4}},
+        "path": {},
+        "network_g": nets[arch],
+        "train": {"ema": 0.999, "grad_clip": True,
+                  "optim_g": {"type": "adamw", "lr": 1e-4, "betas": [0.9, 0.99], "weight_decay": 0.0},
+                  "pixel_opt": {"type": "L1Loss", "loss_weight": 1.0}},
+        "logger": {"total_iter": 1000000, "print_freq": 100, "save_checkpoint_freq": 100000,
+                   "use_tb_logger": False},
+    }
+
+
+def cpu_baseline(arch: str, budget_s: float) -> dict:
+    """Time the CPU oracle on a bounded sample of the same workload (B=1 batches of the same shapes)."""
+    from oracle import neosr_oracle as orc
+    from neosr_amd.archs import build_network
+
+    torch.manual_seed(1024)
+    net = build_network({"type": arch} if arch != "esrgan_small" else
+                        {"type": "esrgan", "num_block": 2, "num_feat": 32, "num_grow_ch": 16})
+    params = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    fwd = (lambda P, x: orc.compact_forward(P, x, 4, "prelu")) if arch == "compact" else (
+        lambda P, x: orc.rrdbnet_forward(P, x, 4))
+    tr = orc.ImageTrainer(fwd, params, lr=1e-4, betas=(0.9, 0.99), weight_decay=0.0, ema=0.999)
+    b = 1
+    lq, gt = torch.rand(b, 3, 64, 64), torch.rand(b, 3, 256, 256)
+    tr.feed_data(lq, gt)
+    tr.optimize_parameters()  # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        tr.feed_data(lq, gt)
+        tr.optimize_parameters()
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 8:
+            break
+    return {"value": round(n * b / el, 4), "unit": "LR-patches/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"{n} iterations of the same training step at batch {b} (64x64 LR -> 256x256), "
+                      f"torch {torch.__version__} CPU fp32, after 1 warm-up; host has {os.cpu_count()} logical cpus"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16, help="per-GPU batch (BASELINE configs[1]: 16)")
+    ap.add_argument("--arch", default="esrgan", choices=["esrgan", "esrgan_small", "compact"])
+    ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU-oracle timing (0 = skip)")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (MI355X); there is no CPU fallback")
+    torch.cuda.set_device(local % torch.cuda.device_count())
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl")
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from neosr_amd import _C
+    from neosr_amd.models import build_model
+    from neosr_amd.utils.options import set_global_opt
+
+    import logging
+    logging.getLogger("neosr").setLevel(logging.WARNING)
+
+    opt = make_opt(args.batch, world, rank, args.arch)
+    set_global_opt(opt)
+    torch.manual_seed(1024 + rank)
+    model = build_model(opt)
+    dev = torch.device("cuda")
+    B = args.batch
+    batch = {"lq": torch.rand(B, 3, 64, 64, device=dev), "gt": torch.rand(B, 3, 256, 256, device=dev)}
+
+    def step(it: int) -> None:
+        model.feed_data(batch)
+        model.optimize_parameters(it)
+
+    def barrier() -> None:
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    it = 0
+    for _ in range(args.warmup):
+        it += 1
+        step(it)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        it += 1
+        step(it)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss = model.get_current_log().get("l_g_pix")
+
+    roofline = None
+    if not args.no_roofline and rank == 0:
+        lib = _C.load()
+        lib.neosr_prof_enable(1)
+        for _ in range(max(1, min(args.steps, 3))):
+            it += 1
+            step(it)
+        ms = (C.c_double * 4)()
+        ln = (C.c_longlong * 4)()
+        fl = (C.c_double * 4)()
+        by = (C.c_double * 4)()
+        _C.check(lib.neosr_prof_collect(ms, ln, fl, by), "neosr_prof_collect")
+        lib.neosr_prof_enable(0)
+        names = ["conv3x3_mfma_kernel<fwd>", "conv3x3_mfma_kernel<dgrad>", "conv3x3_wgrad_kernel",
+                 "conv3x3_wgrad_reduce_kernel"]
+        kern = {}
+        for i, nm in enumerate(names):
+            if ln[i]:
+                kern[nm] = {"launches": int(ln[i]), "avg_us": round(1e3 * ms[i] / ln[i], 2),
+                            "total_ms": round(ms[i], 3),
+                            "tflops": round(fl[i] / (ms[i] * 1e9), 2) if ms[i] > 0 else None,
+                            "algo_GBps": round(by[i] / (ms[i] * 1e6), 1) if ms[i] > 0 else None}
+        dom = max(range(3), key=lambda i: ms[i])
+        ach = fl[dom] / (ms[dom] * 1e9) if ms[dom] > 0 else 0.0
+        allms = sum(ms[i] for i in range(3))
+        allfl = sum(fl[i] for i in range(3))
+        roofline = {"bound": "mfma", "kernel": names[dom], "achieved": round(ach, 2),
+                    "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "avg_launch_us": round(1e3 * ms[dom] / max(1, ln[dom]), 2),
+                    "all_conv_tflops": round(allfl / (allms * 1e9), 2) if allms > 0 else None,
+                    "hbm_algo_frac_of_8TBps": round((by[dom] / (ms[dom] * 1e6)) / PEAK_HBM_GBS, 4) if ms[dom] > 0 else None,
+                    "kernels": kern,
+                    "method": "HIP events around every launch of the class on the launch stream, "
+                              "separate profiled pass after the timed region"}
+
+    if rank != 0:
+        return
+    patches = world * B * args.steps
+    value = patches / elapsed
+    out = {
+        "metric": "LR-patches/sec (64x64 -> 256x256 x4) fwd+bwd+optimizer step",
+        "value": round(value, 3), "unit": "LR-patches/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"{args.arch} RRDB x4, paired 64x64 LR synthetic (U[0,1)), L1 only, "
+                               f"AdamW + grad-clip + EMA, batch={B}/GPU (BASELINE configs[1])"
+                   if args.arch == "esrgan" else f"{args.arch} x4 L1 batch={B}/GPU (not the headline config)",
+                   "global_batch": B * world, "parallelism": f"dp{world}",
+                   "gflop_per_patch": GFLOP_PER_PATCH if args.arch == "esrgan" else None},
+        "whole_step_tflops": round(value * GFLOP_PER_PATCH / 1e3, 2) if args.arch == "esrgan" else None,
+        "final_l_g_pix": loss,
+        "roofline": roofline,
+    }
+    if world == 1 and args.cpu_budget > 0:
+        out["cpu_baseline"] = cpu_baseline(args.arch, args.cpu_budget)
+    else:
+        out["cpu_baseline"] = None
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,222 @@
+/*
+ * neosr_amd.h — C ABI of libneosr_amd.so, the MI355X (gfx950 / CDNA4) kernel library behind
+ * the neosr training hot path (`feed_data()` -> `optimize_parameters()`).
+ *
+ * The reference (muslll/neosr, 100 % Python on PyTorch) has no native layer: every device op on
+ * the path is an ATen call made from a torch.nn module.  Each entry point below therefore names
+ * the reference *call site* whose ATen op(s) it replaces (paths relative to /root/reference).
+ * All pointers are device pointers (HBM) unless stated; `stream` is a hipStream_t passed as
+ * void* (NULL = default stream).  Every function is asynchronous on `stream`, never
+ * synchronises the device, never allocates, and returns 0 on success; on failure it returns
+ * non-zero and neosr_last_error() describes why.
+ *
+ * Activation tensors are channels-last: element (b, y, x, c) of a tensor with channel stride
+ * `cs` lives at ((b*H + y)*W + x)*cs + c.  A tensor pointer may point into the middle of a
+ * wider pixel vector (that is how the RDB dense concatenation is expressed without torch.cat).
+ * Weights stay in PyTorch's canonical (Cout, Cin, 3, 3) fp32 layout so state-dicts round-trip.
+ */
+#ifndef NEOSR_AMD_H
+#define NEOSR_AMD_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NEOSR_ACT_NONE 0
+#define NEOSR_ACT_LRELU 1 /* slope given per call (0.2 esrgan/unet, 0.01 swinir) */
+#define NEOSR_ACT_RELU 2
+#define NEOSR_ACT_PRELU 3 /* per-channel learnable slope (compact) */
+
+#define NEOSR_CONV_FWD 0
+#define NEOSR_CONV_DGRAD 1
+
+/* library / build info ------------------------------------------------------------------ */
+const char* neosr_last_error(void);
+const char* neosr_build_info(void); /* "gfx950 <date> ..." */
+int neosr_abi_version(void);
+
+/*
+ * 3x3 / stride 1 / pad 1 convolution as an implicit GEMM on fp32-input MFMA
+ * (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate).
+ *
+ * Replaces: nn.Conv2d(.,.,3,1,1) + LeakyReLU + residual scale-add + torch.cat in
+ *   neosr/archs/esrgan_arch.py:109-116 (RDB), :137-142 (RRDB), :196-214 (esrgan.forward,
+ *   incl. F.interpolate(nearest, x2) feeding conv_up1/conv_up2 via `ups`),
+ *   neosr/archs/compact_arch.py:76-79 (conv + PReLU chain, PReLU applied on load via in_prelu),
+ *   and their autograd backward-data (mode = NEOSR_CONV_DGRAD: the transposed/flipped kernel).
+ *
+ *   mode FWD  : out[p, n] = sum_{k<K, tap} in'[p+tap, k] * w[n0w+n, k, tap]         (w is (w_cout, w_cin,3,3), K == w_cin)
+ *   mode DGRAD: out[p, n] = sum_{k<K, tap} in'[p-tap, k] * w[k, n, tap]             (K == w_cout, n < N <= w_cin)
+ *   in' = in (optionally nearest-upsampled x2, PReLU'd on load, or multiplied by the
+ *         activation derivative mask: in * (mask > 0 ? 1 : mask_slope[_c]))
+ *   epilogue: v = act(acc + bias[n]);  v = v*alpha + res1 (n < res1_nch);
+ *             v = v*alpha2 + res2 (n < res2_nch);  out = accumulate ? out + v : v
+ */
+typedef struct neosr_conv_desc {
+  const float* in;          /* (B, Hin, Win, in_cs); Hin = ups ? H/2 : H */
+  const float* in_mask;     /* optional, same geometry as `in` (never with ups) */
+  const float* mask_slopes; /* optional per-k slope for the mask (PReLU); else mask_slope */
+  const float* in_prelu;    /* optional per-k PReLU slope applied to `in` on load */
+  const float* w;           /* canonical (w_cout, w_cin, 3, 3) */
+  const float* bias;        /* optional (N) */
+  const float* prelu;       /* per-n slope when act == PRELU */
+  const float* res1;        /* optional */
+  const float* res2;        /* optional */
+  float* out;               /* (B, H, W, out_cs) */
+  int32_t B, H, W;          /* output spatial size */
+  int32_t K, N;
+  int32_t w_cout, w_cin;
+  int32_t in_cs, mask_cs, out_cs, res1_cs, res2_cs;
+  int32_t res1_nch, res2_nch;
+  int32_t mode, ups, act, accumulate;
+  float mask_slope, slope, alpha, alpha2;
+} neosr_conv_desc;
+
+int neosr_conv3x3(const neosr_conv_desc* d, void* stream);
+
+/*
+ * Weight/bias gradient of the same convolution (autograd's convolution_backward, weight part):
+ *   dw[n, k, tap] (+)= scale * sum_p g'[p, n] * in'[p+tap, k],  db[n] (+)= scale * sum_p g'[p, n]
+ * g' = g * (mask > 0 ? 1 : slope) when g_mask is given (LeakyReLU/PReLU derivative).
+ * Two-stage, fixed-order reduction (no float atomics): run-to-run deterministic.
+ * `workspace` must hold neosr_conv3x3_wgrad_workspace_bytes() bytes.
+ * Replaces the backward of the call sites listed for neosr_conv3x3.
+ */
+typedef struct neosr_wgrad_desc {
+  const float* in;          /* (B, Hin, Win, in_cs) forward input of the conv */
+  const float* in_prelu;    /* optional per-k PReLU slope applied to `in` on load */
+  const float* g;           /* (B, H, W, g_cs) gradient wrt the conv output (post-activation if g_mask) */
+  const float* g_mask;      /* optional activation tensor for the derivative mask */
+  const float* mask_slopes; /* optional per-n slopes */
+  float* dw;                /* canonical (N, K, 3, 3) */
+  float* db;                /* optional (N) */
+  float* workspace;
+  int32_t B, H, W, K, N;
+  int32_t in_cs, g_cs, mask_cs;
+  int32_t ups, accumulate;
+  float mask_slope, scale;
+} neosr_wgrad_desc;
+
+int64_t neosr_conv3x3_wgrad_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t K, int32_t N);
+int neosr_conv3x3_wgrad(const neosr_wgrad_desc* d, void* stream);
+
+/* layout / index kernels ----------------------------------------------------------------- */
+/* (B,C,H,W) planar -> channels-last slice; replaces the implicit NCHW contract of every arch
+ * forward (esrgan_arch.py:196, compact_arch.py:76). */
+int neosr_nchw_to_nhwc(const float* in, float* out, int32_t B, int32_t C, int32_t H, int32_t W,
+                       int32_t out_cs, void* stream);
+int neosr_nhwc_to_nchw(const float* in, float* out, int32_t B, int32_t C, int32_t H, int32_t W,
+                       int32_t in_cs, void* stream);
+/* backward of F.interpolate(nearest, x2): 2x2 sum pool (esrgan_arch.py:207-212). in is
+ * (B,2H,2W,in_cs), out (B,H,W,out_cs); out = accumulate ? out + pooled : pooled. */
+int neosr_pool2x2_sum(const float* in, float* out, int32_t B, int32_t H, int32_t W, int32_t C,
+                      int32_t in_cs, int32_t out_cs, int32_t accumulate, void* stream);
+/* nn.PixelShuffle(r) fused with compact's `out += F.interpolate(x, nearest, r)`
+ * (compact_arch.py:81-85): out[b,c,h*r+i,w*r+j] = in[b,h,w,c*r*r+i*r+j] (+ base[b,c,h,w]).
+ * in channels-last (B,H,W,in_cs), out/base planar NCHW.  Pure index math: bit-exact. */
+int neosr_pixel_shuffle_nhwc_to_nchw(const float* in, const float* base, float* out, int32_t B,
+                                     int32_t C, int32_t H, int32_t W, int32_t r, int32_t in_cs,
+                                     void* stream);
+/* its adjoint: gin[b,h,w,c*r*r+i*r+j] = gout[b,c,h*r+i,w*r+j]. */
+int neosr_pixel_unshuffle_nchw_to_nhwc(const float* gout, float* gin, int32_t B, int32_t C,
+                                       int32_t H, int32_t W, int32_t r, int32_t gin_cs,
+                                       void* stream);
+/* PReLU slope gradient: dslope[c] (+)= sum_p dA[p,c] * min(z[p,c], 0)  (compact_arch.py:58-69). */
+int neosr_prelu_dslope(const float* dA, const float* z, float* dslope, float* workspace,
+                       int64_t npix, int32_t C, int32_t da_cs, int32_t z_cs, int32_t accumulate,
+                       void* stream);
+int64_t neosr_prelu_dslope_workspace_bytes(int64_t npix, int32_t C);
+
+/* p[0..n) = v ; out[p,c] += alpha*in[p,c] over a channels-last slice (skip-connection grads:
+ * esrgan_arch.py:205 `feat = feat + body_feat`). */
+int neosr_fill(float* p, int64_t n, float v, void* stream);
+int neosr_axpy_slice(float* out, const float* in, int64_t npix, int32_t C, int32_t out_cs,
+                     int32_t in_cs, float alpha, void* stream);
+
+/* losses ---------------------------------------------------------------------------------- */
+/* L1Loss(reduction="mean") * loss_weight  (neosr/losses/basic_loss.py:10-11,24-53).
+ * Two-stage fixed-order reduction; loss_out is one device float.  workspace >= 4096 floats. */
+int neosr_l1_loss_fwd(const float* pred, const float* target, int64_t n, float loss_weight,
+                      float* loss_out, float* workspace, void* stream);
+/* d loss / d pred = sign(pred-target) * loss_weight / n * (*grad_out)  (grad_out: device scalar) */
+int neosr_l1_loss_bwd(const float* pred, const float* target, const float* grad_out, int64_t n,
+                      float loss_weight, float* grad_pred, void* stream);
+
+/* optimizer step ---------------------------------------------------------------------------- */
+/* clip_grad_norm_(params, max_norm) (neosr/models/image.py:533-544) + torch.optim.AdamW.step
+ * (base.py:151-172 "adamw") + AveragedModel EMA update (image.py:661-662), fused over a flat
+ * fp32 parameter arena: one norm pass, one update pass.
+ *   norm_ws: >= 4100 floats.  ws[0] receives the total grad norm.
+ *   max_norm <= 0 disables clipping.  ema may be NULL.  ema_decay<0: copy (first update).
+ * lr / step are passed by value: hyper-parameters live on the host in the reference too. */
+typedef struct neosr_adamw_desc {
+  float* param;
+  const float* grad;
+  float* exp_avg;
+  float* exp_avg_sq;
+  float* ema; /* optional */
+  float* norm_ws;
+  int64_t n;
+  float lr, beta1, beta2, eps, weight_decay;
+  float max_norm;
+  float ema_decay;
+  float grad_scale; /* multiply grads (e.g. 1/world_size after a sum all-reduce) */
+  int32_t step;     /* 1-based step count for bias correction */
+} neosr_adamw_desc;
+int neosr_grad_norm(const float* grad, int64_t n, float grad_scale, float* norm_ws, void* stream);
+int neosr_adamw_step(const neosr_adamw_desc* d, void* stream);
+
+/* opt-in profiler ------------------------------------------------------------------------------
+ * HIP events around every conv-class launch on the launch stream (classes: 0 conv fwd, 1 conv
+ * dgrad, 2 conv wgrad, 3 wgrad reduce).  Used by bench.py's roofline pass only.  collect()
+ * synchronises the device and fills 4-element arrays. */
+int neosr_prof_enable(int on);
+int neosr_prof_collect(double* ms, long long* launches, double* flops, double* bytes);
+
+/* whole-network plans ------------------------------------------------------------------------ */
+/*
+ * RRDBNet ("esrgan", neosr/archs/esrgan_arch.py:145-214) forward and backward for scale 4 / 2 / 1
+ * as one host-side plan that enqueues every kernel on `stream` (no per-layer Python, no cat).
+ * params / grads: host arrays of device pointers in named_parameters() order
+ *   (conv_first.weight, conv_first.bias, body.0.rdb1.conv1.weight, ..., conv_last.bias).
+ * x: (B, num_in_ch, H, W) NCHW fp32 (after pixel_unshuffle for scale 1/2 the caller passes the
+ * unshuffled tensor); y: (B, num_out_ch, 4H, 4W) NCHW (H, W for scale<4 handled by up_stages).
+ * workspace: neosr_rrdbnet_workspace_bytes(); forward leaves the saved activations in it and
+ * backward must be given the same workspace.
+ */
+typedef struct neosr_rrdbnet_cfg {
+  int32_t B, H, W;
+  int32_t num_in_ch, num_out_ch, num_feat, num_block, num_grow_ch;
+  int32_t training; /* 0: inference (activations not kept) */
+} neosr_rrdbnet_cfg;
+int64_t neosr_rrdbnet_workspace_bytes(const neosr_rrdbnet_cfg* cfg);
+int32_t neosr_rrdbnet_num_params(const neosr_rrdbnet_cfg* cfg);
+int neosr_rrdbnet_forward(const neosr_rrdbnet_cfg* cfg, const float* const* params, const float* x,
+                          float* y, void* workspace, void* stream);
+/* gy: (B,num_out_ch,4H,4W) NCHW. grads[i] written (not accumulated). gx optional (B,C,H,W). */
+int neosr_rrdbnet_backward(const neosr_rrdbnet_cfg* cfg, const float* const* params,
+                           float* const* grads, const float* gy, float* gx, void* workspace,
+                           void* stream);
+
+/*
+ * SRVGGNetCompact ("compact", neosr/archs/compact_arch.py:11-85), act_type prelu|relu|leakyrelu.
+ * params order: body.0.weight, body.0.bias, body.1.weight (PReLU), body.2.weight, ...
+ */
+typedef struct neosr_compact_cfg {
+  int32_t B, H, W;
+  int32_t num_in_ch, num_out_ch, num_feat, num_conv, upscale;
+  int32_t act_type; /* NEOSR_ACT_PRELU | NEOSR_ACT_RELU | NEOSR_ACT_LRELU(0.1) */
+  int32_t training;
+} neosr_compact_cfg;
+int64_t neosr_compact_workspace_bytes(const neosr_compact_cfg* cfg);
+int32_t neosr_compact_num_params(const neosr_compact_cfg* cfg);
+int neosr_compact_forward(const neosr_compact_cfg* cfg, const float* const* params, const float* x,
+                          float* y, void* workspace, void* stream);
+int neosr_compact_backward(const neosr_compact_cfg* cfg, const float* const* params,
+                           float* const* grads, const float* gy, float* gx, void* workspace,
+                           void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NEOSR_AMD_H */

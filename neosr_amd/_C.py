@@ -1,0 +1,256 @@
+"""ctypes binding of ``libneosr_amd.so`` (the C ABI declared in ``include/neosr_amd.h``).
+
+This is the *only* door between the Python host layer and the HIP kernels: plain pointers and
+sizes go in, nothing torch-typed crosses the boundary.  There is deliberately no fallback: if the
+library is missing, or a tensor is not on a HIP device, the caller gets an exception.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+_LIB_PATH = Path(__file__).resolve().parent / "lib" / "libneosr_amd.so"
+
+c_float_p = C.POINTER(C.c_float)
+c_void_pp = C.POINTER(C.c_void_p)
+
+
+class ConvDesc(C.Structure):
+    """neosr_conv_desc"""
+
+    _fields_ = [
+        ("in_", C.c_void_p),
+        ("in_mask", C.c_void_p),
+        ("mask_slopes", C.c_void_p),
+        ("in_prelu", C.c_void_p),
+        ("w", C.c_void_p),
+        ("bias", C.c_void_p),
+        ("prelu", C.c_void_p),
+        ("res1", C.c_void_p),
+        ("res2", C.c_void_p),
+        ("out", C.c_void_p),
+        ("B", C.c_int32),
+        ("H", C.c_int32),
+        ("W", C.c_int32),
+        ("K", C.c_int32),
+        ("N", C.c_int32),
+        ("w_cout", C.c_int32),
+        ("w_cin", C.c_int32),
+        ("in_cs", C.c_int32),
+        ("mask_cs", C.c_int32),
+        ("out_cs", C.c_int32),
+        ("res1_cs", C.c_int32),
+        ("res2_cs", C.c_int32),
+        ("res1_nch", C.c_int32),
+        ("res2_nch", C.c_int32),
+        ("mode", C.c_int32),
+        ("ups", C.c_int32),
+        ("act", C.c_int32),
+        ("accumulate", C.c_int32),
+        ("mask_slope", C.c_float),
+        ("slope", C.c_float),
+        ("alpha", C.c_float),
+        ("alpha2", C.c_float),
+    ]
+
+
+class WgradDesc(C.Structure):
+    """neosr_wgrad_desc"""
+
+    _fields_ = [
+        ("in_", C.c_void_p),
+        ("in_prelu", C.c_void_p),
+        ("g", C.c_void_p),
+        ("g_mask", C.c_void_p),
+        ("mask_slopes", C.c_void_p),
+        ("dw", C.c_void_p),
+        ("db", C.c_void_p),
+        ("workspace", C.c_void_p),
+        ("B", C.c_int32),
+        ("H", C.c_int32),
+        ("W", C.c_int32),
+        ("K", C.c_int32),
+        ("N", C.c_int32),
+        ("in_cs", C.c_int32),
+        ("g_cs", C.c_int32),
+        ("mask_cs", C.c_int32),
+        ("ups", C.c_int32),
+        ("accumulate", C.c_int32),
+        ("mask_slope", C.c_float),
+        ("scale", C.c_float),
+    ]
+
+
+class AdamWDesc(C.Structure):
+    """neosr_adamw_desc"""
+
+    _fields_ = [
+        ("param", C.c_void_p),
+        ("grad", C.c_void_p),
+        ("exp_avg", C.c_void_p),
+        ("exp_avg_sq", C.c_void_p),
+        ("ema", C.c_void_p),
+        ("norm_ws", C.c_void_p),
+        ("n", C.c_int64),
+        ("lr", C.c_float),
+        ("beta1", C.c_float),
+        ("beta2", C.c_float),
+        ("eps", C.c_float),
+        ("weight_decay", C.c_float),
+        ("max_norm", C.c_float),
+        ("ema_decay", C.c_float),
+        ("grad_scale", C.c_float),
+        ("step", C.c_int32),
+    ]
+
+
+class RRDBNetCfg(C.Structure):
+    """neosr_rrdbnet_cfg"""
+
+    _fields_ = [
+        ("B", C.c_int32),
+        ("H", C.c_int32),
+        ("W", C.c_int32),
+        ("num_in_ch", C.c_int32),
+        ("num_out_ch", C.c_int32),
+        ("num_feat", C.c_int32),
+        ("num_block", C.c_int32),
+        ("num_grow_ch", C.c_int32),
+        ("training", C.c_int32),
+    ]
+
+
+class CompactCfg(C.Structure):
+    """neosr_compact_cfg"""
+
+    _fields_ = [
+        ("B", C.c_int32),
+        ("H", C.c_int32),
+        ("W", C.c_int32),
+        ("num_in_ch", C.c_int32),
+        ("num_out_ch", C.c_int32),
+        ("num_feat", C.c_int32),
+        ("num_conv", C.c_int32),
+        ("upscale", C.c_int32),
+        ("act_type", C.c_int32),
+        ("training", C.c_int32),
+    ]
+
+
+ACT_NONE, ACT_LRELU, ACT_RELU, ACT_PRELU = 0, 1, 2, 3
+CONV_FWD, CONV_DGRAD = 0, 1
+
+# name -> (restype, argtypes); mirrors include/neosr_amd.h one to one
+_i32, _i64, _f32, _vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
+SIGNATURES: dict[str, tuple] = {
+    "neosr_last_error": (C.c_char_p, []),
+    "neosr_build_info": (C.c_char_p, []),
+    "neosr_abi_version": (C.c_int, []),
+    "neosr_conv3x3": (C.c_int, [C.POINTER(ConvDesc), _vp]),
+    "neosr_conv3x3_wgrad_workspace_bytes": (_i64, [_i32, _i32, _i32, _i32, _i32]),
+    "neosr_conv3x3_wgrad": (C.c_int, [C.POINTER(WgradDesc), _vp]),
+    "neosr_nchw_to_nhwc": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "neosr_nhwc_to_nchw": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "neosr_pool2x2_sum": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "neosr_pixel_shuffle_nhwc_to_nchw": (
+        C.c_int,
+        [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
+    ),
+    "neosr_pixel_unshuffle_nchw_to_nhwc": (
+        C.c_int,
+        [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
+    ),
+    "neosr_prelu_dslope": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
+    "neosr_prelu_dslope_workspace_bytes": (_i64, [_i64, _i32]),
+    "neosr_fill": (C.c_int, [_vp, _i64, _f32, _vp]),
+    "neosr_axpy_slice": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _f32, _vp]),
+    "neosr_l1_loss_fwd": (C.c_int, [_vp, _vp, _i64, _f32, _vp, _vp, _vp]),
+    "neosr_l1_loss_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _f32, _vp, _vp]),
+    "neosr_grad_norm": (C.c_int, [_vp, _i64, _f32, _vp, _vp]),
+    "neosr_adamw_step": (C.c_int, [C.POINTER(AdamWDesc), _vp]),
+    "neosr_prof_enable": (C.c_int, [C.c_int]),
+    "neosr_prof_collect": (
+        C.c_int,
+        [C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double), C.POINTER(C.c_double)],
+    ),
+    "neosr_rrdbnet_workspace_bytes": (_i64, [C.POINTER(RRDBNetCfg)]),
+    "neosr_rrdbnet_num_params": (_i32, [C.POINTER(RRDBNetCfg)]),
+    "neosr_rrdbnet_forward": (C.c_int, [C.POINTER(RRDBNetCfg), c_void_pp, _vp, _vp, _vp, _vp]),
+    "neosr_rrdbnet_backward": (
+        C.c_int,
+        [C.POINTER(RRDBNetCfg), c_void_pp, c_void_pp, _vp, _vp, _vp, _vp],
+    ),
+    "neosr_compact_workspace_bytes": (_i64, [C.POINTER(CompactCfg)]),
+    "neosr_compact_num_params": (_i32, [C.POINTER(CompactCfg)]),
+    "neosr_compact_forward": (C.c_int, [C.POINTER(CompactCfg), c_void_pp, _vp, _vp, _vp, _vp]),
+    "neosr_compact_backward": (
+        C.c_int,
+        [C.POINTER(CompactCfg), c_void_pp, c_void_pp, _vp, _vp, _vp, _vp],
+    ),
+}
+
+_lib = None
+
+
+class NeosrAmdError(RuntimeError):
+    pass
+
+
+def lib_path() -> Path:
+    return Path(os.environ.get("NEOSR_AMD_LIB", str(_LIB_PATH)))
+
+
+def load():
+    """Load the shared library (once).  Raises if it has not been built: there is no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not path.exists():
+        msg = (
+            f"{path} not found. Build the HIP extension first: "
+            "`python -c 'import __graft_entry__ as g; g.build()'` or `bash neosr_amd/csrc/build.sh`. "
+            "neosr_amd has no CPU/PyTorch fallback for its kernels."
+        )
+        raise NeosrAmdError(msg)
+    lib = C.CDLL(str(path))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing: loud by design
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        err = load().neosr_last_error().decode()
+        raise NeosrAmdError(f"{what or 'libneosr_amd'} failed (rc={rc}): {err}")
+
+
+def stream_ptr() -> int:
+    """hipStream_t of torch's current stream on the current device."""
+    import torch
+
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_device(t, name: str = "tensor"):
+    """The product path never silently runs on the CPU."""
+    import torch
+
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        msg = f"neosr_amd: {name} must live on a HIP device (got {getattr(t, 'device', type(t))})"
+        raise NeosrAmdError(msg)
+    if t.dtype != torch.float32:
+        raise NeosrAmdError(f"neosr_amd: {name} must be float32 (got {t.dtype})")
+    return t
+
+
+def ptr_table(tensors) -> C.Array:
+    arr = (C.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr()
+    return arr

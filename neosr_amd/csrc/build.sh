@@ -1,0 +1,16 @@
+#!/bin/bash
+# Builds libneosr_amd.so for gfx950 (MI355X) in-tree.  hipcc cross-compiles without a GPU.
+set -e
+HERE="$(cd "$(dirname "$0")" && pwd)"
+OUT="$HERE/../lib"
+mkdir -p "$OUT"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
+OBJS=""
+for f in api prof conv3x3 elementwise nets; do
+  "$HIPCC" $FLAGS -c "$HERE/$f.hip" -o "$OUT/$f.o" "$@" &
+  OBJS="$OBJS $OUT/$f.o"
+done
+wait
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC $OBJS -o "$OUT/libneosr_amd.so"
+echo "built $OUT/libneosr_amd.so"

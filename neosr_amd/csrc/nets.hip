@@ -1,0 +1,538 @@
+// nets.hip — host-side execution plans: whole-network forward/backward for the generators on the
+// hot path, expressed as a fixed sequence of kernel launches on one HIP stream.  No per-layer
+// Python, no torch.cat (the RDB concat lives in one 192-channel channels-last buffer), no
+// allocation (the caller hands in one workspace), no host synchronisation -> graph-capturable.
+//
+// Reference behaviour restated here: neosr/archs/esrgan_arch.py:82-214 (ResidualDenseBlock, RRDB,
+// esrgan.forward) and neosr/archs/compact_arch.py:11-85 (compact.forward), plus their autograd
+// backward.
+#include "common.h"
+#include "../../include/neosr_amd.h"
+#include <string.h>
+#include <vector>
+
+extern "C" int neosr_fill(float* p, int64_t n, float v, void* stream);
+extern "C" int neosr_axpy_slice(float* out, const float* in, int64_t npix, int32_t C,
+                                int32_t out_cs, int32_t in_cs, float alpha, void* stream);
+
+namespace {
+
+struct Bump {
+  char* base;
+  int64_t off = 0;
+  explicit Bump(void* b) : base((char*)b) {}
+  float* take(int64_t nfloats) {
+    off = (off + 255) & ~(int64_t)255;
+    float* p = base ? (float*)(base + off) : nullptr;
+    off += nfloats * 4;
+    return p;
+  }
+};
+
+inline int pad4(int c) { return (c + 3) & ~3; }
+
+neosr_conv_desc conv_base(int B, int H, int W) {
+  neosr_conv_desc d;
+  memset(&d, 0, sizeof(d));
+  d.B = B;
+  d.H = H;
+  d.W = W;
+  d.alpha = 1.f;
+  d.alpha2 = 1.f;
+  d.mask_slope = 1.f;
+  return d;
+}
+
+neosr_wgrad_desc wgrad_base(int B, int H, int W) {
+  neosr_wgrad_desc d;
+  memset(&d, 0, sizeof(d));
+  d.B = B;
+  d.H = H;
+  d.W = W;
+  d.scale = 1.f;
+  d.mask_slope = 1.f;
+  return d;
+}
+
+#define RUN(expr)                \
+  do {                           \
+    if (int rc__ = (expr)) return rc__; \
+  } while (0)
+
+// ------------------------------------------------------------------------------ RRDBNet
+struct RrdbLayout {
+  int B, H, W, Cin, Cout, F, G, NB, CC, cin_cs, cout_cs, nact;
+  int64_t np1, np2, np4;
+  float* x_nhwc;
+  std::vector<float*> act;
+  float *trunk, *fea, *u1, *u2, *hr, *y_nhwc;
+  float *gy_nhwc, *g_hr, *g_u2, *g_up2in, *g_u1, *g_up1in, *g_fea, *g_trunk, *gx_nhwc;
+  float* gb[4];
+  float* wg_ws;
+  int64_t total;
+};
+
+int64_t max64(int64_t a, int64_t b) { return a > b ? a : b; }
+
+RrdbLayout rrdb_layout(const neosr_rrdbnet_cfg& c, void* ws) {
+  RrdbLayout L;
+  L.B = c.B; L.H = c.H; L.W = c.W;
+  L.Cin = c.num_in_ch; L.Cout = c.num_out_ch; L.F = c.num_feat; L.G = c.num_grow_ch;
+  L.NB = c.num_block;
+  L.CC = L.F + 4 * L.G;
+  L.cin_cs = pad4(L.Cin);
+  L.cout_cs = pad4(L.Cout);
+  L.np1 = (int64_t)c.B * c.H * c.W;
+  L.np2 = L.np1 * 4;
+  L.np4 = L.np1 * 16;
+  Bump b(ws);
+  L.x_nhwc = b.take(L.np1 * L.cin_cs);
+  L.nact = c.training ? 3 * L.NB : 5;  // inference: act[0] (conv_first, needed by the skip) + ring of 4
+  L.act.resize(L.nact);
+  for (int i = 0; i < L.nact; ++i) L.act[i] = b.take(L.np1 * L.CC);
+  L.trunk = b.take(L.np1 * L.F);
+  L.fea = b.take(L.np1 * L.F);
+  L.u1 = b.take(L.np2 * L.F);
+  L.u2 = b.take(L.np4 * L.F);
+  L.hr = b.take(L.np4 * L.F);
+  L.y_nhwc = b.take(L.np4 * L.cout_cs);
+  if (c.training) {
+    L.gy_nhwc = L.y_nhwc;  // y_nhwc is dead after the final layout transform
+    L.g_hr = b.take(L.np4 * L.F);
+    L.g_u2 = b.take(L.np4 * L.F);
+    L.g_up2in = L.g_hr;    // g_hr is dead once conv_hr's dgrad/wgrad have run
+    L.g_u1 = b.take(L.np2 * L.F);
+    L.g_up1in = b.take(L.np2 * L.F);
+    L.g_fea = b.take(L.np1 * L.F);
+    L.g_trunk = b.take(L.np1 * L.F);
+    L.gx_nhwc = b.take(L.np1 * L.cin_cs);
+    for (int i = 0; i < 4; ++i) L.gb[i] = b.take(L.np1 * L.CC);
+    int64_t w = 0;
+    const int B = c.B, H = c.H, W = c.W, F = L.F, G = L.G;
+    w = max64(w, neosr_conv3x3_wgrad_workspace_bytes(B, H, W, L.Cin, F));
+    for (int k = 0; k < 4; ++k) w = max64(w, neosr_conv3x3_wgrad_workspace_bytes(B, H, W, F + k * G, G));
+    w = max64(w, neosr_conv3x3_wgrad_workspace_bytes(B, H, W, L.CC, F));
+    w = max64(w, neosr_conv3x3_wgrad_workspace_bytes(B, H, W, F, F));
+    w = max64(w, neosr_conv3x3_wgrad_workspace_bytes(B, 2 * H, 2 * W, F, F));
+    w = max64(w, neosr_conv3x3_wgrad_workspace_bytes(B, 4 * H, 4 * W, F, F));
+    w = max64(w, neosr_conv3x3_wgrad_workspace_bytes(B, 4 * H, 4 * W, F, L.Cout));
+    L.wg_ws = b.take(w / 4 + 64);
+  }
+  L.total = ((b.off + 255) & ~(int64_t)255);
+  return L;
+}
+
+int rrdb_check(const neosr_rrdbnet_cfg* c) {
+  NEOSR_CHECK(c, "rrdbnet: null cfg");
+  NEOSR_CHECK(c->B > 0 && c->H > 0 && c->W > 0 && c->num_in_ch > 0 && c->num_out_ch > 0 &&
+                  c->num_feat > 0 && c->num_block > 0 && c->num_grow_ch > 0,
+              "rrdbnet: bad cfg");
+  NEOSR_CHECK(c->num_feat % 4 == 0 && c->num_grow_ch % 4 == 0,
+              "rrdbnet: num_feat and num_grow_ch must be multiples of 4");
+  return 0;
+}
+
+// activation buffer of RDB i (i = 3*n + r); inference keeps slot 0 and recycles a ring of 4
+inline int act_idx(const RrdbLayout& L, int i) {
+  if (L.nact == 3 * L.NB || i == 0) return i;
+  return 1 + ((i - 1) & 3);
+}
+
+// parameter index helpers (named_parameters order)
+inline int p_first() { return 0; }
+inline int p_rdb(int n, int r, int k) { return 2 + ((n * 3 + r) * 5 + k) * 2; }
+inline int p_tail(const RrdbLayout& L, int i) { return 2 + L.NB * 30 + 2 * i; }  // body,up1,up2,hr,last
+
+}  // namespace
+
+extern "C" int32_t neosr_rrdbnet_num_params(const neosr_rrdbnet_cfg* c) {
+  return 2 + c->num_block * 30 + 10;
+}
+
+extern "C" int64_t neosr_rrdbnet_workspace_bytes(const neosr_rrdbnet_cfg* c) {
+  if (rrdb_check(c)) return -1;
+  return rrdb_layout(*c, nullptr).total;
+}
+
+extern "C" int neosr_rrdbnet_forward(const neosr_rrdbnet_cfg* c, const float* const* P,
+                                     const float* x, float* y, void* ws, void* st) {
+  RUN(rrdb_check(c));
+  NEOSR_CHECK(P && x && y && ws, "rrdbnet_forward: null pointer");
+  const RrdbLayout L = rrdb_layout(*c, ws);
+  const int B = L.B, H = L.H, W = L.W, F = L.F, G = L.G, CC = L.CC;
+  RUN(neosr_nchw_to_nhwc(x, L.x_nhwc, B, L.Cin, H, W, L.cin_cs, st));
+  {
+    neosr_conv_desc d = conv_base(B, H, W);
+    d.in = L.x_nhwc; d.in_cs = L.cin_cs; d.K = L.Cin;
+    d.w = P[0]; d.bias = P[1]; d.w_cout = F; d.w_cin = L.Cin;
+    d.out = L.act[0]; d.out_cs = CC; d.N = F;
+    RUN(neosr_conv3x3(&d, st));
+  }
+  for (int n = 0; n < L.NB; ++n) {
+    for (int r = 0; r < 3; ++r) {
+      float* A = L.act[act_idx(L, 3 * n + r)];
+      for (int k = 0; k < 4; ++k) {
+        neosr_conv_desc d = conv_base(B, H, W);
+        d.in = A; d.in_cs = CC; d.K = F + k * G;
+        d.w = P[p_rdb(n, r, k)]; d.bias = P[p_rdb(n, r, k) + 1]; d.w_cout = G; d.w_cin = F + k * G;
+        d.out = A + F + k * G; d.out_cs = CC; d.N = G;
+        d.act = NEOSR_ACT_LRELU; d.slope = 0.2f;
+        RUN(neosr_conv3x3(&d, st));
+      }
+      neosr_conv_desc d = conv_base(B, H, W);
+      d.in = A; d.in_cs = CC; d.K = CC;
+      d.w = P[p_rdb(n, r, 4)]; d.bias = P[p_rdb(n, r, 4) + 1]; d.w_cout = F; d.w_cin = CC;
+      const bool last = (n == L.NB - 1 && r == 2);
+      d.out = last ? L.trunk : L.act[act_idx(L, 3 * n + r + 1)];
+      d.out_cs = last ? F : CC;
+      d.N = F;
+      d.alpha = 0.2f; d.res1 = A; d.res1_cs = CC; d.res1_nch = F;
+      if (r == 2) {
+        d.alpha2 = 0.2f; d.res2 = L.act[act_idx(L, 3 * n)]; d.res2_cs = CC; d.res2_nch = F;
+      }
+      RUN(neosr_conv3x3(&d, st));
+    }
+  }
+  {  // conv_body + skip
+    neosr_conv_desc d = conv_base(B, H, W);
+    d.in = L.trunk; d.in_cs = F; d.K = F;
+    d.w = P[p_tail(L, 0)]; d.bias = P[p_tail(L, 0) + 1]; d.w_cout = F; d.w_cin = F;
+    d.out = L.fea; d.out_cs = F; d.N = F;
+    d.res1 = L.act[0]; d.res1_cs = CC; d.res1_nch = F;
+    RUN(neosr_conv3x3(&d, st));
+  }
+  {  // conv_up1 on nearest x2
+    neosr_conv_desc d = conv_base(B, 2 * H, 2 * W);
+    d.ups = 1; d.in = L.fea; d.in_cs = F; d.K = F;
+    d.w = P[p_tail(L, 1)]; d.bias = P[p_tail(L, 1) + 1]; d.w_cout = F; d.w_cin = F;
+    d.out = L.u1; d.out_cs = F; d.N = F; d.act = NEOSR_ACT_LRELU; d.slope = 0.2f;
+    RUN(neosr_conv3x3(&d, st));
+  }
+  {  // conv_up2 on nearest x2
+    neosr_conv_desc d = conv_base(B, 4 * H, 4 * W);
+    d.ups = 1; d.in = L.u1; d.in_cs = F; d.K = F;
+    d.w = P[p_tail(L, 2)]; d.bias = P[p_tail(L, 2) + 1]; d.w_cout = F; d.w_cin = F;
+    d.out = L.u2; d.out_cs = F; d.N = F; d.act = NEOSR_ACT_LRELU; d.slope = 0.2f;
+    RUN(neosr_conv3x3(&d, st));
+  }
+  {  // conv_hr
+    neosr_conv_desc d = conv_base(B, 4 * H, 4 * W);
+    d.in = L.u2; d.in_cs = F; d.K = F;
+    d.w = P[p_tail(L, 3)]; d.bias = P[p_tail(L, 3) + 1]; d.w_cout = F; d.w_cin = F;
+    d.out = L.hr; d.out_cs = F; d.N = F; d.act = NEOSR_ACT_LRELU; d.slope = 0.2f;
+    RUN(neosr_conv3x3(&d, st));
+  }
+  {  // conv_last
+    neosr_conv_desc d = conv_base(B, 4 * H, 4 * W);
+    d.in = L.hr; d.in_cs = F; d.K = F;
+    d.w = P[p_tail(L, 4)]; d.bias = P[p_tail(L, 4) + 1]; d.w_cout = L.Cout; d.w_cin = F;
+    d.out = L.y_nhwc; d.out_cs = L.cout_cs; d.N = L.Cout;
+    RUN(neosr_conv3x3(&d, st));
+  }
+  RUN(neosr_nhwc_to_nchw(L.y_nhwc, y, B, L.Cout, 4 * H, 4 * W, L.cout_cs, st));
+  return 0;
+}
+
+extern "C" int neosr_rrdbnet_backward(const neosr_rrdbnet_cfg* c, const float* const* P,
+                                      float* const* Gp, const float* gy, float* gx, void* ws,
+                                      void* st) {
+  RUN(rrdb_check(c));
+  NEOSR_CHECK(P && Gp && gy && ws, "rrdbnet_backward: null pointer");
+  NEOSR_CHECK(c->training, "rrdbnet_backward: cfg.training must be set (activations are needed)");
+  const RrdbLayout L = rrdb_layout(*c, ws);
+  const int B = L.B, H = L.H, W = L.W, F = L.F, G = L.G, CC = L.CC;
+  const int H2 = 2 * H, W2 = 2 * W, H4 = 4 * H, W4 = 4 * W;
+
+  RUN(neosr_nchw_to_nhwc(gy, L.gy_nhwc, B, L.Cout, H4, W4, L.cout_cs, st));
+  {  // conv_last
+    neosr_wgrad_desc w = wgrad_base(B, H4, W4);
+    w.in = L.hr; w.in_cs = F; w.K = F; w.g = L.gy_nhwc; w.g_cs = L.cout_cs; w.N = L.Cout;
+    w.dw = Gp[p_tail(L, 4)]; w.db = Gp[p_tail(L, 4) + 1]; w.workspace = L.wg_ws;
+    RUN(neosr_conv3x3_wgrad(&w, st));
+    neosr_conv_desc d = conv_base(B, H4, W4);
+    d.mode = NEOSR_CONV_DGRAD;
+    d.in = L.gy_nhwc; d.in_cs = L.cout_cs; d.K = L.Cout;
+    d.w = P[p_tail(L, 4)]; d.w_cout = L.Cout; d.w_cin = F;
+    d.out = L.g_hr; d.out_cs = F; d.N = F;
+    RUN(neosr_conv3x3(&d, st));
+  }
+  {  // conv_hr (LeakyReLU output hr)
+    neosr_wgrad_desc w = wgrad_base(B, H4, W4);
+    w.in = L.u2; w.in_cs = F; w.K = F; w.g = L.g_hr; w.g_cs = F; w.N = F;
+    w.g_mask = L.hr; w.mask_cs = F; w.mask_slope = 0.2f;
+    w.dw = Gp[p_tail(L, 3)]; w.db = Gp[p_tail(L, 3) + 1]; w.workspace = L.wg_ws;
+    RUN(neosr_conv3x3_wgrad(&w, st));
+    neosr_conv_desc d = conv_base(B, H4, W4);
+    d.mode = NEOSR_CONV_DGRAD;
+    d.in = L.g_hr; d.in_cs = F; d.K = F; d.in_mask = L.hr; d.mask_cs = F; d.mask_slope = 0.2f;
+    d.w = P[p_tail(L, 3)]; d.w_cout = F; d.w_cin = F;
+    d.out = L.g_u2; d.out_cs = F; d.N = F;
+    RUN(neosr_conv3x3(&d, st));
+  }
+  {  // conv_up2 (input = nearest x2 of u1, LeakyReLU output u2)
+    neosr_wgrad_desc w = wgrad_base(B, H4, W4);
+    w.ups = 1; w.in = L.u1; w.in_cs = F; w.K = F; w.g = L.g_u2; w.g_cs = F; w.N = F;
+    w.g_mask = L.u2; w.mask_cs = F; w.mask_slope = 0.2f;
+    w.dw = Gp[p_tail(L, 2)]; w.db = Gp[p_tail(L, 2) + 1]; w.workspace = L.wg_ws;
+    RUN(neosr_conv3x3_wgrad(&w, st));
+    neosr_conv_desc d = conv_base(B, H4, W4);
+    d.mode = NEOSR_CONV_DGRAD;
+    d.in = L.g_u2; d.in_cs = F; d.K = F; d.in_mask = L.u2; d.mask_cs = F; d.mask_slope = 0.2f;
+    d.w = P[p_tail(L, 2)]; d.w_cout = F; d.w_cin = F;
+    d.out = L.g_up2in; d.out_cs = F; d.N = F;
+    RUN(neosr_conv3x3(&d, st));
+    RUN(neosr_pool2x2_sum(L.g_up2in, L.g_u1, B, H2, W2, F, F, F, 0, st));
+  }
+  {  // conv_up1
+    neosr_wgrad_desc w = wgrad_base(B, H2, W2);
+    w.ups = 1; w.in = L.fea; w.in_cs = F; w.K = F; w.g = L.g_u1; w.g_cs = F; w.N = F;
+    w.g_mask = L.u1; w.mask_cs = F; w.mask_slope = 0.2f;
+    w.dw = Gp[p_tail(L, 1)]; w.db = Gp[p_tail(L, 1) + 1]; w.workspace = L.wg_ws;
+    RUN(neosr_conv3x3_wgrad(&w, st));
+    neosr_conv_desc d = conv_base(B, H2, W2);
+    d.mode = NEOSR_CONV_DGRAD;
+    d.in = L.g_u1; d.in_cs = F; d.K = F; d.in_mask = L.u1; d.mask_cs = F; d.mask_slope = 0.2f;
+    d.w = P[p_tail(L, 1)]; d.w_cout = F; d.w_cin = F;
+    d.out = L.g_up1in; d.out_cs = F; d.N = F;
+    RUN(neosr_conv3x3(&d, st));
+    RUN(neosr_pool2x2_sum(L.g_up1in, L.g_fea, B, H, W, F, F, F, 0, st));
+  }
+  {  // conv_body
+    neosr_wgrad_desc w = wgrad_base(B, H, W);
+    w.in = L.trunk; w.in_cs = F; w.K = F; w.g = L.g_fea; w.g_cs = F; w.N = F;
+    w.dw = Gp[p_tail(L, 0)]; w.db = Gp[p_tail(L, 0) + 1]; w.workspace = L.wg_ws;
+    RUN(neosr_conv3x3_wgrad(&w, st));
+    neosr_conv_desc d = conv_base(B, H, W);
+    d.mode = NEOSR_CONV_DGRAD;
+    d.in = L.g_fea; d.in_cs = F; d.K = F;
+    d.w = P[p_tail(L, 0)]; d.w_cout = F; d.w_cin = F;
+    d.out = L.g_trunk; d.out_cs = F; d.N = F;
+    RUN(neosr_conv3x3(&d, st));
+  }
+  // trunk: 23 x RRDB, reversed
+  const float* dOut = L.g_trunk;
+  int dOut_cs = F;
+  int gbi = 0;
+  float* prev = nullptr;
+  for (int n = L.NB - 1; n >= 0; --n) {
+    for (int r = 2; r >= 0; --r) {
+      const float* A = L.act[3 * n + r];
+      float* GB = L.gb[gbi];
+      const float* dO = (r == 2) ? dOut : prev;
+      const int dO_cs = (r == 2) ? dOut_cs : CC;
+      {  // conv5: x5*0.2 + x  (and RRDB-level *0.2 + x for r==2)
+        neosr_wgrad_desc w = wgrad_base(B, H, W);
+        w.in = A; w.in_cs = CC; w.K = CC; w.g = dO; w.g_cs = dO_cs; w.N = F;
+        w.scale = (r == 2) ? 0.04f : 0.2f;
+        w.dw = Gp[p_rdb(n, r, 4)]; w.db = Gp[p_rdb(n, r, 4) + 1]; w.workspace = L.wg_ws;
+        RUN(neosr_conv3x3_wgrad(&w, st));
+        neosr_conv_desc d = conv_base(B, H, W);
+        d.mode = NEOSR_CONV_DGRAD;
+        d.in = dO; d.in_cs = dO_cs; d.K = F;
+        d.w = P[p_rdb(n, r, 4)]; d.w_cout = F; d.w_cin = CC;
+        d.out = GB; d.out_cs = CC; d.N = CC;
+        d.alpha = 0.2f; d.res1 = dO; d.res1_cs = dO_cs; d.res1_nch = F;
+        if (r == 2) d.alpha2 = 0.2f;
+        if (r == 0) { d.res2 = dOut; d.res2_cs = dOut_cs; d.res2_nch = F; }
+        RUN(neosr_conv3x3(&d, st));
+      }
+      for (int k = 3; k >= 0; --k) {
+        const int Kin = F + k * G;
+        neosr_wgrad_desc w = wgrad_base(B, H, W);
+        w.in = A; w.in_cs = CC; w.K = Kin; w.g = GB + Kin; w.g_cs = CC; w.N = G;
+        w.g_mask = A + Kin; w.mask_cs = CC; w.mask_slope = 0.2f;
+        w.dw = Gp[p_rdb(n, r, k)]; w.db = Gp[p_rdb(n, r, k) + 1]; w.workspace = L.wg_ws;
+        RUN(neosr_conv3x3_wgrad(&w, st));
+        neosr_conv_desc d = conv_base(B, H, W);
+        d.mode = NEOSR_CONV_DGRAD;
+        d.in = GB + Kin; d.in_cs = CC; d.K = G;
+        d.in_mask = A + Kin; d.mask_cs = CC; d.mask_slope = 0.2f;
+        d.w = P[p_rdb(n, r, k)]; d.w_cout = G; d.w_cin = Kin;
+        d.out = GB; d.out_cs = CC; d.N = Kin; d.accumulate = 1;
+        RUN(neosr_conv3x3(&d, st));
+      }
+      prev = GB;
+      gbi = (gbi + 1) & 3;
+    }
+    dOut = prev;
+    dOut_cs = CC;
+  }
+  // skip connection feat + body_feat, then conv_first
+  RUN(neosr_axpy_slice(prev, L.g_fea, L.np1, F, CC, F, 1.0f, st));
+  {
+    neosr_wgrad_desc w = wgrad_base(B, H, W);
+    w.in = L.x_nhwc; w.in_cs = L.cin_cs; w.K = L.Cin; w.g = prev; w.g_cs = CC; w.N = F;
+    w.dw = Gp[0]; w.db = Gp[1]; w.workspace = L.wg_ws;
+    RUN(neosr_conv3x3_wgrad(&w, st));
+    if (gx) {
+      neosr_conv_desc d = conv_base(B, H, W);
+      d.mode = NEOSR_CONV_DGRAD;
+      d.in = prev; d.in_cs = CC; d.K = F;
+      d.w = P[0]; d.w_cout = F; d.w_cin = L.Cin;
+      d.out = L.gx_nhwc; d.out_cs = L.cin_cs; d.N = L.Cin;
+      RUN(neosr_conv3x3(&d, st));
+      RUN(neosr_nhwc_to_nchw(L.gx_nhwc, gx, B, L.Cin, H, W, L.cin_cs, st));
+    }
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------ SRVGGNetCompact
+namespace {
+
+struct CompactLayout {
+  int B, H, W, Cin, Cout, F, NC, r, Clast, cin_cs, clast_cs, nz;
+  int has_prelu;
+  int64_t np;
+  float* x_nhwc;
+  std::vector<float*> z;  // pre-activation outputs of conv 0..NC
+  float* zl;              // last conv output (Cout*r*r)
+  float* slopes_const;    // constant slope vector for relu / leakyrelu
+  float *g_zl, *dA[2], *wg_ws, *ps_ws;
+  int64_t total;
+};
+
+CompactLayout compact_layout(const neosr_compact_cfg& c, void* ws) {
+  CompactLayout L;
+  L.B = c.B; L.H = c.H; L.W = c.W; L.Cin = c.num_in_ch; L.Cout = c.num_out_ch;
+  L.F = c.num_feat; L.NC = c.num_conv; L.r = c.upscale;
+  L.Clast = L.Cout * L.r * L.r;
+  L.cin_cs = pad4(L.Cin);
+  L.clast_cs = pad4(L.Clast);
+  L.has_prelu = c.act_type == NEOSR_ACT_PRELU;
+  L.np = (int64_t)c.B * c.H * c.W;
+  Bump b(ws);
+  L.x_nhwc = b.take(L.np * L.cin_cs);
+  L.slopes_const = b.take(L.F);
+  L.nz = c.training ? L.NC + 1 : 2;
+  L.z.resize(L.nz);
+  for (int i = 0; i < L.nz; ++i) L.z[i] = b.take(L.np * L.F);
+  L.zl = b.take(L.np * L.clast_cs);
+  if (c.training) {
+    L.g_zl = L.zl;  // dead after the pixel shuffle
+    L.dA[0] = b.take(L.np * L.F);
+    L.dA[1] = b.take(L.np * L.F);
+    int64_t w = neosr_conv3x3_wgrad_workspace_bytes(c.B, c.H, c.W, L.Cin, L.F);
+    w = max64(w, neosr_conv3x3_wgrad_workspace_bytes(c.B, c.H, c.W, L.F, L.F));
+    w = max64(w, neosr_conv3x3_wgrad_workspace_bytes(c.B, c.H, c.W, L.F, L.Clast));
+    L.wg_ws = b.take(w / 4 + 64);
+    L.ps_ws = b.take(neosr_prelu_dslope_workspace_bytes(L.np, L.F) / 4 + 64);
+  }
+  L.total = (b.off + 255) & ~(int64_t)255;
+  return L;
+}
+
+int compact_check(const neosr_compact_cfg* c) {
+  NEOSR_CHECK(c, "compact: null cfg");
+  NEOSR_CHECK(c->B > 0 && c->H > 0 && c->W > 0 && c->num_in_ch > 0 && c->num_out_ch > 0 &&
+                  c->num_feat > 0 && c->num_conv >= 0 && c->upscale > 0,
+              "compact: bad cfg");
+  NEOSR_CHECK(c->num_feat % 4 == 0 && c->num_feat <= 256, "compact: num_feat must be 4k <= 256");
+  NEOSR_CHECK(c->num_in_ch == c->num_out_ch,
+              "compact: `out += nearest(x)` needs num_in_ch == num_out_ch (compact_arch.py:83-84)");
+  NEOSR_CHECK(c->act_type == NEOSR_ACT_PRELU || c->act_type == NEOSR_ACT_RELU ||
+                  c->act_type == NEOSR_ACT_LRELU,
+              "compact: bad act_type");
+  return 0;
+}
+
+// parameter indices: conv i (0..NC) then last conv
+inline int cp_stride(const CompactLayout& L) { return L.has_prelu ? 3 : 2; }
+inline int cp_w(const CompactLayout& L, int i) { return i * cp_stride(L); }
+inline int cp_last(const CompactLayout& L) { return (L.NC + 1) * cp_stride(L); }
+inline const float* cp_slope(const CompactLayout& L, const float* const* P, int i) {
+  return L.has_prelu ? P[cp_w(L, i) + 2] : L.slopes_const;
+}
+
+}  // namespace
+
+extern "C" int32_t neosr_compact_num_params(const neosr_compact_cfg* c) {
+  return (c->num_conv + 1) * (c->act_type == NEOSR_ACT_PRELU ? 3 : 2) + 2;
+}
+
+extern "C" int64_t neosr_compact_workspace_bytes(const neosr_compact_cfg* c) {
+  if (compact_check(c)) return -1;
+  return compact_layout(*c, nullptr).total;
+}
+
+extern "C" int neosr_compact_forward(const neosr_compact_cfg* c, const float* const* P,
+                                     const float* x, float* y, void* ws, void* st) {
+  RUN(compact_check(c));
+  NEOSR_CHECK(P && x && y && ws, "compact_forward: null pointer");
+  const CompactLayout L = compact_layout(*c, ws);
+  const int B = L.B, H = L.H, W = L.W, F = L.F;
+  if (!L.has_prelu)
+    RUN(neosr_fill(L.slopes_const, F, c->act_type == NEOSR_ACT_RELU ? 0.f : 0.1f, st));
+  RUN(neosr_nchw_to_nhwc(x, L.x_nhwc, B, L.Cin, H, W, L.cin_cs, st));
+  for (int i = 0; i <= L.NC; ++i) {
+    neosr_conv_desc d = conv_base(B, H, W);
+    if (i == 0) {
+      d.in = L.x_nhwc; d.in_cs = L.cin_cs; d.K = L.Cin; d.w_cin = L.Cin;
+    } else {
+      d.in = L.z[(i - 1) % L.nz]; d.in_cs = F; d.K = F; d.w_cin = F;
+      d.in_prelu = cp_slope(L, P, i - 1);
+    }
+    d.w = P[cp_w(L, i)]; d.bias = P[cp_w(L, i) + 1]; d.w_cout = F;
+    d.out = L.z[i % L.nz]; d.out_cs = F; d.N = F;
+    RUN(neosr_conv3x3(&d, st));
+  }
+  {
+    neosr_conv_desc d = conv_base(B, H, W);
+    d.in = L.z[L.NC % L.nz]; d.in_cs = F; d.K = F; d.w_cin = F;
+    d.in_prelu = cp_slope(L, P, L.NC);
+    d.w = P[cp_last(L)]; d.bias = P[cp_last(L) + 1]; d.w_cout = L.Clast;
+    d.out = L.zl; d.out_cs = L.clast_cs; d.N = L.Clast;
+    RUN(neosr_conv3x3(&d, st));
+  }
+  RUN(neosr_pixel_shuffle_nhwc_to_nchw(L.zl, x, y, B, L.Cout, H, W, L.r, L.clast_cs, st));
+  return 0;
+}
+
+extern "C" int neosr_compact_backward(const neosr_compact_cfg* c, const float* const* P,
+                                      float* const* Gp, const float* gy, float* gx, void* ws,
+                                      void* st) {
+  RUN(compact_check(c));
+  NEOSR_CHECK(P && Gp && gy && ws, "compact_backward: null pointer");
+  NEOSR_CHECK(c->training, "compact_backward: cfg.training must be set");
+  NEOSR_CHECK(gx == nullptr, "compact_backward: input gradient is not implemented");
+  const CompactLayout L = compact_layout(*c, ws);
+  const int B = L.B, H = L.H, W = L.W, F = L.F;
+  RUN(neosr_pixel_unshuffle_nchw_to_nhwc(gy, L.g_zl, B, L.Cout, H, W, L.r, L.clast_cs, st));
+  {  // last conv: input prelu(z_NC)
+    neosr_wgrad_desc w = wgrad_base(B, H, W);
+    w.in = L.z[L.NC]; w.in_cs = F; w.K = F; w.in_prelu = cp_slope(L, P, L.NC);
+    w.g = L.g_zl; w.g_cs = L.clast_cs; w.N = L.Clast;
+    w.dw = Gp[cp_last(L)]; w.db = Gp[cp_last(L) + 1]; w.workspace = L.wg_ws;
+    RUN(neosr_conv3x3_wgrad(&w, st));
+    neosr_conv_desc d = conv_base(B, H, W);
+    d.mode = NEOSR_CONV_DGRAD;
+    d.in = L.g_zl; d.in_cs = L.clast_cs; d.K = L.Clast;
+    d.w = P[cp_last(L)]; d.w_cout = L.Clast; d.w_cin = F;
+    d.out = L.dA[L.NC & 1]; d.out_cs = F; d.N = F;
+    RUN(neosr_conv3x3(&d, st));
+  }
+  for (int i = L.NC; i >= 0; --i) {
+    const float* dAi = L.dA[i & 1];  // gradient wrt a_i = act(z_i)
+    const float* si = cp_slope(L, P, i);
+    if (L.has_prelu)
+      RUN(neosr_prelu_dslope(dAi, L.z[i], Gp[cp_w(L, i) + 2], L.ps_ws, L.np, F, F, F, 0, st));
+    neosr_wgrad_desc w = wgrad_base(B, H, W);
+    if (i == 0) {
+      w.in = L.x_nhwc; w.in_cs = L.cin_cs; w.K = L.Cin;
+    } else {
+      w.in = L.z[i - 1]; w.in_cs = F; w.K = F; w.in_prelu = cp_slope(L, P, i - 1);
+    }
+    w.g = dAi; w.g_cs = F; w.N = F; w.g_mask = L.z[i]; w.mask_cs = F; w.mask_slopes = si;
+    w.dw = Gp[cp_w(L, i)]; w.db = Gp[cp_w(L, i) + 1]; w.workspace = L.wg_ws;
+    RUN(neosr_conv3x3_wgrad(&w, st));
+    if (i > 0) {
+      neosr_conv_desc d = conv_base(B, H, W);
+      d.mode = NEOSR_CONV_DGRAD;
+      d.in = dAi; d.in_cs = F; d.K = F; d.in_mask = L.z[i]; d.mask_cs = F; d.mask_slopes = si;
+      d.w = P[cp_w(L, i)]; d.w_cout = F; d.w_cin = F;
+      d.out = L.dA[(i - 1) & 1]; d.out_cs = F; d.N = F;
+      RUN(neosr_conv3x3(&d, st));
+    }
+  }
+  return 0;
+}

@@ -1,0 +1,225 @@
+"""Autograd bridges from torch modules to the whole-network HIP plans, and the flat HBM arenas
+(parameters / gradients) the fused optimizer and the RCCL all-reduce operate on.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+from torch import nn
+
+from neosr_amd import _C
+
+
+# --------------------------------------------------------------------------------------------
+# flat arenas
+# --------------------------------------------------------------------------------------------
+def flatten_parameters_(module: nn.Module) -> torch.Tensor:
+    """Re-home every parameter of ``module`` into one contiguous fp32 arena (in named_parameters
+    order) and make each ``nn.Parameter`` a view of it.  Idempotent; returns the arena."""
+    params = [p for p in module.parameters()]
+    if not params:
+        raise ValueError("module has no parameters")
+    arena = getattr(module, "_neosr_arena", None)
+    if arena is not None and _is_flat(params, arena):
+        return arena
+    total = sum(p.numel() for p in params)
+    dev = params[0].device
+    arena = torch.empty(total, device=dev, dtype=torch.float32)
+    off = 0
+    with torch.no_grad():
+        for p in params:
+            n = p.numel()
+            view = arena[off : off + n].view(p.shape)
+            view.copy_(p.data)
+            p.data = view
+            off += n
+    module._neosr_arena = arena  # noqa: SLF001
+    return arena
+
+
+def _is_flat(tensors, arena: torch.Tensor) -> bool:
+    off = arena.data_ptr()
+    for t in tensors:
+        if t is None or t.data_ptr() != off or not t.is_contiguous():
+            return False
+        off += t.numel() * 4
+    return off == arena.data_ptr() + arena.numel() * 4
+
+
+def flat_grad_of(params) -> torch.Tensor | None:
+    """If all ``p.grad`` sit back-to-back in one buffer (as our backward emits them), return that
+    buffer as a 1-D tensor without copying; else None."""
+    params = list(params)
+    g0 = params[0].grad
+    if g0 is None:
+        return None
+    total = sum(p.numel() for p in params)
+    base = g0.data_ptr()
+    off = base
+    for p in params:
+        g = p.grad
+        if g is None or g.data_ptr() != off or not g.is_contiguous():
+            return None
+        off += g.numel() * 4
+    # rebuild a flat view over the same storage
+    storage_off = g0.storage_offset()
+    flat = torch.empty(0, device=g0.device, dtype=torch.float32)
+    flat.set_(g0.untyped_storage(), storage_off, (total,), (1,))
+    return flat
+
+
+def _alloc_flat_grads(params):
+    total = sum(p.numel() for p in params)
+    flat = torch.empty(total, device=params[0].device, dtype=torch.float32)
+    views, off = [], 0
+    for p in params:
+        n = p.numel()
+        views.append(flat[off : off + n].view(p.shape))
+        off += n
+    return flat, views
+
+
+# --------------------------------------------------------------------------------------------
+# RRDBNet
+# --------------------------------------------------------------------------------------------
+class RRDBNetFunction(torch.autograd.Function):
+    """y = RRDBNet(x; params) on the HIP plan ``neosr_rrdbnet_forward/backward``."""
+
+    @staticmethod
+    def forward(ctx, x, hp: dict, *params):
+        lib = _C.load()
+        _C.require_device(x, "input")
+        for p in params:
+            _C.require_device(p, "parameter")
+        x = x.contiguous()
+        B, cin, H, W = x.shape
+        training = bool(hp["training"]) and torch.is_grad_enabled()
+        cfg = _C.RRDBNetCfg(B, H, W, cin, hp["num_out_ch"], hp["num_feat"], hp["num_block"],
+                            hp["num_grow_ch"], int(training))
+        nexp = lib.neosr_rrdbnet_num_params(C.byref(cfg))
+        if nexp != len(params):
+            raise _C.NeosrAmdError(f"rrdbnet expects {nexp} parameter tensors, got {len(params)}")
+        nbytes = lib.neosr_rrdbnet_workspace_bytes(C.byref(cfg))
+        if nbytes < 0:
+            _C.check(1, "neosr_rrdbnet_workspace_bytes")
+        ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
+        y = torch.empty(B, hp["num_out_ch"], 4 * H, 4 * W, device=x.device, dtype=torch.float32)
+        ptab = _C.ptr_table(params)
+        _C.check(lib.neosr_rrdbnet_forward(C.byref(cfg), ptab, x.data_ptr(), y.data_ptr(),
+                                           ws.data_ptr(), _C.stream_ptr()), "neosr_rrdbnet_forward")
+        if training:
+            ctx.cfg = cfg
+            ctx.ws = ws
+            ctx.x = x
+            ctx.params = params
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _C.load()
+        params = ctx.params
+        gy = gy.contiguous()
+        _flat, gviews = _alloc_flat_grads(params)
+        gx = torch.empty_like(ctx.x) if ctx.needs_input_grad[0] else None
+        ptab = _C.ptr_table(params)
+        gtab = _C.ptr_table(gviews)
+        _C.check(lib.neosr_rrdbnet_backward(C.byref(ctx.cfg), ptab, gtab, gy.data_ptr(),
+                                            None if gx is None else gx.data_ptr(),
+                                            ctx.ws.data_ptr(), _C.stream_ptr()),
+                 "neosr_rrdbnet_backward")
+        ctx.ws = None
+        grads = tuple(g if need else None for g, need in zip(gviews, ctx.needs_input_grad[2:]))
+        return (gx, None, *grads)
+
+
+# --------------------------------------------------------------------------------------------
+# SRVGGNetCompact
+# --------------------------------------------------------------------------------------------
+class CompactFunction(torch.autograd.Function):
+    """y = SRVGGNetCompact(x; params) on ``neosr_compact_forward/backward``."""
+
+    @staticmethod
+    def forward(ctx, x, hp: dict, *params):
+        lib = _C.load()
+        _C.require_device(x, "input")
+        for p in params:
+            _C.require_device(p, "parameter")
+        x = x.contiguous()
+        B, cin, H, W = x.shape
+        training = bool(hp["training"]) and torch.is_grad_enabled()
+        cfg = _C.CompactCfg(B, H, W, cin, hp["num_out_ch"], hp["num_feat"], hp["num_conv"],
+                            hp["upscale"], hp["act_type"], int(training))
+        nexp = lib.neosr_compact_num_params(C.byref(cfg))
+        if nexp != len(params):
+            raise _C.NeosrAmdError(f"compact expects {nexp} parameter tensors, got {len(params)}")
+        nbytes = lib.neosr_compact_workspace_bytes(C.byref(cfg))
+        if nbytes < 0:
+            _C.check(1, "neosr_compact_workspace_bytes")
+        ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
+        r = hp["upscale"]
+        y = torch.empty(B, hp["num_out_ch"], r * H, r * W, device=x.device, dtype=torch.float32)
+        ptab = _C.ptr_table(params)
+        _C.check(lib.neosr_compact_forward(C.byref(cfg), ptab, x.data_ptr(), y.data_ptr(),
+                                           ws.data_ptr(), _C.stream_ptr()), "neosr_compact_forward")
+        if training:
+            ctx.cfg = cfg
+            ctx.ws = ws
+            ctx.params = params
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _C.load()
+        if ctx.needs_input_grad[0]:
+            raise _C.NeosrAmdError("compact: gradient w.r.t. the input image is not implemented")
+        params = ctx.params
+        gy = gy.contiguous()
+        _flat, gviews = _alloc_flat_grads(params)
+        ptab = _C.ptr_table(params)
+        gtab = _C.ptr_table(gviews)
+        _C.check(lib.neosr_compact_backward(C.byref(ctx.cfg), ptab, gtab, gy.data_ptr(), None,
+                                            ctx.ws.data_ptr(), _C.stream_ptr()),
+                 "neosr_compact_backward")
+        ctx.ws = None
+        grads = tuple(g if need else None for g, need in zip(gviews, ctx.needs_input_grad[2:]))
+        return (None, None, *grads)
+
+
+# --------------------------------------------------------------------------------------------
+# L1 loss
+# --------------------------------------------------------------------------------------------
+class L1LossFunction(torch.autograd.Function):
+    """loss_weight * mean(|pred - target|) with a fixed-order two-stage reduction."""
+
+    @staticmethod
+    def forward(ctx, pred, target, loss_weight: float):
+        lib = _C.load()
+        _C.require_device(pred, "pred")
+        _C.require_device(target, "target")
+        pred = pred.contiguous()
+        target = target.contiguous()
+        if pred.shape != target.shape:
+            raise _C.NeosrAmdError(f"L1Loss: shape mismatch {tuple(pred.shape)} vs {tuple(target.shape)}")
+        n = pred.numel()
+        out = torch.empty((), device=pred.device, dtype=torch.float32)
+        ws = torch.empty(4096, device=pred.device, dtype=torch.float32)
+        _C.check(lib.neosr_l1_loss_fwd(pred.data_ptr(), target.data_ptr(), n, float(loss_weight),
+                                       out.data_ptr(), ws.data_ptr(), _C.stream_ptr()),
+                 "neosr_l1_loss_fwd")
+        ctx.save_for_backward(pred, target)
+        ctx.loss_weight = float(loss_weight)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = _C.load()
+        pred, target = ctx.saved_tensors
+        gout = gout.contiguous().to(torch.float32)
+        gp = torch.empty_like(pred)
+        _C.check(lib.neosr_l1_loss_bwd(pred.data_ptr(), target.data_ptr(), gout.data_ptr(),
+                                       pred.numel(), ctx.loss_weight, gp.data_ptr(),
+                                       _C.stream_ptr()), "neosr_l1_loss_bwd")
+        gt = -gp if ctx.needs_input_grad[1] else None
+        return gp, gt, None

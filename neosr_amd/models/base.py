@@ -1,0 +1,223 @@
+"""``base`` model: device placement, optimizer/scheduler factories, LR warm-up, loss-dict reduce,
+checkpoint I/O.  Mirrors the public surface of neosr/models/base.py:21-526.
+
+MI355X-first differences (behaviour-preserving):
+* no DistributedDataParallel wrapper: each rank owns flat parameter/gradient arenas and the model
+  issues one RCCL all-reduce per network on the flat gradient (`allreduce_flat_`), with the
+  1/world_size folded into the fused optimizer kernel;
+* `reduce_loss_dict` implements the *intent* of base.py:498-526 (mean over ranks, visible on
+  rank 0) — the reference assigns `None` from `dist.reduce` and crashes under DDP
+  — and defers the device->host read of the scalars to `get_current_log()`.
+"""
+
+from __future__ import annotations
+
+import sys
+import time
+from collections import OrderedDict
+from copy import deepcopy
+from pathlib import Path
+from typing import Any
+
+import torch
+import torch.distributed as dist
+from torch import nn
+
+from neosr_amd import optimizers
+from neosr_amd.hip.nets import flatten_parameters_
+from neosr_amd.utils.dist_util import master_only
+from neosr_amd.utils.misc import get_root_logger, tc
+
+
+def allreduce_flat_(flat: torch.Tensor, bucket_bytes: int = 64 << 20) -> None:
+    """SUM all-reduce of a flat gradient arena in a few large buckets (RCCL over xGMI on ROCm;
+    gloo in the CPU tests).  xGMI is point-to-point: few, large messages beat many small ones;
+    the division by world_size happens inside the optimizer kernel (`grad_scale`)."""
+    n = flat.numel()
+    per = max(1, bucket_bytes // 4)
+    handles = []
+    for lo in range(0, n, per):
+        handles.append(dist.all_reduce(flat[lo : min(n, lo + per)], op=dist.ReduceOp.SUM, async_op=True))
+    for h in handles:
+        h.wait()
+
+
+class base:
+    """Default model."""
+
+    def __init__(self, opt: dict[str, Any]) -> None:
+        self.opt = opt
+        self.device = torch.device("cuda")
+        self.is_train = opt["is_train"]
+        self.optimizers: list[Any] = []
+        self.schedulers: list[Any] = []
+        self.log_dict: dict[str, Any] = OrderedDict()
+        self._log_dev: tuple[list[str], torch.Tensor] | None = None
+        self.n_accumulated = 0
+        if self.is_train:
+            self.sf_optim_g = opt["train"]["optim_g"].get("schedule_free", False)
+            self.net_d = opt.get("network_d")
+            if self.net_d is not None:
+                self.sf_optim_d = opt["train"]["optim_d"].get("schedule_free", False)
+        else:
+            self.sf_optim_g = None
+            self.sf_optim_d = None
+
+    # -- interface stubs (image/otf override) ----------------------------------------------
+    def feed_data(self, data) -> None: ...
+    def optimize_parameters(self, current_iter: int) -> None: ...
+    def get_current_visuals(self): ...
+    def save(self, epoch: int, current_iter: int) -> None: ...
+
+    def validation(self, dataloader, current_iter, tb_logger, save_img=True) -> None:
+        msg = "validation is outside the accelerated hot path (SURVEY §2.1 row 17)"
+        raise NotImplementedError(msg)
+
+    # -- logging ------------------------------------------------------------------------
+    def get_current_log(self) -> dict[str, Any]:
+        """Materialise the (possibly rank-reduced) loss scalars: the only device->host read of the
+        iteration, paid when the caller actually logs.  NaN in the generator loss raises here
+        (reference: ValueError at image.py:611-619, checked every iteration)."""
+        if self._log_dev is not None:
+            keys, vals = self._log_dev
+            host = vals.detach().float().cpu().tolist()
+            self.log_dict = OrderedDict(zip(keys, host))
+            self._log_dev = None
+            tot = self.log_dict.get("l_g_total")
+            if tot is not None and tot != tot:
+                msg = (f"{tc.red}NaN found, aborting training. Make sure you're using a proper "
+                       f"learning rate.{tc.end}")
+                raise ValueError(msg)
+        return self.log_dict
+
+    def reduce_loss_dict(self, loss_dict: dict[str, torch.Tensor]) -> None:
+        """Average the losses over ranks (intent of base.py:498-526); result read lazily."""
+        with torch.no_grad():
+            keys = list(loss_dict.keys())
+            vals = torch.stack([v.detach().reshape(-1)[0].float() for v in loss_dict.values()])
+            if self.opt["dist"]:
+                dist.reduce(vals, dst=0)
+                if self.opt["rank"] == 0:
+                    vals /= self.opt["world_size"]
+            self._log_dev = (keys, vals)
+
+    # -- device / parallel ----------------------------------------------------------------
+    def model_to_device(self, net: nn.Module) -> nn.Module:
+        """Move to the HIP device and re-home the parameters into one flat arena
+        (base.py:120-149 wraps in DDP here; we all-reduce the flat gradient arena instead)."""
+        if self.opt.get("use_amp", False) is True:
+            msg = "use_amp: the HIP kernels on this path are fp32 (north_star: 1e-3 rel fp32)"
+            raise NotImplementedError(msg)
+        if self.opt.get("compile", False) is True:
+            get_root_logger().warning("`compile = true` ignored: kernels are hand-written HIP")
+        if not torch.cuda.is_available():
+            msg = "neosr_amd models need a HIP device (no CPU fallback on the product path)"
+            raise RuntimeError(msg)
+        net = net.to(self.device)
+        flatten_parameters_(net)
+        if self.opt["dist"]:  # identical start on every rank (DDP broadcasts from rank 0 too)
+            dist.broadcast(net._neosr_arena, src=0)  # noqa: SLF001
+        return net
+
+    def get_bare_model(self, net: nn.Module) -> nn.Module:
+        return getattr(net, "module", net) if not hasattr(net, "_neosr_arena") else net
+
+    def get_optimizer(self, optim_type: str, params, lr: float, **kwargs):
+        if optim_type in {"AdamW", "adamw"}:
+            return optimizers.AdamW(params, lr, **kwargs)
+        logger = get_root_logger()
+        logger.error(f"{tc.red}Optimizer {optim_type} has no HIP implementation yet "
+                     f"(available: adamw).{tc.end}")
+        sys.exit(1)
+
+    def setup_schedulers(self) -> None:
+        train_opt = self.opt["train"]
+        if train_opt.get("scheduler") is None:
+            return
+        sched = dict(train_opt["scheduler"])
+        scheduler_type = sched.pop("type")
+        if scheduler_type in {"MultiStepLR", "multisteplr"}:
+            cls = torch.optim.lr_scheduler.MultiStepLR
+        elif scheduler_type in {"CosineAnnealing", "cosineannealing"}:
+            cls = torch.optim.lr_scheduler.CosineAnnealingLR
+        else:
+            get_root_logger().error(f"{tc.red}Scheduler {scheduler_type} is not implemented yet.{tc.end}")
+            sys.exit(1)
+        for optimizer in self.optimizers:
+            self.schedulers.append(cls(optimizer, **sched))
+
+    def _set_lr(self, lr_groups_l) -> None:
+        for optimizer, lr_groups in zip(self.optimizers, lr_groups_l):
+            for param_group, lr in zip(optimizer.param_groups, lr_groups):
+                param_group["lr"] = lr
+
+    def _get_init_lr(self):
+        return [[v["initial_lr"] for v in o.param_groups] for o in self.optimizers]
+
+    def update_learning_rate(self, current_iter: int, warmup_iter: int = -1) -> None:
+        """base.py:229-254: scheduler step once per optimizer step, linear warm-up."""
+        if current_iter > 0 and self.n_accumulated == 0:
+            for scheduler in self.schedulers:
+                scheduler.step()
+        if current_iter < warmup_iter:
+            init = self._get_init_lr()
+            self._set_lr([[v / warmup_iter * current_iter for v in g] for g in init])
+
+    def get_current_learning_rate(self):
+        return [g["lr"] for g in self.optimizers[0].param_groups]
+
+    # -- checkpoints (wire format of base.py:281-475) ----------------------------------------
+    @master_only
+    def save_network(self, net, net_label: str, current_iter: int, param_key: str = "params") -> None:
+        it = "latest" if current_iter == -1 else current_iter
+        path = Path(self.opt["path"]["models"]) / f"{net_label}_{it}.pth"
+        path.parent.mkdir(parents=True, exist_ok=True)
+        nets = net if isinstance(net, list) else [net]
+        keys = param_key if isinstance(param_key, list) else [param_key]
+        save_dict = {}
+        for n, k in zip(nets, keys):
+            sd = OrderedDict()
+            for name, p in n.state_dict().items():
+                if name == "n_averaged":
+                    continue
+                sd[name.removeprefix("module.")] = p.detach().cpu().clone()
+            save_dict[k] = sd
+        for retry in range(3):
+            try:
+                torch.save(save_dict, path)
+                break
+            except OSError as e:
+                get_root_logger().warning(f"Save model error: {e}, remaining retry times: {2 - retry}")
+                time.sleep(1)
+
+    def load_network(self, net, load_path, param_key: str | None = None, strict: bool = True) -> None:
+        load_net = torch.load(load_path, map_location="cpu", weights_only=True)
+        if param_key is None:
+            for k in ("params-ema", "params_ema", "params"):
+                if k in load_net:
+                    param_key = k
+                    break
+        if param_key is not None and param_key in load_net:
+            load_net = load_net[param_key]
+        load_net = OrderedDict((k.removeprefix("module."), v) for k, v in load_net.items())
+        self.get_bare_model(net).load_state_dict(load_net, strict=strict)
+
+    @master_only
+    def save_training_state(self, epoch: int, current_iter: int) -> None:
+        if current_iter == -1:
+            return
+        state = {"epoch": epoch, "iter": current_iter,
+                 "optimizers": [o.state_dict() for o in self.optimizers],
+                 "schedulers": [s.state_dict() for s in self.schedulers]}
+        path = Path(self.opt["path"]["training_states"]) / f"{current_iter}.state"
+        path.parent.mkdir(parents=True, exist_ok=True)
+        torch.save(state, path)
+
+    def resume_training(self, resume_state) -> None:
+        for i, o in enumerate(resume_state["optimizers"]):
+            self.optimizers[i].load_state_dict(o)
+        for i, s in enumerate(resume_state["schedulers"]):
+            self.schedulers[i].load_state_dict(s)
+
+
+__all__ = ["allreduce_flat_", "base", "deepcopy"]

@@ -1,0 +1,214 @@
+"""``image`` — the SISR training model (drop-in for neosr/models/image.py:27-662 on the hot path).
+
+`feed_data(batch)` / `optimize_parameters(it)` / `get_current_log()` keep the reference contract
+and the same `log_dict` keys; the work is re-staged for one MI355X per process:
+
+  closure:   net_g forward+backward = two calls into libneosr_amd (whole-network HIP plans);
+             losses on HIP reduction kernels; gradients land in one flat arena
+  step:      (RCCL all-reduce of the flat arena) -> fused clip + AdamW + EMA kernel
+  logging:   loss scalars stay on the device until `get_current_log()`
+
+Options the reference supports but that are not on the benchmarked path (SAM, ECO, wavelet
+guidance, AMP, match_lq_colors, augmentations) raise `NotImplementedError` instead of silently
+doing something else.
+"""
+
+from __future__ import annotations
+
+import sys
+from collections import OrderedDict
+from copy import deepcopy
+from typing import Any
+
+import torch
+from torch import Tensor, nn
+
+from neosr_amd.archs import build_network
+from neosr_amd.hip.nets import flat_grad_of, flatten_parameters_
+from neosr_amd.losses import build_loss
+from neosr_amd.models.base import allreduce_flat_, base
+from neosr_amd.utils.misc import get_root_logger, tc
+from neosr_amd.utils.registry import MODEL_REGISTRY
+
+
+class EMAModel(nn.Module):
+    """`AveragedModel(net, multi_avg_fn=get_ema_multi_avg_fn(decay))` (image.py:82-86) with the
+    shadow weights in a flat arena so the update rides inside the optimizer kernel.
+    State-dict layout is AveragedModel's: `n_averaged` + `module.*`."""
+
+    def __init__(self, model: nn.Module, decay: float) -> None:
+        super().__init__()
+        self.module = deepcopy(model)
+        self.module._neosr_arena = None  # noqa: SLF001  (deepcopy re-homed the params)
+        self.decay = decay
+        self.register_buffer("n_averaged", torch.tensor(0, dtype=torch.long, device="cpu"))
+        self._count = 0
+        for p in self.module.parameters():
+            p.requires_grad_(False)
+
+    def arena(self) -> Tensor:
+        return flatten_parameters_(self.module)
+
+    def forward(self, *args, **kwargs):
+        return self.module(*args, **kwargs)
+
+    def mark_updated(self) -> None:
+        self._count += 1
+        self.n_averaged.fill_(self._count)
+
+    @property
+    def first(self) -> bool:
+        return self._count == 0
+
+
+_UNSUPPORTED_TRAIN_FLAGS = ("sam", "eco", "wavelet_guided", "match_lq_colors")
+_UNSUPPORTED_LOSSES = ("mssim_opt", "consistency_opt", "perceptual_opt", "dists_opt", "gan_opt",
+                       "ldl_opt", "ff_opt", "gw_opt")
+
+
+@MODEL_REGISTRY.register()
+class image(base):
+    """Single-Image Super-Resolution model."""
+
+    def __init__(self, opt: dict[str, Any]) -> None:
+        super().__init__(opt)
+        self.net_g = build_network(opt["network_g"])
+        self.net_g = self.model_to_device(self.net_g)
+        self.net_d = self.opt.get("network_d", None)
+        if self.net_d is not None:
+            msg = "network_d (GAN training) is the next row of the build plan; not in this round"
+            raise NotImplementedError(msg)
+        load_path = self.opt["path"].get("pretrain_network_g", None)
+        if load_path is not None:
+            self.load_network(self.net_g, load_path, self.opt["path"].get("param_key_g"),
+                              self.opt["path"].get("strict_load_g", True))
+            flatten_parameters_(self.net_g)
+        if self.is_train:
+            self.init_training_settings()
+
+    # ------------------------------------------------------------------------------------
+    def init_training_settings(self) -> None:
+        train_opt = self.opt["train"]
+        logger = get_root_logger()
+        for flag in _UNSUPPORTED_TRAIN_FLAGS:
+            if train_opt.get(flag):
+                raise NotImplementedError(f"train.{flag} is outside the accelerated hot path")
+        for key in _UNSUPPORTED_LOSSES:
+            if train_opt.get(key):
+                raise NotImplementedError(f"train.{key}: no HIP implementation yet (next rows of SURVEY §8)")
+
+        self.ema = train_opt.get("ema", -1)
+        if self.ema > 0:
+            self.net_g_ema = EMAModel(self.net_g, self.ema)
+            self.net_g_ema.arena()
+            logger.info("Using exponential-moving average.")
+        self.sam = None
+
+        self.setup_optimizers()
+        self.setup_schedulers()
+        self.net_g.train()
+
+        self.scale = self.opt["scale"]
+        ds = self.opt["datasets"]["train"]
+        self.patch_size = ds.get("patch_size")
+        self.aug = ds.get("augmentation", None)
+        self.aug_prob = ds.get("aug_prob", None)
+        if self.aug is not None and not (len(self.aug) == 1 and "none" in self.aug):
+            raise NotImplementedError("batch augmentations are a 'next' row (SURVEY §8 a9)")
+        self.use_amp = False
+        self.total_iter = train_opt.get("total_iter", 200000)
+        self.n_accumulated = 0
+        self.accum_iters = ds.get("accumulate", 1) or 1
+
+        if train_opt.get("pixel_opt"):
+            self.cri_pix = build_loss(train_opt["pixel_opt"]).to(self.device)
+        else:
+            self.cri_pix = None
+        self.gradclip = train_opt.get("grad_clip", True)
+
+        if self.cri_pix is None:
+            logger.error(f"{tc.red}Both pixel/mssim and perceptual losses are None. "
+                         f"Please enable at least one.{tc.end}")
+            sys.exit(1)
+        if train_opt.get("optim_d") is not None:
+            logger.error(f"{tc.red}Please set a discriminator in network_d or disable optim_d.{tc.end}")
+            sys.exit(1)
+
+    def setup_optimizers(self) -> None:
+        train_opt = self.opt["train"]
+        logger = get_root_logger()
+        optim_params = []
+        for k, v in self.net_g.named_parameters():
+            if v.requires_grad:
+                optim_params.append(v)
+            else:
+                logger.warning(f"Params {k} will not be optimized.")
+        og = dict(train_opt["optim_g"])
+        optim_type = og.pop("type")
+        og.pop("schedule_free", None)
+        self.optimizer_g = self.get_optimizer(optim_type, optim_params, **og)
+        self.optimizers.append(self.optimizer_g)
+
+    # ------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def feed_data(self, data: dict[str, Any]) -> None:
+        self.lq = data["lq"].to(self.device, non_blocking=True)
+        if "gt" in data:
+            self.gt = data["gt"].to(self.device, non_blocking=True)
+
+    def closure(self, current_iter: int):  # noqa: ARG002
+        self.n_accumulated += 1
+        if self.n_accumulated >= self.accum_iters:
+            self.n_accumulated = 0
+
+        self.output = self.net_g(self.lq)
+
+        l_g_total = torch.zeros(1, device=self.device)
+        loss_dict = OrderedDict()
+        if self.cri_pix:
+            l_g_pix = self.cri_pix(self.output, self.gt)
+            l_g_total = l_g_total + l_g_pix
+            loss_dict["l_g_pix"] = l_g_pix
+        loss_dict["l_g_total"] = l_g_total
+        l_g_total = l_g_total / self.accum_iters
+        l_g_total.backward()
+
+        if self.n_accumulated % self.accum_iters == 0:
+            params = self.optimizer_g.param_groups[0]["params"]
+            if self.opt["dist"]:
+                flat = flat_grad_of(params)
+                if flat is None:
+                    flat = torch.cat([p.grad.reshape(-1) for p in params])
+                    off = 0
+                    for p in params:
+                        p.grad = flat[off : off + p.numel()].view_as(p)
+                        off += p.numel()
+                allreduce_flat_(flat)
+                self.optimizer_g.set_grad_scale(1.0 / self.opt["world_size"])
+            if self.gradclip:
+                self.optimizer_g.set_clip(1.0)
+
+        self.reduce_loss_dict(loss_dict)
+        return l_g_total
+
+    def optimize_parameters(self, current_iter: int) -> None:
+        self.n_accumulated += 1
+        if self.n_accumulated >= self.accum_iters:
+            self.n_accumulated = 0
+        self.closure(current_iter)
+        if self.n_accumulated % self.accum_iters == 0:
+            if self.ema > 0:
+                self.optimizer_g.set_ema(self.net_g_ema.arena(), self.ema, self.net_g_ema.first)
+            self.optimizer_g.step()
+            self.optimizer_g.zero_grad(set_to_none=True)
+            if self.ema > 0:
+                self.net_g_ema.mark_updated()
+
+    # ------------------------------------------------------------------------------------
+    def save(self, epoch: int, current_iter: int) -> None:
+        """image.py:932-942: EMA weights are saved as `net_g` when EMA is on."""
+        if self.ema > 0:
+            self.save_network(self.net_g_ema, "net_g", current_iter, param_key="params")
+        else:
+            self.save_network(self.net_g, "net_g", current_iter)
+        self.save_training_state(epoch, current_iter)

@@ -1,0 +1,208 @@
+"""CPU oracle for the neosr training hot path — TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+A plain PyTorch-CPU fp32 restatement of the reference algorithm for the path named by
+BASELINE.json (`feed_data` -> `optimize_parameters`).  Only `tests/`, `__graft_entry__.smoke()`
+and `bench.py`'s `cpu_baseline` leg may import this module; nothing under `neosr_amd/` does.
+
+Parity status: PINNED.  Every function here is checked (tests/test_oracle_golden.py) against
+fixtures in tests/golden/*.npz that were produced by importing and running the reference itself
+(/root/reference @ 2024-10-16) on CPU in the build container — script: tests/golden/gen_golden.py.
+Exception: VGG19 ImageNet weights are not available offline, so anything perceptual is pinned on
+structure with seeded random weights only ("parity unpinned" for real VGG weights).
+
+Functional style on purpose: parameters are passed as a ``dict[str, Tensor]`` keyed exactly like
+the reference ``state_dict`` so that fixtures, the reference and the HIP product all share names.
+"""
+
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+# --------------------------------------------------------------------------------------------
+# index ops (bit-exact)
+# --------------------------------------------------------------------------------------------
+
+
+def pixel_shuffle_np(x: np.ndarray, r: int) -> np.ndarray:
+    """nn.PixelShuffle(r): out[b,c,h*r+i,w*r+j] = in[b,c*r*r+i*r+j,h,w]
+    (compact_arch.py:74,81; swinir_arch.py:782-783).  Explicit index loops over (i, j)."""
+    b, crr, h, w = x.shape
+    c = crr // (r * r)
+    out = np.empty((b, c, h * r, w * r), dtype=x.dtype)
+    for i in range(r):
+        for j in range(r):
+            out[:, :, i::r, j::r] = x[:, i * r + j :: r * r, :, :][:, :c]
+    return out
+
+
+def pixel_unshuffle_np(x: np.ndarray, s: int) -> np.ndarray:
+    """esrgan_arch.py:60-79: (b,c,hh,hw) -> (b,c*s*s,hh/s,hw/s), channel index c*s*s + i*s + j."""
+    b, c, hh, hw = x.shape
+    h, w = hh // s, hw // s
+    out = np.empty((b, c * s * s, h, w), dtype=x.dtype)
+    for i in range(s):
+        for j in range(s):
+            out[:, i * s + j :: s * s][:, :c] = x[:, :, i::s, j::s]
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# generators
+# --------------------------------------------------------------------------------------------
+
+
+def _conv(P, name: str, x: torch.Tensor) -> torch.Tensor:
+    return F.conv2d(x, P[f"{name}.weight"], P[f"{name}.bias"], stride=1, padding=1)
+
+
+def rdb_forward(P, prefix: str, x: torch.Tensor) -> torch.Tensor:
+    """ResidualDenseBlock.forward (esrgan_arch.py:109-116)."""
+    lrelu = lambda t: F.leaky_relu(t, 0.2)  # noqa: E731
+    x1 = lrelu(_conv(P, f"{prefix}.conv1", x))
+    x2 = lrelu(_conv(P, f"{prefix}.conv2", torch.cat((x, x1), 1)))
+    x3 = lrelu(_conv(P, f"{prefix}.conv3", torch.cat((x, x1, x2), 1)))
+    x4 = lrelu(_conv(P, f"{prefix}.conv4", torch.cat((x, x1, x2, x3), 1)))
+    x5 = _conv(P, f"{prefix}.conv5", torch.cat((x, x1, x2, x3, x4), 1))
+    return x5 * 0.2 + x
+
+
+def rrdb_forward(P, prefix: str, x: torch.Tensor) -> torch.Tensor:
+    """RRDB.forward (esrgan_arch.py:137-142)."""
+    out = rdb_forward(P, f"{prefix}.rdb1", x)
+    out = rdb_forward(P, f"{prefix}.rdb2", out)
+    out = rdb_forward(P, f"{prefix}.rdb3", out)
+    return out * 0.2 + x
+
+
+def rrdbnet_forward(P, x: torch.Tensor, scale: int = 4) -> torch.Tensor:
+    """esrgan.forward (esrgan_arch.py:196-214)."""
+    if scale in (1, 2):  # esrgan_arch.py:197-200: scale 2 -> unshuffle 2, scale 1 -> unshuffle 4
+        s = 2 if scale == 2 else 4
+        b, c, hh, hw = x.shape
+        feat = x.view(b, c, hh // s, s, hw // s, s).permute(0, 1, 3, 5, 2, 4)
+        feat = feat.reshape(b, c * s * s, hh // s, hw // s)
+    else:
+        feat = x
+    num_block = 1 + max(int(k.split(".")[1]) for k in P if k.startswith("body."))
+    feat = _conv(P, "conv_first", feat)
+    body = feat
+    for n in range(num_block):
+        body = rrdb_forward(P, f"body.{n}", body)
+    feat = feat + _conv(P, "conv_body", body)
+    lrelu = lambda t: F.leaky_relu(t, 0.2)  # noqa: E731
+    feat = lrelu(_conv(P, "conv_up1", F.interpolate(feat, scale_factor=2, mode="nearest")))
+    feat = lrelu(_conv(P, "conv_up2", F.interpolate(feat, scale_factor=2, mode="nearest")))
+    return _conv(P, "conv_last", lrelu(_conv(P, "conv_hr", feat)))
+
+
+def compact_forward(P, x: torch.Tensor, upscale: int = 4, act_type: str = "prelu") -> torch.Tensor:
+    """compact.forward (compact_arch.py:76-85): conv/act chain, PixelShuffle, + nearest(x)."""
+    conv_ids = sorted({int(k.split(".")[1]) for k in P if k.startswith("body.") and P[k].dim() == 4})
+    out = x
+    for n, i in enumerate(conv_ids):
+        out = F.conv2d(out, P[f"body.{i}.weight"], P[f"body.{i}.bias"], stride=1, padding=1)
+        if n == len(conv_ids) - 1:
+            break
+        if act_type == "prelu":
+            out = F.prelu(out, P[f"body.{i + 1}.weight"])
+        elif act_type == "relu":
+            out = F.relu(out)
+        else:
+            out = F.leaky_relu(out, 0.1)
+    out = F.pixel_shuffle(out, upscale)
+    return out + F.interpolate(x, scale_factor=upscale, mode="nearest")
+
+
+# --------------------------------------------------------------------------------------------
+# losses
+# --------------------------------------------------------------------------------------------
+
+
+def l1_loss(pred: torch.Tensor, target: torch.Tensor, loss_weight: float = 1.0) -> torch.Tensor:
+    """L1Loss.forward, reduction='mean' (basic_loss.py:10-11,44-53)."""
+    return loss_weight * (pred - target).abs().mean()
+
+
+# --------------------------------------------------------------------------------------------
+# optimizer step pieces
+# --------------------------------------------------------------------------------------------
+
+
+def clip_grad_norm_(grads: list[torch.Tensor], max_norm: float = 1.0) -> float:
+    """torch.nn.utils.clip_grad_norm_(…, max_norm, error_if_nonfinite=False) as called at
+    image.py:533-544: total = || [||g_i||_2] ||_2 ; g *= min(1, max_norm / (total + 1e-6))."""
+    total = torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(g) for g in grads]))
+    coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+    for g in grads:
+        g.mul_(coef)
+    return float(total)
+
+
+def adamw_step(params, grads, exp_avg, exp_avg_sq, step: int, lr: float, betas=(0.9, 0.999),
+               eps: float = 1e-8, weight_decay: float = 0.01) -> None:
+    """torch.optim.AdamW single-tensor update (what base.get_optimizer("adamw") steps,
+    base.py:151-172): decoupled decay, lerp first moment, bias-corrected step."""
+    b1, b2 = betas
+    bc1 = 1 - b1**step
+    bc2 = 1 - b2**step
+    for p, g, m, v in zip(params, grads, exp_avg, exp_avg_sq):
+        p.mul_(1 - lr * weight_decay)
+        m.lerp_(g, 1 - b1)
+        v.mul_(b2).addcmul_(g, g, value=1 - b2)
+        denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
+        p.addcdiv_(m, denom, value=-(lr / bc1))
+
+
+def ema_update(ema, params, decay: float, first: bool) -> None:
+    """AveragedModel.update_parameters with get_ema_multi_avg_fn(decay) (image.py:82-86,661-662):
+    first call copies, afterwards ema.lerp_(p, 1 - decay)."""
+    for e, p in zip(ema, params):
+        if first:
+            e.copy_(p)
+        else:
+            e.lerp_(p, 1 - decay)
+
+
+class ImageTrainer:
+    """`image.feed_data` + `image.optimize_parameters` (image.py:374-391,427-662) for the subset on
+    the benchmarked path: generator only, L1 pixel loss, AdamW, grad clip 1.0, EMA, accumulate=1."""
+
+    def __init__(self, forward_fn, params: "OrderedDict[str, torch.Tensor]", lr: float,
+                 betas=(0.9, 0.999), weight_decay: float = 0.01, eps: float = 1e-8,
+                 ema: float = 0.999, grad_clip: bool = True, loss_weight: float = 1.0) -> None:
+        self.forward_fn = forward_fn
+        self.P = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in params.items())
+        self.names = list(self.P)
+        self.m = [torch.zeros_like(v) for v in self.P.values()]
+        self.v = [torch.zeros_like(v) for v in self.P.values()]
+        self.ema = [v.detach().clone() for v in self.P.values()]
+        self.lr, self.betas, self.wd, self.eps = lr, betas, weight_decay, eps
+        self.ema_decay, self.grad_clip, self.loss_weight = ema, grad_clip, loss_weight
+        self.step = 0
+        self.log: dict[str, float] = {}
+        self.output = None
+
+    def feed_data(self, lq: torch.Tensor, gt: torch.Tensor) -> None:
+        self.lq, self.gt = lq, gt
+
+    def optimize_parameters(self) -> None:
+        out = self.forward_fn(self.P, self.lq)
+        l_pix = l1_loss(out, self.gt, self.loss_weight)
+        l_total = torch.zeros(1) + l_pix
+        grads = torch.autograd.grad(l_total.sum(), list(self.P.values()))
+        grads = [g.clone() for g in grads]
+        if self.grad_clip:
+            clip_grad_norm_(grads, 1.0)
+        self.step += 1
+        with torch.no_grad():
+            plist = list(self.P.values())
+            adamw_step(plist, grads, self.m, self.v, self.step, self.lr, self.betas, self.eps, self.wd)
+            if self.ema_decay > 0:
+                ema_update(self.ema, plist, self.ema_decay, first=self.step == 1)
+        self.output = out.detach()
+        self.log = {"l_g_pix": float(l_pix), "l_g_total": float(l_total)}
