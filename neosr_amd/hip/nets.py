@@ -95,7 +95,7 @@ class RRDBNetFunction(torch.autograd.Function):
             _C.require_device(p, "parameter")
         x = x.contiguous()
         B, cin, H, W = x.shape
-        training = bool(hp["training"]) and torch.is_grad_enabled()
+        training = bool(hp["training"]) and any(ctx.needs_input_grad)
         cfg = _C.RRDBNetCfg(B, H, W, cin, hp["num_out_ch"], hp["num_feat"], hp["num_block"],
                             hp["num_grow_ch"], int(training))
         nexp = lib.neosr_rrdbnet_num_params(C.byref(cfg))
@@ -148,7 +148,7 @@ class CompactFunction(torch.autograd.Function):
             _C.require_device(p, "parameter")
         x = x.contiguous()
         B, cin, H, W = x.shape
-        training = bool(hp["training"]) and torch.is_grad_enabled()
+        training = bool(hp["training"]) and any(ctx.needs_input_grad)
         cfg = _C.CompactCfg(B, H, W, cin, hp["num_out_ch"], hp["num_feat"], hp["num_conv"],
                             hp["upscale"], hp["act_type"], int(training))
         nexp = lib.neosr_compact_num_params(C.byref(cfg))
