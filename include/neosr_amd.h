@@ -99,6 +99,14 @@ typedef struct neosr_wgrad_desc {
 
 int64_t neosr_conv3x3_wgrad_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t K, int32_t N);
 int neosr_conv3x3_wgrad(const neosr_wgrad_desc* d, void* stream);
+/* Up to NEOSR_WGRAD_MAX convolutions that share (B, H, W, ups) in ONE launch — e.g. the five
+ * convs of a Residual Dense Block (esrgan_arch.py:109-116) — so every workgroup gets a long
+ * pixel strip and the chip is filled by a single resident round.  `workspace` (shared) must
+ * hold neosr_conv3x3_wgrad_multi_workspace_bytes(); the per-descriptor workspace field is unused. */
+#define NEOSR_WGRAD_MAX 8
+int64_t neosr_conv3x3_wgrad_multi_workspace_bytes(const neosr_wgrad_desc* descs, int32_t n);
+int neosr_conv3x3_wgrad_multi(const neosr_wgrad_desc* descs, int32_t n, float* workspace,
+                              void* stream);
 
 /* layout / index kernels ----------------------------------------------------------------- */
 /* (B,C,H,W) planar -> channels-last slice; replaces the implicit NCHW contract of every arch

@@ -151,6 +151,8 @@ SIGNATURES: dict[str, tuple] = {
     "neosr_conv3x3": (C.c_int, [C.POINTER(ConvDesc), _vp]),
     "neosr_conv3x3_wgrad_workspace_bytes": (_i64, [_i32, _i32, _i32, _i32, _i32]),
     "neosr_conv3x3_wgrad": (C.c_int, [C.POINTER(WgradDesc), _vp]),
+    "neosr_conv3x3_wgrad_multi_workspace_bytes": (_i64, [C.POINTER(WgradDesc), _i32]),
+    "neosr_conv3x3_wgrad_multi": (C.c_int, [C.POINTER(WgradDesc), _i32, _vp, _vp]),
     "neosr_nchw_to_nhwc": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "neosr_nhwc_to_nchw": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "neosr_pool2x2_sum": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),

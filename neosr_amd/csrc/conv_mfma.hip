@@ -285,176 +285,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs arg
   }
 }
 
-// ------------------------------------------------------------------------------------------
-// backward-weight
-// ------------------------------------------------------------------------------------------
-constexpr int WG_TILE = 9 * 32 * 32;  // one (cout32 x cin32 x 9 taps) partial tile, floats
-
-struct WgradArgs {
-  neosr_wgrad_desc d;
-  int rows_per_block;
-  int nsplit;
-  int nkt;  // number of 32-wide cin tiles
-};
-
-__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const WgradArgs args) {
-  const neosr_wgrad_desc& d = args.d;
-  __shared__ float red[WG_TILE];
-  __shared__ float bred[4 * 32];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int l31 = lane & 31, lh = lane >> 5;
-  const int s = blockIdx.x, kt = blockIdx.y, ntile = blockIdx.z;
-  const int H = d.H, W = d.W;
-  const int Hin = d.ups ? (H >> 1) : H, Win = d.ups ? (W >> 1) : W;
-  const int R = d.B * H;
-  const int row_lo = s * args.rows_per_block;
-  const int row_hi = min(R, row_lo + args.rows_per_block);
-
-  const int co = ntile * 32 + l31, ci = kt * 32 + l31;
-  const bool cook = co < d.N, ciok = ci < d.K;
-  const float mslope = (d.mask_slopes && cook) ? d.mask_slopes[co] : d.mask_slope;
-  const float islope = (d.in_prelu && ciok) ? d.in_prelu[ci] : 1.f;
-
-  f32x16 acc[9];
-#pragma unroll
-  for (int t = 0; t < 9; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-  float bsum = 0.f;
-
-  const int xsteps = (W + 1) >> 1;
-  const int nrows = (row_hi - row_lo - wave + 3) >> 2;  // rows row_lo+wave, +4, ...
-  const int nsteps = nrows > 0 ? nrows * xsteps : 0;
-
-  auto load_step = [&](int step, float& a, float (&bv)[9]) {
-    const int ri = step / xsteps;
-    const int x = ((step - ri * xsteps) << 1) + lh;
-    const int Rr = row_lo + wave + (ri << 2);
-    const int bimg = Rr / H, y = Rr - bimg * H;
-    const bool xok = x < W;
-    a = 0.f;
-    if (cook && xok) {
-      const int64_t p = (int64_t)Rr * W + x;
-      a = d.g[p * d.g_cs + co];
-      if (d.g_mask) {
-        const float m = d.g_mask[p * d.mask_cs + co];
-        a = m > 0.f ? a : a * mslope;
-      }
-    }
-#pragma unroll
-    for (int ty = 0; ty < 3; ++ty) {
-      const int yy = y + ty - 1;
-      const bool yok = yy >= 0 && yy < H;
-      const int sy = d.ups ? (yy >> 1) : yy;
-      const float* inrow = d.in + ((int64_t)bimg * Hin + sy) * Win * d.in_cs + ci;
-#pragma unroll
-      for (int tx = 0; tx < 3; ++tx) {
-        const int xx = x + tx - 1;
-        float v = 0.f;
-        if (yok && ciok && xx >= 0 && xx < W) {
-          const int sx = d.ups ? (xx >> 1) : xx;
-          v = inrow[(int64_t)sx * d.in_cs];
-          if (d.in_prelu) v = v > 0.f ? v : v * islope;
-        }
-        bv[ty * 3 + tx] = v;
-      }
-    }
-  };
-
-  float a_cur = 0.f, b_cur[9];
-  if (nsteps > 0) load_step(0, a_cur, b_cur);
-  for (int step = 0; step < nsteps; ++step) {
-    float a_nxt = 0.f, b_nxt[9];
-    if (step + 1 < nsteps) load_step(step + 1, a_nxt, b_nxt);
-    bsum += a_cur;
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b_cur[t], acc[t], 0, 0, 0);
-    a_cur = a_nxt;
-#pragma unroll
-    for (int t = 0; t < 9; ++t) b_cur[t] = b_nxt[t];
-  }
-
-  // fixed-order reduction of the 4 waves through LDS: tile[tap][co_i][ci_j]
-  for (int w = 0; w < 4; ++w) {
-    if (wave == w) {
-#pragma unroll
-      for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
-          float* p = red + t * 1024 + i * 32 + l31;
-          *p = (w == 0) ? acc[t][r] : (*p + acc[t][r]);
-        }
-    }
-    __syncthreads();
-  }
-  float* part = d.workspace +
-                ((int64_t)(ntile * args.nkt + kt) * args.nsplit + s) * WG_TILE;
-  for (int e = tid; e < WG_TILE; e += 256) part[e] = red[e];
-
-  if (d.db && kt == 0) {
-    bsum += __shfl_xor(bsum, 32, 64);
-    if (lh == 0) bred[wave * 32 + l31] = bsum;
-    __syncthreads();
-    if (tid < 32) {
-      const float v = ((bred[tid] + bred[32 + tid]) + bred[64 + tid]) + bred[96 + tid];
-      float* bpart = d.workspace + (int64_t)gridDim.z * args.nkt * args.nsplit * WG_TILE;
-      bpart[((int64_t)ntile * args.nsplit + s) * 32 + tid] = v;
-    }
-  }
-}
-
-// stage 2: sum partials over splits in index order, scatter into canonical (N,K,3,3)
-__global__ __launch_bounds__(256) void conv3x3_wgrad_reduce_kernel(const WgradArgs args,
-                                                                   int nnt) {
-  const neosr_wgrad_desc& d = args.d;
-  const int64_t total = (int64_t)nnt * args.nkt * WG_TILE;
-  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (e < total) {
-    const int tile = (int)(e / WG_TILE);
-    const int r = (int)(e - (int64_t)tile * WG_TILE);
-    const int tap = r >> 10, i = (r >> 5) & 31, j = r & 31;
-    const int ntile = tile / args.nkt, kt = tile - ntile * args.nkt;
-    const int co = ntile * 32 + i, ci = kt * 32 + j;
-    if (co < d.N && ci < d.K) {
-      const float* p = d.workspace + (int64_t)tile * args.nsplit * WG_TILE + r;
-      float sum = 0.f;
-      for (int s = 0; s < args.nsplit; ++s) sum += p[(int64_t)s * WG_TILE];
-      sum *= d.scale;
-      float* o = d.dw + ((int64_t)co * d.K + ci) * 9 + tap;
-      *o = d.accumulate ? (*o + sum) : sum;
-    }
-  }
-  if (d.db && blockIdx.x == 0) {
-    const float* bpart = d.workspace + total * args.nsplit;
-    for (int co = threadIdx.x; co < d.N; co += 256) {
-      const int ntile = co >> 5, i = co & 31;
-      float sum = 0.f;
-      for (int s = 0; s < args.nsplit; ++s) sum += bpart[((int64_t)ntile * args.nsplit + s) * 32 + i];
-      sum *= d.scale;
-      d.db[co] = d.accumulate ? (d.db[co] + sum) : sum;
-    }
-  }
-}
-
-void wgrad_geometry(int B, int H, int W, int K, int N, int& nnt, int& nkt, int& rows_per_block,
-                    int& nsplit) {
-  nnt = ceil_div(N, 32);
-  nkt = ceil_div(K, 32);
-  const int R = B * H;
-  int want = ceil_div(768, nnt * nkt);  // ~3 workgroups per CU over the whole launch
-  if (want < 1) want = 1;
-  rows_per_block = ceil_div(R, want);
-  rows_per_block = ceil_div(rows_per_block, 4) * 4;
-  // keep enough k-steps per wave to amortise the partial write-out
-  const int min_rows = (W >= 128) ? 4 : 8;
-  if (rows_per_block < min_rows) rows_per_block = min_rows;
-  nsplit = ceil_div(R, rows_per_block);
-}
-
 }  // namespace
 
 extern "C" int neosr_conv3x3(const neosr_conv_desc* dp, void* stream) {
@@ -496,36 +326,3 @@ extern "C" int neosr_conv3x3(const neosr_conv_desc* dp, void* stream) {
   return 0;
 }
 
-extern "C" int64_t neosr_conv3x3_wgrad_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t K,
-                                                       int32_t N) {
-  int nnt, nkt, rpb, nsplit;
-  wgrad_geometry(B, H, W, K, N, nnt, nkt, rpb, nsplit);
-  return ((int64_t)nnt * nkt * nsplit * WG_TILE + (int64_t)nnt * nsplit * 32) * 4;
-}
-
-extern "C" int neosr_conv3x3_wgrad(const neosr_wgrad_desc* dp, void* stream) {
-  const neosr_wgrad_desc& d = *dp;
-  NEOSR_CHECK(d.in && d.g && d.dw && d.workspace, "wgrad: null tensor");
-  NEOSR_CHECK(d.B > 0 && d.H > 0 && d.W > 0 && d.K > 0 && d.N > 0, "wgrad: bad geometry");
-  NEOSR_CHECK(!d.ups || ((d.H % 2 == 0) && (d.W % 2 == 0)), "wgrad: ups needs even H,W");
-  WgradArgs a;
-  a.d = d;
-  int nnt;
-  wgrad_geometry(d.B, d.H, d.W, d.K, d.N, nnt, a.nkt, a.rows_per_block, a.nsplit);
-  hipStream_t st = (hipStream_t)stream;
-  const bool prof = neosr_prof_on();
-  const double px = (double)d.B * d.H * d.W;
-  if (prof)  // algorithmic traffic: read |dy| + |x|, write |dW|
-    neosr_prof_begin(NEOSR_PROF_CONV_WGRAD, stream, 2.0 * px * d.K * d.N * 9.0,
-                     4.0 * (px * d.N + px / (d.ups ? 4.0 : 1.0) * d.K + 9.0 * d.K * d.N));
-  hipLaunchKernelGGL(conv3x3_wgrad_kernel, dim3(a.nsplit, a.nkt, nnt), dim3(256), 0, st, a);
-  if (prof) neosr_prof_end(stream);
-  NEOSR_LAUNCH_CHECK();
-  const int64_t total = (int64_t)nnt * a.nkt * WG_TILE;
-  if (prof) neosr_prof_begin(NEOSR_PROF_WGRAD_REDUCE, stream, 0.0, 0.0);
-  hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256),
-                     0, st, a, nnt);
-  if (prof) neosr_prof_end(stream);
-  NEOSR_LAUNCH_CHECK();
-  return 0;
-}

@@ -112,6 +112,16 @@ RrdbLayout rrdb_layout(const neosr_rrdbnet_cfg& c, void* ws) {
     w = max64(w, neosr_conv3x3_wgrad_workspace_bytes(B, H, W, L.Cin, F));
     for (int k = 0; k < 4; ++k) w = max64(w, neosr_conv3x3_wgrad_workspace_bytes(B, H, W, F + k * G, G));
     w = max64(w, neosr_conv3x3_wgrad_workspace_bytes(B, H, W, L.CC, F));
+    {  // the five convs of one RDB go in a single multi-conv launch
+      neosr_wgrad_desc wd[5];
+      for (int k = 0; k < 5; ++k) {
+        wd[k] = wgrad_base(B, H, W);
+        wd[k].in = wd[k].g = (const float*)16; wd[k].dw = (float*)16;
+        wd[k].K = (k < 4) ? F + k * G : L.CC;
+        wd[k].N = (k < 4) ? G : F;
+      }
+      w = max64(w, neosr_conv3x3_wgrad_multi_workspace_bytes(wd, 5));
+    }
     w = max64(w, neosr_conv3x3_wgrad_workspace_bytes(B, H, W, F, F));
     w = max64(w, neosr_conv3x3_wgrad_workspace_bytes(B, 2 * H, 2 * W, F, F));
     w = max64(w, neosr_conv3x3_wgrad_workspace_bytes(B, 4 * H, 4 * W, F, F));
@@ -318,14 +328,15 @@ extern "C" int neosr_rrdbnet_backward(const neosr_rrdbnet_cfg* c, const float* c
     for (int r = 2; r >= 0; --r) {
       const float* A = L.act[3 * n + r];
       float* GB = L.gb[gbi];
+      neosr_wgrad_desc wd[5];
       const float* dO = (r == 2) ? dOut : prev;
       const int dO_cs = (r == 2) ? dOut_cs : CC;
       {  // conv5: x5*0.2 + x  (and RRDB-level *0.2 + x for r==2)
         neosr_wgrad_desc w = wgrad_base(B, H, W);
         w.in = A; w.in_cs = CC; w.K = CC; w.g = dO; w.g_cs = dO_cs; w.N = F;
         w.scale = (r == 2) ? 0.04f : 0.2f;
-        w.dw = Gp[p_rdb(n, r, 4)]; w.db = Gp[p_rdb(n, r, 4) + 1]; w.workspace = L.wg_ws;
-        RUN(neosr_conv3x3_wgrad(&w, st));
+        w.dw = Gp[p_rdb(n, r, 4)]; w.db = Gp[p_rdb(n, r, 4) + 1];
+        wd[4] = w;
         neosr_conv_desc d = conv_base(B, H, W);
         d.mode = NEOSR_CONV_DGRAD;
         d.in = dO; d.in_cs = dO_cs; d.K = F;
@@ -341,8 +352,8 @@ extern "C" int neosr_rrdbnet_backward(const neosr_rrdbnet_cfg* c, const float* c
         neosr_wgrad_desc w = wgrad_base(B, H, W);
         w.in = A; w.in_cs = CC; w.K = Kin; w.g = GB + Kin; w.g_cs = CC; w.N = G;
         w.g_mask = A + Kin; w.mask_cs = CC; w.mask_slope = 0.2f;
-        w.dw = Gp[p_rdb(n, r, k)]; w.db = Gp[p_rdb(n, r, k) + 1]; w.workspace = L.wg_ws;
-        RUN(neosr_conv3x3_wgrad(&w, st));
+        w.dw = Gp[p_rdb(n, r, k)]; w.db = Gp[p_rdb(n, r, k) + 1];
+        wd[k] = w;
         neosr_conv_desc d = conv_base(B, H, W);
         d.mode = NEOSR_CONV_DGRAD;
         d.in = GB + Kin; d.in_cs = CC; d.K = G;
@@ -351,6 +362,8 @@ extern "C" int neosr_rrdbnet_backward(const neosr_rrdbnet_cfg* c, const float* c
         d.out = GB; d.out_cs = CC; d.N = Kin; d.accumulate = 1;
         RUN(neosr_conv3x3(&d, st));
       }
+      // all five weight gradients of this RDB in one launch (g slices are final, A untouched)
+      RUN(neosr_conv3x3_wgrad_multi(wd, 5, L.wg_ws, st));
       prev = GB;
       gbi = (gbi + 1) & 3;
     }

@@ -1,0 +1,355 @@
+// wgrad.hip — backward-weight of the 3x3/s1/p1 convolution for gfx950, one launch for up to
+// 8 convolutions that share the same pixel grid (all 5 convs of a Residual Dense Block).
+//
+// GEMM view per (conv, cout-tile of 32, cin-tile of 32):  D[co][ci](tap) += G[p][co] * X[p+tap][ci]
+//   M = 32 cout, N = 32 cin, 9 accumulators (one per tap), K = pixels, on
+//   v_mfma_f32_32x32x2_f32 (exact fp32).
+// A workgroup (4 waves) walks a strip of 4x32-pixel tiles.  Per tile the gradient tile
+// G[128 px][32 co] and the input halo tile X[6x34 px][32 ci] are staged through LDS (lanes run
+// along channels -> conflict-free ds_read_b32, no address VALU in the MFMA loop) while the next
+// tile's global loads are already in flight in registers.  Wave w owns row w of every tile; the
+// four waves' accumulators are summed through LDS in a fixed order and each workgroup writes one
+// partial; a second kernel sums the partials over the pixel splits, again in a fixed order
+// (no float atomics => run-to-run deterministic), applies `scale` and scatters into the canonical
+// (Cout, Cin, 3, 3) layout.
+//
+// Reference call sites replaced: autograd's convolution_backward (weight/bias part) for
+// neosr/archs/esrgan_arch.py:109-116,196-214 and neosr/archs/compact_arch.py:76-79.
+#include "common.h"
+#include "prof.h"
+#include <string.h>
+#include "../../include/neosr_amd.h"
+
+namespace {
+
+constexpr int TH = 4, TW = 32;
+constexpr int HALO_W = TW + 2, HALO_H = TH + 2;
+constexpr int G_PIX = TH * TW;            // 128
+constexpr int X_PIX = HALO_H * HALO_W;    // 204
+constexpr int G_F4 = G_PIX * 8 / 256;     // 4 float4 per thread
+constexpr int X_F4 = (X_PIX * 8 + 255) / 256;  // 7 float4 per thread
+constexpr int G_LDS = G_PIX * 32;         // floats
+constexpr int X_LDS = X_PIX * 32;
+constexpr int WG_TILE = 9 * 32 * 32;      // partial tile, floats
+constexpr int MAXD = NEOSR_WGRAD_MAX;
+
+struct WgradMultiArgs {
+  neosr_wgrad_desc d[MAXD];
+  int pair_start[MAXD + 1];  // prefix sums of (nnt*nkt) per desc
+  int nkt[MAXD];
+  int vec_in[MAXD], vec_g[MAXD], vec_m[MAXD];
+  int ndesc;
+  int B, H, W, ups;
+  int tiles_x, tiles_y, ntiles, tiles_per_split, nsplit;
+  float* part;    // [pair][split][WG_TILE]
+  float* bpart;   // [desc-cout-tile][split][32]
+  int btile_start[MAXD + 1];  // prefix sums of nnt per desc
+};
+
+__device__ __forceinline__ float4 ld4(const float* p, bool vec, int c, int C) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c >= C) return v;
+  if (vec && c + 3 < C) return *reinterpret_cast<const float4*>(p);
+  v.x = p[0];
+  if (c + 1 < C) v.y = p[1];
+  if (c + 2 < C) v.z = p[2];
+  if (c + 3 < C) v.w = p[3];
+  return v;
+}
+
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_multi_kernel(const WgradMultiArgs args) {
+  __shared__ __attribute__((aligned(16))) float lds[G_LDS + X_LDS];  // 42.5 KB (>= WG_TILE)
+  __shared__ float bred[4 * 32];
+  float* lg = lds;
+  float* lx = lds + G_LDS;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  // which conv / tile pair does this workgroup own?
+  const int pair = blockIdx.x;
+  int di = 0;
+#pragma unroll
+  for (int i = 1; i < MAXD; ++i)
+    if (i < args.ndesc && pair >= args.pair_start[i]) di = i;
+  const neosr_wgrad_desc& d = args.d[di];
+  const int local = pair - args.pair_start[di];
+  const int nkt = args.nkt[di];
+  const int ntile = local / nkt, kt = local - ntile * nkt;
+  const int co0 = ntile * 32, ci0 = kt * 32;
+  const bool vec_in = args.vec_in[di], vec_g = args.vec_g[di], vec_m = args.vec_m[di];
+
+  const int s = blockIdx.y;
+  const int t_lo = s * args.tiles_per_split;
+  const int t_hi = min(args.ntiles, t_lo + args.tiles_per_split);
+
+  const int H = args.H, W = args.W;
+  const int Hin = args.ups ? (H >> 1) : H, Win = args.ups ? (W >> 1) : W;
+
+  // staging slots: (pixel, 4-channel quad) per thread
+  const int q4 = (tid & 7) << 2;  // channel quad within the 32-wide tile
+  float4 rg[G_F4], rm[G_F4], rx[X_F4];
+
+  auto gload = [&](int t) {
+    const int txi = t % args.tiles_x;
+    const int r = t / args.tiles_x;
+    const int tyi = r % args.tiles_y;
+    const int b = r / args.tiles_y;
+    const int x0 = txi * TW, y0 = tyi * TH;
+#pragma unroll
+    for (int i = 0; i < G_F4; ++i) {
+      const int pix = (tid >> 3) + i * 32;  // 0..127
+      const int py = pix >> 5, px = pix & 31;
+      const int gy = y0 + py, gx = x0 + px;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f), m = make_float4(1.f, 1.f, 1.f, 1.f);
+      if (gy < H && gx < W) {
+        const int64_t p = ((int64_t)b * H + gy) * W + gx;
+        v = ld4(d.g + p * d.g_cs + co0 + q4, vec_g, co0 + q4, d.N);
+        if (d.g_mask) m = ld4(d.g_mask + p * d.mask_cs + co0 + q4, vec_m, co0 + q4, d.N);
+      }
+      rg[i] = v;
+      rm[i] = m;
+    }
+#pragma unroll
+    for (int i = 0; i < X_F4; ++i) {
+      const int idx = tid + i * 256;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idx < X_PIX * 8) {
+        const int pix = idx >> 3;
+        const int py = pix / HALO_W, px = pix - py * HALO_W;
+        const int gy = y0 + py - 1, gx = x0 + px - 1;
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+          const int sy = args.ups ? (gy >> 1) : gy, sx = args.ups ? (gx >> 1) : gx;
+          const int64_t p = ((int64_t)b * Hin + sy) * Win + sx;
+          v = ld4(d.in + p * d.in_cs + ci0 + q4, vec_in, ci0 + q4, d.K);
+        }
+      }
+      rx[i] = v;
+    }
+  };
+
+  // per-channel slopes of this thread's quad (mask derivative / PReLU on load)
+  float ms[4] = {d.mask_slope, d.mask_slope, d.mask_slope, d.mask_slope};
+  float ps[4] = {1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (d.mask_slopes && co0 + q4 + j < d.N) ms[j] = d.mask_slopes[co0 + q4 + j];
+    if (d.in_prelu && ci0 + q4 + j < d.K) ps[j] = d.in_prelu[ci0 + q4 + j];
+  }
+
+  auto sstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < G_F4; ++i) {
+      float4 v = rg[i];
+      if (d.g_mask) {
+        const float4 m = rm[i];
+        v.x = m.x > 0.f ? v.x : v.x * ms[0];
+        v.y = m.y > 0.f ? v.y : v.y * ms[1];
+        v.z = m.z > 0.f ? v.z : v.z * ms[2];
+        v.w = m.w > 0.f ? v.w : v.w * ms[3];
+      }
+      const int pix = (tid >> 3) + i * 32;
+      *reinterpret_cast<float4*>(lg + pix * 32 + q4) = v;
+    }
+#pragma unroll
+    for (int i = 0; i < X_F4; ++i) {
+      const int idx = tid + i * 256;
+      if (idx < X_PIX * 8) {
+        float4 v = rx[i];
+        if (d.in_prelu) {
+          v.x = v.x > 0.f ? v.x : v.x * ps[0];
+          v.y = v.y > 0.f ? v.y : v.y * ps[1];
+          v.z = v.z > 0.f ? v.z : v.z * ps[2];
+          v.w = v.w > 0.f ? v.w : v.w * ps[3];
+        }
+        *reinterpret_cast<float4*>(lx + (idx >> 3) * 32 + q4) = v;
+      }
+    }
+  };
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  float bsum = 0.f;
+
+  if (t_lo < t_hi) gload(t_lo);
+  for (int t = t_lo; t < t_hi; ++t) {
+    __syncthreads();
+    sstore();
+    __syncthreads();
+    if (t + 1 < t_hi) gload(t + 1);
+    // wave `wave` owns row `wave` of the tile: 16 k-steps of 2 pixels
+    const float* ga = lg + (wave * TW + lh) * 32 + l31;
+    const float* xb = lx + (wave * HALO_W + lh) * 32 + l31;
+#pragma unroll 4
+    for (int ks = 0; ks < TW / 2; ++ks) {
+      const float a = ga[ks * 64];
+      bsum += a;
+#pragma unroll
+      for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx) {
+          const float bv = xb[(ty * HALO_W + ks * 2 + tx) * 32];
+          acc[ty * 3 + tx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[ty * 3 + tx], 0, 0, 0);
+        }
+    }
+  }
+
+  // fixed-order reduction of the 4 waves through LDS: tile[tap][co_i][ci_j]
+  __syncthreads();
+  float* red = lds;
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
+          float* p = red + t * 1024 + i * 32 + l31;
+          *p = (w == 0) ? acc[t][r] : (*p + acc[t][r]);
+        }
+    }
+    __syncthreads();
+  }
+  float* part = args.part + ((int64_t)pair * args.nsplit + s) * WG_TILE;
+  for (int e = tid * 4; e < WG_TILE; e += 1024)
+    *reinterpret_cast<float4*>(part + e) = *reinterpret_cast<const float4*>(red + e);
+
+  if (d.db && kt == 0) {
+    bsum += __shfl_xor(bsum, 32, 64);
+    if (lh == 0) bred[wave * 32 + l31] = bsum;
+    __syncthreads();
+    if (tid < 32) {
+      const float v = ((bred[tid] + bred[32 + tid]) + bred[64 + tid]) + bred[96 + tid];
+      args.bpart[((int64_t)(args.btile_start[di] + ntile) * args.nsplit + s) * 32 + tid] = v;
+    }
+  }
+}
+
+// stage 2: sum partials over splits in index order, scatter into canonical (N,K,3,3)
+__global__ __launch_bounds__(256) void conv3x3_wgrad_reduce_kernel(const WgradMultiArgs args) {
+  const int pair = blockIdx.y;
+  int di = 0;
+#pragma unroll
+  for (int i = 1; i < MAXD; ++i)
+    if (i < args.ndesc && pair >= args.pair_start[i]) di = i;
+  const neosr_wgrad_desc& d = args.d[di];
+  const int local = pair - args.pair_start[di];
+  const int nkt = args.nkt[di];
+  const int ntile = local / nkt, kt = local - ntile * nkt;
+  const int r = blockIdx.x * 256 + threadIdx.x;  // < WG_TILE
+  const int tap = r >> 10, i = (r >> 5) & 31, j = r & 31;
+  const int co = ntile * 32 + i, ci = kt * 32 + j;
+  if (co < d.N && ci < d.K) {
+    const float* p = args.part + (int64_t)pair * args.nsplit * WG_TILE + r;
+    float sum = 0.f;
+    for (int s = 0; s < args.nsplit; ++s) sum += p[(int64_t)s * WG_TILE];
+    sum *= d.scale;
+    float* o = d.dw + ((int64_t)co * d.K + ci) * 9 + tap;
+    *o = d.accumulate ? (*o + sum) : sum;
+  }
+  if (d.db && kt == 0 && blockIdx.x == 0 && threadIdx.x < 32) {
+    const int cb = ntile * 32 + threadIdx.x;
+    if (cb < d.N) {
+      const float* bp = args.bpart + (int64_t)(args.btile_start[di] + ntile) * args.nsplit * 32 + threadIdx.x;
+      float sum = 0.f;
+      for (int s = 0; s < args.nsplit; ++s) sum += bp[(int64_t)s * 32];
+      sum *= d.scale;
+      d.db[cb] = d.accumulate ? (d.db[cb] + sum) : sum;
+    }
+  }
+}
+
+int plan(const neosr_wgrad_desc* ds, int n, WgradMultiArgs& a) {
+  NEOSR_CHECK(ds && n >= 1 && n <= MAXD, "wgrad: need 1..%d descriptors", MAXD);
+  a.ndesc = n;
+  a.B = ds[0].B; a.H = ds[0].H; a.W = ds[0].W; a.ups = ds[0].ups;
+  NEOSR_CHECK(a.B > 0 && a.H > 0 && a.W > 0, "wgrad: bad geometry");
+  NEOSR_CHECK(!a.ups || ((a.H % 2 == 0) && (a.W % 2 == 0)), "wgrad: ups needs even H,W");
+  int pairs = 0, btiles = 0;
+  for (int i = 0; i < n; ++i) {
+    const neosr_wgrad_desc& d = ds[i];
+    NEOSR_CHECK(d.B == a.B && d.H == a.H && d.W == a.W && d.ups == a.ups,
+                "wgrad: descriptors of one launch must share B,H,W,ups");
+    NEOSR_CHECK(d.in && d.g && d.dw && d.K > 0 && d.N > 0, "wgrad: null tensor / bad K,N");
+    a.d[i] = d;
+    a.pair_start[i] = pairs;
+    a.btile_start[i] = btiles;
+    a.nkt[i] = ceil_div(d.K, 32);
+    pairs += ceil_div(d.N, 32) * a.nkt[i];
+    btiles += ceil_div(d.N, 32);
+    a.vec_in[i] = (d.in_cs % 4 == 0) && ((uintptr_t)d.in % 16 == 0);
+    a.vec_g[i] = (d.g_cs % 4 == 0) && ((uintptr_t)d.g % 16 == 0);
+    a.vec_m[i] = d.g_mask && (d.mask_cs % 4 == 0) && ((uintptr_t)d.g_mask % 16 == 0);
+  }
+  for (int i = n; i <= MAXD; ++i) { a.pair_start[i] = pairs; a.btile_start[i] = btiles; }
+  a.tiles_x = ceil_div(a.W, TW);
+  a.tiles_y = ceil_div(a.H, TH);
+  a.ntiles = a.tiles_x * a.tiles_y * a.B;
+  // one resident round of workgroups (2 per CU on 256 CUs)
+  int nsplit = 512 / pairs;
+  if (nsplit < 1) nsplit = 1;
+  if (nsplit > a.ntiles) nsplit = a.ntiles;
+  a.tiles_per_split = ceil_div(a.ntiles, nsplit);
+  a.nsplit = ceil_div(a.ntiles, a.tiles_per_split);
+  return 0;
+}
+
+int64_t ws_floats(const WgradMultiArgs& a) {
+  return (int64_t)a.pair_start[MAXD] * a.nsplit * WG_TILE + (int64_t)a.btile_start[MAXD] * a.nsplit * 32 + 64;
+}
+
+}  // namespace
+
+extern "C" int64_t neosr_conv3x3_wgrad_multi_workspace_bytes(const neosr_wgrad_desc* ds, int32_t n) {
+  WgradMultiArgs a;
+  if (plan(ds, n, a)) return -1;
+  return ws_floats(a) * 4;
+}
+
+extern "C" int neosr_conv3x3_wgrad_multi(const neosr_wgrad_desc* ds, int32_t n, float* workspace,
+                                         void* stream) {
+  WgradMultiArgs a;
+  if (int rc = plan(ds, n, a)) return rc;
+  NEOSR_CHECK(workspace && (uintptr_t)workspace % 16 == 0, "wgrad: workspace missing/unaligned");
+  a.part = workspace;
+  a.bpart = workspace + (int64_t)a.pair_start[MAXD] * a.nsplit * WG_TILE;
+  hipStream_t st = (hipStream_t)stream;
+  const bool prof = neosr_prof_on();
+  if (prof) {
+    double fl = 0, by = 0;
+    const double px = (double)a.B * a.H * a.W;
+    for (int i = 0; i < n; ++i) {
+      fl += 2.0 * px * ds[i].K * ds[i].N * 9.0;
+      by += 4.0 * (px * ds[i].N + px / (a.ups ? 4.0 : 1.0) * ds[i].K + 9.0 * ds[i].K * ds[i].N);
+    }
+    neosr_prof_begin(NEOSR_PROF_CONV_WGRAD, stream, fl, by);
+  }
+  hipLaunchKernelGGL(conv3x3_wgrad_multi_kernel, dim3(a.pair_start[MAXD], a.nsplit), dim3(256), 0,
+                     st, a);
+  if (prof) neosr_prof_end(stream);
+  NEOSR_LAUNCH_CHECK();
+  if (prof) neosr_prof_begin(NEOSR_PROF_WGRAD_REDUCE, stream, 0.0, 0.0);
+  hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3(WG_TILE / 256, a.pair_start[MAXD]),
+                     dim3(256), 0, st, a);
+  if (prof) neosr_prof_end(stream);
+  NEOSR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int64_t neosr_conv3x3_wgrad_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t K,
+                                                       int32_t N) {
+  neosr_wgrad_desc d;
+  memset(&d, 0, sizeof(d));
+  d.B = B; d.H = H; d.W = W; d.K = K; d.N = N;
+  d.in = d.g = (const float*)16; d.dw = (float*)16;  // geometry query only
+  return neosr_conv3x3_wgrad_multi_workspace_bytes(&d, 1);
+}
+
+extern "C" int neosr_conv3x3_wgrad(const neosr_wgrad_desc* dp, void* stream) {
+  NEOSR_CHECK(dp && dp->workspace, "wgrad: null descriptor/workspace");
+  return neosr_conv3x3_wgrad_multi(dp, 1, dp->workspace, stream);
+}
