@@ -73,6 +73,9 @@ typedef struct neosr_conv_desc {
 } neosr_conv_desc;
 
 int neosr_conv3x3(const neosr_conv_desc* d, void* stream);
+/* Debug aid: device buffer (4 x 64 uint64) that NEOSR_TIMELINE builds of the conv kernel fill with
+ * per-wave clock stamps of workgroup 0; NULL (default) disables.  No effect in normal builds. */
+int neosr_debug_set_timeline(void* dev_buf);
 
 /*
  * Weight/bias gradient of the same convolution (autograd's convolution_backward, weight part):

@@ -149,6 +149,7 @@ SIGNATURES: dict[str, tuple] = {
     "neosr_build_info": (C.c_char_p, []),
     "neosr_abi_version": (C.c_int, []),
     "neosr_conv3x3": (C.c_int, [C.POINTER(ConvDesc), _vp]),
+    "neosr_debug_set_timeline": (C.c_int, [_vp]),
     "neosr_conv3x3_wgrad_workspace_bytes": (_i64, [_i32, _i32, _i32, _i32, _i32]),
     "neosr_conv3x3_wgrad": (C.c_int, [C.POINTER(WgradDesc), _vp]),
     "neosr_conv3x3_wgrad_multi_workspace_bytes": (_i64, [C.POINTER(WgradDesc), _i32]),

@@ -2,7 +2,7 @@
 # Builds libneosr_amd.so for gfx950 (MI355X) in-tree.  hipcc cross-compiles without a GPU.
 set -e
 HERE="$(cd "$(dirname "$0")" && pwd)"
-OUT="$HERE/../lib"
+OUT="${NEOSR_AMD_OUT:-$HERE/../lib}"
 mkdir -p "$OUT"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"

@@ -1,0 +1,46 @@
+#!/usr/bin/env python
+"""Dump the per-wave phase timeline of workgroup 0 of the conv kernel (needs a NEOSR_TIMELINE build:
+`bash neosr_amd/csrc/build.sh -DNEOSR_TIMELINE` into a separate lib via NEOSR_AMD_OUT)."""
+from __future__ import annotations
+
+import sys
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+from neosr_amd import _C  # noqa: E402
+from neosr_amd.hip import ops  # noqa: E402
+
+
+def run(name, H, W, K, N, CC, B=16, dgrad=False):
+    lib = _C.load()
+    x = torch.randn(B, H, W, CC, device="cuda")
+    w = torch.randn(N, K, 3, 3, device="cuda") * 0.05
+    out = torch.empty(B, H, W, N, device="cuda")
+    tl = torch.zeros(4 * 64, dtype=torch.int64, device="cuda")
+    for _ in range(3):
+        ops.conv3x3(x, w, None, out=out, k_in=K)
+    torch.cuda.synchronize()
+    lib.neosr_debug_set_timeline(tl.data_ptr())
+    ops.conv3x3(x, w, None, out=out, k_in=K)
+    torch.cuda.synchronize()
+    lib.neosr_debug_set_timeline(None)
+    t = tl.cpu().view(4, 64)
+    nchunks = (K + 15) // 16
+    print(f"== {name}: K={K} N={N} chunks={nchunks}  (cycles relative to wave start; s_memtime ticks)")
+    for wv in range(4):
+        r = t[wv]
+        base = int(r[0])
+        row = [f"gl0={int(r[1]) - base}"]
+        for c in range(nchunks):
+            b1, b2, gl, cp = (int(r[2 + 4 * c + j]) - base for j in range(4))
+            row.append(f"[c{c} bar1@{b1} sst+bar2@{b2} gload@{gl} comp_end@{cp} (comp {cp - gl})]")
+        row.append(f"epi@{int(r[62]) - base} end@{int(r[63]) - base}")
+        print(f" wave{wv}: " + " ".join(row))
+
+
+if __name__ == "__main__":
+    run("rdb.conv1", 64, 64, 64, 32, 192)
+    run("rdb.conv5", 64, 64, 192, 64, 192)
+    run("conv_hr@256", 256, 256, 64, 64, 64)
