@@ -61,6 +61,27 @@ def make_opt(batch: int, world: int, rank: int, arch: str) -> dict:
     }
 
 
+def pmc_traffic(kernel_class: str) -> dict | None:
+    """HBM traffic per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (tools/profile_round.sh -> profiles/*_pmc_summary.json; bench.py cannot drive rocprofv3 on
+    itself).  FETCH_SIZE is doubled as MI355X_MICROARCH.md §HBM prescribes for gfx950 (it counts
+    128-B requests at 64 B); both counters are in KiB."""
+    files = sorted((ROOT / "profiles").glob("r*_bench_pmc_summary.json"))
+    if not files:
+        return None
+    summ = json.loads(files[-1].read_text())
+    want = {"conv3x3_mfma_kernel<fwd>": "conv3x3_mfma_kernel<false, false, false>",
+            "conv3x3_mfma_kernel<dgrad>": "conv3x3_mfma_kernel<true, true, false>",
+            "conv3x3_wgrad_kernel": "conv3x3_wgrad_multi_kernel"}[kernel_class]
+    for name, d in summ.items():
+        if want in name and "FETCH_SIZE_per_dispatch" in d:
+            rd = 2.0 * d["FETCH_SIZE_per_dispatch"] * 1024
+            wr = d.get("WRITE_SIZE_per_dispatch", 0.0) * 1024
+            return {"bytes_per_launch": round(rd + wr), "read": round(rd), "write": round(wr),
+                    "source": files[-1].name, "kernel": want}
+    return None
+
+
 def cpu_baseline(arch: str, budget_s: float) -> dict:
     """Time the CPU oracle on a bounded sample of the same workload (B=1 batches of the same shapes)."""
     from oracle import neosr_oracle as orc
@@ -73,7 +94,7 @@ def cpu_baseline(arch: str, budget_s: float) -> dict:
     fwd = (lambda P, x: orc.compact_forward(P, x, 4, "prelu")) if arch == "compact" else (
         lambda P, x: orc.rrdbnet_forward(P, x, 4))
     tr = orc.ImageTrainer(fwd, params, lr=1e-4, betas=(0.9, 0.99), weight_decay=0.0, ema=0.999)
-    b = 1
+    b = 2
     lq, gt = torch.rand(b, 3, 64, 64), torch.rand(b, 3, 256, 256)
     tr.feed_data(lq, gt)
     tr.optimize_parameters()  # warm-up
@@ -83,7 +104,7 @@ def cpu_baseline(arch: str, budget_s: float) -> dict:
         tr.optimize_parameters()
         n += 1
         el = time.perf_counter() - t0
-        if el > budget_s or n >= 8:
+        if el > budget_s or n >= 6:
             break
     return {"value": round(n * b / el, 4), "unit": "LR-patches/s", "cores": torch.get_num_threads(),
             "kind": "port",
@@ -184,9 +205,12 @@ def main() -> None:
         ach = fl[dom] / (ms[dom] * 1e9) if ms[dom] > 0 else 0.0
         allms = sum(ms[i] for i in range(3))
         allfl = sum(fl[i] for i in range(3))
+        tr = pmc_traffic(names[dom]) if args.arch == "esrgan" and B == 16 else None
         roofline = {"bound": "mfma", "kernel": names[dom], "achieved": round(ach, 2),
                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+                    "traffic": tr["bytes_per_launch"] if tr else None, "traffic_detail": tr,
+                    "algo_bytes_per_launch": round(by[dom] / max(1, ln[dom])),
                     "avg_launch_us": round(1e3 * ms[dom] / max(1, ln[dom]), 2),
                     "all_conv_tflops": round(allfl / (allms * 1e9), 2) if allms > 0 else None,
                     "hbm_algo_frac_of_8TBps": round((by[dom] / (ms[dom] * 1e6)) / PEAK_HBM_GBS, 4) if ms[dom] > 0 else None,
