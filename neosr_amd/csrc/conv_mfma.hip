@@ -20,6 +20,9 @@
 #include "prof.h"
 #include "../../include/neosr_amd.h"
 
+#ifndef NEOSR_INTERLEAVE
+#define NEOSR_INTERLEAVE 1  // spread the next chunk's global loads over the taps of the current one
+#endif
 #ifndef NEOSR_CONV_WPS
 #define NEOSR_CONV_WPS 2  // waves per SIMD the register allocator must leave room for
 #endif
@@ -58,12 +61,18 @@ struct ConvArgs {
 #define TL_MARK(slot) do {} while (0)
 #endif
 
-template <bool DGRAD, int NTV>
+template <bool DGRAD, int NTV, class Hook>
 __device__ __forceinline__ void compute_chunk(const float* __restrict__ lin,
                                               const float* __restrict__ lw, int wave, int l31,
-                                              int lh, f32x16 (&acc)[NT]) {
+                                              int lh, f32x16 (&acc)[NT], Hook&& hook) {
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap) {
+    // per-tap hook: issues a slice of the next chunk's global loads so that the 13 loads of a
+    // chunk are spread over the 72..144 MFMAs instead of hitting the memory pipe as one burst
+    hook(tap);
+#if NEOSR_INTERLEAVE
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     const int ty = tap / 3, tx = tap % 3;
     const float* ap = lin + ((wave + ty) * HALO_W + l31 + tx) * INS + lh;
 #pragma unroll
@@ -76,7 +85,10 @@ __device__ __forceinline__ void compute_chunk(const float* __restrict__ lin,
           b = lw[(ks * 2 + lh) * WROW_D + (nt * 32 + l31) * 9 + (8 - tap)];
         else
           b = lw[(nt * 32 + l31) * WROW_F + (ks * 2 + lh) * 9 + tap];
-        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[nt], 0, 0, 0);
+        // D = W * X^T: rows i = output channel, cols j = pixel.  Each lane then holds, for ITS
+        // pixel (lane&31), four runs of 4 consecutive channels -> dwordx4 epilogue stores
+        // (dword-per-lane stores are issue-bound at ~7 B/clk/CU on gfx950).
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(b, a, acc[nt], 0, 0, 0);
       }
     }
   }
@@ -87,7 +99,7 @@ __device__ __forceinline__ void compute_chunk(const float* __restrict__ lin,
 // epilogue is straight-line code: a select on the DATA side makes hipcc wait for the load right
 // where it was issued, which serialises the prefetch (measured: 1.6-5.6k cycles per chunk).
 __device__ __attribute__((aligned(256))) float g_zero_page[64];
-__device__ __attribute__((aligned(256))) float g_trash[256];
+__device__ __attribute__((aligned(256))) float g_trash[1024];  // 16 B per thread of a workgroup
 
 // generic guarded 4-channel load (any alignment, ragged channel count)
 __device__ __forceinline__ float4 ld4_generic(const float* p, int c, int C, float fill) {
@@ -98,6 +110,10 @@ __device__ __forceinline__ float4 ld4_generic(const float* p, int c, int C, floa
   if (c + 3 < C) v.w = p[3];
   return v;
 }
+
+// staging loads are issued early in the chunk so they have >= 3 taps of MFMAs to land:
+// input quads i (0..3) in pieces 0,0,1,1; weight quads rr (0..8) in pieces 1,2,2,3,3,4,4,5,5
+__device__ __forceinline__ constexpr int w_piece(int rr) { return 1 + ((rr + 1) >> 1); }
 
 // FAST path preconditions (checked on the host): in/mask/w 16-byte aligned, in_cs, mask_cs, K,
 // w_cin, N multiples of 4, no PReLU-on-load, no per-channel mask slopes.
@@ -160,10 +176,12 @@ __global__ __launch_bounds__(256, GENERIC ? 2 : NEOSR_CONV_WPS) void conv3x3_mfm
   float4 rmk[(MASK || GENERIC) ? IN_F4 : 1];
   float4 rw[W_F4];
 
-  auto gload = [&](int c0) {
+  // piece p (0..8) of the staging loads of the chunk starting at channel c0; p < 0 = all pieces
+  auto gload = [&](int c0, int piece) {
     const int c = c0 + q4;
 #pragma unroll
     for (int i = 0; i < IN_F4; ++i) {
+      if (piece >= 0 && piece != (i >> 1)) continue;
       const bool ok = in_off[i] >= 0 && c < K;
       if (!GENERIC) {
         rin[i] = *reinterpret_cast<const float4*>(ok ? inb + in_off[i] + c0 : g_zero_page);
@@ -181,6 +199,7 @@ __global__ __launch_bounds__(256, GENERIC ? 2 : NEOSR_CONV_WPS) void conv3x3_mfm
       const int rlim = ckv * 9;  // valid floats in this row
 #pragma unroll
       for (int rr = 0; rr < W_F4; ++rr) {
+        if (piece >= 0 && piece != w_piece(rr)) continue;
         const int r = (w_q + W_QSTEP * rr) * 4;
         const bool ok = n < nvalid && r < rlim;
         if (!GENERIC)
@@ -194,6 +213,7 @@ __global__ __launch_bounds__(256, GENERIC ? 2 : NEOSR_CONV_WPS) void conv3x3_mfm
       const int rlim = nvalid * 9;
 #pragma unroll
       for (int rr = 0; rr < W_F4; ++rr) {
+        if (piece >= 0 && piece != w_piece(rr)) continue;
         const int r = (w_q + W_QSTEP * rr) * 4;
         const bool ok = k < ckv && r < rlim;
         if (!GENERIC)
@@ -255,7 +275,7 @@ __global__ __launch_bounds__(256, GENERIC ? 2 : NEOSR_CONV_WPS) void conv3x3_mfm
     for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
 
   const int nchunks = (K + CK - 1) / CK;
-  gload(0);
+  gload(0, -1);
   TL_MARK(1);
   for (int c = 0; c < nchunks; ++c) {
     __syncthreads();
@@ -263,73 +283,114 @@ __global__ __launch_bounds__(256, GENERIC ? 2 : NEOSR_CONV_WPS) void conv3x3_mfm
     sstore(c * CK);
     __syncthreads();
     TL_MARK(3 + c * 4);
-    if (c + 1 < nchunks) gload((c + 1) * CK);
+    const int cn = (c + 1) * CK;
+#if NEOSR_INTERLEAVE
     TL_MARK(4 + c * 4);
-    if (ntv == 2)
-      compute_chunk<DGRAD, 2>(lin, lw, wave, l31, lh, acc);
-    else
-      compute_chunk<DGRAD, 1>(lin, lw, wave, l31, lh, acc);
+    if (c + 1 < nchunks) {
+      auto hook = [&](int tap) { gload(cn, tap); };
+      if (ntv == 2) compute_chunk<DGRAD, 2>(lin, lw, wave, l31, lh, acc, hook);
+      else compute_chunk<DGRAD, 1>(lin, lw, wave, l31, lh, acc, hook);
+    } else {
+      auto hook = [](int) {};
+      if (ntv == 2) compute_chunk<DGRAD, 2>(lin, lw, wave, l31, lh, acc, hook);
+      else compute_chunk<DGRAD, 1>(lin, lw, wave, l31, lh, acc, hook);
+    }
+#else
+    if (c + 1 < nchunks) gload(cn, -1);
+    TL_MARK(4 + c * 4);
+    auto hook = [](int) {};
+    if (ntv == 2) compute_chunk<DGRAD, 2>(lin, lw, wave, l31, lh, acc, hook);
+    else compute_chunk<DGRAD, 1>(lin, lw, wave, l31, lh, acc, hook);
+#endif
     TL_MARK(5 + c * 4);
   }
 
-  // epilogue.  D layout (32x32): col j = lane&31 -> channel, row i = (r&3)+8*(r>>2)+4*(lane>>5) -> pixel
-  // Straight-line code: invalid lanes are redirected on the address side (zero page / trash), all
-  // residual loads of a tile are issued before any arithmetic, then 16 stores back to back.
+  // D layout (32x32, D = W * X^T): col j = lane&31 -> pixel x0+j of this wave's row,
+  // row i = (r&3) + 8*(r>>2) + 4*(lane>>5) -> channel: register quad g = r>>2 holds channels
+  // 8g + 4*(lane>>5) + {0,1,2,3}.  Straight-line code: invalid lanes are redirected on the
+  // address side (zero page / trash); FAST path moves 16 bytes per lane per instruction.
   TL_MARK(62);
-  const int y = y0 + wave;
-  const bool row_ok = y < H;
-  const int64_t rowpix = ((int64_t)b * H + (row_ok ? y : 0)) * W;
+  const int y = y0 + wave, x = x0 + l31;
+  const bool pix_ok = y < H && x < W;
+  const int64_t pix = pix_ok ? ((int64_t)b * H + y) * W + x : 0;
+  // every supported activation is  v > 0 ? v : v * s
+  float s_uni = 1.f;
+  if (d.act == ACT_LRELU) s_uni = d.slope;
+  else if (d.act == ACT_RELU) s_uni = 0.f;
   const bool extra = d.res1 || d.res2 || d.accumulate;  // wave-uniform
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     if (nt >= ntv) break;
-    const int ch = n0 + nt * 32 + l31;
-    const bool ch_ok = ch < d.N;
-    const int chs = ch_ok ? ch : 0;
-    const float bias = d.bias ? d.bias[chs] : 0.f;
-    // every supported activation is  v > 0 ? v : v * s
-    float s = 1.f;
-    if (d.act == ACT_LRELU) s = d.slope;
-    else if (d.act == ACT_RELU) s = 0.f;
-    else if (d.act == ACT_PRELU) s = d.prelu[chs];
-    float* const obase = d.out + rowpix * d.out_cs + chs;
-    float vals[16];
-    if (extra) {
-      const bool r1 = d.res1 && ch < d.res1_nch, r2 = d.res2 && ch < d.res2_nch;
-      const float* const r1base = d.res1 ? d.res1 + rowpix * d.res1_cs + chs : g_zero_page;
-      const float* const r2base = d.res2 ? d.res2 + rowpix * d.res2_cs + chs : g_zero_page;
-      float a0[16], a1[16], a2[16];
+    if (!GENERIC) {
+      // phase 1: every load of this 32-channel tile is issued before any arithmetic or store
+      float4 bias[4], sl[4], a0[4], a1[4], a2[4];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int x = x0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const bool ok = row_ok && ch_ok && x < W;
-        a1[r] = *((ok && r1) ? r1base + x * d.res1_cs : g_zero_page);
-        a2[r] = *((ok && r2) ? r2base + x * d.res2_cs : g_zero_page);
-        a0[r] = *((ok && d.accumulate) ? obase + x * d.out_cs : g_zero_page);
+      for (int g = 0; g < 4; ++g) {
+        const int chq = n0 + nt * 32 + 8 * g + 4 * lh;
+        const bool ok = pix_ok && chq < d.N;
+        const int cs0 = chq < d.N ? chq : 0;
+        bias[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+        sl[g] = make_float4(s_uni, s_uni, s_uni, s_uni);
+        a0[g] = a1[g] = a2[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (d.bias) bias[g] = *reinterpret_cast<const float4*>(d.bias + cs0);
+        if (d.act == ACT_PRELU) sl[g] = *reinterpret_cast<const float4*>(d.prelu + cs0);
+        if (extra) {
+          a1[g] = *reinterpret_cast<const float4*>(
+              (ok && d.res1 && chq < d.res1_nch) ? d.res1 + pix * d.res1_cs + chq : g_zero_page);
+          a2[g] = *reinterpret_cast<const float4*>(
+              (ok && d.res2 && chq < d.res2_nch) ? d.res2 + pix * d.res2_cs + chq : g_zero_page);
+          a0[g] = *reinterpret_cast<const float4*>(
+              (ok && d.accumulate) ? d.out + pix * d.out_cs + chq : g_zero_page);
+        }
+      }
+      // phase 2: arithmetic; phase 3: four 16-byte stores back to back
+      float4 o[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float bb[4] = {bias[g].x, bias[g].y, bias[g].z, bias[g].w};
+        const float ss[4] = {sl[g].x, sl[g].y, sl[g].z, sl[g].w};
+        const float r1[4] = {a1[g].x, a1[g].y, a1[g].z, a1[g].w};
+        const float r2[4] = {a2[g].x, a2[g].y, a2[g].z, a2[g].w};
+        const float r0[4] = {a0[g].x, a0[g].y, a0[g].z, a0[g].w};
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float t = acc[nt][4 * g + e] + bb[e];
+          t = t > 0.f ? t : t * ss[e];
+          t = t * d.alpha + r1[e];
+          t = t * d.alpha2 + r2[e];
+          v[e] = t + r0[e];
+        }
+        o[g] = make_float4(v[0], v[1], v[2], v[3]);
       }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float v = acc[nt][r] + bias;
-        v = v > 0.f ? v : v * s;
-        v = v * d.alpha + a1[r];
-        v = v * d.alpha2 + a2[r];
-        vals[r] = v + a0[r];
+      for (int g = 0; g < 4; ++g) {
+        const int chq = n0 + nt * 32 + 8 * g + 4 * lh;
+        const bool ok = pix_ok && chq < d.N;
+        *reinterpret_cast<float4*>(ok ? d.out + pix * d.out_cs + chq : g_trash + tid * 4) = o[g];
       }
     } else {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float v = acc[nt][r] + bias;
-        v = v > 0.f ? v : v * s;
-        v *= d.alpha;
-        vals[r] = v * d.alpha2;
-      }
-    }
+      for (int g = 0; g < 4; ++g) {
+        const int chq = n0 + nt * 32 + 8 * g + 4 * lh;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int x = x0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      const bool ok = row_ok && ch_ok && x < W;
-      float* p = ok ? obase + x * d.out_cs : g_trash + tid;
-      *p = vals[r];
+        for (int e = 0; e < 4; ++e) {
+          const int ch = chq + e;
+          const bool ok = pix_ok && ch < d.N;
+          const int cs0 = ch < d.N ? ch : 0;
+          const float bias = d.bias ? d.bias[cs0] : 0.f;
+          const float sl = d.act == ACT_PRELU ? d.prelu[cs0] : s_uni;
+          const float a1 = *((ok && d.res1 && ch < d.res1_nch) ? d.res1 + pix * d.res1_cs + ch : g_zero_page);
+          const float a2 = *((ok && d.res2 && ch < d.res2_nch) ? d.res2 + pix * d.res2_cs + ch : g_zero_page);
+          float* const op = d.out + pix * d.out_cs + ch;
+          const float a0 = *((ok && d.accumulate) ? op : g_zero_page);
+          float t = acc[nt][4 * g + e] + bias;
+          t = t > 0.f ? t : t * sl;
+          t = t * d.alpha + a1;
+          t = t * d.alpha2 + a2;
+          *(ok ? op : g_trash + tid * 4 + e) = t + a0;
+        }
+      }
     }
   }
   TL_MARK(63);
@@ -367,8 +428,12 @@ extern "C" int neosr_conv3x3(const neosr_conv_desc* dp, void* stream) {
   const bool al_in = (d.in_cs % 4 == 0) && ((uintptr_t)d.in % 16 == 0);
   const bool al_mk = !d.in_mask || ((d.mask_cs % 4 == 0) && ((uintptr_t)d.in_mask % 16 == 0));
   const bool al_w = ((uintptr_t)d.w % 16 == 0) && (d.w_cin % 4 == 0);
-  const bool fast = al_in && al_mk && al_w && (d.K % 4 == 0) && (d.N % 4 == 0) && !d.in_prelu &&
-                    !d.mask_slopes;
+  auto al16 = [](const void* p, int cs) { return !p || (((uintptr_t)p % 16 == 0) && (cs % 4 == 0)); };
+  const bool al_ep = al16(d.out, d.out_cs) && al16(d.res1, d.res1_cs) && al16(d.res2, d.res2_cs) &&
+                     al16(d.bias, 0) && al16(d.prelu, 0) && (d.res1_nch % 4 == 0) &&
+                     (d.res2_nch % 4 == 0);
+  const bool fast = al_in && al_mk && al_w && al_ep && (d.K % 4 == 0) && (d.N % 4 == 0) &&
+                    !d.in_prelu && !d.mask_slopes;
   dim3 grid(a.tiles_x * a.tiles_y * d.B, ceil_div(d.N, NB));
   hipStream_t st = (hipStream_t)stream;
   const bool prof = neosr_prof_on();
