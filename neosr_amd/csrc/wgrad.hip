@@ -57,6 +57,10 @@ __device__ __forceinline__ float4 ld4(const float* p, bool vec, int c, int C) {
   return v;
 }
 
+__device__ __attribute__((aligned(256))) float wg_zero_page[64];
+
+// FAST: every descriptor has 16-byte aligned tensors, channel strides / K / N multiples of 4.
+template <bool FAST>
 __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_multi_kernel(const WgradMultiArgs args) {
   __shared__ __attribute__((aligned(16))) float lds[G_LDS + X_LDS];  // 42.5 KB (>= WG_TILE)
   __shared__ float bred[4 * 32];
@@ -103,7 +107,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_multi_kernel(const Wgrad
       const int py = pix >> 5, px = pix & 31;
       const int gy = y0 + py, gx = x0 + px;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f), m = make_float4(1.f, 1.f, 1.f, 1.f);
-      if (gy < H && gx < W) {
+      if (FAST) {
+        // branch-free: invalid lanes read the zero page (address-side redirect, see conv_mfma.hip)
+        const bool ok = gy < H && gx < W && co0 + q4 < d.N;
+        const int64_t p = ok ? ((int64_t)b * H + gy) * W + gx : 0;
+        v = *reinterpret_cast<const float4*>(ok ? d.g + p * d.g_cs + co0 + q4 : wg_zero_page);
+        if (d.g_mask)
+          m = *reinterpret_cast<const float4*>(ok ? d.g_mask + p * d.mask_cs + co0 + q4 : wg_zero_page);
+      } else if (gy < H && gx < W) {
         const int64_t p = ((int64_t)b * H + gy) * W + gx;
         v = ld4(d.g + p * d.g_cs + co0 + q4, vec_g, co0 + q4, d.N);
         if (d.g_mask) m = ld4(d.g_mask + p * d.mask_cs + co0 + q4, vec_m, co0 + q4, d.N);
@@ -115,7 +126,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_multi_kernel(const Wgrad
     for (int i = 0; i < X_F4; ++i) {
       const int idx = tid + i * 256;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (idx < X_PIX * 8) {
+      if (FAST) {
+        const int pix = idx >> 3;
+        const int py = pix / HALO_W, px = pix - py * HALO_W;
+        const int gy = y0 + py - 1, gx = x0 + px - 1;
+        const bool ok = idx < X_PIX * 8 && gy >= 0 && gy < H && gx >= 0 && gx < W && ci0 + q4 < d.K;
+        const int sy = args.ups ? (gy >> 1) : gy, sx = args.ups ? (gx >> 1) : gx;
+        const int64_t p = ok ? ((int64_t)b * Hin + sy) * Win + sx : 0;
+        v = *reinterpret_cast<const float4*>(ok ? d.in + p * d.in_cs + ci0 + q4 : wg_zero_page);
+      } else if (idx < X_PIX * 8) {
         const int pix = idx >> 3;
         const int py = pix / HALO_W, px = pix - py * HALO_W;
         const int gy = y0 + py - 1, gx = x0 + px - 1;
@@ -328,8 +347,16 @@ extern "C" int neosr_conv3x3_wgrad_multi(const neosr_wgrad_desc* ds, int32_t n, 
     }
     neosr_prof_begin(NEOSR_PROF_CONV_WGRAD, stream, fl, by);
   }
-  hipLaunchKernelGGL(conv3x3_wgrad_multi_kernel, dim3(a.pair_start[MAXD], a.nsplit), dim3(256), 0,
-                     st, a);
+  bool fast = true;
+  for (int i = 0; i < n; ++i)
+    fast = fast && a.vec_in[i] && a.vec_g[i] && (!ds[i].g_mask || a.vec_m[i]) &&
+           (ds[i].K % 4 == 0) && (ds[i].N % 4 == 0);
+  if (fast)
+    hipLaunchKernelGGL(conv3x3_wgrad_multi_kernel<true>, dim3(a.pair_start[MAXD], a.nsplit),
+                       dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL(conv3x3_wgrad_multi_kernel<false>, dim3(a.pair_start[MAXD], a.nsplit),
+                       dim3(256), 0, st, a);
   if (prof) neosr_prof_end(stream);
   NEOSR_LAUNCH_CHECK();
   if (prof) neosr_prof_begin(NEOSR_PROF_WGRAD_REDUCE, stream, 0.0, 0.0);
