@@ -177,6 +177,58 @@ typedef struct neosr_adamw_desc {
 int neosr_grad_norm(const float* grad, int64_t n, float grad_scale, float* norm_ws, void* stream);
 int neosr_adamw_step(const neosr_adamw_desc* d, void* stream);
 
+/* on-the-fly degradation bank (otf.feed_data) ------------------------------------------------
+ * Images are planar (B, C, H, W) fp32 in [0,1], exactly the tensors neosr/models/otf.py:92-283
+ * moves through its 2nd-order Real-ESRGAN pipeline.  Random DRAWS (noise fields, Poisson counts,
+ * qualities, scales, modes, offsets, permutations) are inputs: the host draws them (device RNG in
+ * production, captured reference draws in the parity tests) and the kernels are the deterministic
+ * functions of (image, draws). */
+#define NEOSR_RESIZE_AREA 0
+#define NEOSR_RESIZE_BILINEAR 1
+#define NEOSR_RESIZE_BICUBIC 2
+/* filter2D (neosr/utils/diffjpeg.py:558-584): reflect-pad k//2 then cross-correlate every plane
+ * of sample b with kernel[b] (k x k, k odd <= 21); kernel_batched = 0 uses kernel[0] for all. */
+int neosr_filter2d(const float* img, const float* kernel, float* out, int32_t B, int32_t C,
+                   int32_t H, int32_t W, int32_t k, int32_t kernel_batched, void* stream);
+/* F.interpolate(mode = area | bilinear | bicubic, align_corners=False, antialias=False)
+ * (otf.py:126,179-186,222-226,243-247).  rs_h / rs_w = source-coordinate scale: 1/scale_factor
+ * for the scale_factor form, in/out for the size form (ignored by area = adaptive_avg_pool2d). */
+int neosr_resize(const float* in, float* out, int32_t planes, int32_t Hin, int32_t Win,
+                 int32_t Hout, int32_t Wout, int32_t mode, float rs_h, float rs_w, void* stream);
+/* add_gaussian_noise_pt (degradations.py:569-624), clip=True rounds=False:
+ * out = clamp(img + n*(sigma_b/255)*(1-g_b) + n_gray*(sigma_b/255)*g_b, 0, 1); n (B,C,H,W) and the
+ * single (H,W) field n_gray (may be NULL) are standard normal draws; sigma, gray are (B). */
+int neosr_gaussian_noise(const float* img, const float* noise, const float* noise_gray,
+                         const float* sigma, const float* gray, float* out, int32_t B, int32_t C,
+                         int32_t H, int32_t W, void* stream);
+/* generate_poisson_noise_pt part 1 (degradations.py:762-781): per-sample count of distinct 8-bit
+ * levels (256-bit presence bitmap, integer atomics: deterministic, no sort, no host sync) ->
+ * vals[b] = 2^ceil(log2(count)); rate = clamp(round(x*255),0,255)/255 * vals[b] where x is the
+ * image (gray=0, rate (B,3,H,W)) or rgb_to_grayscale(image) (gray=1, rate (B,1,H,W)).
+ * levels_ws: B*8 uint32 scratch. */
+int neosr_poisson_rate(const float* img, uint32_t* levels_ws, float* vals, float* rate, int32_t B,
+                       int32_t H, int32_t W, int32_t gray, void* stream);
+/* part 2 (degradations.py:768-786,820-828): given P ~ Poisson(rate) (and P_gray, optional):
+ * out = clamp(img + ((P/vals - q(img))*(1-g) + (P_gray/vals_gray - q(gray(img)))*g)*scale, 0, 1). */
+int neosr_poisson_noise(const float* img, const float* P, const float* vals, const float* P_gray,
+                        const float* vals_gray, const float* scale, const float* gray, float* out,
+                        int32_t B, int32_t H, int32_t W, void* stream);
+/* DiffJPEG(differentiable=False)(x, quality) (neosr/utils/diffjpeg.py:514-555): pad to x16 with
+ * zeros, RGB*255 -> YCbCr, 2x2 chroma mean, 8x8 DCT, quantise with the (transposed-as-stored)
+ * tables * quality_to_factor(quality[b]) and round-half-even, dequantise, IDCT, chroma repeat,
+ * -> RGB, clamp, /255, crop.  One wavefront per 16x16 MCU; one read + one write of the image. */
+int neosr_diffjpeg(const float* img, const float* quality, float* out, int32_t B, int32_t H,
+                   int32_t W, void* stream);
+/* clamp((x*255).round(), 0, 255)/255 (otf.py:251) and clamp(x, 0, 1) (otf.py:153). */
+int neosr_quantize_u8(const float* in, float* out, int64_t n, void* stream);
+int neosr_clamp01(const float* in, float* out, int64_t n, void* stream);
+/* paired_random_crop's tensor branch (neosr/data/transforms.py:38-131): one window for the batch. */
+int neosr_crop(const float* in, float* out, int32_t planes, int32_t H, int32_t W, int32_t top,
+               int32_t left, int32_t h, int32_t w, void* stream);
+/* training-pair pool shuffle `queue = queue[randperm]` (otf.py:70-72): dst[i] = src[idx[i]]. */
+int neosr_gather_rows(const float* src, const int64_t* idx, float* dst, int32_t nrows,
+                      int64_t row_elems, void* stream);
+
 /* opt-in profiler ------------------------------------------------------------------------------
  * HIP events around every conv-class launch on the launch stream (classes: 0 conv fwd, 1 conv
  * dgrad, 2 conv wgrad, 3 wgrad reduce).  Used by bench.py's roofline pass only.  collect()

@@ -173,6 +173,16 @@ SIGNATURES: dict[str, tuple] = {
     "neosr_l1_loss_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _f32, _vp, _vp]),
     "neosr_grad_norm": (C.c_int, [_vp, _i64, _f32, _vp, _vp]),
     "neosr_adamw_step": (C.c_int, [C.POINTER(AdamWDesc), _vp]),
+    "neosr_filter2d": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "neosr_resize": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _vp]),
+    "neosr_gaussian_noise": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "neosr_poisson_rate": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "neosr_poisson_noise": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "neosr_diffjpeg": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "neosr_quantize_u8": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "neosr_clamp01": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "neosr_crop": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "neosr_gather_rows": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _vp]),
     "neosr_prof_enable": (C.c_int, [C.c_int]),
     "neosr_prof_collect": (
         C.c_int,

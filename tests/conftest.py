@@ -49,3 +49,22 @@ def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
     b = b.detach().double().cpu().flatten()
     denom = float(b.norm())
     return float((a - b).norm()) / (denom if denom > 0 else 1.0)
+
+
+def load_draws(fix: dict[str, np.ndarray], prefix: str):
+    """[(kind, value), ...] recorded by tests/golden/gen_golden_otf.py under `prefix/NNN`."""
+    kinds = [str(k) for k in fix[f"{prefix}/kinds"]]
+    out = []
+    for i, kind in enumerate(kinds):
+        v = fix[f"{prefix}/{i:03d}"]
+        out.append((kind, str(v) if v.dtype.kind in "US" else v))
+    return out
+
+
+DEG_OPT = {  # tests/golden/golden_otf.toml [degradations]
+    "resize_prob": [0.3, 0.4, 0.3], "resize_range": [0.5, 1.5], "gaussian_noise_prob": 0.5,
+    "noise_range": [0, 2], "poisson_scale_range": [0.05, 0.25], "gray_noise_prob": 0.4,
+    "jpeg_range": [40, 95], "second_blur_prob": 0.5, "resize_prob2": [0.3, 0.4, 0.3],
+    "resize_range2": [0.3, 1.5], "gaussian_noise_prob2": 0.5, "noise_range2": [0, 2],
+    "poisson_scale_range2": [0.05, 0.1], "gray_noise_prob2": 0.4, "jpeg_range2": [35, 95],
+}

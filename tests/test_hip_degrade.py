@@ -1,0 +1,157 @@
+"""GPU parity of the degradation-bank kernels (through the C ABI) against fixtures produced by the
+reference's own `filter2D`, `F.interpolate`, `random_add_*_noise_pt`, `DiffJPEG` and `otf.feed_data`
+(stochastic parts replay the reference's recorded draws).  Tolerance 1e-3 rel (north_star); JPEG and
+the 8-bit quantised LQ also report / bound isolated 1/255 rounding flips."""
+
+from __future__ import annotations
+
+import numpy as np
+import pytest
+import torch
+
+from tests.conftest import DEG_OPT, GOLDEN, ROOT, load_draws, load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def prims():
+    return load_golden("degrade_prims.npz")
+
+
+def G(a):
+    return torch.from_numpy(np.array(a)).to(DEV)
+
+
+def test_filter2d_vs_reference(prims):
+    from neosr_amd.hip import degrade as D
+
+    img = G(prims["f2d_img"])
+    assert rel_err(D.filter2d(img, G(prims["f2d_k"])), torch.from_numpy(prims["f2d_out"])) < 1e-5
+    assert rel_err(D.filter2d(img, G(prims["f2d_k1"])), torch.from_numpy(prims["f2d_out1"])) < 1e-5
+    with pytest.raises(ValueError, match="Wrong kernel size"):
+        D.filter2d(img, torch.ones(1, 4, 4, device=DEV))
+
+
+def test_filter2d_full_size_vs_oracle():
+    """blur1 shape of config 3 on one sample: (1,3,512,512), 21x21 anisotropic kernel."""
+    from neosr_amd.hip import degrade as D
+    from oracle import degrade_oracle as dorc
+
+    g = torch.Generator().manual_seed(0)
+    img = torch.rand(1, 3, 512, 512, generator=g)
+    k = torch.rand(1, 21, 21, generator=g)
+    k /= k.sum()
+    assert rel_err(D.filter2d(img.to(DEV), k.to(DEV)), dorc.filter2d(img, k)) < 1e-5
+
+
+def test_resize_all_forms_vs_reference(prims):
+    from neosr_amd.hip import degrade as D
+
+    img = G(prims["f2d_img"])
+    worst = 0.0
+    for mode in ("area", "bilinear", "bicubic"):
+        for s in (0.5, 0.73, 1.37):
+            ref = torch.from_numpy(prims[f"rs_sf_{mode}_{s}"])
+            out = D.resize(img, scale_factor=s, mode=mode)
+            assert out.shape == ref.shape
+            worst = max(worst, rel_err(out, ref))
+        for size in ((25, 35), (32, 32), (61, 90)):
+            ref = torch.from_numpy(prims[f"rs_sz_{mode}_{size[0]}x{size[1]}"])
+            worst = max(worst, rel_err(D.resize(img, size=size, mode=mode), ref))
+    assert worst < 1e-5, worst
+
+
+def test_noise_kernels_replaying_reference_draws(prims):
+    from neosr_amd.data.draws import ReplayDraws
+    from neosr_amd.hip import degrade as D
+
+    img = G(prims["f2d_img"])
+    b, _, h, w = img.shape
+    for tag, gray_prob in (("gn", 0.6), ("gn0", 0.0)):
+        d = ReplayDraws(load_draws(prims, f"{tag}_draws"), DEV)
+        sigma = d.rand(b) * (30 - 1) + 1
+        gray = (d.rand(b) < gray_prob).float()
+        ngray = d.randn(h, w) if float(gray.sum()) > 0 else None
+        noise = d.randn(b, 3, h, w)
+        assert d.exhausted()
+        assert rel_err(D.gaussian_noise(img, noise, ngray, sigma, gray), torch.from_numpy(prims[f"{tag}_out"])) < 1e-5
+    for tag, gray_prob in (("pn", 0.6), ("pn0", 0.0)):
+        d = ReplayDraws(load_draws(prims, f"{tag}_draws"), DEV)
+        scale = d.rand(b) * (3 - 0.05) + 0.05
+        gray = (d.rand(b) < gray_prob).float()
+        pg = vg = None
+        if float(gray.sum()) > 0:
+            rate_g, vg = D.poisson_rate(img, gray=True)
+            pg = d.poisson(rate_g)
+        rate, vals = D.poisson_rate(img, gray=False)
+        p = d.poisson(rate)
+        assert d.exhausted()
+        assert rel_err(D.poisson_noise(img, p, vals, pg, vg, scale, gray), torch.from_numpy(prims[f"{tag}_out"])) < 1e-5
+
+
+def test_poisson_rate_level_count_vs_oracle():
+    """2^ceil(log2(#distinct 8-bit levels)) from the bitmap kernel == torch.unique on the CPU."""
+    from neosr_amd.hip import degrade as D
+    from oracle import degrade_oracle as dorc
+
+    g = torch.Generator().manual_seed(3)
+    img = torch.rand(3, 3, 40, 56, generator=g)
+    img[1] = (img[1] * 5).round() / 5          # few levels
+    img[2] = 0.5                                # a single level
+    for gray in (False, True):
+        rate, vals = D.poisson_rate(img.to(DEV), gray)
+        rate_ref, vals_ref = dorc.poisson_rate(img, gray)
+        assert torch.equal(vals.cpu(), vals_ref)
+        assert rel_err(rate, rate_ref) < 1e-6
+
+
+def test_diffjpeg_vs_reference(prims):
+    from neosr_amd.hip import degrade as D
+
+    for name in ("a", "b"):
+        q = G(prims[f"jpg_{name}_q"])
+        out = D.diffjpeg(G(prims[f"jpg_{name}_img"]), q).cpu()
+        ref = torch.from_numpy(prims[f"jpg_{name}_out"])
+        diff = (out - ref).abs()
+        flips = float((diff > 1e-3).float().mean())  # a coefficient rounding the other way moves 64 px
+        assert rel_err(out, ref) < 1e-3, rel_err(out, ref)
+        assert flips < 0.02, flips
+        assert torch.equal(q.cpu(), torch.from_numpy(prims[f"jpg_{name}_q"]))  # quality not mutated
+
+
+def test_quantise_crop_gather_bit_exact(prims):
+    from neosr_amd.hip import degrade as D
+
+    assert torch.equal(D.quantize_u8(G(prims["q_in"])).cpu(), torch.from_numpy(prims["q_out"]))
+    x = torch.arange(2 * 3 * 9 * 11, dtype=torch.float32).reshape(2, 3, 9, 11)
+    assert torch.equal(D.crop(x.to(DEV), 2, 3, 5, 6).cpu(), x[:, :, 2:7, 3:9])
+    idx = torch.tensor([3, 0, 2, 1, 1])
+    rows = torch.arange(4 * 6, dtype=torch.float32).reshape(4, 2, 3)
+    assert torch.equal(D.gather_rows(rows.to(DEV), idx.to(DEV)).cpu(), rows[idx])
+
+
+def test_otf_feed_data_replaying_reference_draws():
+    """OUR otf.feed_data (HIP kernels) on the reference's inputs and recorded draws, 3 calls incl. the
+    pair pool filling and shuffling: same LQ/GT pair as the reference produced."""
+    from neosr_amd.data.draws import ReplayDraws
+    from neosr_amd.models import build_model
+    from neosr_amd.utils.options import parse_options
+
+    fix = load_golden("otf_feed.npz")
+    opt, _ = parse_options(str(ROOT), True, argv=["-opt", str(GOLDEN / "golden_otf.toml")])
+    assert opt["degradations"] == DEG_OPT
+    model = build_model(opt)
+    for it in (1, 2, 3):
+        d = ReplayDraws(load_draws(fix, f"it{it}/draws"), DEV)
+        model.draws = d
+        model.feed_data({k: torch.from_numpy(fix[f"it{it}/{k}"]) for k in ("gt", "kernel1", "kernel2", "sinc_kernel")})
+        assert d.exhausted()
+        ref_lq = torch.from_numpy(fix[f"it{it}/lq"])
+        diff = (model.lq.cpu() - ref_lq).abs()
+        assert float(diff.max()) <= 1.0 / 255 + 1e-6, float(diff.max())
+        assert float((diff > 1e-6).float().mean()) < 0.01
+        assert torch.equal(model.gt.cpu(), torch.from_numpy(fix[f"it{it}/gt_out"]))
+    model.optimize_parameters(1)  # the degraded pair feeds the HIP training step
+    assert np.isfinite(model.get_current_log()["l_g_pix"])
