@@ -229,6 +229,57 @@ int neosr_crop(const float* in, float* out, int32_t planes, int32_t H, int32_t W
 int neosr_gather_rows(const float* src, const int64_t* idx, float* dst, int32_t nrows,
                       int64_t row_elems, void* stream);
 
+/* GAN / perceptual branch: non-conv layers and losses (channels-last activations) ---------------
+ * U-Net-SN discriminator (neosr/archs/unet_arch.py:9-67), VGG19 feature extractor
+ * (neosr/archs/vgg_arch.py:76-199), chc and BCE losses (neosr/losses/basic_loss.py:132-219,
+ * neosr/losses/gan_loss.py:45-82). */
+/* space-to-depth by 2: out[b,Y,X,(dy*2+dx)*C+c] = in[b,2Y+dy,2X+dx,c] (inverse=1: the adjoint).
+ * A 4x4/stride-2/pad-1 convolution (unet conv1-3) is a 3x3/s1/p1 convolution of this tensor with
+ * the 16 taps scattered into a (N, 4C, 3, 3) weight, so it runs on neosr_conv3x3[_wgrad]. */
+int neosr_space_to_depth2(const float* in, float* out, int32_t B, int32_t Hlo, int32_t Wlo,
+                          int32_t C, int32_t inverse, void* stream);
+/* F.interpolate(scale_factor=2, mode="bilinear", align_corners=False) (unet_arch.py:45,51,57);
+ * backward=1: its adjoint in gather form (in = grad (B,2H,2W,C), out = (B,H,W,C)). */
+int neosr_bilinear_up2(const float* in, float* out, int32_t B, int32_t H, int32_t W, int32_t C,
+                       int32_t backward, void* stream);
+/* nn.MaxPool2d(2, 2) (vgg_arch.py:140-146). gout == NULL: out (B,Ho,Wo,C) = pool(in (B,2Ho,2Wo,C));
+ * else out (B,2Ho,2Wo,C) = gradient routed to the first maximum of each window. */
+int neosr_maxpool2(const float* in, const float* gout, float* out, int32_t B, int32_t Ho, int32_t Wo,
+                   int32_t C, void* stream);
+int neosr_add(const float* a, const float* b, float* out, int64_t n, void* stream);
+/* g == NULL: out = leaky_relu(x, slope) (slope 0 = ReLU); else out = x > 0 ? g : g*slope. */
+int neosr_leaky_relu(const float* x, const float* g, float slope, float* out, int64_t n, void* stream);
+/* VGG input normalisation fused with the layout change: out_nhwc = (in_nchw - mean) / std
+ * (vgg_arch.py:159-173, 190-191); backward=1: in = NHWC grad, out = NCHW grad / std. */
+int neosr_norm_nchw_nhwc(const float* in, float* out, int32_t B, int32_t C, int32_t H, int32_t W,
+                         int32_t cs, float mean, float std, int32_t backward, void* stream);
+/* chc_loss with loss_lambda = 0 (basic_loss.py:192-219): d = (a - b)*pre,
+ * loss = w * mean(clamp(huber ? sqrt(d^2+1e-12) : |d|, clip_min, clip_max)); workspace >= 1024 floats.
+ * bwd: grad_a (+)= w/n * 1[clip_min <= t <= clip_max] * dt/dd * pre * (*grad_out). */
+int neosr_chc_loss_fwd(const float* a, const float* b, int64_t n, float pre, int32_t huber,
+                       float clip_min, float clip_max, float loss_weight, float* loss_out,
+                       float* workspace, void* stream);
+int neosr_chc_loss_bwd(const float* a, const float* b, const float* grad_out, int64_t n, float pre,
+                       int32_t huber, float clip_min, float clip_max, float loss_weight, float* grad_a,
+                       int32_t accumulate, void* stream);
+/* nn.BCEWithLogitsLoss()(x, full_like(x, target)) * loss_weight (gan_loss.py:59-82);
+ * mean_out (optional) receives mean(x) (`out_d_real/out_d_fake`, image.py:566,579).
+ * workspace >= 2048 floats. */
+int neosr_bce_logits_fwd(const float* x, int64_t n, float target, float loss_weight, float* loss_out,
+                         float* mean_out, float* workspace, void* stream);
+int neosr_bce_logits_bwd(const float* x, const float* grad_out, int64_t n, float target,
+                         float loss_weight, float* grad_x, void* stream);
+/* torch.nn.utils.spectral_norm, n_power_iterations = 1 (unet_arch.py:21-34): W is (rows, cols)
+ * = (Cout, Cin*k*k).  update_uv (train mode): v = normalize(W^T u), u = normalize(W v) in place;
+ * sigma = u.(W v); w_out = W / sigma.  scratch_rows: rows floats.
+ * bwd: g_orig = (gw - <gw, w> u v^T) / sigma (u, v constants); workspace >= 1028 floats. */
+int neosr_spectral_norm_fwd(const float* w_orig, float* u, float* v, float* w_out, float* sigma,
+                            float* scratch_rows, int32_t rows, int32_t cols, int32_t update_uv,
+                            float eps, void* stream);
+int neosr_spectral_norm_bwd(const float* gw, const float* w, const float* u, const float* v,
+                            const float* sigma, float* g_orig, float* workspace, int32_t rows,
+                            int32_t cols, void* stream);
+
 /* opt-in profiler ------------------------------------------------------------------------------
  * HIP events around every conv-class launch on the launch stream (classes: 0 conv fwd, 1 conv
  * dgrad, 2 conv wgrad, 3 wgrad reduce).  Used by bench.py's roofline pass only.  collect()

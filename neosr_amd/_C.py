@@ -183,6 +183,18 @@ SIGNATURES: dict[str, tuple] = {
     "neosr_clamp01": (C.c_int, [_vp, _vp, _i64, _vp]),
     "neosr_crop": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "neosr_gather_rows": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _vp]),
+    "neosr_space_to_depth2": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "neosr_bilinear_up2": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "neosr_maxpool2": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "neosr_add": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
+    "neosr_leaky_relu": (C.c_int, [_vp, _vp, _f32, _vp, _i64, _vp]),
+    "neosr_norm_nchw_nhwc": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _i32, _vp]),
+    "neosr_chc_loss_fwd": (C.c_int, [_vp, _vp, _i64, _f32, _i32, _f32, _f32, _f32, _vp, _vp, _vp]),
+    "neosr_chc_loss_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _f32, _i32, _f32, _f32, _f32, _vp, _i32, _vp]),
+    "neosr_bce_logits_fwd": (C.c_int, [_vp, _i64, _f32, _f32, _vp, _vp, _vp, _vp]),
+    "neosr_bce_logits_bwd": (C.c_int, [_vp, _vp, _i64, _f32, _f32, _vp, _vp]),
+    "neosr_spectral_norm_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp]),
+    "neosr_spectral_norm_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
     "neosr_prof_enable": (C.c_int, [C.c_int]),
     "neosr_prof_collect": (
         C.c_int,

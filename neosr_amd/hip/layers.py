@@ -1,0 +1,345 @@
+"""Differentiable layer fronts over the C ABI for networks that are composed op-by-op in Python
+(U-Net-SN discriminator, VGG19 feature extractor) and the GAN / perceptual losses.
+
+Every `autograd.Function` here moves channels-last `(B,H,W,C)` fp32 HBM tensors through HIP
+kernels (`neosr_conv3x3[_wgrad]`, `neosr_space_to_depth2`, `neosr_bilinear_up2`, `neosr_maxpool2`,
+`neosr_leaky_relu`, `neosr_spectral_norm_*`, `neosr_chc_loss_*`, `neosr_bce_logits_*`, …).  torch is
+used for allocation, the autograd graph, and index plumbing on small weight tensors only.
+"""
+
+from __future__ import annotations
+
+import torch
+
+from neosr_amd import _C
+from neosr_amd.hip import ops
+
+ACT_NONE, ACT_LRELU, ACT_RELU = _C.ACT_NONE, _C.ACT_LRELU, _C.ACT_RELU
+
+
+def _st():
+    return _C.stream_ptr()
+
+
+# --------------------------------------------------------------------------------------------
+# layout
+# --------------------------------------------------------------------------------------------
+class ToNHWC(torch.autograd.Function):
+    """(B,C,H,W) -> (B,H,W,cs) channels-last (cs >= C, zero padded)."""
+
+    @staticmethod
+    def forward(ctx, x, cs):
+        ctx.c = x.shape[1]
+        return ops.nchw_to_nhwc(_C.require_device(x, "x"), cs)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.nhwc_to_nchw(g.contiguous(), ctx.c), None
+
+
+class ToNCHW(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, c):
+        ctx.cs = x.shape[3]
+        return ops.nhwc_to_nchw(_C.require_device(x, "x").contiguous(), c)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.nchw_to_nhwc(g.contiguous(), ctx.cs), None
+
+
+class VGGInput(torch.autograd.Function):
+    """(x - mean) / std fused with NCHW -> NHWC (vgg_arch.py:190-191)."""
+
+    @staticmethod
+    def forward(ctx, x, mean, std, cs):
+        lib = _C.load()
+        x = _C.require_device(x, "x").contiguous()
+        B, C_, H, W = x.shape
+        out = torch.zeros(B, H, W, cs, device=x.device, dtype=torch.float32)
+        _C.check(lib.neosr_norm_nchw_nhwc(x.data_ptr(), out.data_ptr(), B, C_, H, W, cs, mean, std, 0, _st()),
+                 "neosr_norm_nchw_nhwc")
+        ctx.meta = (B, C_, H, W, cs, mean, std)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _C.load()
+        B, C_, H, W, cs, mean, std = ctx.meta
+        g = g.contiguous()
+        out = torch.empty(B, C_, H, W, device=g.device, dtype=torch.float32)
+        _C.check(lib.neosr_norm_nchw_nhwc(g.data_ptr(), out.data_ptr(), B, C_, H, W, cs, mean, std, 1, _st()),
+                 "neosr_norm_nchw_nhwc")
+        return out, None, None, None
+
+
+# --------------------------------------------------------------------------------------------
+# convolution
+# --------------------------------------------------------------------------------------------
+class Conv3x3(torch.autograd.Function):
+    """y = act(conv3x3(x[..., :K], w) + b), fused bias/activation; backward = MFMA dgrad (activation
+    derivative applied on load) + multi-conv wgrad kernel."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, act, slope):
+        _C.require_device(x, "x")
+        w = _C.require_device(w, "weight").contiguous()
+        y = ops.conv3x3(x, w, b, act=act, slope=slope, k_in=w.shape[1])
+        ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
+        ctx.act, ctx.slope, ctx.has_bias = act, slope, b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, y = ctx.saved_tensors
+        g = g.contiguous()
+        slope = ctx.slope if ctx.act == ACT_LRELU else 0.0
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = ops.conv3x3(g, w, None, mode=ops.CONV_DGRAD, in_mask=y, mask_slope=slope)
+            if x.shape[3] > gx.shape[3]:  # conv read a channel prefix of a wider buffer
+                pad = torch.zeros(*x.shape[:3], x.shape[3] - gx.shape[3], device=g.device)
+                gx = torch.cat((gx, pad), 3)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            gw, gb = ops.conv3x3_wgrad(x, g, w.shape[0], w.shape[1], g_mask=y, mask_slope=slope,
+                                       want_bias=ctx.has_bias)
+        return gx, gw, gb, None, None
+
+
+def conv3x3(x, w, b=None, act=ACT_NONE, slope=0.0):
+    return Conv3x3.apply(x, w, b, act, slope)
+
+
+class SpaceToDepth2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        lib = _C.load()
+        x = _C.require_device(x, "x").contiguous()
+        B, H, W, C_ = x.shape
+        if H % 2 or W % 2:
+            raise _C.NeosrAmdError("4x4/s2 conv needs even H, W")
+        out = torch.empty(B, H // 2, W // 2, 4 * C_, device=x.device, dtype=torch.float32)
+        _C.check(lib.neosr_space_to_depth2(x.data_ptr(), out.data_ptr(), B, H // 2, W // 2, C_, 0, _st()),
+                 "neosr_space_to_depth2")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _C.load()
+        g = g.contiguous()
+        B, Hl, Wl, C4 = g.shape
+        out = torch.empty(B, 2 * Hl, 2 * Wl, C4 // 4, device=g.device, dtype=torch.float32)
+        _C.check(lib.neosr_space_to_depth2(g.data_ptr(), out.data_ptr(), B, Hl, Wl, C4 // 4, 1, _st()),
+                 "neosr_space_to_depth2")
+        return out
+
+
+_S2D_INDEX: dict[tuple, torch.Tensor] = {}
+
+
+def expand_4x4s2_weight(w: torch.Tensor) -> torch.Tensor:
+    """(N, C, 4, 4) stride-2/pad-1 kernel -> the (N, 4C, 3, 3) kernel acting on the space-to-depth
+    tensor: tap ky -> (block row, sub row) = (0,1), (1,0), (1,1), (2,0); same for kx.  A single
+    differentiable gather (index plumbing on the weight, 20 of 36 entries are structural zeros)."""
+    N, C_, _, _ = w.shape
+    key = (N, C_, w.device)
+    idx = _S2D_INDEX.get(key)
+    if idx is None:
+        m = [(0, 1), (1, 0), (1, 1), (2, 0)]
+        src = torch.full((N, 4, C_, 3, 3), N * C_ * 16, dtype=torch.long)  # -> appended zero
+        base = torch.arange(N * C_ * 16).view(N, C_, 4, 4)
+        for ky, (by, dy) in enumerate(m):
+            for kx, (bx, dx) in enumerate(m):
+                src[:, dy * 2 + dx, :, by, bx] = base[:, :, ky, kx]
+        idx = src.view(-1).to(w.device)
+        _S2D_INDEX[key] = idx
+    flat = torch.cat((w.reshape(-1), w.new_zeros(1)))
+    return flat[idx].view(N, 4 * C_, 3, 3)
+
+
+def conv4x4s2(x, w, b=None, act=ACT_NONE, slope=0.0):
+    """nn.Conv2d(C, N, 4, 2, 1) on channels-last x, as space-to-depth + the MFMA 3x3 kernel."""
+    return conv3x3(SpaceToDepth2.apply(x), expand_4x4s2_weight(w), b, act, slope)
+
+
+# --------------------------------------------------------------------------------------------
+# resampling / pooling / pointwise
+# --------------------------------------------------------------------------------------------
+class BilinearUp2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        lib = _C.load()
+        x = _C.require_device(x, "x").contiguous()
+        B, H, W, C_ = x.shape
+        out = torch.empty(B, 2 * H, 2 * W, C_, device=x.device, dtype=torch.float32)
+        _C.check(lib.neosr_bilinear_up2(x.data_ptr(), out.data_ptr(), B, H, W, C_, 0, _st()), "neosr_bilinear_up2")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _C.load()
+        g = g.contiguous()
+        B, H2, W2, C_ = g.shape
+        out = torch.empty(B, H2 // 2, W2 // 2, C_, device=g.device, dtype=torch.float32)
+        _C.check(lib.neosr_bilinear_up2(g.data_ptr(), out.data_ptr(), B, H2 // 2, W2 // 2, C_, 1, _st()),
+                 "neosr_bilinear_up2")
+        return out
+
+
+class MaxPool2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        lib = _C.load()
+        x = _C.require_device(x, "x").contiguous()
+        B, H, W, C_ = x.shape
+        out = torch.empty(B, H // 2, W // 2, C_, device=x.device, dtype=torch.float32)
+        _C.check(lib.neosr_maxpool2(x.data_ptr(), None, out.data_ptr(), B, H // 2, W // 2, C_, _st()), "neosr_maxpool2")
+        ctx.save_for_backward(x)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _C.load()
+        (x,) = ctx.saved_tensors
+        g = g.contiguous()
+        B, H, W, C_ = x.shape
+        gx = torch.zeros_like(x) if (H % 2 or W % 2) else torch.empty_like(x)
+        _C.check(lib.neosr_maxpool2(x.data_ptr(), g.data_ptr(), gx.data_ptr(), B, H // 2, W // 2, C_, _st()),
+                 "neosr_maxpool2")
+        return gx
+
+
+class Add(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        lib = _C.load()
+        a = _C.require_device(a, "a").contiguous()
+        b = _C.require_device(b, "b").contiguous()
+        out = torch.empty_like(a)
+        _C.check(lib.neosr_add(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _st()), "neosr_add")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+class LeakyReLU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, slope):
+        lib = _C.load()
+        x = _C.require_device(x, "x").contiguous()
+        out = torch.empty_like(x)
+        _C.check(lib.neosr_leaky_relu(x.data_ptr(), None, slope, out.data_ptr(), x.numel(), _st()), "neosr_leaky_relu")
+        ctx.save_for_backward(x)
+        ctx.slope = slope
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _C.load()
+        (x,) = ctx.saved_tensors
+        g = g.contiguous()
+        out = torch.empty_like(x)
+        _C.check(lib.neosr_leaky_relu(x.data_ptr(), g.data_ptr(), ctx.slope, out.data_ptr(), x.numel(), _st()),
+                 "neosr_leaky_relu")
+        return out, None
+
+
+# --------------------------------------------------------------------------------------------
+# spectral norm
+# --------------------------------------------------------------------------------------------
+class SpectralNorm(torch.autograd.Function):
+    """w = W / sigma(W; u, v) with one in-place power iteration of the (u, v) buffers in train mode
+    (torch.nn.utils.spectral_norm semantics: u, v are constants for the gradient)."""
+
+    @staticmethod
+    def forward(ctx, w_orig, u, v, training, eps):
+        lib = _C.load()
+        w_orig = _C.require_device(w_orig, "weight_orig").contiguous()
+        rows, cols = w_orig.shape[0], w_orig[0].numel()
+        w = torch.empty_like(w_orig)
+        sigma = torch.empty(1, device=w.device, dtype=torch.float32)
+        scratch = torch.empty(rows, device=w.device, dtype=torch.float32)
+        _C.check(lib.neosr_spectral_norm_fwd(w_orig.data_ptr(), u.data_ptr(), v.data_ptr(), w.data_ptr(),
+                                             sigma.data_ptr(), scratch.data_ptr(), rows, cols, int(training),
+                                             eps, _st()), "neosr_spectral_norm_fwd")
+        # u, v advance with every train-mode forward: keep this call's values for the backward
+        ctx.save_for_backward(w, u.clone(), v.clone(), sigma)
+        return w
+
+    @staticmethod
+    def backward(ctx, gw):
+        lib = _C.load()
+        w, u, v, sigma = ctx.saved_tensors
+        gw = gw.contiguous()
+        rows, cols = w.shape[0], w[0].numel()
+        out = torch.empty_like(w)
+        ws = torch.empty(1032, device=w.device, dtype=torch.float32)
+        _C.check(lib.neosr_spectral_norm_bwd(gw.data_ptr(), w.data_ptr(), u.data_ptr(), v.data_ptr(),
+                                             sigma.data_ptr(), out.data_ptr(), ws.data_ptr(), rows, cols, _st()),
+                 "neosr_spectral_norm_bwd")
+        return out, None, None, None, None
+
+
+# --------------------------------------------------------------------------------------------
+# losses
+# --------------------------------------------------------------------------------------------
+class ChcLoss(torch.autograd.Function):
+    """w * mean(clamp(charbonnier|l1((a-b)*pre), lo, hi)) (chc_loss with loss_lambda = 0)."""
+
+    @staticmethod
+    def forward(ctx, a, b, pre, huber, lo, hi, weight):
+        lib = _C.load()
+        a = _C.require_device(a, "pred").contiguous()
+        b = _C.require_device(b, "target").contiguous()
+        if a.shape != b.shape:
+            raise _C.NeosrAmdError(f"chc_loss: shape mismatch {tuple(a.shape)} vs {tuple(b.shape)}")
+        out = torch.empty((), device=a.device, dtype=torch.float32)
+        ws = torch.empty(1024, device=a.device, dtype=torch.float32)
+        _C.check(lib.neosr_chc_loss_fwd(a.data_ptr(), b.data_ptr(), a.numel(), pre, int(huber), lo, hi, weight,
+                                        out.data_ptr(), ws.data_ptr(), _st()), "neosr_chc_loss_fwd")
+        ctx.save_for_backward(a, b)
+        ctx.cfg = (pre, int(huber), lo, hi, weight)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _C.load()
+        a, b = ctx.saved_tensors
+        pre, huber, lo, hi, weight = ctx.cfg
+        g = g.contiguous().float()
+        ga = torch.empty_like(a)
+        _C.check(lib.neosr_chc_loss_bwd(a.data_ptr(), b.data_ptr(), g.data_ptr(), a.numel(), pre, huber, lo, hi,
+                                        weight, ga.data_ptr(), 0, _st()), "neosr_chc_loss_bwd")
+        gb = -ga if ctx.needs_input_grad[1] else None
+        return ga, gb, None, None, None, None, None
+
+
+class BceLogits(torch.autograd.Function):
+    """weight * BCEWithLogits(x, constant target); also returns mean(x)."""
+
+    @staticmethod
+    def forward(ctx, x, target, weight):
+        lib = _C.load()
+        x = _C.require_device(x, "logits").contiguous()
+        out = torch.empty((), device=x.device, dtype=torch.float32)
+        mean = torch.empty((), device=x.device, dtype=torch.float32)
+        ws = torch.empty(2048, device=x.device, dtype=torch.float32)
+        _C.check(lib.neosr_bce_logits_fwd(x.data_ptr(), x.numel(), target, weight, out.data_ptr(),
+                                          mean.data_ptr(), ws.data_ptr(), _st()), "neosr_bce_logits_fwd")
+        ctx.save_for_backward(x)
+        ctx.cfg = (target, weight)
+        ctx.mark_non_differentiable(mean)
+        return out, mean
+
+    @staticmethod
+    def backward(ctx, g, _gmean):
+        lib = _C.load()
+        (x,) = ctx.saved_tensors
+        target, weight = ctx.cfg
+        g = g.contiguous().float()
+        gx = torch.empty_like(x)
+        _C.check(lib.neosr_bce_logits_bwd(x.data_ptr(), g.data_ptr(), x.numel(), target, weight, gx.data_ptr(),
+                                          _st()), "neosr_bce_logits_bwd")
+        return gx, None, None

@@ -9,6 +9,7 @@ from __future__ import annotations
 
 from torch import Tensor, nn
 
+from neosr_amd.hip.layers import ChcLoss
 from neosr_amd.hip.nets import L1LossFunction
 from neosr_amd.utils.registry import LOSS_REGISTRY
 
@@ -32,3 +33,29 @@ class L1Loss(nn.Module):
 
     def forward(self, pred: Tensor, target: Tensor, **kwargs) -> Tensor:  # noqa: ARG002
         return L1LossFunction.apply(pred, target, self.loss_weight)
+
+
+@LOSS_REGISTRY.register()
+class chc_loss(nn.Module):
+    """Clipped pseudo-Huber (+ cosine term) loss (basic_loss.py:132-219).
+
+    `loss_weight * mean(clamp(t + loss_lambda * (1 - cos_sim).mean(), clip_min, clip_max))` with
+    `t = |d|` ("l1") or `sqrt(d^2 + 1e-12)` ("huber").  The HIP kernels implement loss_lambda = 0 —
+    the value every call site on the path uses (the class default and vgg_perceptual_loss.py:144)."""
+
+    def __init__(self, loss_weight: float = 1.0, reduction: str = "mean", criterion: str = "huber",
+                 loss_lambda: float = 0, clip_min: float = 0.003921, clip_max: float = 0.996078) -> None:
+        super().__init__()
+        if reduction not in {"none", "mean", "sum"}:
+            msg = f"Unsupported reduction mode: {reduction}. Supported ones are: {_reduction_modes}"
+            raise ValueError(msg)
+        if criterion not in {"l1", "huber"}:
+            raise NotImplementedError(f"{criterion} not implemented.")
+        if loss_lambda != 0:
+            raise NotImplementedError("chc_loss: the cosine-similarity term (loss_lambda != 0) has no HIP kernel yet")
+        self.loss_weight, self.criterion = loss_weight, criterion
+        self.loss_lambda, self.clip_min, self.clip_max = loss_lambda, clip_min, clip_max
+
+    def forward(self, pred: Tensor, target: Tensor, **kwargs) -> Tensor:  # noqa: ARG002
+        return ChcLoss.apply(pred, target, 1.0, self.criterion == "huber", float(self.clip_min),
+                             float(self.clip_max), float(self.loss_weight))

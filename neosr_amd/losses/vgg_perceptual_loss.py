@@ -1,0 +1,44 @@
+"""``vgg_perceptual_loss`` (drop-in for neosr/losses/vgg_perceptual_loss.py:57-242, non-patch path):
+`loss_weight * sum_k w_k * chc(f_k(x)/10, f_k(gt)/10)` with the chc criterion at
+(lambda=0, clip 0..1) exactly as the reference builds it (:143-144, 232-236).  The /10 is folded
+into the loss kernel (`pre = 0.1`); features of `gt` are computed without a graph."""
+
+from __future__ import annotations
+
+import torch
+from torch import Tensor, nn
+
+from neosr_amd.archs.vgg_arch import VGGFeatureExtractor
+from neosr_amd.hip.layers import ChcLoss
+from neosr_amd.utils.registry import LOSS_REGISTRY
+
+
+@LOSS_REGISTRY.register()
+class vgg_perceptual_loss(nn.Module):
+    def __init__(self, layer_weights: dict[str, float] | None = None, vgg_type: str = "vgg19",
+                 use_input_norm: bool = True, range_norm: bool = False, loss_weight: float = 1.0,
+                 criterion: str = "chc", patchloss: bool = False, ipk: bool = False,
+                 patch_weight: float = 1.0, **kwargs) -> None:  # noqa: ARG002
+        super().__init__()
+        if patchloss is False and ipk is True:
+            raise ValueError("Please enable PatchLoss to use IPK.")
+        if patchloss:
+            raise NotImplementedError("PatchLoss / IPK are off by default and outside the hot path")
+        if criterion != "chc":
+            raise NotImplementedError(f"criterion '{criterion}': only 'chc' (the default) has a HIP kernel")
+        self.loss_weight = loss_weight
+        self.layer_weights = layer_weights if layer_weights is not None else {
+            "conv1_2": 0.1, "conv2_2": 0.1, "conv3_4": 1.0, "conv4_4": 1.0, "conv5_4": 1.0}
+        self.vgg = VGGFeatureExtractor(layer_name_list=list(self.layer_weights.keys()), vgg_type=vgg_type,
+                                       use_input_norm=use_input_norm, range_norm=range_norm)
+
+    def forward(self, x: Tensor, gt: Tensor) -> Tensor:
+        fx = self.vgg.features_nhwc(x)
+        with torch.no_grad():
+            fg = self.vgg.features_nhwc(gt.detach())
+        total = None
+        for k in fx:
+            # chc_loss(loss_lambda=0, clip_min=0, clip_max=1, criterion="huber") on features / 10
+            term = ChcLoss.apply(fx[k], fg[k], 0.1, True, 0.0, 1.0, float(self.layer_weights[k]))
+            total = term if total is None else total + term
+        return total * self.loss_weight

@@ -62,8 +62,7 @@ class EMAModel(nn.Module):
 
 
 _UNSUPPORTED_TRAIN_FLAGS = ("sam", "eco", "wavelet_guided", "match_lq_colors")
-_UNSUPPORTED_LOSSES = ("mssim_opt", "consistency_opt", "perceptual_opt", "dists_opt", "gan_opt",
-                       "ldl_opt", "ff_opt", "gw_opt")
+_UNSUPPORTED_LOSSES = ("mssim_opt", "consistency_opt", "dists_opt", "ldl_opt", "ff_opt", "gw_opt")
 
 
 @MODEL_REGISTRY.register()
@@ -76,13 +75,18 @@ class image(base):
         self.net_g = self.model_to_device(self.net_g)
         self.net_d = self.opt.get("network_d", None)
         if self.net_d is not None:
-            msg = "network_d (GAN training) is the next row of the build plan; not in this round"
-            raise NotImplementedError(msg)
+            self.net_d = build_network(self.opt["network_d"])
+            self.net_d = self.model_to_device(self.net_d)
         load_path = self.opt["path"].get("pretrain_network_g", None)
         if load_path is not None:
             self.load_network(self.net_g, load_path, self.opt["path"].get("param_key_g"),
                               self.opt["path"].get("strict_load_g", True))
             flatten_parameters_(self.net_g)
+        load_path = self.opt["path"].get("pretrain_network_d", None)
+        if load_path is not None and self.net_d is not None:
+            self.load_network(self.net_d, load_path, self.opt["path"].get("param_key_d"),
+                              self.opt["path"].get("strict_load_d", True))
+            flatten_parameters_(self.net_d)
         if self.is_train:
             self.init_training_settings()
 
@@ -107,6 +111,8 @@ class image(base):
         self.setup_optimizers()
         self.setup_schedulers()
         self.net_g.train()
+        if self.net_d is not None:
+            self.net_d.train()
 
         self.scale = self.opt["scale"]
         ds = self.opt["datasets"]["train"]
@@ -120,18 +126,30 @@ class image(base):
         self.n_accumulated = 0
         self.accum_iters = ds.get("accumulate", 1) or 1
 
-        if train_opt.get("pixel_opt"):
-            self.cri_pix = build_loss(train_opt["pixel_opt"]).to(self.device)
-        else:
-            self.cri_pix = None
+        def crit(key):
+            return build_loss(train_opt[key]).to(self.device) if train_opt.get(key) else None
+
+        self.cri_pix = crit("pixel_opt")
+        self.cri_perceptual = crit("perceptual_opt")
+        self.cri_gan = crit("gan_opt")
         self.gradclip = train_opt.get("grad_clip", True)
 
-        if self.cri_pix is None:
+        optim_d = train_opt.get("optim_d", None)
+        if self.cri_pix is None and self.cri_perceptual is None:
             logger.error(f"{tc.red}Both pixel/mssim and perceptual losses are None. "
                          f"Please enable at least one.{tc.end}")
             sys.exit(1)
-        if train_opt.get("optim_d") is not None:
+        if self.net_d is None and optim_d is not None:
             logger.error(f"{tc.red}Please set a discriminator in network_d or disable optim_d.{tc.end}")
+            sys.exit(1)
+        if self.net_d is not None and optim_d is None:
+            logger.error(f"{tc.red}Please set an optimizer for the discriminator or disable network_d.{tc.end}")
+            sys.exit(1)
+        if self.net_d is not None and self.cri_gan is None:
+            logger.error(f"{tc.red}Discriminator needs GAN to be enabled.{tc.end}")
+            sys.exit(1)
+        if self.net_d is None and self.cri_gan is not None:
+            logger.error(f"{tc.red}GAN requires a discriminator to be set.{tc.end}")
             sys.exit(1)
 
     def setup_optimizers(self) -> None:
@@ -148,6 +166,12 @@ class image(base):
         og.pop("schedule_free", None)
         self.optimizer_g = self.get_optimizer(optim_type, optim_params, **og)
         self.optimizers.append(self.optimizer_g)
+        if self.net_d is not None:
+            od = dict(train_opt["optim_d"])
+            optim_type = od.pop("type")
+            od.pop("schedule_free", None)
+            self.optimizer_d = self.get_optimizer(optim_type, list(self.net_d.parameters()), **od)
+            self.optimizers.append(self.optimizer_d)
 
     # ------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -156,10 +180,32 @@ class image(base):
         if "gt" in data:
             self.gt = data["gt"].to(self.device, non_blocking=True)
 
+    def _sync_grads(self, optimizer) -> None:
+        """data-parallel exchange + clip request for one network (after its backward)"""
+        params = optimizer.param_groups[0]["params"]
+        if self.opt["dist"]:
+            flat = flat_grad_of(params)
+            if flat is None:
+                flat = torch.cat([p.grad.reshape(-1) for p in params])
+                off = 0
+                for p in params:
+                    p.grad = flat[off : off + p.numel()].view_as(p)
+                    off += p.numel()
+            allreduce_flat_(flat)
+            optimizer.set_grad_scale(1.0 / self.opt["world_size"])
+        if self.gradclip:
+            optimizer.set_clip(1.0)
+
     def closure(self, current_iter: int):  # noqa: ARG002
+        """image.py:427-625: G forward, weighted losses, G backward; then D real/fake forward+backward."""
+        if self.net_d is not None:
+            for p in self.net_d.parameters():
+                p.requires_grad = False
+
         self.n_accumulated += 1
         if self.n_accumulated >= self.accum_iters:
             self.n_accumulated = 0
+        step_now = self.n_accumulated % self.accum_iters == 0
 
         self.output = self.net_g(self.lq)
 
@@ -169,24 +215,39 @@ class image(base):
             l_g_pix = self.cri_pix(self.output, self.gt)
             l_g_total = l_g_total + l_g_pix
             loss_dict["l_g_pix"] = l_g_pix
+        if self.cri_perceptual:
+            l_g_percep = self.cri_perceptual(self.output, self.gt)
+            l_g_total = l_g_total + l_g_percep
+            loss_dict["l_g_percep"] = l_g_percep
+        if self.cri_gan:
+            fake_g_pred = self.net_d(self.output)
+            l_g_gan = self.cri_gan(fake_g_pred, target_is_real=True, is_disc=False)
+            l_g_total = l_g_total + l_g_gan
+            loss_dict["l_g_gan"] = l_g_gan
         loss_dict["l_g_total"] = l_g_total
         l_g_total = l_g_total / self.accum_iters
         l_g_total.backward()
+        if step_now:
+            self._sync_grads(self.optimizer_g)
 
-        if self.n_accumulated % self.accum_iters == 0:
-            params = self.optimizer_g.param_groups[0]["params"]
-            if self.opt["dist"]:
-                flat = flat_grad_of(params)
-                if flat is None:
-                    flat = torch.cat([p.grad.reshape(-1) for p in params])
-                    off = 0
-                    for p in params:
-                        p.grad = flat[off : off + p.numel()].view_as(p)
-                        off += p.numel()
-                allreduce_flat_(flat)
-                self.optimizer_g.set_grad_scale(1.0 / self.opt["world_size"])
-            if self.gradclip:
-                self.optimizer_g.set_clip(1.0)
+        if self.net_d is not None:
+            for p in self.net_d.parameters():
+                p.requires_grad = True
+            if self.cri_gan:
+                # both forwards first, then both backwards (image.py:559,574,593-594)
+                real_d_pred = self.net_d(self.gt)
+                l_d_real = self.cri_gan(real_d_pred, target_is_real=True, is_disc=True) / self.accum_iters
+                loss_dict["l_d_real"] = l_d_real
+                loss_dict["out_d_real"] = self.cri_gan.last_mean
+                fake_d_pred = self.net_d(self.output.detach())
+                l_d_fake = self.cri_gan(fake_d_pred, target_is_real=False, is_disc=True) / self.accum_iters
+                loss_dict["l_d_fake"] = l_d_fake
+                loss_dict["out_d_fake"] = self.cri_gan.last_mean
+                loss_dict["l_d_total"] = (l_d_real + l_d_fake) / 2
+                l_d_real.backward()
+                l_d_fake.backward()
+            if step_now:
+                self._sync_grads(self.optimizer_d)
 
         self.reduce_loss_dict(loss_dict)
         return l_g_total
@@ -200,7 +261,11 @@ class image(base):
             if self.ema > 0:
                 self.optimizer_g.set_ema(self.net_g_ema.arena(), self.ema, self.net_g_ema.first)
             self.optimizer_g.step()
+            if self.net_d is not None:
+                self.optimizer_d.step()
             self.optimizer_g.zero_grad(set_to_none=True)
+            if self.net_d is not None:
+                self.optimizer_d.zero_grad(set_to_none=True)
             if self.ema > 0:
                 self.net_g_ema.mark_updated()
 
