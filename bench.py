@@ -119,6 +119,9 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16, help="per-GPU batch (BASELINE configs[1]: 16)")
     ap.add_argument("--arch", default="esrgan", choices=["esrgan", "esrgan_small", "compact"])
+    ap.add_argument("--workload", default="paired_l1", choices=["paired_l1", "otf_gan"],
+                    help="paired_l1 = BASELINE configs[1] (headline); otf_gan = configs[2]: otf degradation + "
+                         "unet D + VGG perceptual + GAN (use --batch 32)")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU-oracle timing (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -144,12 +147,29 @@ def main() -> None:
     logging.getLogger("neosr").setLevel(logging.WARNING)
 
     opt = make_opt(args.batch, world, rank, args.arch)
+    if args.workload == "otf_gan":
+        from tools.bench_degrade import DEG_TABLE
+        opt["model_type"] = "otf"
+        opt["degradations"] = dict(DEG_TABLE)
+        opt["datasets"]["train"].update({"type": "otf", "queue_size": 180})
+        opt["network_d"] = {"type": "unet"}
+        opt["train"]["optim_d"] = {"type": "adamw", "lr": 1e-4, "betas": [0.9, 0.99], "weight_decay": 0.0}
+        opt["train"]["perceptual_opt"] = {"type": "vgg_perceptual_loss", "loss_weight": 0.5, "criterion": "chc"}
+        opt["train"]["gan_opt"] = {"type": "gan_loss", "gan_type": "bce", "loss_weight": 0.3}
     set_global_opt(opt)
     torch.manual_seed(1024 + rank)
     model = build_model(opt)
     dev = torch.device("cuda")
     B = args.batch
-    batch = {"lq": torch.rand(B, 3, 64, 64, device=dev), "gt": torch.rand(B, 3, 256, 256, device=dev)}
+    if args.workload == "otf_gan":
+        import random
+        import numpy as np
+        from neosr_amd.data.degradations import KernelSampler
+        random.seed(1024 + rank)
+        ks = KernelSampler(np.random.default_rng(1024 + rank)).otf_kernel_batch(opt["degradations"], B)
+        batch = {"gt": torch.rand(B, 3, 512, 512, device=dev), **{k: v.to(dev) for k, v in ks.items()}}
+    else:
+        batch = {"lq": torch.rand(B, 3, 64, 64, device=dev), "gt": torch.rand(B, 3, 256, 256, device=dev)}
 
     def step(it: int) -> None:
         model.feed_data(batch)
@@ -237,7 +257,10 @@ def main() -> None:
         "final_l_g_pix": loss,
         "roofline": roofline,
     }
-    if world == 1 and args.cpu_budget > 0:
+    if args.workload == "otf_gan":
+        out["config"]["workload"] = (f"{args.arch} RRDB x4 + unet-SN D + VGG19 perceptual (random weights) + GAN, "
+                                     f"otf degradation from 512x512 GT, AdamW x2, batch={B}/GPU (BASELINE configs[2])")
+    if world == 1 and args.cpu_budget > 0 and args.workload == "paired_l1":
         out["cpu_baseline"] = cpu_baseline(args.arch, args.cpu_budget)
     else:
         out["cpu_baseline"] = None

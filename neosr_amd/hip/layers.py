@@ -141,20 +141,43 @@ def expand_4x4s2_weight(w: torch.Tensor) -> torch.Tensor:
     """(N, C, 4, 4) stride-2/pad-1 kernel -> the (N, 4C, 3, 3) kernel acting on the space-to-depth
     tensor: tap ky -> (block row, sub row) = (0,1), (1,0), (1,1), (2,0); same for kx.  A single
     differentiable gather (index plumbing on the weight, 20 of 36 entries are structural zeros)."""
-    N, C_, _, _ = w.shape
-    key = (N, C_, w.device)
-    idx = _S2D_INDEX.get(key)
-    if idx is None:
+    return _Expand4x4s2.apply(w)
+
+
+def _s2d_indices(N: int, C_: int, device) -> tuple[torch.Tensor, torch.Tensor]:
+    """(fwd, inv): expanded[i] = cat(w, 0)[fwd[i]];  w_grad[j] = expanded_grad[inv[j]]"""
+    key = (N, C_, device)
+    hit = _S2D_INDEX.get(key)
+    if hit is None:
         m = [(0, 1), (1, 0), (1, 1), (2, 0)]
         src = torch.full((N, 4, C_, 3, 3), N * C_ * 16, dtype=torch.long)  # -> appended zero
         base = torch.arange(N * C_ * 16).view(N, C_, 4, 4)
+        dst = torch.arange(N * 4 * C_ * 9).view(N, 4, C_, 3, 3)
+        inv = torch.empty(N, C_, 4, 4, dtype=torch.long)
         for ky, (by, dy) in enumerate(m):
             for kx, (bx, dx) in enumerate(m):
                 src[:, dy * 2 + dx, :, by, bx] = base[:, :, ky, kx]
-        idx = src.view(-1).to(w.device)
-        _S2D_INDEX[key] = idx
-    flat = torch.cat((w.reshape(-1), w.new_zeros(1)))
-    return flat[idx].view(N, 4 * C_, 3, 3)
+                inv[:, :, ky, kx] = dst[:, dy * 2 + dx, :, by, bx]
+        hit = (src.view(-1).to(device), inv.view(-1).to(device))
+        _S2D_INDEX[key] = hit
+    return hit
+
+
+class _Expand4x4s2(torch.autograd.Function):
+    """weight scatter expressed as a gather in BOTH directions (torch's generic index backward is a
+    serialised scatter-add: 19 ms per call for the 512x256x4x4 kernel)."""
+
+    @staticmethod
+    def forward(ctx, w):
+        N, C_ = w.shape[:2]
+        fwd, inv = _s2d_indices(N, C_, w.device)
+        ctx.inv, ctx.shape = inv, w.shape
+        flat = torch.cat((w.reshape(-1), w.new_zeros(1)))
+        return flat.index_select(0, fwd).view(N, 4 * C_, 3, 3)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.reshape(-1).index_select(0, ctx.inv).view(ctx.shape)
 
 
 def conv4x4s2(x, w, b=None, act=ACT_NONE, slope=0.0):

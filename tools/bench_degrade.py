@@ -18,6 +18,19 @@ from neosr_amd.hip import degrade as D  # noqa: E402
 
 DEV = "cuda"
 
+# options/train_esrgan_otf.toml [degradations] of the reference (values only)
+_K = ["iso", "aniso", "generalized_iso", "generalized_aniso", "plateau_iso", "plateau_aniso"]
+_P = [0.45, 0.25, 0.12, 0.03, 0.12, 0.03]
+DEG_TABLE = {"resize_prob": [0.3, 0.4, 0.3], "resize_range": [0.5, 1.5], "gaussian_noise_prob": 0.2,
+             "noise_range": [0, 2], "poisson_scale_range": [0.05, 0.25], "gray_noise_prob": 0.1,
+             "jpeg_range": [40, 95], "second_blur_prob": 0.4, "resize_prob2": [0.3, 0.4, 0.3],
+             "resize_range2": [0.3, 1.5], "gaussian_noise_prob2": 0.2, "noise_range2": [0, 2],
+             "poisson_scale_range2": [0.05, 0.1], "gray_noise_prob2": 0.1, "jpeg_range2": [35, 95],
+             "kernel_list": _K, "kernel_prob": _P, "sinc_prob": 0.1, "blur_sigma": [0.2, 3],
+             "betag_range": [0.5, 4], "betap_range": [1, 2], "kernel_list2": _K, "kernel_prob2": _P,
+             "sinc_prob2": 0.1, "blur_sigma2": [0.2, 1.5], "betag_range2": [0.5, 4], "betap_range2": [1, 2],
+             "final_sinc_prob": 0.8}
+
 
 def timeit(fn, iters=10, warm=2):
     for _ in range(warm):
@@ -78,7 +91,8 @@ def main():
     from neosr_amd.utils.options import set_global_opt
     import logging
     logging.getLogger("neosr").setLevel(logging.WARNING)
-    deg = {"resize_prob": [0.3, 0.4, 0.3], "resize_range": [0.5, 1.5], "gaussian_noise_prob": 0.2,
+    deg = DEG_TABLE
+    _unused = {"resize_prob": [0.3, 0.4, 0.3], "resize_range": [0.5, 1.5], "gaussian_noise_prob": 0.2,
            "noise_range": [0, 2], "poisson_scale_range": [0.05, 0.25], "gray_noise_prob": 0.1,
            "jpeg_range": [40, 95], "second_blur_prob": 0.4, "resize_prob2": [0.3, 0.4, 0.3],
            "resize_range2": [0.3, 1.5], "gaussian_noise_prob2": 0.2, "noise_range2": [0, 2],
