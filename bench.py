@@ -45,6 +45,8 @@ def make_opt(batch: int, world: int, rank: int, arch: str) -> dict:
         "esrgan": {"type": "esrgan"},
         "esrgan_small": {"type": "esrgan", "num_block": 2, "num_feat": 32, "num_grow_ch": 16},
         "compact": {"type": "compact"},
+        "swinir_small": {"type": "swinir_small"},
+        "swinir_medium": {"type": "swinir_medium"},
     }
     return {
         "name": f"bench_{arch}", "model_type": "image", "scale": 4, "manual_seed": 1024,
@@ -118,10 +120,11 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16, help="per-GPU batch (BASELINE configs[1]: 16)")
-    ap.add_argument("--arch", default="esrgan", choices=["esrgan", "esrgan_small", "compact"])
-    ap.add_argument("--workload", default="paired_l1", choices=["paired_l1", "otf_gan"],
+    ap.add_argument("--arch", default="esrgan", choices=["esrgan", "esrgan_small", "compact", "swinir_small", "swinir_medium"])
+    ap.add_argument("--workload", default="paired_l1", choices=["paired_l1", "otf_gan", "swinir_percep"],
                     help="paired_l1 = BASELINE configs[1] (headline); otf_gan = configs[2]: otf degradation + "
-                         "unet D + VGG perceptual + GAN (use --batch 32)")
+                         "unet D + VGG perceptual + GAN (use --batch 32); swinir_percep = configs[3]: "
+                         "swinir_medium, L1 + VGG perceptual (use --batch 8)")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU-oracle timing (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -146,7 +149,11 @@ def main() -> None:
     import logging
     logging.getLogger("neosr").setLevel(logging.WARNING)
 
+    if args.workload == "swinir_percep" and not args.arch.startswith("swinir"):
+        args.arch = "swinir_medium"
     opt = make_opt(args.batch, world, rank, args.arch)
+    if args.workload == "swinir_percep":
+        opt["train"]["perceptual_opt"] = {"type": "vgg_perceptual_loss", "loss_weight": 1.0, "criterion": "chc"}
     if args.workload == "otf_gan":
         from tools.bench_degrade import DEG_TABLE
         opt["model_type"] = "otf"
@@ -200,7 +207,7 @@ def main() -> None:
     loss = model.get_current_log().get("l_g_pix")
 
     roofline = None
-    if not args.no_roofline and rank == 0:
+    if not args.no_roofline and rank == 0 and not args.arch.startswith("swinir"):
         lib = _C.load()
         lib.neosr_prof_enable(1)
         for _ in range(max(1, min(args.steps, 3))):
@@ -260,7 +267,10 @@ def main() -> None:
     if args.workload == "otf_gan":
         out["config"]["workload"] = (f"{args.arch} RRDB x4 + unet-SN D + VGG19 perceptual (random weights) + GAN, "
                                      f"otf degradation from 512x512 GT, AdamW x2, batch={B}/GPU (BASELINE configs[2])")
-    if world == 1 and args.cpu_budget > 0 and args.workload == "paired_l1":
+    if args.workload == "swinir_percep":
+        out["config"]["workload"] = (f"{args.arch} x4, paired 64x64 LR synthetic, L1 + VGG19 perceptual (random weights), "
+                                     f"window-attention path, AdamW + grad-clip + EMA, batch={B}/GPU (BASELINE configs[3])")
+    if world == 1 and args.cpu_budget > 0 and args.workload == "paired_l1" and not args.arch.startswith("swinir"):
         out["cpu_baseline"] = cpu_baseline(args.arch, args.cpu_budget)
     else:
         out["cpu_baseline"] = None

@@ -280,6 +280,74 @@ int neosr_spectral_norm_bwd(const float* gw, const float* w, const float* u, con
                             const float* sigma, float* g_orig, float* workspace, int32_t rows,
                             int32_t cols, void* stream);
 
+/* transformer generators (SwinIR) ---------------------------------------------------------------
+ * Tokens are channels-last pixels: the (B, H*W, C) token matrix of neosr/archs/swinir_arch.py IS the
+ * (B, H, W, C) activation buffer, so PatchEmbed/PatchUnEmbed (swinir_arch.py:666-765) cost nothing. */
+#define NEOSR_GEMM_NT 0 /* C[M,N] = A[M,K] B[N,K]^T   nn.Linear forward  (B = weight)          */
+#define NEOSR_GEMM_NN 1 /* C[M,N] = A[M,K] B[K,N]     nn.Linear backward-data (A = dY, B = W)   */
+#define NEOSR_GEMM_TN 2 /* C[M,N] = A[K,M]^T B[K,N]   nn.Linear backward-weight (A = dY, B = X) */
+/* fp32 MFMA GEMM for the Linear layers (swinir_arch.py:15-38 Mlp, :139-143,209 qkv/proj).
+ * NT/NN epilogue, in this order: + bias[n]; aux_out = value (pre-activation kept for backward);
+ * exact-erf GELU (gelu=1); * GELU'(aux_in[m,n]); * row_scale[m / rows_per_scale] (DropPath);
+ * + res[m,n].  TN: fixed-order split-K through `workspace` (neosr_gemm_workspace_bytes), dense C,
+ * C = accumulate ? C + result : result. */
+typedef struct neosr_gemm_desc {
+  const float* A;
+  const float* B;
+  float* C;
+  const float* bias;
+  const float* res;
+  const float* aux_in;
+  float* aux_out;
+  const float* row_scale;
+  float* workspace;
+  int32_t M, N, K, lda, ldb, ldc, ldres, ldaux, rows_per_scale, mode, gelu, accumulate;
+} neosr_gemm_desc;
+int64_t neosr_gemm_workspace_bytes(const neosr_gemm_desc* d);
+int neosr_gemm(const neosr_gemm_desc* d, void* stream);
+/* out[c] (+)= sum_r x[r, c]  (bias gradients); workspace >= 256*cols floats. */
+int neosr_colsum(const float* x, float* out, float* workspace, int32_t rows, int32_t cols, int32_t ld,
+                 int32_t accumulate, void* stream);
+/* nn.LayerNorm(C) over the last dim, eps 1e-5, biased variance (swinir_arch.py:284,297,960,1035).
+ * fwd keeps (mean, rstd) per row in `stats` (2*rows floats).  bwd: dx, and dgamma/dbeta (+)= via a
+ * fixed-order two-stage column reduction; workspace >= 2*512*C floats.  C <= 512. */
+int neosr_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stats,
+                        int64_t rows, int32_t C, float eps, void* stream);
+int neosr_layernorm_bwd(const float* dy, const float* x, const float* stats, const float* gamma,
+                        float* dx, float* dgamma, float* dbeta, float* workspace, int64_t rows,
+                        int32_t C, int32_t accumulate, void* stream);
+/* (Shifted-)window multi-head self-attention (swinir_arch.py:150-212,343-392) on the fused
+ * qkv matrix [B*H*W, 3*C] in IMAGE order: torch.roll, window_partition/reverse and the head split are
+ * folded into addressing; relative-position bias is gathered from `rpb_table` ((2ws-1)^2, heads) by
+ * the analytic index; the shifted-window mask (0 / -100) is computed analytically (the reference
+ * rebuilds it 18x per forward).  One workgroup per (window, head); QK^T and PV on fp32 MFMA.
+ * fwd: out [B*H*W, C] image order, lse [B*nW*heads*N] kept for backward.
+ * bwd: dqkv [B*H*W, 3*C] (every element written once), d_rpb_table (+)= (fixed-order reduction
+ * over windows; workspace >= (B*nW + 256)*heads*(2ws-1)^2 floats). */
+typedef struct neosr_wattn_desc {
+  const float* qkv;
+  const float* rpb_table;
+  float* out;
+  float* lse;
+  const float* dout;   /* bwd */
+  float* dqkv;         /* bwd */
+  float* d_rpb_table;  /* bwd */
+  float* workspace;    /* bwd */
+  int32_t B, H, W, C, heads, ws, shift, accumulate_rpb;
+  float scale;
+} neosr_wattn_desc;
+int neosr_window_attention_fwd(const neosr_wattn_desc* d, void* stream);
+int neosr_window_attention_bwd(const neosr_wattn_desc* d, void* stream);
+/* nn.PixelShuffle(r) on channels-last tensors (swinir_arch.py:782-783): in (B,H,W,C*r*r) ->
+ * out (B,H*r,W*r,C); inverse=1: the adjoint. */
+int neosr_pixel_shuffle_nhwc(const float* in, float* out, int32_t B, int32_t H, int32_t W, int32_t C,
+                             int32_t r, int32_t inverse, void* stream);
+/* out = (in + shift) * scale elementwise, NCHW<->NHWC not involved (swinir_arch.py:1041,1078). */
+int neosr_affine(const float* in, float* out, int64_t n, float shift, float scale, void* stream);
+/* DropPath (archs/arch_util.py:118-133): out[m, :] = in[m, :] * scale[m / rows_per_scale]. */
+int neosr_row_scale(const float* in, const float* scale, float* out, int64_t rows, int32_t cols,
+                    int32_t rows_per_scale, void* stream);
+
 /* opt-in profiler ------------------------------------------------------------------------------
  * HIP events around every conv-class launch on the launch stream (classes: 0 conv fwd, 1 conv
  * dgrad, 2 conv wgrad, 3 wgrad reduce).  Used by bench.py's roofline pass only.  collect()

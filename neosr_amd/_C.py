@@ -139,6 +139,26 @@ class CompactCfg(C.Structure):
     ]
 
 
+class GemmDesc(C.Structure):
+    """neosr_gemm_desc"""
+
+    _fields_ = [(n, C.c_void_p) for n in ("A", "B", "C", "bias", "res", "aux_in", "aux_out", "row_scale", "workspace")] + [
+        (n, C.c_int32)
+        for n in ("M", "N", "K", "lda", "ldb", "ldc", "ldres", "ldaux", "rows_per_scale", "mode", "gelu", "accumulate")
+    ]
+
+
+class WattnDesc(C.Structure):
+    """neosr_wattn_desc"""
+
+    _fields_ = (
+        [(n, C.c_void_p) for n in ("qkv", "rpb_table", "out", "lse", "dout", "dqkv", "d_rpb_table", "workspace")]
+        + [(n, C.c_int32) for n in ("B", "H", "W", "C", "heads", "ws", "shift", "accumulate_rpb")]
+        + [("scale", C.c_float)]
+    )
+
+
+GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_PRELU = 0, 1, 2, 3
 CONV_FWD, CONV_DGRAD = 0, 1
 
@@ -195,6 +215,16 @@ SIGNATURES: dict[str, tuple] = {
     "neosr_bce_logits_bwd": (C.c_int, [_vp, _vp, _i64, _f32, _f32, _vp, _vp]),
     "neosr_spectral_norm_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp]),
     "neosr_spectral_norm_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
+    "neosr_gemm_workspace_bytes": (_i64, [C.POINTER(GemmDesc)]),
+    "neosr_gemm": (C.c_int, [C.POINTER(GemmDesc), _vp]),
+    "neosr_colsum": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "neosr_layernorm_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp]),
+    "neosr_layernorm_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
+    "neosr_window_attention_fwd": (C.c_int, [C.POINTER(WattnDesc), _vp]),
+    "neosr_window_attention_bwd": (C.c_int, [C.POINTER(WattnDesc), _vp]),
+    "neosr_pixel_shuffle_nhwc": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "neosr_affine": (C.c_int, [_vp, _vp, _i64, _f32, _f32, _vp]),
+    "neosr_row_scale": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     "neosr_prof_enable": (C.c_int, [C.c_int]),
     "neosr_prof_collect": (
         C.c_int,

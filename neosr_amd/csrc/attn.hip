@@ -1,0 +1,471 @@
+// attn.hip — LayerNorm and (shifted-)window multi-head self-attention of SwinIR for gfx950, plus
+// the channels-last PixelShuffle of its upsampler.
+//
+// Window attention (neosr/archs/swinir_arch.py:150-212 WindowAttention.forward, :343-392
+// SwinTransformerBlock.forward): window 8x8 -> N = 64 tokens, head_dim <= 32.  One 256-thread
+// workgroup per (window, head).  Q (pre-scaled), K, V (and dO) tiles live in LDS with odd row
+// strides; QK^T, PV and the four backward products run on v_mfma_f32_32x32x2_f32 with fragments read
+// straight from those tiles (transposed operands are free: lanes walk the contiguous index).
+// torch.roll(-shift) + window_partition + head split + window_reverse + torch.roll(+shift) are pure
+// addressing: token n of window (Wy, Wx) is pixel ((Wy*8 + n/8 + shift) % H, (Wx*8 + n%8 + shift) % W).
+// The relative-position index and the shifted-window mask are evaluated analytically.
+// Softmax statistics (log-sum-exp per row) are the only thing kept for backward; P is recomputed.
+#include "common.h"
+#include "../../include/neosr_amd.h"
+
+namespace {
+
+inline int grid_for(int64_t work_items, int cap = 4096) {
+  int64_t g = (work_items + 255) / 256;
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return (int)g;
+}
+
+__device__ __forceinline__ float wave_allreduce_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// ------------------------------------------------------------------------------ LayerNorm
+constexpr int LN_MAXI = 8;  // C <= 512
+
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta,
+                                                            float* __restrict__ y,
+                                                            float* __restrict__ stats, int64_t rows,
+                                                            int C, float eps) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ni = (C + 63) >> 6;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+    const float* xr = x + row * C;
+    float v[LN_MAXI];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXI; ++i) {
+      const int c = lane + 64 * i;
+      v[i] = (i < ni && c < C) ? xr[c] : 0.f;
+      s += v[i];
+    }
+    const float mean = wave_allreduce_sum(s) / C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXI; ++i) {
+      const int c = lane + 64 * i;
+      const float dlt = (i < ni && c < C) ? v[i] - mean : 0.f;
+      q += dlt * dlt;
+    }
+    const float rstd = rsqrtf(wave_allreduce_sum(q) / C + eps);
+    float* yr = y + row * C;
+#pragma unroll
+    for (int i = 0; i < LN_MAXI; ++i) {
+      const int c = lane + 64 * i;
+      if (i < ni && c < C) yr[c] = (v[i] - mean) * rstd * gamma[c] + beta[c];
+    }
+    if (lane == 0) {
+      stats[2 * row] = mean;
+      stats[2 * row + 1] = rstd;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy,
+                                                            const float* __restrict__ x,
+                                                            const float* __restrict__ stats,
+                                                            const float* __restrict__ gamma,
+                                                            float* __restrict__ dx,
+                                                            float* __restrict__ part, int64_t rows,
+                                                            int C) {
+  __shared__ float red[2][4][LN_MAXI * 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ni = (C + 63) >> 6;
+  float dg[LN_MAXI], db[LN_MAXI];
+#pragma unroll
+  for (int i = 0; i < LN_MAXI; ++i) dg[i] = db[i] = 0.f;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+    const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+    float gy[LN_MAXI], xh[LN_MAXI];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXI; ++i) {
+      const int c = lane + 64 * i;
+      const bool ok = i < ni && c < C;
+      const float g = ok ? dy[row * C + c] : 0.f;
+      xh[i] = ok ? (x[row * C + c] - mean) * rstd : 0.f;
+      gy[i] = ok ? g * gamma[c] : 0.f;
+      s1 += gy[i];
+      s2 += gy[i] * xh[i];
+      dg[i] += g * xh[i];
+      db[i] += g;
+    }
+    s1 = wave_allreduce_sum(s1) / C;
+    s2 = wave_allreduce_sum(s2) / C;
+#pragma unroll
+    for (int i = 0; i < LN_MAXI; ++i) {
+      const int c = lane + 64 * i;
+      if (i < ni && c < C) dx[row * C + c] = rstd * (gy[i] - s1 - xh[i] * s2);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < LN_MAXI; ++i) {
+    red[0][wave][lane + 64 * i] = dg[i];
+    red[1][wave][lane + 64 * i] = db[i];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    part[((int64_t)blockIdx.x * 2 + 0) * C + c] = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
+    part[((int64_t)blockIdx.x * 2 + 1) * C + c] = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
+  }
+}
+
+// ------------------------------------------------------------------------------ window attention
+constexpr int WS = 8, NTOK = 64, HD_MAX = 32, QS = 33 /* q/k/v row stride */, PS = 65 /* P row stride */;
+constexpr int NB = (2 * WS - 1) * (2 * WS - 1);  // 225 relative positions
+
+struct Win {
+  int b, Wy, Wx, head;
+};
+
+__device__ __forceinline__ Win decode(const neosr_wattn_desc& d, int bid, int& nWx, int& nW) {
+  nWx = d.W / WS;
+  nW = (d.H / WS) * nWx;
+  Win w;
+  w.head = bid % d.heads;
+  const int t = bid / d.heads;
+  const int wi = t % nW;
+  w.b = t / nW;
+  w.Wy = wi / nWx;
+  w.Wx = wi - w.Wy * nWx;
+  return w;
+}
+
+__device__ __forceinline__ int64_t token_of(const neosr_wattn_desc& d, const Win& w, int n) {
+  const int y = (w.Wy * WS + (n >> 3) + d.shift) % d.H;
+  const int x = (w.Wx * WS + (n & 7) + d.shift) % d.W;
+  return ((int64_t)w.b * d.H + y) * d.W + x;
+}
+
+// shifted-window mask region id of token n (swinir_arch.py:313-341 calculate_mask)
+__device__ __forceinline__ int region_of(const neosr_wattn_desc& d, const Win& w, int n) {
+  const int ys = w.Wy * WS + (n >> 3), xs = w.Wx * WS + (n & 7);
+  const int ry = ys < d.H - WS ? 0 : (ys < d.H - d.shift ? 1 : 2);
+  const int rx = xs < d.W - WS ? 0 : (xs < d.W - d.shift ? 1 : 2);
+  return ry * 3 + rx;
+}
+
+__device__ __forceinline__ int rel_index(int i, int j) {
+  return ((i >> 3) - (j >> 3) + WS - 1) * (2 * WS - 1) + ((i & 7) - (j & 7) + WS - 1);
+}
+
+// stage one [64 x hd] slice of the fused qkv matrix (or of dout) into LDS, zero padded to 32 cols
+__device__ __forceinline__ void load_tile(const neosr_wattn_desc& d, const Win& w, const float* src,
+                                          int ld, int col0, int hd, float mul, float* dst) {
+  const int n = threadIdx.x >> 2, part = threadIdx.x & 3;  // 64 tokens x 4 column groups of 8
+  const float* row = src + token_of(d, w, n) * ld + col0;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = part * 8 + e;
+    dst[n * QS + c] = c < hd ? row[c] * mul : 0.f;
+  }
+}
+
+// D[i][j] (one 32x32 tile: rows 32*ti.., cols 32*tj..) = sum_k A[i][k] * B[j][k], k < kdim (even)
+// A, B in LDS with row strides sa, sb.  Returns the tile in MFMA layout (col j = lane&31).
+__device__ __forceinline__ f32x16 tile_abt(const float* A, int sa, const float* B, int sb, int ti, int tj,
+                                           int kdim, int l31, int lh) {
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const float* ap = A + (32 * ti + l31) * sa + lh;
+  const float* bp = B + (32 * tj + l31) * sb + lh;
+  for (int ks = 0; ks < kdim / 2; ++ks)
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * ks], bp[2 * ks], acc, 0, 0, 0);
+  return acc;
+}
+
+// D[i][j] = sum_k A[k][i] * B[k][j]  (A^T B), k < 64: lanes walk the contiguous index of both
+__device__ __forceinline__ f32x16 tile_atb(const float* A, int sa, const float* B, int sb, int ti, int tj,
+                                           int l31, int lh) {
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const float* ap = A + lh * sa + 32 * ti + l31;
+  const float* bp = B + lh * sb + 32 * tj + l31;
+#pragma unroll 8
+  for (int ks = 0; ks < NTOK / 2; ++ks)
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * ks * sa], bp[2 * ks * sb], acc, 0, 0, 0);
+  return acc;
+}
+
+// D[i][j] = sum_k A[i][k] * B[k][j], k < 64
+__device__ __forceinline__ f32x16 tile_ab(const float* A, int sa, const float* B, int sb, int ti, int tj,
+                                          int l31, int lh) {
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const float* ap = A + (32 * ti + l31) * sa + lh;
+  const float* bp = B + lh * sb + 32 * tj + l31;
+#pragma unroll 8
+  for (int ks = 0; ks < NTOK / 2; ++ks)
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * ks], bp[2 * ks * sb], acc, 0, 0, 0);
+  return acc;
+}
+
+// scores tile -> LDS: s = q.k (+ rpb + mask); if lse != nullptr store exp(s - lse[i]) instead
+__device__ __forceinline__ void scores_to_lds(const neosr_wattn_desc& d, const Win& w, const f32x16& acc,
+                                              int ti, int tj, int l31, int lh, const float* lse_row,
+                                              float* P) {
+  const int j = 32 * tj + l31;
+  const int rj = d.shift > 0 ? region_of(d, w, j) : 0;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int i = 32 * ti + (r & 3) + 8 * (r >> 2) + 4 * lh;
+    float s = acc[r] + d.rpb_table[rel_index(i, j) * d.heads + w.head];
+    if (d.shift > 0 && region_of(d, w, i) != rj) s += -100.f;
+    P[i * PS + j] = lse_row ? expf(s - lse_row[i]) : s;
+  }
+}
+
+__global__ __launch_bounds__(256) void window_attention_fwd_kernel(const neosr_wattn_desc d) {
+  __shared__ float Qs[NTOK * QS], Ks[NTOK * QS], Vs[NTOK * QS], P[NTOK * PS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  int nWx, nW;
+  const Win w = decode(d, blockIdx.x, nWx, nW);
+  const int hd = d.C / d.heads, ld = 3 * d.C;
+  load_tile(d, w, d.qkv, ld, w.head * hd, hd, d.scale, Qs);
+  load_tile(d, w, d.qkv, ld, d.C + w.head * hd, hd, 1.f, Ks);
+  load_tile(d, w, d.qkv, ld, 2 * d.C + w.head * hd, hd, 1.f, Vs);
+  __syncthreads();
+  {
+    const int ti = wave >> 1, tj = wave & 1;
+    const f32x16 acc = tile_abt(Qs, QS, Ks, QS, ti, tj, (hd + 1) & ~1, l31, lh);
+    scores_to_lds(d, w, acc, ti, tj, l31, lh, nullptr, P);
+  }
+  __syncthreads();
+  {  // row softmax: 4 threads per row
+    const int i = tid >> 2, q = tid & 3;
+    float* row = P + i * PS + q * 16;
+    float m = row[0];
+#pragma unroll
+    for (int c = 1; c < 16; ++c) m = fmaxf(m, row[c]);
+    m = fmaxf(m, __shfl_xor(m, 1, 64));
+    m = fmaxf(m, __shfl_xor(m, 2, 64));
+    float s = 0.f, e[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      e[c] = expf(row[c] - m);
+      s += e[c];
+    }
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    const float inv = 1.f / s;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) row[c] = e[c] * inv;
+    if (q == 0 && d.lse) d.lse[(int64_t)blockIdx.x * NTOK + i] = m + logf(s);
+  }
+  __syncthreads();
+  if (wave < 2) {  // O = P V : rows 32*wave.., cols d
+    const f32x16 acc = tile_ab(P, PS, Vs, QS, wave, 0, l31, lh);
+    if (l31 < hd) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        d.out[token_of(d, w, i) * d.C + w.head * hd + l31] = acc[r];
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void window_attention_bwd_kernel(const neosr_wattn_desc d) {
+  __shared__ float Qs[NTOK * QS], Ks[NTOK * QS], Vs[NTOK * QS], Gs[NTOK * QS];
+  __shared__ float P[NTOK * PS], dS[NTOK * PS];
+  __shared__ float lse_s[NTOK];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  int nWx, nW;
+  const Win w = decode(d, blockIdx.x, nWx, nW);
+  const int hd = d.C / d.heads, ld = 3 * d.C, kq = (hd + 1) & ~1;
+  load_tile(d, w, d.qkv, ld, w.head * hd, hd, d.scale, Qs);
+  load_tile(d, w, d.qkv, ld, d.C + w.head * hd, hd, 1.f, Ks);
+  load_tile(d, w, d.qkv, ld, 2 * d.C + w.head * hd, hd, 1.f, Vs);
+  load_tile(d, w, d.dout, d.C, w.head * hd, hd, 1.f, Gs);
+  if (tid < NTOK) lse_s[tid] = d.lse[(int64_t)blockIdx.x * NTOK + tid];
+  __syncthreads();
+  {
+    const int ti = wave >> 1, tj = wave & 1;
+    const f32x16 s = tile_abt(Qs, QS, Ks, QS, ti, tj, kq, l31, lh);
+    scores_to_lds(d, w, s, ti, tj, l31, lh, lse_s, P);            // P = softmax (recomputed)
+    const f32x16 dp = tile_abt(Gs, QS, Vs, QS, ti, tj, kq, l31, lh);  // dP = dO V^T
+    const int j = 32 * tj + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dS[(32 * ti + (r & 3) + 8 * (r >> 2) + 4 * lh) * PS + j] = dp[r];
+  }
+  __syncthreads();
+  {  // dS = P * (dP - sum_j P dP), 4 threads per row
+    const int i = tid >> 2, q = tid & 3;
+    const float* pr = P + i * PS + q * 16;
+    float* gr = dS + i * PS + q * 16;
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) s += pr[c] * gr[c];
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+#pragma unroll
+    for (int c = 0; c < 16; ++c) gr[c] = pr[c] * (gr[c] - s);
+  }
+  __syncthreads();
+  // relative-position-bias gradient of this (window, head): bin sums in a fixed order
+  if (tid < NB) {
+    const int dy = tid / (2 * WS - 1) - (WS - 1), dx = tid % (2 * WS - 1) - (WS - 1);
+    float s = 0.f;
+    for (int yi = max(0, dy); yi <= min(WS - 1, WS - 1 + dy); ++yi)
+      for (int xi = max(0, dx); xi <= min(WS - 1, WS - 1 + dx); ++xi)
+        s += dS[(yi * WS + xi) * PS + (yi - dy) * WS + (xi - dx)];
+    d.workspace[((int64_t)(blockIdx.x / d.heads) * NB + tid) * d.heads + w.head] = s;
+  }
+  const int col = w.head * hd + l31;
+  if (wave < 2) {
+    // dV[j][d] = sum_i P[i][j] dO[i][d]
+    const f32x16 dv = tile_atb(P, PS, Gs, QS, wave, 0, l31, lh);
+    // dQ[i][d] = scale * sum_j dS[i][j] K[j][d]
+    const f32x16 dq = tile_ab(dS, PS, Ks, QS, wave, 0, l31, lh);
+    if (l31 < hd) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int64_t t = token_of(d, w, n) * ld;
+        d.dqkv[t + 2 * d.C + col] = dv[r];
+        d.dqkv[t + col] = dq[r] * d.scale;
+      }
+    }
+  } else {
+    // dK[j][d] = sum_i dS[i][j] (scale * Q[i][d])   (Qs holds the scaled q)
+    const f32x16 dk = tile_atb(dS, PS, Qs, QS, wave - 2, 0, l31, lh);
+    if (l31 < hd) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = 32 * (wave - 2) + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        d.dqkv[token_of(d, w, n) * ld + d.C + col] = dk[r];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------ misc
+__global__ __launch_bounds__(256) void pixel_shuffle_nhwc_kernel(const float* __restrict__ in,
+                                                                 float* __restrict__ out, int B, int H,
+                                                                 int W, int C, int r, int inverse) {
+  // lo (B,H,W,C*r*r)  <->  hi (B,H*r,W*r,C): hi[b, h*r+i, w*r+j, c] = lo[b, h, w, c*r*r + i*r + j]
+  const int64_t total = (int64_t)B * H * W * C * r * r;
+  const int Wh = W * r;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * 256) {
+    const int c = (int)(e % C);
+    int64_t t = e / C;
+    const int xo = (int)(t % Wh);
+    t /= Wh;
+    const int yo = (int)(t % (H * r));
+    const int b = (int)(t / (H * r));
+    const int h = yo / r, i = yo - h * r, wq = xo / r, j = xo - wq * r;
+    const int64_t lo = (((int64_t)b * H + h) * W + wq) * (C * r * r) + c * r * r + i * r + j;
+    if (!inverse) out[e] = in[lo];
+    else out[lo] = in[e];
+  }
+}
+
+__global__ __launch_bounds__(256) void affine_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                     int64_t n, float shift, float scale) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256)
+    out[e] = (in[e] + shift) * scale;
+}
+
+__global__ __launch_bounds__(256) void row_scale_kernel(const float* __restrict__ in,
+                                                        const float* __restrict__ scale,
+                                                        float* __restrict__ out, int64_t n, int cols,
+                                                        int rows_per_scale) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256)
+    out[e] = in[e] * scale[(e / cols) / rows_per_scale];
+}
+
+int wattn_check(const neosr_wattn_desc* d) {
+  NEOSR_CHECK(d && d->qkv && d->rpb_table, "window_attention: null tensor");
+  NEOSR_CHECK(d->B > 0 && d->H > 0 && d->W > 0 && d->C > 0 && d->heads > 0, "window_attention: bad geometry");
+  NEOSR_CHECK(d->ws == WS, "window_attention: only window_size 8 is implemented (got %d)", d->ws);
+  NEOSR_CHECK(d->H % WS == 0 && d->W % WS == 0, "window_attention: H, W must be multiples of the window size");
+  NEOSR_CHECK(d->C % d->heads == 0 && d->C / d->heads <= HD_MAX, "window_attention: head_dim must be <= 32");
+  NEOSR_CHECK(d->shift >= 0 && d->shift < WS, "window_attention: 0 <= shift < window size");
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int neosr_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y,
+                                   float* stats, int64_t rows, int32_t C, float eps, void* stream) {
+  NEOSR_CHECK(x && gamma && beta && y && stats && rows > 0 && C > 0 && C <= LN_MAXI * 64, "layernorm_fwd: bad args (C <= 512)");
+  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(grid_for(rows * 64, 2048)), dim3(256), 0, (hipStream_t)stream,
+                     x, gamma, beta, y, stats, rows, C, eps);
+  NEOSR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int neosr_layernorm_bwd(const float* dy, const float* x, const float* stats, const float* gamma,
+                                   float* dx, float* dgamma, float* dbeta, float* workspace, int64_t rows,
+                                   int32_t C, int32_t accumulate, void* stream) {
+  NEOSR_CHECK(dy && x && stats && gamma && dx && dgamma && dbeta && workspace && rows > 0 && C > 0 &&
+                  C <= LN_MAXI * 64, "layernorm_bwd: bad args");
+  int nblk = (int)((rows + 31) / 32);  // 8 rows per wave
+  if (nblk > 512) nblk = 512;
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, dy, x, stats, gamma,
+                     dx, workspace, rows, C);
+  NEOSR_LAUNCH_CHECK();
+  // per-workgroup partials [nblk][2][C] -> dgamma | dbeta (nblk <= 1024: single-launch column sums)
+  if (int rc = neosr_colsum(workspace, dgamma, workspace, nblk, C, 2 * C, accumulate, stream)) return rc;
+  return neosr_colsum(workspace + C, dbeta, workspace, nblk, C, 2 * C, accumulate, stream);
+}
+
+extern "C" int neosr_window_attention_fwd(const neosr_wattn_desc* d, void* stream) {
+  if (int rc = wattn_check(d)) return rc;
+  NEOSR_CHECK(d->out, "window_attention_fwd: out missing");
+  const int nblk = d->B * (d->H / WS) * (d->W / WS) * d->heads;
+  hipLaunchKernelGGL(window_attention_fwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, *d);
+  NEOSR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int neosr_window_attention_bwd(const neosr_wattn_desc* d, void* stream) {
+  if (int rc = wattn_check(d)) return rc;
+  NEOSR_CHECK(d->dout && d->dqkv && d->lse && d->d_rpb_table && d->workspace, "window_attention_bwd: null tensor");
+  const int nbw = d->B * (d->H / WS) * (d->W / WS);
+  hipLaunchKernelGGL(window_attention_bwd_kernel, dim3(nbw * d->heads), dim3(256), 0, (hipStream_t)stream, *d);
+  NEOSR_LAUNCH_CHECK();
+  // d_table[bin][head] (+)= column sums of the [nbw][bin*heads + head] per-window matrix (fixed order)
+  const int cols = NB * d->heads;
+  return neosr_colsum(d->workspace, d->d_rpb_table, d->workspace + (int64_t)nbw * cols, nbw, cols, cols,
+                      d->accumulate_rpb, stream);
+}
+
+extern "C" int neosr_pixel_shuffle_nhwc(const float* in, float* out, int32_t B, int32_t H, int32_t W,
+                                        int32_t C, int32_t r, int32_t inverse, void* stream) {
+  NEOSR_CHECK(in && out && B > 0 && H > 0 && W > 0 && C > 0 && r > 0, "pixel_shuffle_nhwc: bad args");
+  hipLaunchKernelGGL(pixel_shuffle_nhwc_kernel, dim3(grid_for((int64_t)B * H * W * C * r * r)), dim3(256), 0,
+                     (hipStream_t)stream, in, out, B, H, W, C, r, inverse);
+  NEOSR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int neosr_affine(const float* in, float* out, int64_t n, float shift, float scale, void* stream) {
+  NEOSR_CHECK(in && out && n > 0, "affine: bad args");
+  hipLaunchKernelGGL(affine_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, in, out, n, shift, scale);
+  NEOSR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int neosr_row_scale(const float* in, const float* scale, float* out, int64_t rows, int32_t cols,
+                               int32_t rows_per_scale, void* stream) {
+  NEOSR_CHECK(in && scale && out && rows > 0 && cols > 0 && rows_per_scale > 0, "row_scale: bad args");
+  hipLaunchKernelGGL(row_scale_kernel, dim3(grid_for(rows * cols)), dim3(256), 0, (hipStream_t)stream, in, scale,
+                     out, rows * cols, cols, rows_per_scale);
+  NEOSR_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,332 @@
+// gemm_mfma.hip — fp32 GEMMs of the transformer generators (SwinIR / HAT `nn.Linear` layers) on
+// v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulate) for gfx950.
+//
+//   NT  C[M,N] = A[M,K] * B[N,K]^T          Linear forward   (B = weight (out,in))
+//   NN  C[M,N] = A[M,K] * B[K,N]            Linear backward-data (A = dY, B = weight)
+//   TN  C[M,N] = A[K,M]^T * B[K,N]          Linear backward-weight (A = dY, B = X), split over K
+// 128x64 output tile per 256-thread workgroup (each wave 32 rows x 64 cols = 2 MFMA tiles), K in
+// chunks of 32 staged through LDS ([row][32+1] layouts -> conflict-free fragment reads) with the
+// next chunk's global loads in flight in registers.  D is formed as B_frag x A_frag so each lane
+// owns one output row and runs of 4 consecutive columns -> 16-byte epilogue stores.
+// Epilogue (NT/NN): + bias[n]; exact-erf GELU with the pre-activation kept in `aux_out`;
+// multiply by GELU'(aux_in) (backward through the activation); per-sample row scale (DropPath);
+// + residual.  TN writes split-K partials that `gemm_tn_reduce_kernel` sums in a fixed order.
+//
+// Reference call sites: neosr/archs/swinir_arch.py:15-38 (Mlp), :139-143,150-156,209-210
+// (qkv / proj Linears), and the same layers of neosr/archs/hat_arch.py.
+#include "common.h"
+#include "../../include/neosr_amd.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 64, BK = 32, LDK = BK + 1;
+constexpr int A_LDS = BM * LDK, B_LDS = BN * LDK;
+
+__device__ __attribute__((aligned(256))) float gm_zero_page[64];
+__device__ __attribute__((aligned(256))) float gm_trash[1024];
+
+__device__ __forceinline__ float gelu_exact(float z) { return 0.5f * z * (1.f + erff(z * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad(float z) {
+  return 0.5f * (1.f + erff(z * 0.70710678118654752f)) + z * 0.3989422804014327f * expf(-0.5f * z * z);
+}
+
+struct GemmArgs {
+  neosr_gemm_desc d;
+  int ksplit_len;  // TN: K range per split
+  int b_vec;       // B (and bias) 16-byte aligned -> float4 loads; else dword loads (weights that sit
+                   // at a 4-byte-aligned offset of a packed parameter arena)
+};
+
+__device__ __forceinline__ float4 ld4(const float* p, int vec) {
+  if (vec) return *reinterpret_cast<const float4*>(p);
+  return make_float4(p[0], p[1], p[2], p[3]);
+}
+
+// MODE 0 = NT, 1 = NN, 2 = TN
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(const GemmArgs args) {
+  const neosr_gemm_desc& d = args.d;
+  __shared__ float lds[A_LDS + B_LDS];
+  float* As = lds;          // [m][k]
+  float* Bs = lds + A_LDS;  // [n][k]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int M = d.M, N = d.N;
+  int k_lo = 0, k_hi = d.K;
+  if (MODE == 2) {
+    k_lo = blockIdx.z * args.ksplit_len;
+    k_hi = min(d.K, k_lo + args.ksplit_len);
+  }
+
+  // staging registers: A tile 128x32 floats = 4 float4 / thread, B tile 64x32 = 2 float4 / thread
+  float4 ra[4], rb[2];
+  auto gload = [&](int k0) {
+    if (MODE != 2) {
+      // A rows m (contiguous along k): thread -> (row = tid/8 + 32 i, k4 = (tid%8)*4)
+      const int k4 = (tid & 7) << 2;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = m0 + (tid >> 3) + 32 * i;
+        const bool ok = m < M && k0 + k4 < k_hi;
+        ra[i] = *reinterpret_cast<const float4*>(ok ? d.A + (int64_t)m * d.lda + k0 + k4 : gm_zero_page);
+      }
+    } else {
+      // A = dY[K rows = samples][M cols]: rows kk (chunk of 32), cols m tile (128): thread ->
+      // (kk = tid/32 + 8 i, m4 = (tid%32)*4)
+      const int m4 = (tid & 31) << 2;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int kk = k0 + (tid >> 5) + 8 * i;
+        const bool ok = kk < k_hi && m0 + m4 < M;
+        ra[i] = *reinterpret_cast<const float4*>(ok ? d.A + (int64_t)kk * d.lda + m0 + m4 : gm_zero_page);
+      }
+    }
+    if (MODE == 0) {
+      // B = W[N rows][K cols]: thread -> (row = tid/8 + 32 i, k4)
+      const int k4 = (tid & 7) << 2;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int n = n0 + (tid >> 3) + 32 * i;
+        const bool ok = n < N && k0 + k4 < k_hi;
+        rb[i] = ld4(ok ? d.B + (int64_t)n * d.ldb + k0 + k4 : gm_zero_page, args.b_vec);
+      }
+    } else {
+      // B[K rows][N cols] (contiguous along n): thread -> (kk = tid/16 + 16 i, n4 = (tid%16)*4)
+      const int n4 = (tid & 15) << 2;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int kk = k0 + (tid >> 4) + 16 * i;
+        const bool ok = kk < k_hi && n0 + n4 < N;
+        rb[i] = ld4(ok ? d.B + (int64_t)kk * d.ldb + n0 + n4 : gm_zero_page, args.b_vec);
+      }
+    }
+  };
+  auto sstore = [&]() {
+    if (MODE != 2) {
+      const int k4 = (tid & 7) << 2;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float* p = As + ((tid >> 3) + 32 * i) * LDK + k4;
+        p[0] = ra[i].x; p[1] = ra[i].y; p[2] = ra[i].z; p[3] = ra[i].w;
+      }
+    } else {
+      const int m4 = (tid & 31) << 2;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int kk = (tid >> 5) + 8 * i;
+        As[(m4 + 0) * LDK + kk] = ra[i].x;
+        As[(m4 + 1) * LDK + kk] = ra[i].y;
+        As[(m4 + 2) * LDK + kk] = ra[i].z;
+        As[(m4 + 3) * LDK + kk] = ra[i].w;
+      }
+    }
+    if (MODE == 0) {
+      const int k4 = (tid & 7) << 2;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        float* p = Bs + ((tid >> 3) + 32 * i) * LDK + k4;
+        p[0] = rb[i].x; p[1] = rb[i].y; p[2] = rb[i].z; p[3] = rb[i].w;
+      }
+    } else {
+      const int n4 = (tid & 15) << 2;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int kk = (tid >> 4) + 16 * i;
+        Bs[(n4 + 0) * LDK + kk] = rb[i].x;
+        Bs[(n4 + 1) * LDK + kk] = rb[i].y;
+        Bs[(n4 + 2) * LDK + kk] = rb[i].z;
+        Bs[(n4 + 3) * LDK + kk] = rb[i].w;
+      }
+    }
+  };
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  const int nchunks = (k_hi - k_lo + BK - 1) / BK;
+  if (nchunks > 0) gload(k_lo);
+  for (int c = 0; c < nchunks; ++c) {
+    __syncthreads();
+    sstore();
+    __syncthreads();
+    if (c + 1 < nchunks) gload(k_lo + (c + 1) * BK);
+    const float* ap = As + (wave * 32 + l31) * LDK + lh;
+    const float* bp = Bs + l31 * LDK + lh;
+#pragma unroll
+    for (int ks = 0; ks < BK / 2; ++ks) {
+      const float a = ap[ks * 2];
+      const float b0 = bp[ks * 2], b1 = bp[32 * LDK + ks * 2];
+      // D = Bfrag x Afrag: rows i = column n of C, cols j = row m of C
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0, a, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b1, a, acc[1], 0, 0, 0);
+    }
+  }
+
+  // epilogue: lane owns C row m = m0 + 32*wave + l31 and column quads 32t + 8g + 4lh + {0..3}
+  const int m = m0 + wave * 32 + l31;
+  const bool m_ok = m < M;
+  const int64_t mrow = m_ok ? m : 0;
+  float* Cbase = d.C;
+  if (MODE == 2) Cbase = d.C + (int64_t)blockIdx.z * M * d.ldc;  // split-K partial slab
+  const float rs = (MODE != 2 && d.row_scale && m_ok) ? d.row_scale[m / d.rows_per_scale] : 1.f;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int n = n0 + 32 * t + 8 * g + 4 * lh;
+      const bool ok = m_ok && n < N;
+      float v[4] = {acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
+      if (MODE != 2) {
+        const int ns = n < N ? n : 0;
+        if (d.bias) {
+          const float4 b = ld4(d.bias + ns, args.b_vec);
+          v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+        }
+        if (d.aux_out)  // keep the pre-activation for the backward pass
+          *reinterpret_cast<float4*>(ok ? d.aux_out + mrow * d.ldaux + n : gm_trash + tid * 4) =
+              make_float4(v[0], v[1], v[2], v[3]);
+        if (d.gelu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = gelu_exact(v[e]);
+        }
+        if (d.aux_in) {  // dz = da * GELU'(z)
+          const float4 z = *reinterpret_cast<const float4*>(ok ? d.aux_in + mrow * d.ldaux + n : gm_zero_page);
+          v[0] *= gelu_grad(z.x); v[1] *= gelu_grad(z.y); v[2] *= gelu_grad(z.z); v[3] *= gelu_grad(z.w);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= rs;
+        if (d.res) {
+          const float4 r = *reinterpret_cast<const float4*>(ok ? d.res + mrow * d.ldres + n : gm_zero_page);
+          v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+        }
+      }
+      *reinterpret_cast<float4*>(ok ? Cbase + mrow * d.ldc + n : gm_trash + tid * 4) =
+          make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+// C[m][n] = scale * sum_s part[s][m][n] (+ C if accumulate), fixed order
+__global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const float* __restrict__ part,
+                                                             float* __restrict__ C, int64_t mn,
+                                                             int nsplit, int accumulate) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < mn; e += (int64_t)gridDim.x * 256) {
+    float s = 0.f;
+    for (int k = 0; k < nsplit; ++k) s += part[(int64_t)k * mn + e];
+    C[e] = accumulate ? C[e] + s : s;
+  }
+}
+
+// column sums of a row-major [rows, cols] matrix (bias gradients, LayerNorm / relative-position-bias
+// partials): 64 columns x 4 row lanes per workgroup, each row lane walks its rows with 256-byte
+// coalesced wave loads, the 4 lanes are combined through LDS in a fixed order.  Two launches when
+// rows > 1024 (per-slab partials, then the same kernel over the partial matrix).
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                     int rows, int cols, int ld, int rows_per_block,
+                                                     int accumulate) {
+  __shared__ float red[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + tx;
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < cols) {
+    const float* p = x + c;
+    int r = r0 + ty;
+    for (; r + 12 < r1; r += 16) {
+      s0 += p[(int64_t)r * ld];
+      s1 += p[(int64_t)(r + 4) * ld];
+      s2 += p[(int64_t)(r + 8) * ld];
+      s3 += p[(int64_t)(r + 12) * ld];
+    }
+    for (; r < r1; r += 4) s0 += p[(int64_t)r * ld];
+  }
+  red[ty][tx] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (ty == 0 && c < cols) {
+    const float s = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+    float* o = out + (int64_t)blockIdx.y * cols + c;
+    *o = accumulate ? *o + s : s;
+  }
+}
+
+int tn_splits(int K) {
+  int s = K / 1024;
+  if (s < 1) s = 1;
+  if (s > 64) s = 64;
+  return s;
+}
+
+}  // namespace
+
+extern "C" int64_t neosr_gemm_workspace_bytes(const neosr_gemm_desc* d) {
+  if (!d || d->mode != NEOSR_GEMM_TN) return 256;
+  return ((int64_t)tn_splits(d->K) * d->M * d->N + 64) * 4;
+}
+
+extern "C" int neosr_gemm(const neosr_gemm_desc* dp, void* stream) {
+  NEOSR_CHECK(dp, "gemm: null descriptor");
+  neosr_gemm_desc d = *dp;
+  NEOSR_CHECK(d.A && d.B && d.C && d.M > 0 && d.N > 0 && d.K > 0, "gemm: bad args");
+  NEOSR_CHECK(d.mode >= 0 && d.mode <= 2, "gemm: bad mode");
+  auto al = [](const void* p, int ld) { return !p || ((uintptr_t)p % 16 == 0 && ld % 4 == 0); };
+  NEOSR_CHECK(al(d.A, d.lda) && al(d.C, d.ldc) && al(d.res, d.ldres) && al(d.aux_in, d.ldaux) &&
+                  al(d.aux_out, d.ldaux) && d.ldb % 4 == 0,
+              "gemm: A/C/res/aux must be 16-byte aligned and all leading dimensions multiples of 4");
+  NEOSR_CHECK((uintptr_t)d.B % 4 == 0 && (uintptr_t)d.bias % 4 == 0, "gemm: B / bias must be 4-byte aligned");
+  NEOSR_CHECK(d.N % 4 == 0 && (d.mode == NEOSR_GEMM_TN ? d.M % 4 == 0 : d.K % 4 == 0),
+              "gemm: N and the contiguous reduction/row extent must be multiples of 4");
+  NEOSR_CHECK(!d.row_scale || d.rows_per_scale > 0, "gemm: row_scale needs rows_per_scale");
+  hipStream_t st = (hipStream_t)stream;
+  GemmArgs a;
+  a.d = d;
+  a.ksplit_len = d.K;
+  a.b_vec = al(d.B, d.ldb) && al(d.bias, 0);
+  dim3 grid(ceil_div(d.M, BM), ceil_div(d.N, BN), 1);
+  if (d.mode == NEOSR_GEMM_NT) {
+    hipLaunchKernelGGL(gemm_mfma_kernel<0>, grid, dim3(256), 0, st, a);
+  } else if (d.mode == NEOSR_GEMM_NN) {
+    hipLaunchKernelGGL(gemm_mfma_kernel<1>, grid, dim3(256), 0, st, a);
+  } else {
+    NEOSR_CHECK(d.workspace, "gemm TN: workspace missing");
+    const int ns = tn_splits(d.K);
+    a.ksplit_len = ceil_div(ceil_div(d.K, ns), BK) * BK;
+    const int nsplit = ceil_div(d.K, a.ksplit_len);
+    float* out = d.C;
+    const int ldc = d.ldc;
+    NEOSR_CHECK(ldc == d.N, "gemm TN: C must be dense (ldc == N)");
+    a.d.C = d.workspace;
+    grid.z = nsplit;
+    hipLaunchKernelGGL(gemm_mfma_kernel<2>, grid, dim3(256), 0, st, a);
+    NEOSR_LAUNCH_CHECK();
+    const int64_t mn = (int64_t)d.M * d.N;
+    int g = (int)((mn + 255) / 256);
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3(g), dim3(256), 0, st, d.workspace, out, mn, nsplit,
+                       d.accumulate);
+  }
+  NEOSR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int neosr_colsum(const float* x, float* out, float* workspace, int32_t rows, int32_t cols,
+                            int32_t ld, int32_t accumulate, void* stream) {
+  NEOSR_CHECK(x && out && workspace && rows > 0 && cols > 0 && ld >= cols, "colsum: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  const int gx = ceil_div(cols, 64);
+  if (rows <= 1024) {
+    hipLaunchKernelGGL(colsum_kernel, dim3(gx, 1), dim3(256), 0, st, x, out, rows, cols, ld, rows, accumulate);
+  } else {
+    int nblk = ceil_div(rows, 128);
+    if (nblk > 256) nblk = 256;
+    const int rpb = ceil_div(ceil_div(rows, nblk), 4) * 4;
+    nblk = ceil_div(rows, rpb);
+    hipLaunchKernelGGL(colsum_kernel, dim3(gx, nblk), dim3(256), 0, st, x, workspace, rows, cols, ld, rpb, 0);
+    hipLaunchKernelGGL(colsum_kernel, dim3(gx, 1), dim3(256), 0, st, workspace, out, nblk, cols, cols, nblk,
+                       accumulate);
+  }
+  NEOSR_LAUNCH_CHECK();
+  return 0;
+}

@@ -77,16 +77,19 @@ class VGGInput(torch.autograd.Function):
 # convolution
 # --------------------------------------------------------------------------------------------
 class Conv3x3(torch.autograd.Function):
-    """y = act(conv3x3(x[..., :K], w) + b), fused bias/activation; backward = MFMA dgrad (activation
-    derivative applied on load) + multi-conv wgrad kernel."""
+    """y = act(conv3x3(x'[..., :K], w) + b) (+ res), fused bias/activation/residual; x' = x or its
+    nearest x2 upsampling (`ups`, folded into the conv loader).  backward = MFMA dgrad (activation
+    derivative applied on load; 2x2 sum-pool after it for `ups`) + multi-conv wgrad kernel."""
 
     @staticmethod
-    def forward(ctx, x, w, b, act, slope):
+    def forward(ctx, x, w, b, act, slope, ups, res):
         _C.require_device(x, "x")
         w = _C.require_device(w, "weight").contiguous()
-        y = ops.conv3x3(x, w, b, act=act, slope=slope, k_in=w.shape[1])
+        y = ops.conv3x3(x, w, b, act=act, slope=slope, k_in=w.shape[1], ups=ups, res1=res)
         ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
-        ctx.act, ctx.slope, ctx.has_bias = act, slope, b is not None
+        ctx.act, ctx.slope, ctx.has_bias, ctx.ups, ctx.has_res = act, slope, b is not None, ups, res is not None
+        if act != ACT_NONE and res is not None:
+            raise _C.NeosrAmdError("Conv3x3: activation + residual cannot be differentiated from the output")
         return y
 
     @staticmethod
@@ -97,17 +100,19 @@ class Conv3x3(torch.autograd.Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             gx = ops.conv3x3(g, w, None, mode=ops.CONV_DGRAD, in_mask=y, mask_slope=slope)
+            if ctx.ups:
+                gx = ops.pool2x2_sum(gx)
             if x.shape[3] > gx.shape[3]:  # conv read a channel prefix of a wider buffer
                 pad = torch.zeros(*x.shape[:3], x.shape[3] - gx.shape[3], device=g.device)
                 gx = torch.cat((gx, pad), 3)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             gw, gb = ops.conv3x3_wgrad(x, g, w.shape[0], w.shape[1], g_mask=y, mask_slope=slope,
-                                       want_bias=ctx.has_bias)
-        return gx, gw, gb, None, None
+                                       want_bias=ctx.has_bias, ups=ctx.ups)
+        return gx, gw, gb, None, None, None, (g if ctx.has_res else None)
 
 
-def conv3x3(x, w, b=None, act=ACT_NONE, slope=0.0):
-    return Conv3x3.apply(x, w, b, act, slope)
+def conv3x3(x, w, b=None, act=ACT_NONE, slope=0.0, ups=False, res=None):
+    return Conv3x3.apply(x, w, b, act, slope, ups, res)
 
 
 class SpaceToDepth2(torch.autograd.Function):

@@ -1,0 +1,270 @@
+"""Differentiable fronts for the transformer generators (SwinIR): fp32 MFMA GEMM Linear / Mlp with
+fused bias / exact GELU / DropPath row scale / residual epilogues, LayerNorm, (shifted-)window
+attention, channels-last PixelShuffle.  Tokens are channels-last pixels, i.e. the (B, H*W, C) token
+matrix of neosr/archs/swinir_arch.py is the (B, H, W, C) HBM buffer itself.
+
+torch is used for allocation and the autograd graph only; every FLOP runs in libneosr_amd.so.
+"""
+
+from __future__ import annotations
+
+import torch
+
+from neosr_amd import _C
+
+
+def _st():
+    return _C.stream_ptr()
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _new(shape, like):
+    return torch.empty(shape, device=like.device, dtype=torch.float32)
+
+
+def gemm(mode, A, B, M, N, K, *, out=None, bias=None, res=None, aux_in=None, aux_out=None, row_scale=None,
+         rows_per_scale=0, gelu=False, accumulate=False):
+    """C = op(A) op(B) with the fused epilogue of `neosr_gemm` (include/neosr_amd.h). Dense operands."""
+    lib = _C.load()
+    if out is None:
+        out = _new((M, N), A)
+    lda = K if mode != _C.GEMM_TN else M
+    ldb = K if mode == _C.GEMM_NT else N
+    d = _C.GemmDesc(A=A.data_ptr(), B=B.data_ptr(), C=out.data_ptr(), bias=_p(bias), res=_p(res),
+                    aux_in=_p(aux_in), aux_out=_p(aux_out), row_scale=_p(row_scale), workspace=None,
+                    M=M, N=N, K=K, lda=lda, ldb=ldb, ldc=N, ldres=N, ldaux=N, rows_per_scale=rows_per_scale,
+                    mode=mode, gelu=int(gelu), accumulate=int(accumulate))
+    ws = None
+    if mode == _C.GEMM_TN:
+        ws = torch.empty(lib.neosr_gemm_workspace_bytes(d) // 4, device=A.device, dtype=torch.float32)
+        d.workspace = ws.data_ptr()
+    _C.check(lib.neosr_gemm(d, _st()), "neosr_gemm")
+    return out
+
+
+def colsum(x2d):
+    lib = _C.load()
+    rows, cols = x2d.shape
+    out = _new((cols,), x2d)
+    ws = _new((256 * cols,), x2d)
+    _C.check(lib.neosr_colsum(x2d.data_ptr(), out.data_ptr(), ws.data_ptr(), rows, cols, cols, 0, _st()),
+             "neosr_colsum")
+    return out
+
+
+def row_scale(x2d, scale, rows_per_scale):
+    lib = _C.load()
+    out = torch.empty_like(x2d)
+    _C.check(lib.neosr_row_scale(x2d.data_ptr(), scale.data_ptr(), out.data_ptr(), x2d.shape[0], x2d.shape[1],
+                                 rows_per_scale, _st()), "neosr_row_scale")
+    return out
+
+
+def _as2d(x):
+    x = _C.require_device(x, "x")
+    if not x.is_contiguous():
+        x = x.contiguous()
+    return x.view(-1, x.shape[-1])
+
+
+class Linear(torch.autograd.Function):
+    """y = (x W^T + b) * row_scale[sample] + res  — nn.Linear with the DropPath + shortcut of
+    swinir_arch.py:387 fused into the GEMM epilogue.  W is (N, K) as in nn.Linear."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, res, rs, rows_per_scale):
+        x2 = _as2d(x)
+        w = _C.require_device(w, "weight").contiguous()
+        M, K = x2.shape
+        N = w.shape[0]
+        r2 = None if res is None else _as2d(res)
+        y = gemm(_C.GEMM_NT, x2, w, M, N, K, bias=b, res=r2, row_scale=rs, rows_per_scale=rows_per_scale)
+        ctx.save_for_backward(x2, w, rs)
+        ctx.meta = (M, N, K, rows_per_scale, b is not None, res is not None)
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, w, rs = ctx.saved_tensors
+        M, N, K, rps, has_b, has_res = ctx.meta
+        g2 = _as2d(g)
+        gs = g2 if rs is None else row_scale(g2, rs, rps)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = gemm(_C.GEMM_NN, gs, w, M, K, N).view(*g.shape[:-1], K)
+        if ctx.needs_input_grad[1]:
+            gw = gemm(_C.GEMM_TN, gs, x2, N, K, M)
+        if has_b and ctx.needs_input_grad[2]:
+            gb = colsum(gs)
+        return gx, gw, gb, (g if has_res else None), None, None
+
+
+def linear(x, w, b=None, res=None, rs=None, rows_per_scale=0):
+    return Linear.apply(x, w, b, res, rs, rows_per_scale)
+
+
+class Mlp(torch.autograd.Function):
+    """y = (GELU(x W1^T + b1) W2^T + b2) * row_scale + res   (swinir_arch.py:15-38, :388).
+    Bias, exact-erf GELU, DropPath scale and the residual live in the two GEMM epilogues; backward
+    multiplies by GELU' in the epilogue of the fc2 data-gradient GEMM."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, res, rs, rows_per_scale):
+        x2 = _as2d(x)
+        w1 = _C.require_device(w1, "fc1.weight").contiguous()
+        w2 = _C.require_device(w2, "fc2.weight").contiguous()
+        M, K = x2.shape
+        Hd, N = w1.shape[0], w2.shape[0]
+        keep = any(ctx.needs_input_grad)
+        pre = _new((M, Hd), x2) if keep else None
+        h = gemm(_C.GEMM_NT, x2, w1, M, Hd, K, bias=b1, aux_out=pre, gelu=True)
+        r2 = None if res is None else _as2d(res)
+        y = gemm(_C.GEMM_NT, h, w2, M, N, Hd, bias=b2, res=r2, row_scale=rs, rows_per_scale=rows_per_scale)
+        if keep:
+            ctx.save_for_backward(x2, w1, w2, pre, h, rs)
+        ctx.meta = (M, K, Hd, N, rows_per_scale, res is not None)
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, w1, w2, pre, h, rs = ctx.saved_tensors
+        M, K, Hd, N, rps, has_res = ctx.meta
+        g2 = _as2d(g)
+        gs = g2 if rs is None else row_scale(g2, rs, rps)
+        gw2 = gemm(_C.GEMM_TN, gs, h, N, Hd, M)
+        gb2 = colsum(gs)
+        gpre = gemm(_C.GEMM_NN, gs, w2, M, Hd, N, aux_in=pre)  # (g W2) * GELU'(pre)
+        gw1 = gemm(_C.GEMM_TN, gpre, x2, Hd, K, M)
+        gb1 = colsum(gpre)
+        gx = gemm(_C.GEMM_NN, gpre, w1, M, K, Hd).view(*g.shape[:-1], K) if ctx.needs_input_grad[0] else None
+        return gx, gw1, gb1, gw2, gb2, (g if has_res else None), None, None
+
+
+def mlp(x, w1, b1, w2, b2, res=None, rs=None, rows_per_scale=0):
+    return Mlp.apply(x, w1, b1, w2, b2, res, rs, rows_per_scale)
+
+
+class LayerNorm(torch.autograd.Function):
+    """nn.LayerNorm over the last dim (swinir_arch.py:284,297,960)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        lib = _C.load()
+        x2 = _as2d(x)
+        rows, C_ = x2.shape
+        y = torch.empty_like(x2)
+        stats = _new((rows, 2), x2)
+        _C.check(lib.neosr_layernorm_fwd(x2.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
+                                         stats.data_ptr(), rows, C_, eps, _st()), "neosr_layernorm_fwd")
+        ctx.save_for_backward(x2, gamma, stats)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _C.load()
+        x2, gamma, stats = ctx.saved_tensors
+        rows, C_ = x2.shape
+        g2 = _as2d(g)
+        dx = torch.empty_like(x2)
+        dg, db = _new((C_,), x2), _new((C_,), x2)
+        ws = _new((2 * 512 * C_,), x2)
+        _C.check(lib.neosr_layernorm_bwd(g2.data_ptr(), x2.data_ptr(), stats.data_ptr(), gamma.data_ptr(),
+                                         dx.data_ptr(), dg.data_ptr(), db.data_ptr(), ws.data_ptr(), rows, C_, 0,
+                                         _st()), "neosr_layernorm_bwd")
+        return dx.view(g.shape), dg, db, None
+
+
+def layer_norm(x, gamma, beta, eps=1e-5):
+    return LayerNorm.apply(x, gamma, beta, eps)
+
+
+class WindowAttention(torch.autograd.Function):
+    """softmax(q k^T * scale + rpb + shift-mask) v per (window, head) on the fused qkv matrix
+    (B, H, W, 3C) in image order (swinir_arch.py:150-212 inside :343-385)."""
+
+    @staticmethod
+    def forward(ctx, qkv, table, heads, ws, shift, scale):
+        lib = _C.load()
+        qkv = _C.require_device(qkv, "qkv").contiguous()
+        table = _C.require_device(table, "relative_position_bias_table").contiguous()
+        B, H, W, C3 = qkv.shape
+        C_ = C3 // 3
+        nW = (H // ws) * (W // ws) if ws else 0
+        out = _new((B, H, W, C_), qkv)
+        lse = _new((max(B * nW * heads * ws * ws, 1),), qkv)
+        d = _C.WattnDesc(qkv=qkv.data_ptr(), rpb_table=table.data_ptr(), out=out.data_ptr(), lse=lse.data_ptr(),
+                         B=B, H=H, W=W, C=C_, heads=heads, ws=ws, shift=shift, accumulate_rpb=0, scale=scale)
+        _C.check(lib.neosr_window_attention_fwd(d, _st()), "neosr_window_attention_fwd")
+        ctx.save_for_backward(qkv, table, lse)
+        ctx.meta = (B, H, W, C_, heads, ws, shift, scale, nW)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _C.load()
+        qkv, table, lse = ctx.saved_tensors
+        B, H, W, C_, heads, ws, shift, scale, nW = ctx.meta
+        g = g.contiguous()
+        dqkv = torch.empty_like(qkv)
+        dtab = torch.empty_like(table)
+        wsp = _new(((B * nW + 256) * heads * (2 * ws - 1) ** 2,), qkv)
+        d = _C.WattnDesc(qkv=qkv.data_ptr(), rpb_table=table.data_ptr(), out=None, lse=lse.data_ptr(),
+                         dout=g.data_ptr(), dqkv=dqkv.data_ptr(), d_rpb_table=dtab.data_ptr(),
+                         workspace=wsp.data_ptr(), B=B, H=H, W=W, C=C_, heads=heads, ws=ws, shift=shift,
+                         accumulate_rpb=0, scale=scale)
+        _C.check(lib.neosr_window_attention_bwd(d, _st()), "neosr_window_attention_bwd")
+        return dqkv, dtab, None, None, None, None
+
+
+def window_attention(qkv, table, heads, ws, shift, scale):
+    return WindowAttention.apply(qkv, table, heads, ws, shift, scale)
+
+
+class PixelShuffleNHWC(torch.autograd.Function):
+    """nn.PixelShuffle(r) on channels-last tensors: (B,H,W,C*r*r) -> (B,H*r,W*r,C). Bit-exact."""
+
+    @staticmethod
+    def forward(ctx, x, r):
+        lib = _C.load()
+        x = _C.require_device(x, "x").contiguous()
+        B, H, W, Crr = x.shape
+        C_ = Crr // (r * r)
+        out = _new((B, H * r, W * r, C_), x)
+        _C.check(lib.neosr_pixel_shuffle_nhwc(x.data_ptr(), out.data_ptr(), B, H, W, C_, r, 0, _st()),
+                 "neosr_pixel_shuffle_nhwc")
+        ctx.meta = (B, H, W, C_, r)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _C.load()
+        B, H, W, C_, r = ctx.meta
+        g = g.contiguous()
+        out = _new((B, H, W, C_ * r * r), g)
+        _C.check(lib.neosr_pixel_shuffle_nhwc(g.data_ptr(), out.data_ptr(), B, H, W, C_, r, 1, _st()),
+                 "neosr_pixel_shuffle_nhwc")
+        return out, None
+
+
+class Affine(torch.autograd.Function):
+    """(x + shift) * scale."""
+
+    @staticmethod
+    def forward(ctx, x, shift, scale):
+        lib = _C.load()
+        x = _C.require_device(x, "x").contiguous()
+        out = torch.empty_like(x)
+        _C.check(lib.neosr_affine(x.data_ptr(), out.data_ptr(), x.numel(), shift, scale, _st()), "neosr_affine")
+        ctx.scale = scale
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _C.load()
+        g = g.contiguous()
+        out = torch.empty_like(g)
+        _C.check(lib.neosr_affine(g.data_ptr(), out.data_ptr(), g.numel(), 0.0, ctx.scale, _st()), "neosr_affine")
+        return out, None, None

@@ -1,0 +1,297 @@
+"""GPU parity tests of the SwinIR window-attention path through the C ABI: fp32 MFMA GEMM (all modes
+and epilogues), LayerNorm, (shifted-)window attention, channels-last PixelShuffle, whole Swin blocks
+and whole nets against fixtures produced by the reference, and the `image` model trajectory with
+network_g = swinir_small.
+
+Tolerance (BASELINE.json north_star): 1e-3 relative (per-tensor ||d||/||ref||) in fp32; PixelShuffle
+is index math and must be bit-exact.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.conftest import group, load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def T(a):
+    return torch.from_numpy(np.array(a))
+
+
+GEMM_CASES = [(200, 180, 60), (128, 64, 32), (4096, 540, 180), (333, 360, 180), (70, 8, 8), (1000, 180, 360)]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_CASES)
+def test_gemm_modes_vs_float64(M, N, K):
+    from neosr_amd import _C
+    from neosr_amd.hip import transformer as tr
+
+    g = torch.Generator().manual_seed(M + N + K)
+    A, W = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g)
+    Y = torch.randn(M, N, generator=g)
+    nt = tr.gemm(_C.GEMM_NT, A.to(DEV), W.to(DEV), M, N, K)
+    assert rel_err(nt, A.double() @ W.double().t()) < 1e-5
+    nn_ = tr.gemm(_C.GEMM_NN, Y.to(DEV), W.to(DEV), M, K, N)
+    assert rel_err(nn_, Y.double() @ W.double()) < 1e-5
+    tn = tr.gemm(_C.GEMM_TN, Y.to(DEV), A.to(DEV), N, K, M)
+    assert rel_err(tn, Y.double().t() @ A.double()) < 1e-5
+    cs = tr.colsum(Y.to(DEV))
+    assert rel_err(cs, Y.double().sum(0)) < 1e-5
+
+
+def test_gemm_weight_at_unaligned_arena_offset():
+    """weights living at a 4-byte-aligned (not 16-byte) offset of the packed parameter arena"""
+    from neosr_amd import _C
+    from neosr_amd.hip import transformer as tr
+
+    g = torch.Generator().manual_seed(8)
+    M, N, K = 300, 180, 60
+    A = torch.randn(M, K, generator=g)
+    arena = torch.randn(2 + N * K + N, generator=g).to(DEV)
+    W, b = arena[2 : 2 + N * K].view(N, K), arena[2 + N * K :]
+    assert W.data_ptr() % 16 != 0
+    y = tr.gemm(_C.GEMM_NT, A.to(DEV), W, M, N, K, bias=b)
+    assert rel_err(y, A.double() @ W.double().cpu().t() + b.double().cpu()) < 1e-5
+    gy = torch.randn(M, N, generator=g)
+    gx = tr.gemm(_C.GEMM_NN, gy.to(DEV), W, M, K, N)
+    assert rel_err(gx, gy.double() @ W.double().cpu()) < 1e-5
+
+
+def test_gemm_epilogues():
+    from neosr_amd import _C
+    from neosr_amd.hip import transformer as tr
+
+    g = torch.Generator().manual_seed(3)
+    M, N, K, rps = 6 * 50, 120, 60, 50
+    A, W, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.2, torch.randn(N, generator=g)
+    res, rs = torch.randn(M, N, generator=g), torch.rand(M // rps, generator=g)
+    aux = torch.empty(M, N, device=DEV)
+    y = tr.gemm(_C.GEMM_NT, A.to(DEV), W.to(DEV), M, N, K, bias=b.to(DEV), res=res.to(DEV), aux_out=aux,
+                row_scale=rs.to(DEV), rows_per_scale=rps, gelu=True)
+    pre = A.double() @ W.double().t() + b.double()
+    ref = F.gelu(pre) * rs.double().repeat_interleave(rps)[:, None] + res.double()
+    assert rel_err(aux, pre) < 1e-5 and rel_err(y, ref) < 1e-5
+    # backward-data epilogue: (g W) * GELU'(aux_in)
+    gy = torch.randn(M, N, generator=g)
+    h_pre = torch.randn(M, K, generator=g)
+    out = tr.gemm(_C.GEMM_NN, gy.to(DEV), W.to(DEV), M, K, N, aux_in=h_pre.to(DEV))
+    hp = h_pre.double().requires_grad_(True)
+    F.gelu(hp).backward(gy.double() @ W.double())
+    assert rel_err(out, hp.grad) < 1e-5
+
+
+def test_linear_and_mlp_autograd_vs_torch():
+    from neosr_amd.hip import transformer as tr
+
+    g = torch.Generator().manual_seed(4)
+    B, HW, C, Hd = 3, 40, 60, 120
+    x = torch.randn(B, HW, C, generator=g)
+    w1, b1 = torch.randn(Hd, C, generator=g) * 0.1, torch.randn(Hd, generator=g) * 0.1
+    w2, b2 = torch.randn(C, Hd, generator=g) * 0.1, torch.randn(C, generator=g) * 0.1
+    rs = torch.tensor([1 / 0.8, 0.0, 1 / 0.8])
+    r = torch.randn(B, HW, C, generator=g)
+
+    def run(dev, dt, fn, r=r):
+        ts = [t.to(dev, dt).requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+        y = fn(*ts, rs.to(dev, dt))
+        (y * r.to(dev, dt)).sum().backward()
+        return [y] + [t.grad for t in ts]
+
+    ref = run("cpu", torch.float64, lambda x_, a, b, c, d, s: x_ + s[:, None, None] * F.linear(
+        F.gelu(F.linear(x_, a, b)), c, d))
+    got = run(DEV, torch.float32, lambda x_, a, b, c, d, s: tr.mlp(x_, a, b, c, d, x_, s, HW))
+    for a, b in zip(got, ref):
+        assert rel_err(a, b) < 1e-5
+    r2 = torch.randn(B, HW, Hd, generator=g)
+    ref = run("cpu", torch.float64, lambda x_, a, b, c, d, s: s[:, None, None] * F.linear(x_, a, b), r2)
+    got = run(DEV, torch.float32, lambda x_, a, b, c, d, s: tr.linear(x_, a, b, None, s, HW), r2)
+    for a, b in zip(got[:4], ref[:4]):
+        assert rel_err(a, b) < 1e-5
+
+
+@pytest.mark.parametrize("rows,C", [(1000, 180), (77, 60), (4096, 240), (5, 24)])
+def test_layernorm_fwd_bwd(rows, C):
+    from neosr_amd.hip import transformer as tr
+
+    g = torch.Generator().manual_seed(rows)
+    x = torch.randn(rows, C, generator=g) * 2 + 0.5
+    gamma, beta, r = torch.randn(C, generator=g), torch.randn(C, generator=g), torch.randn(rows, C, generator=g)
+
+    def run(dev, dt, fn):
+        ts = [t.to(dev, dt).requires_grad_(True) for t in (x, gamma, beta)]
+        y = fn(*ts)
+        (y * r.to(dev, dt)).sum().backward()
+        return [y] + [t.grad for t in ts]
+
+    ref = run("cpu", torch.float64, lambda a, b, c: F.layer_norm(a, (C,), b, c, 1e-5))
+    got = run(DEV, torch.float32, lambda a, b, c: tr.layer_norm(a, b, c, 1e-5))
+    for a, b in zip(got, ref):
+        assert rel_err(a, b) < 1e-5
+
+
+@pytest.mark.parametrize("shift", [0, 4])
+@pytest.mark.parametrize("B,H,W,C,heads", [(2, 16, 24, 60, 6), (1, 8, 8, 24, 2), (2, 32, 16, 180, 6), (1, 16, 16, 64, 2)])
+def test_window_attention_fwd_bwd_vs_oracle(B, H, W, C, heads, shift):
+    """kernel (addressing-folded roll / partition / head split, analytic index + mask) vs the oracle's
+    roll -> window_partition -> softmax(qk^T + bias + mask) v -> window_reverse -> roll."""
+    from neosr_amd.hip import transformer as tr
+    from oracle import swinir_oracle as sorc
+
+    g = torch.Generator().manual_seed(B * H + C + shift)
+    qkv = torch.randn(B, H, W, 3 * C, generator=g)
+    table = torch.randn(225, heads, generator=g) * 0.5
+    r = torch.randn(B, H, W, C, generator=g)
+    scale = (C // heads) ** -0.5
+
+    def oracle(qkv_, table_):
+        x = torch.roll(qkv_, (-shift, -shift), (1, 2)) if shift else qkv_
+        xw = sorc.window_partition(x, 8).view(-1, 64, 3 * C)
+        q, k, v = xw.reshape(-1, 64, 3, heads, C // heads).permute(2, 0, 3, 1, 4)
+        attn = (q * scale) @ k.transpose(-2, -1)
+        bias = table_[sorc.relative_position_index(8).view(-1)].view(64, 64, -1).permute(2, 0, 1)
+        attn = attn + bias.unsqueeze(0)
+        if shift:
+            m = sorc.calculate_mask(H, W, 8, shift).to(attn.dtype)
+            attn = (attn.view(B, m.shape[0], heads, 64, 64) + m[None, :, None]).view(-1, heads, 64, 64)
+        o = (attn.softmax(-1) @ v).transpose(1, 2).reshape(-1, 8, 8, C)
+        o = sorc.window_reverse(o, 8, H, W)
+        return torch.roll(o, (shift, shift), (1, 2)) if shift else o
+
+    a, t = qkv.double().requires_grad_(True), table.double().requires_grad_(True)
+    ref = oracle(a, t)
+    (ref * r.double()).sum().backward()
+    a2, t2 = qkv.to(DEV).requires_grad_(True), table.to(DEV).requires_grad_(True)
+    got = tr.window_attention(a2, t2, heads, 8, shift, scale)
+    (got * r.to(DEV)).sum().backward()
+    assert rel_err(got, ref) < 1e-5
+    assert rel_err(a2.grad, a.grad) < 1e-5
+    assert rel_err(t2.grad, t.grad) < 1e-5
+
+
+def test_window_attention_bwd_is_deterministic():
+    from neosr_amd.hip import transformer as tr
+
+    g = torch.Generator().manual_seed(9)
+    qkv, table = torch.randn(2, 32, 32, 540, generator=g).to(DEV), torch.randn(225, 6, generator=g).to(DEV)
+    r = torch.randn(2, 32, 32, 180, generator=g).to(DEV)
+    outs = []
+    for _ in range(2):
+        a, t = qkv.clone().requires_grad_(True), table.clone().requires_grad_(True)
+        (tr.window_attention(a, t, 6, 8, 4, 30 ** -0.5) * r).sum().backward()
+        outs.append((a.grad.clone(), t.grad.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+def test_pixel_shuffle_nhwc_bit_exact():
+    from neosr_amd.hip import transformer as tr
+
+    g = torch.Generator().manual_seed(1)
+    for r_, c in ((2, 64), (4, 3), (3, 5)):
+        x = torch.randn(2, c * r_ * r_, 6, 10, generator=g)
+        ref = F.pixel_shuffle(x, r_)
+        xin = x.permute(0, 2, 3, 1).contiguous().to(DEV).requires_grad_(True)
+        got = tr.PixelShuffleNHWC.apply(xin, r_)
+        assert torch.equal(got.detach().permute(0, 3, 1, 2).cpu(), ref)
+        got.backward(got.detach())  # adjoint: unshuffle(shuffle(x)) == x
+        assert torch.equal(xin.grad.cpu(), xin.detach().cpu())
+
+
+@pytest.mark.parametrize("shift", [0, 4])
+def test_swin_block_vs_reference_fixture(shift):
+    from neosr_amd.archs.swinir_arch import SwinTransformerBlock
+
+    fix = load_golden("swinir_prims.npz")
+    pre = f"blk_s{shift}"
+    blk = SwinTransformerBlock(24, (16, 24), 2, 8, shift, 2.0)
+    blk.load_state_dict(group(fix, f"{pre}/p"), strict=False)
+    blk = blk.to(DEV).train()
+    x = T(fix[f"{pre}/x"]).view(2, 16, 24, 24).to(DEV).requires_grad_(True)
+    y = blk(x)
+    (y * T(fix[f"{pre}/r"]).view(2, 16, 24, 24).to(DEV)).sum().backward()
+    assert rel_err(y.view(2, -1, 24), T(fix[f"{pre}/y"])) < 1e-4
+    assert rel_err(x.grad.view(2, -1, 24), T(fix[f"{pre}/gx"])) < 1e-3
+    named = dict(blk.named_parameters())
+    for k, g in group(fix, f"{pre}/g").items():
+        assert rel_err(named[k].grad, g) < 1e-3, k
+
+
+NET_CFG = {
+    "ps": dict(embed_dim=24, upsampler="pixelshuffle", resi_connection="1conv"),
+    "psd": dict(embed_dim=24, upsampler="pixelshuffledirect", resi_connection="1conv"),
+    "nc": dict(embed_dim=32, upsampler="nearest+conv", resi_connection="3conv"),
+}
+
+
+@pytest.mark.parametrize("tag", list(NET_CFG))
+def test_swinir_net_vs_reference_fixture(tag):
+    from neosr_amd.archs.swinir_arch import swinir
+
+    fix = load_golden("swinir_nets.npz")
+    net = swinir(img_size=16, depths=(2, 2), num_heads=(2, 2), window_size=8, mlp_ratio=2.0, drop_path_rate=0.0,
+                 upscale=4, **NET_CFG[tag])
+    assert list(net.state_dict().keys()) == [str(k) for k in fix[f"{tag}/keys"]]
+    net.load_state_dict(group(fix, f"{tag}/p"), strict=False)
+    net = net.to(DEV).train()
+    x = T(fix[f"{tag}/x"]).to(DEV).requires_grad_(True)
+    y = net(x)
+    (y * T(fix[f"{tag}/r"]).to(DEV)).sum().backward()
+    assert rel_err(y, T(fix[f"{tag}/y"])) < 1e-4
+    assert rel_err(x.grad, T(fix[f"{tag}/gx"])) < 1e-3
+    named = dict(net.named_parameters())
+    worst = max((rel_err(named[k].grad, g), k) for k, g in group(fix, f"{tag}/g").items())
+    assert worst[0] < 1e-3, worst
+
+
+def test_drop_path_train_mode_scales_rows():
+    """train-mode DropPath: each sample's branch is dropped or scaled by 1/keep (arch_util.py:118-133);
+    with the draws recorded, the block equals the oracle replaying them."""
+    from neosr_amd.archs.swinir_arch import SwinTransformerBlock
+    from oracle import swinir_oracle as sorc
+
+    fix = load_golden("swinir_prims.npz")
+    blk = SwinTransformerBlock(24, (16, 24), 2, 8, 4, 2.0, drop_path=0.5)
+    P = group(fix, "blk_s4/p")
+    blk.load_state_dict(P, strict=False)
+    blk = blk.to(DEV).train()
+    draws = []
+    orig = blk._drop_scale
+    blk._drop_scale = lambda b, dev: draws.append(orig(b, dev)) or draws[-1]
+    x = T(fix["blk_s4/x"])
+    x = torch.cat([x, x, x, x])  # 8 samples so both outcomes occur
+    y = blk(x.view(8, 16, 24, 24).to(DEV))
+    keep = [(d.cpu() * 0.5) for d in draws]
+    assert all(set(k.tolist()) <= {0.0, 1.0} for k in keep)
+    Pb = {f"b.{k}": v for k, v in P.items()}
+    ref = sorc.swin_block(Pb, "b", x, (16, 24), 2, 8, 4, (keep[0], keep[1], 0.5))
+    assert rel_err(y.view(8, -1, 24), ref) < 1e-4
+
+
+def test_image_model_trajectory_swinir_small_vs_reference_fixture():
+    """2 x (feed_data + optimize_parameters) of OUR `image` model with network_g = swinir_small from the
+    same seeded init as the reference run: loss, output and final weights."""
+    from neosr_amd.models import build_model
+    from neosr_amd.utils.options import parse_options
+    from tests.conftest import GOLDEN, ROOT
+
+    fix = load_golden("step_swinir.npz")
+    opt, _ = parse_options(str(ROOT), True, argv=["-opt", str(GOLDEN / "golden_swinir.toml")])
+    model = build_model(opt)
+    s = np.array([float(v.double().sum()) for v in model.net_g.state_dict().values()])
+    np.testing.assert_allclose(s, fix["init/sum"], rtol=1e-5, atol=1e-5)
+    for it in (1, 2):
+        model.feed_data({"lq": T(fix[f"it{it}/lq"]), "gt": T(fix[f"it{it}/gt"])})
+        model.optimize_parameters(it)
+        log = model.get_current_log()
+        ref = float(fix[f"it{it}/log/l_g_pix"])
+        assert abs(log["l_g_pix"] - ref) < 1e-4 * ref
+        assert rel_err(model.output, T(fix[f"it{it}/output"])) < 1e-3
+    sd = model.net_g.state_dict()
+    for k in [f for f in fix if f.startswith("final/w/")]:
+        assert rel_err(sd[k[len("final/w/"):]], T(fix[k])) < 1e-3, k
