@@ -10,7 +10,7 @@
 // owns one output row and runs of 4 consecutive columns -> 16-byte epilogue stores.
 // Epilogue (NT/NN): + bias[n]; exact-erf GELU with the pre-activation kept in `aux_out`;
 // multiply by GELU'(aux_in) (backward through the activation); per-sample row scale (DropPath);
-// + residual.  TN writes split-K partials that `gemm_tn_reduce_kernel` sums in a fixed order.
+// + residual.  TN writes split-K partial slabs that `colsum_kernel` sums in a fixed order.
 //
 // Reference call sites: neosr/archs/swinir_arch.py:15-38 (Mlp), :139-143,150-156,209-210
 // (qkv / proj Linears), and the same layers of neosr/archs/hat_arch.py.
@@ -20,7 +20,13 @@
 namespace {
 
 constexpr int BM = 128, BN = 64, BK = 32, LDK = BK + 1;
-constexpr int A_LDS = BM * LDK, B_LDS = BN * LDK;
+// operands that are contiguous along the reduction index (NT: A and B; NN: A) are staged [row][k]
+// with the odd stride LDK; operands contiguous along the output index (NN: B; TN: A and B) are
+// staged [k][row] with 16-byte row stores (strides LDM / LDN) — the MFMA fragment reads then walk
+// consecutive addresses per lane, so neither layout needs a transposing scatter into LDS
+constexpr int LDM = BM + 4, LDN = BN + 4;
+constexpr int A_LDS = BK * LDM, B_LDS = BK * LDN;
+static_assert(A_LDS >= BM * LDK && B_LDS >= BN * LDK, "LDS carve-up");
 
 __device__ __attribute__((aligned(256))) float gm_zero_page[64];
 __device__ __attribute__((aligned(256))) float gm_trash[1024];
@@ -33,13 +39,15 @@ __device__ __forceinline__ float gelu_grad(float z) {
 struct GemmArgs {
   neosr_gemm_desc d;
   int ksplit_len;  // TN: K range per split
+  int tiles_m, tiles_n, nsplit;
   int b_vec;       // B (and bias) 16-byte aligned -> float4 loads; else dword loads (weights that sit
                    // at a 4-byte-aligned offset of a packed parameter arena)
 };
 
-__device__ __forceinline__ float4 ld4(const float* p, int vec) {
-  if (vec) return *reinterpret_cast<const float4*>(p);
-  return make_float4(p[0], p[1], p[2], p[3]);
+__device__ __forceinline__ f32x4 ld4(const float* p, int vec) {
+  if (vec) return *reinterpret_cast<const f32x4*>(p);
+  f32x4 r = {p[0], p[1], p[2], p[3]};
+  return r;
 }
 
 // MODE 0 = NT, 1 = NN, 2 = TN
@@ -51,16 +59,33 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(const GemmArgs args) 
   float* Bs = lds + A_LDS;  // [n][k]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  // XCD-aware order: workgroup ids go round-robin over the 8 XCDs, each with a private 4 MB L2.
+  // NT/NN: every XCD gets a contiguous run of tiles, n-tile fastest, so the workgroups sharing one
+  // 128-row A panel run back to back on one L2.  TN: all output tiles of one K-split run on ONE XCD
+  // (split s -> XCD s % 8), so that split's rows of dY and X are fetched from HBM once, not once per
+  // tile — K = B*H*W is huge and the (M x N) output tiny, so this is the traffic that matters.
+  const int tiles = args.tiles_m * args.tiles_n;
+  int logical, split = 0;
+  if (MODE == 2) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    split = (j / tiles) * 8 + xcd;
+    logical = j % tiles;
+    if (split >= args.nsplit) return;
+  } else {
+    const int chunk = gridDim.x >> 3;
+    logical = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    if (logical >= tiles) return;
+  }
+  const int m0 = (logical / args.tiles_n) * BM, n0 = (logical % args.tiles_n) * BN;
   const int M = d.M, N = d.N;
   int k_lo = 0, k_hi = d.K;
   if (MODE == 2) {
-    k_lo = blockIdx.z * args.ksplit_len;
+    k_lo = split * args.ksplit_len;
     k_hi = min(d.K, k_lo + args.ksplit_len);
   }
 
   // staging registers: A tile 128x32 floats = 4 float4 / thread, B tile 64x32 = 2 float4 / thread
-  float4 ra[4], rb[2];
+  f32x4 ra[4], rb[2];
   auto gload = [&](int k0) {
     if (MODE != 2) {
       // A rows m (contiguous along k): thread -> (row = tid/8 + 32 i, k4 = (tid%8)*4)
@@ -69,7 +94,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(const GemmArgs args) 
       for (int i = 0; i < 4; ++i) {
         const int m = m0 + (tid >> 3) + 32 * i;
         const bool ok = m < M && k0 + k4 < k_hi;
-        ra[i] = *reinterpret_cast<const float4*>(ok ? d.A + (int64_t)m * d.lda + k0 + k4 : gm_zero_page);
+        ra[i] = *reinterpret_cast<const f32x4*>(ok ? d.A + (int64_t)m * d.lda + k0 + k4 : gm_zero_page);
       }
     } else {
       // A = dY[K rows = samples][M cols]: rows kk (chunk of 32), cols m tile (128): thread ->
@@ -79,7 +104,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(const GemmArgs args) 
       for (int i = 0; i < 4; ++i) {
         const int kk = k0 + (tid >> 5) + 8 * i;
         const bool ok = kk < k_hi && m0 + m4 < M;
-        ra[i] = *reinterpret_cast<const float4*>(ok ? d.A + (int64_t)kk * d.lda + m0 + m4 : gm_zero_page);
+        ra[i] = *reinterpret_cast<const f32x4*>(ok ? d.A + (int64_t)kk * d.lda + m0 + m4 : gm_zero_page);
       }
     }
     if (MODE == 0) {
@@ -108,36 +133,26 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(const GemmArgs args) 
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         float* p = As + ((tid >> 3) + 32 * i) * LDK + k4;
-        p[0] = ra[i].x; p[1] = ra[i].y; p[2] = ra[i].z; p[3] = ra[i].w;
+        p[0] = ra[i][0]; p[1] = ra[i][1]; p[2] = ra[i][2]; p[3] = ra[i][3];
       }
     } else {
       const int m4 = (tid & 31) << 2;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int kk = (tid >> 5) + 8 * i;
-        As[(m4 + 0) * LDK + kk] = ra[i].x;
-        As[(m4 + 1) * LDK + kk] = ra[i].y;
-        As[(m4 + 2) * LDK + kk] = ra[i].z;
-        As[(m4 + 3) * LDK + kk] = ra[i].w;
-      }
+      for (int i = 0; i < 4; ++i)
+        *reinterpret_cast<f32x4*>(As + ((tid >> 5) + 8 * i) * LDM + m4) = ra[i];
     }
     if (MODE == 0) {
       const int k4 = (tid & 7) << 2;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         float* p = Bs + ((tid >> 3) + 32 * i) * LDK + k4;
-        p[0] = rb[i].x; p[1] = rb[i].y; p[2] = rb[i].z; p[3] = rb[i].w;
+        p[0] = rb[i][0]; p[1] = rb[i][1]; p[2] = rb[i][2]; p[3] = rb[i][3];
       }
     } else {
       const int n4 = (tid & 15) << 2;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int kk = (tid >> 4) + 16 * i;
-        Bs[(n4 + 0) * LDK + kk] = rb[i].x;
-        Bs[(n4 + 1) * LDK + kk] = rb[i].y;
-        Bs[(n4 + 2) * LDK + kk] = rb[i].z;
-        Bs[(n4 + 3) * LDK + kk] = rb[i].w;
-      }
+      for (int i = 0; i < 2; ++i)
+        *reinterpret_cast<f32x4*>(Bs + ((tid >> 4) + 16 * i) * LDN + n4) = rb[i];
     }
   };
 
@@ -153,13 +168,18 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(const GemmArgs args) 
     __syncthreads();
     sstore();
     __syncthreads();
+#ifndef GEMM_NO_GLOAD
     if (c + 1 < nchunks) gload(k_lo + (c + 1) * BK);
-    const float* ap = As + (wave * 32 + l31) * LDK + lh;
-    const float* bp = Bs + l31 * LDK + lh;
+#endif
+    // element (row r, k) of the staged A / B tile; strides are compile-time per MODE
+    constexpr int a_rs = MODE == 2 ? 1 : LDK, a_ks = MODE == 2 ? LDM : 1;
+    constexpr int b_rs = MODE == 0 ? LDK : 1, b_ks = MODE == 0 ? 1 : LDN;
+    const float* ap = As + (wave * 32 + l31) * a_rs + lh * a_ks;
+    const float* bp = Bs + l31 * b_rs + lh * b_ks;
 #pragma unroll
     for (int ks = 0; ks < BK / 2; ++ks) {
-      const float a = ap[ks * 2];
-      const float b0 = bp[ks * 2], b1 = bp[32 * LDK + ks * 2];
+      const float a = ap[ks * 2 * a_ks];
+      const float b0 = bp[ks * 2 * b_ks], b1 = bp[32 * b_rs + ks * 2 * b_ks];
       // D = Bfrag x Afrag: rows i = column n of C, cols j = row m of C
       acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0, a, acc[0], 0, 0, 0);
       acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b1, a, acc[1], 0, 0, 0);
@@ -171,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(const GemmArgs args) 
   const bool m_ok = m < M;
   const int64_t mrow = m_ok ? m : 0;
   float* Cbase = d.C;
-  if (MODE == 2) Cbase = d.C + (int64_t)blockIdx.z * M * d.ldc;  // split-K partial slab
+  if (MODE == 2) Cbase = d.C + (int64_t)split * M * d.ldc;  // split-K partial slab
   const float rs = (MODE != 2 && d.row_scale && m_ok) ? d.row_scale[m / d.rows_per_scale] : 1.f;
 #pragma unroll
   for (int t = 0; t < 2; ++t)
@@ -183,8 +203,8 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(const GemmArgs args) 
       if (MODE != 2) {
         const int ns = n < N ? n : 0;
         if (d.bias) {
-          const float4 b = ld4(d.bias + ns, args.b_vec);
-          v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+          const f32x4 b = ld4(d.bias + ns, args.b_vec);
+          v[0] += b[0]; v[1] += b[1]; v[2] += b[2]; v[3] += b[3];
         }
         if (d.aux_out)  // keep the pre-activation for the backward pass
           *reinterpret_cast<float4*>(ok ? d.aux_out + mrow * d.ldaux + n : gm_trash + tid * 4) =
@@ -207,17 +227,6 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(const GemmArgs args) 
       *reinterpret_cast<float4*>(ok ? Cbase + mrow * d.ldc + n : gm_trash + tid * 4) =
           make_float4(v[0], v[1], v[2], v[3]);
     }
-}
-
-// C[m][n] = scale * sum_s part[s][m][n] (+ C if accumulate), fixed order
-__global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const float* __restrict__ part,
-                                                             float* __restrict__ C, int64_t mn,
-                                                             int nsplit, int accumulate) {
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < mn; e += (int64_t)gridDim.x * 256) {
-    float s = 0.f;
-    for (int k = 0; k < nsplit; ++k) s += part[(int64_t)k * mn + e];
-    C[e] = accumulate ? C[e] + s : s;
-  }
 }
 
 // column sums of a row-major [rows, cols] matrix (bias gradients, LayerNorm / relative-position-bias
@@ -252,18 +261,26 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
   }
 }
 
-int tn_splits(int K) {
-  int s = K / 1024;
-  if (s < 1) s = 1;
-  if (s > 64) s = 64;
-  return s;
+// split-K factor of the TN (weight-gradient) GEMM: the output is tiny (<= a few hundred rows and
+// columns) while K = B*H*W is huge, so the K range is cut until ~1024 workgroups exist (4 per CU),
+// never shorter than 4 chunks per workgroup
+#ifndef TN_TARGET_BLOCKS
+#define TN_TARGET_BLOCKS 768
+#endif
+int tn_splits(int M, int N, int K) {
+  const int tiles = ceil_div(M, BM) * ceil_div(N, BN);
+  int s = ceil_div(TN_TARGET_BLOCKS, tiles);
+  const int smax = K / (4 * BK) > 1 ? K / (4 * BK) : 1;
+  if (s > smax) s = smax;
+  if (s > 256) s = 256;
+  return s < 1 ? 1 : s;
 }
 
 }  // namespace
 
 extern "C" int64_t neosr_gemm_workspace_bytes(const neosr_gemm_desc* d) {
   if (!d || d->mode != NEOSR_GEMM_TN) return 256;
-  return ((int64_t)tn_splits(d->K) * d->M * d->N + 64) * 4;
+  return ((int64_t)(tn_splits(d->M, d->N, d->K) + 1) * d->M * d->N + 64) * 4;
 }
 
 extern "C" int neosr_gemm(const neosr_gemm_desc* dp, void* stream) {
@@ -284,28 +301,29 @@ extern "C" int neosr_gemm(const neosr_gemm_desc* dp, void* stream) {
   a.d = d;
   a.ksplit_len = d.K;
   a.b_vec = al(d.B, d.ldb) && al(d.bias, 0);
-  dim3 grid(ceil_div(d.M, BM), ceil_div(d.N, BN), 1);
+  a.tiles_m = ceil_div(d.M, BM);
+  a.tiles_n = ceil_div(d.N, BN);
+  dim3 grid(ceil_div(a.tiles_m * a.tiles_n, 8) * 8, 1, 1);
   if (d.mode == NEOSR_GEMM_NT) {
     hipLaunchKernelGGL(gemm_mfma_kernel<0>, grid, dim3(256), 0, st, a);
   } else if (d.mode == NEOSR_GEMM_NN) {
     hipLaunchKernelGGL(gemm_mfma_kernel<1>, grid, dim3(256), 0, st, a);
   } else {
     NEOSR_CHECK(d.workspace, "gemm TN: workspace missing");
-    const int ns = tn_splits(d.K);
+    const int ns = tn_splits(d.M, d.N, d.K);
     a.ksplit_len = ceil_div(ceil_div(d.K, ns), BK) * BK;
     const int nsplit = ceil_div(d.K, a.ksplit_len);
     float* out = d.C;
     const int ldc = d.ldc;
     NEOSR_CHECK(ldc == d.N, "gemm TN: C must be dense (ldc == N)");
     a.d.C = d.workspace;
-    grid.z = nsplit;
+    a.nsplit = nsplit;
+    grid.x = ceil_div(nsplit, 8) * 8 * a.tiles_m * a.tiles_n;
     hipLaunchKernelGGL(gemm_mfma_kernel<2>, grid, dim3(256), 0, st, a);
     NEOSR_LAUNCH_CHECK();
-    const int64_t mn = (int64_t)d.M * d.N;
-    int g = (int)((mn + 255) / 256);
-    if (g > 2048) g = 2048;
-    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3(g), dim3(256), 0, st, d.workspace, out, mn, nsplit,
-                       d.accumulate);
+    // fixed-order reduction of the split-K slabs == column sums of the [nsplit][M*N] partial matrix
+    return neosr_colsum(d.workspace, out, d.workspace + (int64_t)nsplit * d.M * d.N, nsplit, d.M * d.N,
+                        d.M * d.N, d.accumulate, stream);
   }
   NEOSR_LAUNCH_CHECK();
   return 0;
