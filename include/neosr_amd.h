@@ -310,7 +310,7 @@ int neosr_colsum(const float* x, float* out, float* workspace, int32_t rows, int
                  int32_t accumulate, void* stream);
 /* nn.LayerNorm(C) over the last dim, eps 1e-5, biased variance (swinir_arch.py:284,297,960,1035).
  * fwd keeps (mean, rstd) per row in `stats` (2*rows floats).  bwd: dx, and dgamma/dbeta (+)= via a
- * fixed-order two-stage column reduction; workspace >= 2*512*C floats.  C <= 512. */
+ * fixed-order two-stage column reduction; workspace >= (2*1024 + 256)*C floats.  C <= 512. */
 int neosr_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stats,
                         int64_t rows, int32_t C, float eps, void* stream);
 int neosr_layernorm_bwd(const float* dy, const float* x, const float* stats, const float* gamma,

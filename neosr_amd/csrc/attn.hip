@@ -29,8 +29,11 @@ __device__ __forceinline__ float wave_allreduce_sum(float v) {
 }
 
 // ------------------------------------------------------------------------------ LayerNorm
-constexpr int LN_MAXI = 8;  // C <= 512
+constexpr int LN_MAXI = 8;  // C <= 512 (NI = ceil(C/64) <= 8 values per lane)
 
+// One wave per row, NI = ceil(C / 64) values per lane (compile time, so a row is exactly NI
+// coalesced 256-byte loads); the next row's loads are issued before the current row is reduced.
+template <int NI>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta,
@@ -38,31 +41,39 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
                                                             float* __restrict__ stats, int64_t rows,
                                                             int C, float eps) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int ni = (C + 63) >> 6;
-  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
-    const float* xr = x + row * C;
-    float v[LN_MAXI];
+  const int64_t stride = (int64_t)gridDim.x * 4;
+  int64_t row = (int64_t)blockIdx.x * 4 + wave;
+  float gm[NI], bt[NI], v[NI], nx[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int c = lane + 64 * i;
+    gm[i] = c < C ? gamma[c] : 0.f;
+    bt[i] = c < C ? beta[c] : 0.f;
+    v[i] = (row < rows && c < C) ? x[row * C + c] : 0.f;
+  }
+  for (; row < rows; row += stride) {
+    const int64_t nrow = row + stride;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int c = lane + 64 * i;
+      nx[i] = (nrow < rows && c < C) ? x[nrow * C + c] : 0.f;
+    }
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXI; ++i) {
-      const int c = lane + 64 * i;
-      v[i] = (i < ni && c < C) ? xr[c] : 0.f;
-      s += v[i];
-    }
+    for (int i = 0; i < NI; ++i) s += v[i];
     const float mean = wave_allreduce_sum(s) / C;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXI; ++i) {
-      const int c = lane + 64 * i;
-      const float dlt = (i < ni && c < C) ? v[i] - mean : 0.f;
+    for (int i = 0; i < NI; ++i) {
+      const float dlt = lane + 64 * i < C ? v[i] - mean : 0.f;
       q += dlt * dlt;
     }
     const float rstd = rsqrtf(wave_allreduce_sum(q) / C + eps);
-    float* yr = y + row * C;
 #pragma unroll
-    for (int i = 0; i < LN_MAXI; ++i) {
+    for (int i = 0; i < NI; ++i) {
       const int c = lane + 64 * i;
-      if (i < ni && c < C) yr[c] = (v[i] - mean) * rstd * gamma[c] + beta[c];
+      if (c < C) y[row * C + c] = (v[i] - mean) * rstd * gm[i] + bt[i];
+      v[i] = nx[i];
     }
     if (lane == 0) {
       stats[2 * row] = mean;
@@ -71,6 +82,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
   }
 }
 
+template <int NI>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy,
                                                             const float* __restrict__ x,
                                                             const float* __restrict__ stats,
@@ -78,38 +90,53 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             float* __restrict__ dx,
                                                             float* __restrict__ part, int64_t rows,
                                                             int C) {
-  __shared__ float red[2][4][LN_MAXI * 64];
+  __shared__ float red[2][4][NI * 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int ni = (C + 63) >> 6;
-  float dg[LN_MAXI], db[LN_MAXI];
+  const int64_t stride = (int64_t)gridDim.x * 4;
+  int64_t row = (int64_t)blockIdx.x * 4 + wave;
+  float gm[NI], dg[NI], db[NI], g[NI], xv[NI], ng[NI], nxv[NI];
 #pragma unroll
-  for (int i = 0; i < LN_MAXI; ++i) dg[i] = db[i] = 0.f;
-  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+  for (int i = 0; i < NI; ++i) {
+    const int c = lane + 64 * i;
+    const bool ok = row < rows && c < C;
+    gm[i] = c < C ? gamma[c] : 0.f;
+    dg[i] = db[i] = 0.f;
+    g[i] = ok ? dy[row * C + c] : 0.f;
+    xv[i] = ok ? x[row * C + c] : 0.f;
+  }
+  for (; row < rows; row += stride) {
+    const int64_t nrow = row + stride;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int c = lane + 64 * i;
+      const bool ok = nrow < rows && c < C;
+      ng[i] = ok ? dy[nrow * C + c] : 0.f;
+      nxv[i] = ok ? x[nrow * C + c] : 0.f;
+    }
     const float mean = stats[2 * row], rstd = stats[2 * row + 1];
-    float gy[LN_MAXI], xh[LN_MAXI];
+    float gy[NI], xh[NI];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXI; ++i) {
-      const int c = lane + 64 * i;
-      const bool ok = i < ni && c < C;
-      const float g = ok ? dy[row * C + c] : 0.f;
-      xh[i] = ok ? (x[row * C + c] - mean) * rstd : 0.f;
-      gy[i] = ok ? g * gamma[c] : 0.f;
+    for (int i = 0; i < NI; ++i) {
+      xh[i] = lane + 64 * i < C ? (xv[i] - mean) * rstd : 0.f;
+      gy[i] = g[i] * gm[i];
       s1 += gy[i];
       s2 += gy[i] * xh[i];
-      dg[i] += g * xh[i];
-      db[i] += g;
+      dg[i] += g[i] * xh[i];
+      db[i] += g[i];
     }
     s1 = wave_allreduce_sum(s1) / C;
     s2 = wave_allreduce_sum(s2) / C;
 #pragma unroll
-    for (int i = 0; i < LN_MAXI; ++i) {
+    for (int i = 0; i < NI; ++i) {
       const int c = lane + 64 * i;
-      if (i < ni && c < C) dx[row * C + c] = rstd * (gy[i] - s1 - xh[i] * s2);
+      if (c < C) dx[row * C + c] = rstd * (gy[i] - s1 - xh[i] * s2);
+      g[i] = ng[i];
+      xv[i] = nxv[i];
     }
   }
 #pragma unroll
-  for (int i = 0; i < LN_MAXI; ++i) {
+  for (int i = 0; i < NI; ++i) {
     red[0][wave][lane + 64 * i] = dg[i];
     red[1][wave][lane + 64 * i] = db[i];
   }
@@ -128,9 +155,8 @@ struct Win {
   int b, Wy, Wx, head;
 };
 
-__device__ __forceinline__ Win decode(const neosr_wattn_desc& d, int bid, int& nWx, int& nW) {
-  nWx = d.W / WS;
-  nW = (d.H / WS) * nWx;
+__device__ __forceinline__ Win decode(const neosr_wattn_desc& d, int bid) {
+  const int nWx = d.W / WS, nW = (d.H / WS) * nWx;
   Win w;
   w.head = bid % d.heads;
   const int t = bid / d.heads;
@@ -141,29 +167,39 @@ __device__ __forceinline__ Win decode(const neosr_wattn_desc& d, int bid, int& n
   return w;
 }
 
-__device__ __forceinline__ int64_t token_of(const neosr_wattn_desc& d, const Win& w, int n) {
-  const int y = (w.Wy * WS + (n >> 3) + d.shift) % d.H;
-  const int x = (w.Wx * WS + (n & 7) + d.shift) % d.W;
-  return ((int64_t)w.b * d.H + y) * d.W + x;
-}
+// Per-workgroup tables, built once by the first 64 / 225 threads so the hot loops do no integer
+// division and no global gathers:
+//   tok[n]  pixel row of window token n in the (B*H*W, .) matrices: the cyclic shift (torch.roll) and
+//           window_partition / window_reverse are this one index
+//   reg[n]  shifted-window mask region of token n (swinir_arch.py:313-341 calculate_mask): 3x3 regions
+//           of the rolled image; pairs from different regions get -100
+//   tab[k]  this head's column of relative_position_bias_table
+struct Tables {
+  int tok[NTOK];
+  int reg[NTOK];
+  float tab[NB + 31];
+};
 
-// shifted-window mask region id of token n (swinir_arch.py:313-341 calculate_mask)
-__device__ __forceinline__ int region_of(const neosr_wattn_desc& d, const Win& w, int n) {
-  const int ys = w.Wy * WS + (n >> 3), xs = w.Wx * WS + (n & 7);
-  const int ry = ys < d.H - WS ? 0 : (ys < d.H - d.shift ? 1 : 2);
-  const int rx = xs < d.W - WS ? 0 : (xs < d.W - d.shift ? 1 : 2);
-  return ry * 3 + rx;
-}
-
-__device__ __forceinline__ int rel_index(int i, int j) {
-  return ((i >> 3) - (j >> 3) + WS - 1) * (2 * WS - 1) + ((i & 7) - (j & 7) + WS - 1);
+__device__ __forceinline__ void build_tables(const neosr_wattn_desc& d, const Win& w, Tables& T) {
+  const int n = threadIdx.x;
+  if (n < NTOK) {
+    const int ys = w.Wy * WS + (n >> 3), xs = w.Wx * WS + (n & 7);
+    int y = ys + d.shift, x = xs + d.shift;  // shift < WS <= H, W: one conditional subtract == modulo
+    if (y >= d.H) y -= d.H;
+    if (x >= d.W) x -= d.W;
+    T.tok[n] = (w.b * d.H + y) * d.W + x;
+    const int ry = ys < d.H - WS ? 0 : (ys < d.H - d.shift ? 1 : 2);
+    const int rx = xs < d.W - WS ? 0 : (xs < d.W - d.shift ? 1 : 2);
+    T.reg[n] = d.shift > 0 ? ry * 3 + rx : 0;
+  }
+  if (n < NB) T.tab[n] = d.rpb_table[n * d.heads + w.head];
 }
 
 // stage one [64 x hd] slice of the fused qkv matrix (or of dout) into LDS, zero padded to 32 cols
-__device__ __forceinline__ void load_tile(const neosr_wattn_desc& d, const Win& w, const float* src,
-                                          int ld, int col0, int hd, float mul, float* dst) {
+__device__ __forceinline__ void load_tile(const Tables& T, const float* src, int ld, int col0, int hd,
+                                          float mul, float* dst) {
   const int n = threadIdx.x >> 2, part = threadIdx.x & 3;  // 64 tokens x 4 column groups of 8
-  const float* row = src + token_of(d, w, n) * ld + col0;
+  const float* row = src + (int64_t)T.tok[n] * ld + col0;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const int c = part * 8 + e;
@@ -213,35 +249,41 @@ __device__ __forceinline__ f32x16 tile_ab(const float* A, int sa, const float* B
   return acc;
 }
 
-// scores tile -> LDS: s = q.k (+ rpb + mask); if lse != nullptr store exp(s - lse[i]) instead
-__device__ __forceinline__ void scores_to_lds(const neosr_wattn_desc& d, const Win& w, const f32x16& acc,
-                                              int ti, int tj, int l31, int lh, const float* lse_row,
-                                              float* P) {
+// scores tile -> LDS: s = q.k + rpb + mask; if lse_row != nullptr store exp(s - lse[i]) instead.
+// Register r of the MFMA tile is query token i = 32 ti + (r&3) + 8 (r>>2) + 4 lh, the lane's column is
+// key token j: the relative-position index (yi - yj + 7) * 15 + (xi - xj + 7) splits into a per-lane
+// base and a compile-time term per register.
+__device__ __forceinline__ void scores_to_lds(const Tables& T, const f32x16& acc, int ti, int tj, int l31,
+                                              int lh, const float* lse_row, float* P) {
   const int j = 32 * tj + l31;
-  const int rj = d.shift > 0 ? region_of(d, w, j) : 0;
+  const int rj = T.reg[j];
+  const float* tb = T.tab + (WS - 1 - (j >> 3) + 4 * ti) * (2 * WS - 1) + (WS - 1 - (j & 7)) + 4 * lh;
+  const int i0 = 32 * ti + 4 * lh;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const int i = 32 * ti + (r & 3) + 8 * (r >> 2) + 4 * lh;
-    float s = acc[r] + d.rpb_table[rel_index(i, j) * d.heads + w.head];
-    if (d.shift > 0 && region_of(d, w, i) != rj) s += -100.f;
-    P[i * PS + j] = lse_row ? expf(s - lse_row[i]) : s;
+    const int di = (r & 3) + 8 * (r >> 2);  // i = i0 + di: yi = 4 ti + (r>>2), xi = (r&3) + 4 lh
+    float s = acc[r] + tb[(r >> 2) * (2 * WS - 1) + (r & 3)];
+    if (T.reg[i0 + di] != rj) s -= 100.f;
+    P[(i0 + di) * PS + j] = lse_row ? __expf(s - lse_row[i0 + di]) : s;
   }
 }
 
 __global__ __launch_bounds__(256) void window_attention_fwd_kernel(const neosr_wattn_desc d) {
   __shared__ float Qs[NTOK * QS], Ks[NTOK * QS], Vs[NTOK * QS], P[NTOK * PS];
+  __shared__ Tables T;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
-  int nWx, nW;
-  const Win w = decode(d, blockIdx.x, nWx, nW);
+  const Win w = decode(d, blockIdx.x);
   const int hd = d.C / d.heads, ld = 3 * d.C;
-  load_tile(d, w, d.qkv, ld, w.head * hd, hd, d.scale, Qs);
-  load_tile(d, w, d.qkv, ld, d.C + w.head * hd, hd, 1.f, Ks);
-  load_tile(d, w, d.qkv, ld, 2 * d.C + w.head * hd, hd, 1.f, Vs);
+  build_tables(d, w, T);
+  __syncthreads();
+  load_tile(T, d.qkv, ld, w.head * hd, hd, d.scale, Qs);
+  load_tile(T, d.qkv, ld, d.C + w.head * hd, hd, 1.f, Ks);
+  load_tile(T, d.qkv, ld, 2 * d.C + w.head * hd, hd, 1.f, Vs);
   __syncthreads();
   {
     const int ti = wave >> 1, tj = wave & 1;
     const f32x16 acc = tile_abt(Qs, QS, Ks, QS, ti, tj, (hd + 1) & ~1, l31, lh);
-    scores_to_lds(d, w, acc, ti, tj, l31, lh, nullptr, P);
+    scores_to_lds(T, acc, ti, tj, l31, lh, nullptr, P);
   }
   __syncthreads();
   {  // row softmax: 4 threads per row
@@ -255,7 +297,7 @@ __global__ __launch_bounds__(256) void window_attention_fwd_kernel(const neosr_w
     float s = 0.f, e[16];
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
-      e[c] = expf(row[c] - m);
+      e[c] = __expf(row[c] - m);
       s += e[c];
     }
     s += __shfl_xor(s, 1, 64);
@@ -263,17 +305,16 @@ __global__ __launch_bounds__(256) void window_attention_fwd_kernel(const neosr_w
     const float inv = 1.f / s;
 #pragma unroll
     for (int c = 0; c < 16; ++c) row[c] = e[c] * inv;
-    if (q == 0 && d.lse) d.lse[(int64_t)blockIdx.x * NTOK + i] = m + logf(s);
+    if (q == 0 && d.lse) d.lse[(int64_t)blockIdx.x * NTOK + i] = m + __logf(s);
   }
   __syncthreads();
   if (wave < 2) {  // O = P V : rows 32*wave.., cols d
     const f32x16 acc = tile_ab(P, PS, Vs, QS, wave, 0, l31, lh);
     if (l31 < hd) {
+      float* out = d.out + w.head * hd + l31;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int i = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        d.out[token_of(d, w, i) * d.C + w.head * hd + l31] = acc[r];
-      }
+      for (int r = 0; r < 16; ++r)
+        out[(int64_t)T.tok[32 * wave + (r & 3) + 8 * (r >> 2) + 4 * lh] * d.C] = acc[r];
     }
   }
 }
@@ -282,24 +323,26 @@ __global__ __launch_bounds__(256) void window_attention_bwd_kernel(const neosr_w
   __shared__ float Qs[NTOK * QS], Ks[NTOK * QS], Vs[NTOK * QS], Gs[NTOK * QS];
   __shared__ float P[NTOK * PS], dS[NTOK * PS];
   __shared__ float lse_s[NTOK];
+  __shared__ Tables T;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
-  int nWx, nW;
-  const Win w = decode(d, blockIdx.x, nWx, nW);
+  const Win w = decode(d, blockIdx.x);
   const int hd = d.C / d.heads, ld = 3 * d.C, kq = (hd + 1) & ~1;
-  load_tile(d, w, d.qkv, ld, w.head * hd, hd, d.scale, Qs);
-  load_tile(d, w, d.qkv, ld, d.C + w.head * hd, hd, 1.f, Ks);
-  load_tile(d, w, d.qkv, ld, 2 * d.C + w.head * hd, hd, 1.f, Vs);
-  load_tile(d, w, d.dout, d.C, w.head * hd, hd, 1.f, Gs);
+  build_tables(d, w, T);
   if (tid < NTOK) lse_s[tid] = d.lse[(int64_t)blockIdx.x * NTOK + tid];
+  __syncthreads();
+  load_tile(T, d.qkv, ld, w.head * hd, hd, d.scale, Qs);
+  load_tile(T, d.qkv, ld, d.C + w.head * hd, hd, 1.f, Ks);
+  load_tile(T, d.qkv, ld, 2 * d.C + w.head * hd, hd, 1.f, Vs);
+  load_tile(T, d.dout, d.C, w.head * hd, hd, 1.f, Gs);
   __syncthreads();
   {
     const int ti = wave >> 1, tj = wave & 1;
     const f32x16 s = tile_abt(Qs, QS, Ks, QS, ti, tj, kq, l31, lh);
-    scores_to_lds(d, w, s, ti, tj, l31, lh, lse_s, P);            // P = softmax (recomputed)
+    scores_to_lds(T, s, ti, tj, l31, lh, lse_s, P);                   // P = softmax (recomputed)
     const f32x16 dp = tile_abt(Gs, QS, Vs, QS, ti, tj, kq, l31, lh);  // dP = dO V^T
-    const int j = 32 * tj + l31;
+    float* o = dS + (32 * ti + 4 * lh) * PS + 32 * tj + l31;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) dS[(32 * ti + (r & 3) + 8 * (r >> 2) + 4 * lh) * PS + j] = dp[r];
+    for (int r = 0; r < 16; ++r) o[((r & 3) + 8 * (r >> 2)) * PS] = dp[r];
   }
   __syncthreads();
   {  // dS = P * (dP - sum_j P dP), 4 threads per row
@@ -324,7 +367,7 @@ __global__ __launch_bounds__(256) void window_attention_bwd_kernel(const neosr_w
         s += dS[(yi * WS + xi) * PS + (yi - dy) * WS + (xi - dx)];
     d.workspace[((int64_t)(blockIdx.x / d.heads) * NB + tid) * d.heads + w.head] = s;
   }
-  const int col = w.head * hd + l31;
+  float* g = d.dqkv + w.head * hd + l31;
   if (wave < 2) {
     // dV[j][d] = sum_i P[i][j] dO[i][d]
     const f32x16 dv = tile_atb(P, PS, Gs, QS, wave, 0, l31, lh);
@@ -333,10 +376,9 @@ __global__ __launch_bounds__(256) void window_attention_bwd_kernel(const neosr_w
     if (l31 < hd) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int n = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const int64_t t = token_of(d, w, n) * ld;
-        d.dqkv[t + 2 * d.C + col] = dv[r];
-        d.dqkv[t + col] = dq[r] * d.scale;
+        const int64_t t = (int64_t)T.tok[32 * wave + (r & 3) + 8 * (r >> 2) + 4 * lh] * ld;
+        g[t + 2 * d.C] = dv[r];
+        g[t] = dq[r] * d.scale;
       }
     }
   } else {
@@ -344,10 +386,8 @@ __global__ __launch_bounds__(256) void window_attention_bwd_kernel(const neosr_w
     const f32x16 dk = tile_atb(dS, PS, Qs, QS, wave - 2, 0, l31, lh);
     if (l31 < hd) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int n = 32 * (wave - 2) + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        d.dqkv[token_of(d, w, n) * ld + d.C + col] = dk[r];
-      }
+      for (int r = 0; r < 16; ++r)
+        g[(int64_t)T.tok[32 * (wave - 2) + (r & 3) + 8 * (r >> 2) + 4 * lh] * ld + d.C] = dk[r];
     }
   }
 }
@@ -403,8 +443,19 @@ int wattn_check(const neosr_wattn_desc* d) {
 extern "C" int neosr_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y,
                                    float* stats, int64_t rows, int32_t C, float eps, void* stream) {
   NEOSR_CHECK(x && gamma && beta && y && stats && rows > 0 && C > 0 && C <= LN_MAXI * 64, "layernorm_fwd: bad args (C <= 512)");
-  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(grid_for(rows * 64, 2048)), dim3(256), 0, (hipStream_t)stream,
-                     x, gamma, beta, y, stats, rows, C, eps);
+  const dim3 grid(grid_for(rows * 16, 2048));  // 4 rows per wave
+#define LN_FWD(NI)                                                                                            \
+  hipLaunchKernelGGL(layernorm_fwd_kernel<NI>, grid, dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, \
+                     stats, rows, C, eps)
+  switch ((C + 63) / 64) {
+    case 1: LN_FWD(1); break;
+    case 2: LN_FWD(2); break;
+    case 3: LN_FWD(3); break;
+    case 4: LN_FWD(4); break;
+    case 5: case 6: LN_FWD(6); break;
+    default: LN_FWD(8); break;
+  }
+#undef LN_FWD
   NEOSR_LAUNCH_CHECK();
   return 0;
 }
@@ -414,14 +465,26 @@ extern "C" int neosr_layernorm_bwd(const float* dy, const float* x, const float*
                                    int32_t C, int32_t accumulate, void* stream) {
   NEOSR_CHECK(dy && x && stats && gamma && dx && dgamma && dbeta && workspace && rows > 0 && C > 0 &&
                   C <= LN_MAXI * 64, "layernorm_bwd: bad args");
-  int nblk = (int)((rows + 31) / 32);  // 8 rows per wave
-  if (nblk > 512) nblk = 512;
-  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, dy, x, stats, gamma,
-                     dx, workspace, rows, C);
+  int nblk = (int)((rows + 15) / 16);  // >= 4 rows per wave
+  if (nblk > 1024) nblk = 1024;
+#define LN_BWD(NI)                                                                                              \
+  hipLaunchKernelGGL(layernorm_bwd_kernel<NI>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, dy, x, stats, \
+                     gamma, dx, workspace, rows, C)
+  switch ((C + 63) / 64) {
+    case 1: LN_BWD(1); break;
+    case 2: LN_BWD(2); break;
+    case 3: LN_BWD(3); break;
+    case 4: LN_BWD(4); break;
+    case 5: case 6: LN_BWD(6); break;
+    default: LN_BWD(8); break;
+  }
+#undef LN_BWD
   NEOSR_LAUNCH_CHECK();
-  // per-workgroup partials [nblk][2][C] -> dgamma | dbeta (nblk <= 1024: single-launch column sums)
-  if (int rc = neosr_colsum(workspace, dgamma, workspace, nblk, C, 2 * C, accumulate, stream)) return rc;
-  return neosr_colsum(workspace + C, dbeta, workspace, nblk, C, 2 * C, accumulate, stream);
+  // per-workgroup partials [nblk][2][C] -> dgamma | dbeta; the column sums stage through the tail of
+  // the workspace (behind the 2*1024*C partials)
+  float* stage = workspace + (int64_t)2 * 1024 * C;
+  if (int rc = neosr_colsum(workspace, dgamma, stage, nblk, C, 2 * C, accumulate, stream)) return rc;
+  return neosr_colsum(workspace + C, dbeta, stage, nblk, C, 2 * C, accumulate, stream);
 }
 
 extern "C" int neosr_window_attention_fwd(const neosr_wattn_desc* d, void* stream) {

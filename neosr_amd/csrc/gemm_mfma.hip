@@ -280,7 +280,8 @@ int tn_splits(int M, int N, int K) {
 
 extern "C" int64_t neosr_gemm_workspace_bytes(const neosr_gemm_desc* d) {
   if (!d || d->mode != NEOSR_GEMM_TN) return 256;
-  return ((int64_t)(tn_splits(d->M, d->N, d->K) + 1) * d->M * d->N + 64) * 4;
+  // split-K slabs + the staging area of the column-sum reduction (<= 16384 + M*N floats)
+  return ((int64_t)(tn_splits(d->M, d->N, d->K) + 1) * d->M * d->N + 16384 + 64) * 4;
 }
 
 extern "C" int neosr_gemm(const neosr_gemm_desc* dp, void* stream) {
@@ -334,11 +335,15 @@ extern "C" int neosr_colsum(const float* x, float* out, float* workspace, int32_
   NEOSR_CHECK(x && out && workspace && rows > 0 && cols > 0 && ld >= cols, "colsum: bad args");
   hipStream_t st = (hipStream_t)stream;
   const int gx = ceil_div(cols, 64);
-  if (rows <= 1024) {
+  // row slabs: enough workgroups to fill the chip when there are few column blocks, and never more
+  // than 1024 rows per slab; one launch when a single slab does
+  int nblk = ceil_div(256, gx);
+  if (nblk < ceil_div(rows, 1024)) nblk = ceil_div(rows, 1024);
+  if (nblk > ceil_div(rows, 16)) nblk = ceil_div(rows, 16);
+  if (nblk > 256) nblk = 256;
+  if (nblk <= 1) {
     hipLaunchKernelGGL(colsum_kernel, dim3(gx, 1), dim3(256), 0, st, x, out, rows, cols, ld, rows, accumulate);
   } else {
-    int nblk = ceil_div(rows, 128);
-    if (nblk > 256) nblk = 256;
     const int rpb = ceil_div(ceil_div(rows, nblk), 4) * 4;
     nblk = ceil_div(rows, rpb);
     hipLaunchKernelGGL(colsum_kernel, dim3(gx, nblk), dim3(256), 0, st, x, workspace, rows, cols, ld, rpb, 0);

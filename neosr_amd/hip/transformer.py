@@ -170,7 +170,7 @@ class LayerNorm(torch.autograd.Function):
         g2 = _as2d(g)
         dx = torch.empty_like(x2)
         dg, db = _new((C_,), x2), _new((C_,), x2)
-        ws = _new((2 * 512 * C_,), x2)
+        ws = _new(((2 * 1024 + 256) * C_,), x2)
         _C.check(lib.neosr_layernorm_bwd(g2.data_ptr(), x2.data_ptr(), stats.data_ptr(), gamma.data_ptr(),
                                          dx.data_ptr(), dg.data_ptr(), db.data_ptr(), ws.data_ptr(), rows, C_, 0,
                                          _st()), "neosr_layernorm_bwd")
