@@ -348,6 +348,34 @@ int neosr_affine(const float* in, float* out, int64_t n, float shift, float scal
 int neosr_row_scale(const float* in, const float* scale, float* out, int64_t rows, int32_t cols,
                     int32_t rows_per_scale, void* stream);
 
+/* Schedule-Free Adan (neosr/optimizers/adan_sf.py:138-330, the template optimizer of
+ * options/train_*_otf.toml) fused with the model-level clip_grad_norm_ (models/image.py:533-544) and
+ * the EMA update (image.py:661-662): neosr_grad_norm + one sweep over flat arenas.
+ *   g = grad * grad_scale * min(1, max_norm / (||grad|| + 1e-6));  npg += g  (npg := -g first at step 1)
+ *   m = b1 m + (1-b1) g;  d = b2 d + (1-b2) npg;  npg = b2 npg + g;  n = b3 n + (1-b3) npg^2
+ *   denom = sqrt(n)/sqrt(1-b3^t) + eps;  p *= 1 - lr wd
+ *   schedule_free: p = lerp(p, z, ckp1); p -= lr (1-b1^t)(1-ckp1) m/denom; p -= lr b2/(1-b2^t) (1-ckp1) d/denom;
+ *                  z -= lr g        else: p -= lr/(1-b1^t) m/denom; p -= lr b2/(1-b2^t) d/denom
+ *   npg = -g;  ema as in neosr_adamw_step.  `ckp1` (the averaging weight) is host state. */
+typedef struct neosr_adan_desc {
+  float* param;
+  const float* grad;
+  float* exp_avg;
+  float* exp_avg_sq;
+  float* exp_avg_diff;
+  float* z;            /* schedule_free only */
+  float* neg_pre_grad;
+  float* ema;          /* optional */
+  float* norm_ws;      /* >= 4200 floats when max_norm > 0 */
+  int64_t n;
+  float lr, beta1, beta2, beta3, eps, weight_decay, ckp1;
+  float max_norm, ema_decay, grad_scale;
+  int32_t step, first_step, schedule_free;
+} neosr_adan_desc;
+int neosr_adan_sf_step(const neosr_adan_desc* d, void* stream);
+/* p = torch.lerp(p, end, weight) elementwise: adan_sf.train() / .eval() (adan_sf.py:112-136). */
+int neosr_lerp(float* p, const float* end, int64_t n, float weight, void* stream);
+
 /* opt-in profiler ------------------------------------------------------------------------------
  * HIP events around every conv-class launch on the launch stream (classes: 0 conv fwd, 1 conv
  * dgrad, 2 conv wgrad, 3 wgrad reduce).  Used by bench.py's roofline pass only.  collect()

@@ -106,6 +106,19 @@ class AdamWDesc(C.Structure):
     ]
 
 
+class AdanDesc(C.Structure):
+    """neosr_adan_desc"""
+
+    _fields_ = (
+        [(n, C.c_void_p) for n in ("param", "grad", "exp_avg", "exp_avg_sq", "exp_avg_diff", "z", "neg_pre_grad",
+                                   "ema", "norm_ws")]
+        + [("n", C.c_int64)]
+        + [(n, C.c_float) for n in ("lr", "beta1", "beta2", "beta3", "eps", "weight_decay", "ckp1", "max_norm",
+                                    "ema_decay", "grad_scale")]
+        + [(n, C.c_int32) for n in ("step", "first_step", "schedule_free")]
+    )
+
+
 class RRDBNetCfg(C.Structure):
     """neosr_rrdbnet_cfg"""
 
@@ -225,6 +238,8 @@ SIGNATURES: dict[str, tuple] = {
     "neosr_pixel_shuffle_nhwc": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "neosr_affine": (C.c_int, [_vp, _vp, _i64, _f32, _f32, _vp]),
     "neosr_row_scale": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _vp]),
+    "neosr_adan_sf_step": (C.c_int, [C.POINTER(AdanDesc), _vp]),
+    "neosr_lerp": (C.c_int, [_vp, _vp, _i64, _f32, _vp]),
     "neosr_prof_enable": (C.c_int, [C.c_int]),
     "neosr_prof_collect": (
         C.c_int,

@@ -125,9 +125,11 @@ class base:
     def get_optimizer(self, optim_type: str, params, lr: float, **kwargs):
         if optim_type in {"AdamW", "adamw"}:
             return optimizers.AdamW(params, lr, **kwargs)
+        if optim_type in {"Adan_SF", "adan_sf"}:
+            return optimizers.adan_sf(params, lr, **kwargs)
         logger = get_root_logger()
         logger.error(f"{tc.red}Optimizer {optim_type} has no HIP implementation yet "
-                     f"(available: adamw).{tc.end}")
+                     f"(available: adamw, adan_sf).{tc.end}")
         sys.exit(1)
 
     def setup_schedulers(self) -> None:
@@ -182,6 +184,11 @@ class base:
                     continue
                 sd[name.removeprefix("module.")] = p.detach().cpu().clone()
             save_dict[k] = sd
+        # base.py:325-354: schedule-free optimizers are switched to eval (x weights) around the write
+        sf = [o for o, on in ((getattr(self, "optimizer_g", None), self.sf_optim_g),
+                              (getattr(self, "optimizer_d", None), self.sf_optim_d)) if o is not None and on and self.is_train]
+        for o in sf:
+            o.eval()
         for retry in range(3):
             try:
                 torch.save(save_dict, path)
@@ -189,6 +196,8 @@ class base:
             except OSError as e:
                 get_root_logger().warning(f"Save model error: {e}, remaining retry times: {2 - retry}")
                 time.sleep(1)
+        for o in sf:
+            o.train()
 
     def load_network(self, net, load_path, param_key: str | None = None, strict: bool = True) -> None:
         load_net = torch.load(load_path, map_location="cpu", weights_only=True)

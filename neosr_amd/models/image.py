@@ -111,8 +111,12 @@ class image(base):
         self.setup_optimizers()
         self.setup_schedulers()
         self.net_g.train()
+        if self.sf_optim_g:
+            self.optimizer_g.train()  # image.py:99-105
         if self.net_d is not None:
             self.net_d.train()
+            if self.sf_optim_d:
+                self.optimizer_d.train()
 
         self.scale = self.opt["scale"]
         ds = self.opt["datasets"]["train"]
@@ -161,15 +165,24 @@ class image(base):
                 optim_params.append(v)
             else:
                 logger.warning(f"Params {k} will not be optimized.")
+        sf_types = {"AdamW_SF", "adamw_sf", "adan_sf", "Adan_SF"}
         og = dict(train_opt["optim_g"])
         optim_type = og.pop("type")
-        og.pop("schedule_free", None)
+        if optim_type in sf_types and "schedule_free" not in og:  # image.py:307-314
+            logger.error(f"{tc.red}The option 'schedule_free' must be in the config file.{tc.end}")
+            sys.exit(1)
+        if optim_type not in sf_types:
+            og.pop("schedule_free", None)
         self.optimizer_g = self.get_optimizer(optim_type, optim_params, **og)
         self.optimizers.append(self.optimizer_g)
         if self.net_d is not None:
             od = dict(train_opt["optim_d"])
             optim_type = od.pop("type")
-            od.pop("schedule_free", None)
+            if optim_type in sf_types and "schedule_free" not in od:  # image.py:358-365
+                logger.error(f"{tc.red}The option 'schedule_free' must be in the config file.{tc.end}")
+                sys.exit(1)
+            if optim_type not in sf_types:
+                od.pop("schedule_free", None)
             self.optimizer_d = self.get_optimizer(optim_type, list(self.net_d.parameters()), **od)
             self.optimizers.append(self.optimizer_d)
 

@@ -206,3 +206,104 @@ class ImageTrainer:
                 ema_update(self.ema, plist, self.ema_decay, first=self.step == 1)
         self.output = out.detach()
         self.log = {"l_g_pix": float(l_pix), "l_g_total": float(l_total)}
+
+
+# --------------------------------------------------------------------------------------------
+# Schedule-Free Adan (neosr/optimizers/adan_sf.py) — per-tensor restatement
+# --------------------------------------------------------------------------------------------
+
+
+class AdanSF:
+    """`adan_sf` (adan_sf.py:10-330): `step(grads)` follows `_multi_tensor_adan` op by op on plain
+    tensors; `train()` / `eval()` are the y <-> x lerps; group scalars (`step`, `weight_sum`,
+    `lr_max`) live on the object.  `max_grad_norm` (the optimizer's own clip) is 0 as in the templates."""
+
+    def __init__(self, params: list[torch.Tensor], lr: float, betas=(0.98, 0.92, 0.99), eps: float = 1e-8,
+                 weight_decay: float = 0.02, warmup_steps: int = 0, r: float = 0.0, weight_lr_power: float = 2.0,
+                 schedule_free: bool = True) -> None:
+        self.p = params
+        self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
+        self.warmup_steps, self.r, self.wlp, self.sf = warmup_steps, r, weight_lr_power, schedule_free
+        self.step_n, self.weight_sum, self.lr_max, self.train_mode = 0, 0.0, -1.0, True
+        self.state: list[dict[str, torch.Tensor]] = [{} for _ in params]
+
+    @torch.no_grad()
+    def eval(self) -> None:
+        if self.train_mode:
+            for p, s in zip(self.p, self.state):
+                if "z" in s:
+                    p.lerp_(s["z"], 1 - 1 / self.betas[0])
+            self.train_mode = False
+
+    @torch.no_grad()
+    def train(self) -> None:
+        if not self.train_mode:
+            for p, s in zip(self.p, self.state):
+                if "z" in s:
+                    p.lerp_(s["z"], 1 - self.betas[0])
+            self.train_mode = True
+
+    @torch.no_grad()
+    def step(self, grads: list[torch.Tensor]) -> None:
+        b1, b2, b3 = self.betas
+        self.step_n += 1
+        t = self.step_n
+        bc1, bc2, bc3 = 1.0 - b1**t, 1.0 - b2**t, 1.0 - b3**t
+        ckp1 = None
+        if self.sf:
+            sched = t / self.warmup_steps if t < self.warmup_steps else 1.0
+            lr_eff = self.lr * sched * math.sqrt(bc3)
+            self.lr_max = max(lr_eff, self.lr_max)
+            weight = (t**self.r) * (self.lr_max**self.wlp)
+            self.weight_sum += weight
+            ckp1 = weight / self.weight_sum if self.weight_sum != 0 else 0
+            assert self.train_mode, "Not in train mode!"
+        for p, g, s in zip(self.p, grads, self.state):
+            if not s:
+                s.update(exp_avg=torch.zeros_like(p), exp_avg_sq=torch.zeros_like(p),
+                         exp_avg_diff=torch.zeros_like(p), z=p.detach().clone())
+            if "neg_pre_grad" not in s or t == 1:
+                s["neg_pre_grad"] = g.clone().mul_(-1.0)
+            m, n, d, z, npg = s["exp_avg"], s["exp_avg_sq"], s["exp_avg_diff"], s["z"], s["neg_pre_grad"]
+            npg.add_(g)
+            m.mul_(b1).add_(g, alpha=1 - b1)
+            d.mul_(b2).add_(npg, alpha=1 - b2)
+            npg.mul_(b2).add_(g)
+            n.mul_(b3).addcmul_(npg, npg, value=1 - b3)
+            denom = n.sqrt().div_(math.sqrt(bc3)).add_(self.eps)
+            p.mul_(1 - self.lr * self.wd)
+            if self.sf:
+                p.lerp_(z, ckp1)
+                p.addcdiv_(m, denom, value=-(self.lr * (bc1 * (1 - ckp1))))
+                p.addcdiv_(d, denom, value=-(self.lr * (b2 / bc2 * (1 - ckp1))))
+                z.sub_(g, alpha=self.lr)
+            else:
+                p.addcdiv_(m, denom, value=-(self.lr / bc1))
+                p.addcdiv_(d, denom, value=-(self.lr * b2 / bc2))
+            npg.zero_().add_(g, alpha=-1.0)
+
+
+class AdanImageTrainer(ImageTrainer):
+    """ImageTrainer with `optim_g.type = "adan_sf"` (models/image.py:627-662 with a schedule-free optimizer)."""
+
+    def __init__(self, forward_fn, params, lr: float, betas=(0.98, 0.92, 0.99), weight_decay: float = 0.02,
+                 warmup_steps: int = 0, schedule_free: bool = True, ema: float = 0.999, grad_clip: bool = True,
+                 loss_weight: float = 1.0) -> None:
+        super().__init__(forward_fn, params, lr, ema=ema, grad_clip=grad_clip, loss_weight=loss_weight)
+        self.opt = AdanSF(list(self.P.values()), lr, betas, 1e-8, weight_decay, warmup_steps,
+                          schedule_free=schedule_free)
+
+    def optimize_parameters(self) -> None:
+        out = self.forward_fn(self.P, self.lq)
+        l_pix = l1_loss(out, self.gt, self.loss_weight)
+        l_total = torch.zeros(1) + l_pix
+        grads = [g.clone() for g in torch.autograd.grad(l_total.sum(), list(self.P.values()))]
+        if self.grad_clip:
+            clip_grad_norm_(grads, 1.0)
+        self.step += 1
+        self.opt.step(grads)
+        with torch.no_grad():
+            if self.ema_decay > 0:
+                ema_update(self.ema, list(self.P.values()), self.ema_decay, first=self.step == 1)
+        self.output = out.detach()
+        self.log = {"l_g_pix": float(l_pix.detach()), "l_g_total": float(l_total.detach())}
