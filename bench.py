@@ -154,13 +154,19 @@ def main() -> None:
     opt = make_opt(args.batch, world, rank, args.arch)
     if args.workload == "swinir_percep":
         opt["train"]["perceptual_opt"] = {"type": "vgg_perceptual_loss", "loss_weight": 1.0, "criterion": "chc"}
+        opt["train"]["optim_g"] = {"type": "adan_sf", "lr": 1e-3, "betas": [0.98, 0.92, 0.987], "weight_decay": 0.02,
+                                   "schedule_free": True, "warmup_steps": 1600}
     if args.workload == "otf_gan":
         from tools.bench_degrade import DEG_TABLE
         opt["model_type"] = "otf"
         opt["degradations"] = dict(DEG_TABLE)
         opt["datasets"]["train"].update({"type": "otf", "queue_size": 180})
         opt["network_d"] = {"type": "unet"}
-        opt["train"]["optim_d"] = {"type": "adamw", "lr": 1e-4, "betas": [0.9, 0.99], "weight_decay": 0.0}
+        # template optimizers (options/train_esrgan_otf.toml:103-117)
+        opt["train"]["optim_g"] = {"type": "adan_sf", "lr": 8e-4, "betas": [0.98, 0.92, 0.987], "weight_decay": 0.02,
+                                   "schedule_free": True, "warmup_steps": 1600}
+        opt["train"]["optim_d"] = {"type": "adan_sf", "lr": 5e-4, "betas": [0.98, 0.92, 0.99], "weight_decay": 0.02,
+                                   "schedule_free": True}
         opt["train"]["perceptual_opt"] = {"type": "vgg_perceptual_loss", "loss_weight": 0.5, "criterion": "chc"}
         opt["train"]["gan_opt"] = {"type": "gan_loss", "gan_type": "bce", "loss_weight": 0.3}
     set_global_opt(opt)
@@ -266,10 +272,10 @@ def main() -> None:
     }
     if args.workload == "otf_gan":
         out["config"]["workload"] = (f"{args.arch} RRDB x4 + unet-SN D + VGG19 perceptual (random weights) + GAN, "
-                                     f"otf degradation from 512x512 GT, AdamW x2, batch={B}/GPU (BASELINE configs[2])")
+                                     f"otf degradation from 512x512 GT, adan_sf x2 (template), batch={B}/GPU (BASELINE configs[2])")
     if args.workload == "swinir_percep":
         out["config"]["workload"] = (f"{args.arch} x4, paired 64x64 LR synthetic, L1 + VGG19 perceptual (random weights), "
-                                     f"window-attention path, AdamW + grad-clip + EMA, batch={B}/GPU (BASELINE configs[3])")
+                                     f"window-attention path, adan_sf (template) + grad-clip + EMA, batch={B}/GPU (BASELINE configs[3])")
     if world == 1 and args.cpu_budget > 0 and args.workload == "paired_l1" and not args.arch.startswith("swinir"):
         out["cpu_baseline"] = cpu_baseline(args.arch, args.cpu_budget)
     else:
