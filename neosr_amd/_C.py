@@ -171,6 +171,16 @@ class WattnDesc(C.Structure):
     )
 
 
+class FattnDesc(C.Structure):
+    """neosr_fattn_desc"""
+
+    _fields_ = (
+        [(n, C.c_void_p) for n in ("qkv", "rpb_table", "out", "lse", "dout", "dqkv", "d_rpb_table", "workspace")]
+        + [(n, C.c_int32) for n in ("B", "H", "W", "C", "heads", "ws", "ks", "shift", "accumulate_rpb")]
+        + [("scale", C.c_float)]
+    )
+
+
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_PRELU = 0, 1, 2, 3
 CONV_FWD, CONV_DGRAD = 0, 1
@@ -235,6 +245,9 @@ SIGNATURES: dict[str, tuple] = {
     "neosr_layernorm_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     "neosr_window_attention_fwd": (C.c_int, [C.POINTER(WattnDesc), _vp]),
     "neosr_window_attention_bwd": (C.c_int, [C.POINTER(WattnDesc), _vp]),
+    "neosr_flash_window_attention_workspace_bytes": (_i64, [C.POINTER(FattnDesc)]),
+    "neosr_flash_window_attention_fwd": (C.c_int, [C.POINTER(FattnDesc), _vp]),
+    "neosr_flash_window_attention_bwd": (C.c_int, [C.POINTER(FattnDesc), _vp]),
     "neosr_pixel_shuffle_nhwc": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "neosr_affine": (C.c_int, [_vp, _vp, _i64, _f32, _f32, _vp]),
     "neosr_row_scale": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _vp]),

@@ -1,0 +1,616 @@
+// attn_flash.hip — 16x16-window attention of HAT for gfx950: 256 query tokens against 256 keys of the
+// same (shifted) window (HAB, neosr/archs/hat_arch.py:168-216 inside :299-351) or against the 576
+// keys of the overlapping 24x24 window (OCAB, hat_arch.py:445-516).
+//
+// A 256 x 576 score matrix does not fit in LDS, so the kernels stream 64-key blocks past a 64-query
+// block with an online softmax (running max / sum per row, accumulator rescaled per block); one
+// 256-thread workgroup per (window, head, 64-query block).  Q.K^T, P.V and the backward products run
+// on v_mfma_f32_32x32x2_f32 from LDS tiles; the next key block's K / V rows are prefetched into
+// registers while the current one is consumed.  torch.roll / window_partition / nn.Unfold (zero padded)
+// / einops.rearrange / window_reverse are pure addressing: a key of the overlapping window is pixel
+// (Wy*16 + yk - 4, Wx*16 + xk - 4) or, outside the image, a zero row that still takes part in the
+// softmax with score = bias (that is what Unfold's zero padding does in the reference).
+// Relative-position indices are evaluated analytically, including the reference's negative-index
+// wrap-around of calculate_rpi_oca (hat_arch.py:1035-1068: indices in [-880, 640] into a 1521-row table).
+// Backward: (A) per query block: dQ, and dS tiles dumped for the bias gradient; (B) per key block:
+// dK, dV (written in place for HAB; into an unfolded buffer + a fixed-order fold for OCAB, where up to
+// four windows overlap on a pixel); (C) bias gradient = column sums over windows, then a fixed-order
+// gather per table row.  No float atomics anywhere.
+#include "common.h"
+#include "../../include/neosr_amd.h"
+
+namespace {
+
+constexpr int QB = 64;        // queries / keys per block
+constexpr int QS = 33;        // q/k/v LDS row stride
+constexpr int PS = 65;        // score tile row stride
+constexpr int TAB_MAX = 1536; // >= (16+24-1)^2
+
+template <int WS, int KS>
+struct Geo {
+  static constexpr int NQ = WS * WS, NK = KS * KS, NKB = (NK + QB - 1) / QB, NQB = NQ / QB;
+  static constexpr int PAD = (KS - WS) / 2, L = WS + KS - 1, NBINS = L * L;
+  static constexpr bool SELF = KS == WS;
+};
+
+struct Win {
+  int b, Wy, Wx, head, qb;
+};
+
+// blockIdx -> (batch, window, head, block): block fastest so the 4 query blocks of a (window, head) —
+// which read the same K / V rows — sit next to each other
+__device__ __forceinline__ Win decode(const neosr_fattn_desc& d, int bid, int nblk) {
+  const int nWx = d.W / d.ws, nW = (d.H / d.ws) * nWx;
+  Win w;
+  w.qb = bid % nblk;
+  int t = bid / nblk;
+  w.head = t % d.heads;
+  t /= d.heads;
+  const int wi = t % nW;
+  w.b = t / nW;
+  w.Wy = wi / nWx;
+  w.Wx = wi - w.Wy * nWx;
+  return w;
+}
+
+// query token n (0..NQ) of the window -> pixel row of the (B*H*W, .) matrices, and mask region
+template <int WS>
+__device__ __forceinline__ void query_geom(const neosr_fattn_desc& d, const Win& w, int n, int& tok, int& reg) {
+  const int ys = w.Wy * WS + n / WS, xs = w.Wx * WS + n % WS;
+  int y = ys + d.shift, x = xs + d.shift;
+  if (y >= d.H) y -= d.H;
+  if (x >= d.W) x -= d.W;
+  tok = (w.b * d.H + y) * d.W + x;
+  const int ry = ys < d.H - WS ? 0 : (ys < d.H - d.shift ? 1 : 2);
+  const int rx = xs < d.W - WS ? 0 : (xs < d.W - d.shift ? 1 : 2);
+  reg = d.shift > 0 ? ry * 3 + rx : 0;
+}
+
+// key j (0..NK) -> pixel row (or -1: zero padding / past the end), region, bias key-term
+template <int WS, int KS>
+__device__ __forceinline__ void key_geom(const neosr_fattn_desc& d, const Win& w, int j, int& tok, int& reg,
+                                         int& kterm, bool& exists) {
+  using G = Geo<WS, KS>;
+  exists = j < G::NK;
+  const int yj = j / KS, xj = j % KS;
+  if (G::SELF) {
+    query_geom<WS>(d, w, exists ? j : 0, tok, reg);
+    kterm = -(yj * G::L + xj);
+  } else {
+    const int y = w.Wy * WS + yj - G::PAD, x = w.Wx * WS + xj - G::PAD;
+    const bool in = exists && y >= 0 && y < d.H && x >= 0 && x < d.W;
+    tok = in ? (w.b * d.H + y) * d.W + x : -1;
+    reg = 0;
+    kterm = yj * G::L + xj;
+  }
+  if (!exists) tok = -1;
+}
+
+// bias query-term of query n: idx = kterm + qterm (wrapped into [0, NBINS) for the overlapping form)
+template <int WS, int KS>
+__device__ __forceinline__ int query_term(int n) {
+  using G = Geo<WS, KS>;
+  const int yi = n / WS, xi = n % WS;
+  if (G::SELF) return yi * G::L + xi + (WS - 1) * G::L + (WS - 1);
+  return -(yi * G::L + xi) + (WS - KS + 1) * (G::L + 1);
+}
+
+struct Shared {
+  float Qs[QB * QS], Ks[QB * QS], Vs[QB * QS], P[QB * PS];
+  float tab[TAB_MAX];
+  int qpk[QB];    // qterm * 16 + region
+  int kpk[QB];    // kterm * 16 + region, or INT_MIN for a key that does not exist (masked out)
+  int qtok[QB];
+  float alpha[QB];
+};
+
+constexpr int KEY_NONE = -2147483647 - 1;
+
+// 8 consecutive floats (cols part*8..) of one token row, zero beyond hd or when tok < 0
+__device__ __forceinline__ void load_row8(const float* src, int tok, int ld, int col0, int hd, int part,
+                                          float (&v)[8]) {
+  const float* row = src + (int64_t)(tok < 0 ? 0 : tok) * ld + col0;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = part * 8 + e;
+    v[e] = (tok >= 0 && c < hd) ? row[c] : 0.f;
+  }
+}
+__device__ __forceinline__ void store_row8(float* dst, int n, int part, const float (&v)[8], float mul) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) dst[n * QS + part * 8 + e] = v[e] * mul;
+}
+
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 a;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) a[r] = 0.f;
+  return a;
+}
+// D[i][j] += sum_k A[i][k] B[j][k]   (rows 32 ti.., cols 32 tj..), k < kdim
+__device__ __forceinline__ f32x16 mm_abt(f32x16 acc, const float* A, int sa, const float* B, int sb, int ti,
+                                         int tj, int kdim, int l31, int lh) {
+  const float* ap = A + (32 * ti + l31) * sa + lh;
+  const float* bp = B + (32 * tj + l31) * sb + lh;
+  for (int ks = 0; ks < kdim / 2; ++ks)
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * ks], bp[2 * ks], acc, 0, 0, 0);
+  return acc;
+}
+// D[i][j] += sum_k A[i][k] B[k][j], k < 64
+__device__ __forceinline__ f32x16 mm_ab(f32x16 acc, const float* A, int sa, const float* B, int sb, int ti, int tj,
+                                        int l31, int lh) {
+  const float* ap = A + (32 * ti + l31) * sa + lh;
+  const float* bp = B + lh * sb + 32 * tj + l31;
+#pragma unroll 8
+  for (int ks = 0; ks < QB / 2; ++ks)
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * ks], bp[2 * ks * sb], acc, 0, 0, 0);
+  return acc;
+}
+// D[i][j] += sum_k A[k][i] B[k][j], k < 64
+__device__ __forceinline__ f32x16 mm_atb(f32x16 acc, const float* A, int sa, const float* B, int sb, int ti,
+                                         int tj, int l31, int lh) {
+  const float* ap = A + lh * sa + 32 * ti + l31;
+  const float* bp = B + lh * sb + 32 * tj + l31;
+#pragma unroll 8
+  for (int ks = 0; ks < QB / 2; ++ks)
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * ks * sa], bp[2 * ks * sb], acc, 0, 0, 0);
+  return acc;
+}
+
+// S tile (MFMA layout: lane = key column, registers = query rows) + bias + mask -> P (raw scores, or
+// exp(s - lse[i]) when lse_row != nullptr); keys that do not exist get -inf / 0
+template <int NBINS, bool SELF>
+__device__ __forceinline__ void scores_to_lds(const Shared& S, float* P, const f32x16& acc, int ti, int tj, int l31,
+                                              int lh, const float* lse_row) {
+  const int j = 32 * tj + l31;
+  const int kp = S.kpk[j];
+  const bool none = kp == KEY_NONE;
+  const int kterm = kp >> 4, kreg = kp & 15;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int i = 32 * ti + (r & 3) + 8 * (r >> 2) + 4 * lh;
+    const int qp = S.qpk[i];
+    int idx = kterm + (qp >> 4);
+    if (!SELF && idx < 0) idx += NBINS;
+    float s = acc[r] + S.tab[none ? 0 : idx];
+    if (SELF && (qp & 15) != kreg) s -= 100.f;
+    if (lse_row)
+      P[i * PS + j] = none ? 0.f : __expf(s - lse_row[i]);
+    else
+      P[i * PS + j] = none ? -INFINITY : s;
+  }
+}
+
+template <int WS, int KS>
+__device__ __forceinline__ void setup_block(const neosr_fattn_desc& d, const Win& w, Shared& S) {
+  using G = Geo<WS, KS>;
+  const int tid = threadIdx.x;
+  if (tid < QB) {
+    int tok, reg;
+    query_geom<WS>(d, w, w.qb * QB + tid, tok, reg);
+    S.qtok[tid] = tok;
+    S.qpk[tid] = query_term<WS, KS>(w.qb * QB + tid) * 16 + reg;
+  }
+  for (int k = tid; k < G::NBINS; k += 256) S.tab[k] = d.rpb_table[k * d.heads + w.head];
+}
+
+// ------------------------------------------------------------------------------------------ forward
+template <int WS, int KS>
+__global__ __launch_bounds__(256) void flash_wattn_fwd_kernel(const neosr_fattn_desc d) {
+  using G = Geo<WS, KS>;
+  __shared__ Shared S;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const Win w = decode(d, blockIdx.x, G::NQB);
+  const int hd = d.C / d.heads, ld = 3 * d.C, kq = (hd + 1) & ~1;
+  const int n = tid >> 2, part = tid & 3;
+  setup_block<WS, KS>(d, w, S);
+  __syncthreads();
+  {
+    float q[8];
+    load_row8(d.qkv, S.qtok[n], ld, w.head * hd, hd, part, q);
+    store_row8(S.Qs, n, part, q, d.scale);
+  }
+  // prefetch key block 0
+  float kr[8], vr[8];
+  int ktok, kreg, kterm;
+  bool kex;
+  key_geom<WS, KS>(d, w, n, ktok, kreg, kterm, kex);
+  load_row8(d.qkv, ktok, ld, d.C + w.head * hd, hd, part, kr);
+  load_row8(d.qkv, ktok, ld, 2 * d.C + w.head * hd, hd, part, vr);
+  float m_run = -INFINITY, l_run = 0.f;  // row n, replicated in its 4 threads
+  f32x16 o = zero16();                   // waves 0,1: rows 32 wave.., cols d
+  for (int kb = 0; kb < G::NKB; ++kb) {
+    __syncthreads();  // previous P.V finished with Ks / Vs / P
+    store_row8(S.Ks, n, part, kr, 1.f);
+    store_row8(S.Vs, n, part, vr, 1.f);
+    if (part == 0) S.kpk[n] = kex ? kterm * 16 + kreg : KEY_NONE;
+    __syncthreads();
+    if (kb + 1 < G::NKB) {
+      key_geom<WS, KS>(d, w, (kb + 1) * QB + n, ktok, kreg, kterm, kex);
+      load_row8(d.qkv, ktok, ld, d.C + w.head * hd, hd, part, kr);
+      load_row8(d.qkv, ktok, ld, 2 * d.C + w.head * hd, hd, part, vr);
+    }
+    {
+      const int ti = wave >> 1, tj = wave & 1;
+      const f32x16 acc = mm_abt(zero16(), S.Qs, QS, S.Ks, QS, ti, tj, kq, l31, lh);
+      scores_to_lds<G::NBINS, G::SELF>(S, S.P, acc, ti, tj, l31, lh, nullptr);
+    }
+    __syncthreads();
+    {  // online softmax over this block's 64 columns: 4 threads per row, 16 columns each
+      float* row = S.P + n * PS + part * 16;
+      float m = row[0];
+#pragma unroll
+      for (int c = 1; c < 16; ++c) m = fmaxf(m, row[c]);
+      m = fmaxf(m, __shfl_xor(m, 1, 64));
+      m = fmaxf(m, __shfl_xor(m, 2, 64));
+      const float m_new = fmaxf(m_run, m);
+      float s = 0.f;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const float e = __expf(row[c] - m_new);
+        row[c] = e;
+        s += e;
+      }
+      s += __shfl_xor(s, 1, 64);
+      s += __shfl_xor(s, 2, 64);
+      const float alpha = __expf(m_run - m_new);  // 0 on the first block (m_run = -inf)
+      l_run = l_run * alpha + s;
+      m_run = m_new;
+      if (part == 0) S.alpha[n] = alpha;
+    }
+    __syncthreads();
+    if (wave < 2) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[r] *= S.alpha[32 * wave + (r & 3) + 8 * (r >> 2) + 4 * lh];
+      o = mm_ab(o, S.P, PS, S.Vs, QS, wave, 0, l31, lh);
+    }
+  }
+  __syncthreads();
+  if (part == 0) {
+    S.alpha[n] = 1.f / l_run;
+    if (d.lse) d.lse[(int64_t)blockIdx.x * QB + n] = m_run + __logf(l_run);
+  }
+  __syncthreads();
+  if (wave < 2 && l31 < hd) {
+    float* out = d.out + w.head * hd + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      out[(int64_t)S.qtok[i] * d.C] = o[r] * S.alpha[i];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ backward
+struct SharedBwd {
+  float Qs[QB * QS], Ks[QB * QS], Vs[QB * QS], Gs[QB * QS], P[QB * PS], dS[QB * PS];
+  float tab[TAB_MAX];
+  int qpk[QB], kpk[QB], qtok[QB], ktok[QB];
+  float lse[QB], dsum[QB];
+};
+
+struct BwdWs {  // carve-up of the backward workspace (floats)
+  int64_t dsum, ds_full, dense, stage, unf, total;
+};
+__host__ __device__ inline BwdWs bwd_ws(const neosr_fattn_desc& d) {
+  const int64_t bw = (int64_t)d.B * (d.H / d.ws) * (d.W / d.ws), nq = d.ws * d.ws, nk = d.ks * d.ks;
+  BwdWs w;
+  w.dsum = 0;
+  w.ds_full = w.dsum + bw * d.heads * nq;
+  w.dense = w.ds_full + bw * d.heads * nq * nk;
+  w.stage = w.dense + d.heads * nq * nk;
+  w.unf = w.stage + ((bw + 1023) / 1024) * d.heads * nq * nk;
+  w.total = w.unf + (d.ks > d.ws ? bw * nk * 2 * d.C : 0) + 64;
+  return w;
+}
+
+// shared by both backward kernels: P = exp(S - lse), dP = dO V^T, dS = P (dP - D) for the current
+// (query block in Qs/Gs, key block in Ks/Vs); leaves P and dS tiles in LDS
+template <int NBINS, bool SELF>
+__device__ __forceinline__ void recompute_p_ds(SharedBwd& S, int kq, int wave, int l31, int lh) {
+  const int tid = threadIdx.x;
+  {
+    const int ti = wave >> 1, tj = wave & 1;
+    const f32x16 s = mm_abt(zero16(), S.Qs, QS, S.Ks, QS, ti, tj, kq, l31, lh);
+    // scores_to_lds wants the forward Shared layout: replicate its body on SharedBwd fields
+    const int j = 32 * tj + l31;
+    const int kp = S.kpk[j];
+    const bool none = kp == KEY_NONE;
+    const int kterm = kp >> 4, kreg = kp & 15;
+    const f32x16 dp = mm_abt(zero16(), S.Gs, QS, S.Vs, QS, ti, tj, kq, l31, lh);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = 32 * ti + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int qp = S.qpk[i];
+      int idx = kterm + (qp >> 4);
+      if (!SELF && idx < 0) idx += NBINS;
+      float v = s[r] + S.tab[none ? 0 : idx];
+      if (SELF && (qp & 15) != kreg) v -= 100.f;
+      S.P[i * PS + j] = none ? 0.f : __expf(v - S.lse[i]);
+      S.dS[i * PS + j] = dp[r];
+    }
+  }
+  __syncthreads();
+  {
+    const int i = tid >> 2, q = tid & 3;
+    const float* pr = S.P + i * PS + q * 16;
+    float* gr = S.dS + i * PS + q * 16;
+    const float dsum = S.dsum[i];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) gr[c] = pr[c] * (gr[c] - dsum);
+  }
+  __syncthreads();
+}
+
+// (A) one workgroup per (window, head, query block): dQ, D = rowsum(dO * O), and the dS tiles
+template <int WS, int KS>
+__global__ __launch_bounds__(256) void flash_wattn_bwd_dq_kernel(const neosr_fattn_desc d, const BwdWs ws) {
+  using G = Geo<WS, KS>;
+  __shared__ SharedBwd S;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const Win w = decode(d, blockIdx.x, G::NQB);
+  const int hd = d.C / d.heads, ld = 3 * d.C, kq = (hd + 1) & ~1;
+  const int n = tid >> 2, part = tid & 3;
+  if (tid < QB) {
+    int tok, reg;
+    query_geom<WS>(d, w, w.qb * QB + tid, tok, reg);
+    S.qtok[tid] = tok;
+    S.qpk[tid] = query_term<WS, KS>(w.qb * QB + tid) * 16 + reg;
+    S.lse[tid] = d.lse[(int64_t)blockIdx.x * QB + tid];
+  }
+  for (int k = tid; k < G::NBINS; k += 256) S.tab[k] = d.rpb_table[k * d.heads + w.head];
+  __syncthreads();
+  {
+    float q[8], g[8], o[8];
+    const int tok = S.qtok[n];
+    load_row8(d.qkv, tok, ld, w.head * hd, hd, part, q);
+    load_row8(d.dout, tok, d.C, w.head * hd, hd, part, g);
+    load_row8(d.out, tok, d.C, w.head * hd, hd, part, o);
+    store_row8(S.Qs, n, part, q, d.scale);
+    store_row8(S.Gs, n, part, g, 1.f);
+    float ds = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ds += g[e] * o[e];
+    ds += __shfl_xor(ds, 1, 64);
+    ds += __shfl_xor(ds, 2, 64);
+    if (part == 0) {
+      S.dsum[n] = ds;
+      d.workspace[ws.dsum + (int64_t)blockIdx.x * QB + n] = ds;
+    }
+  }
+  float kr[8], vr[8];
+  int ktok, kreg, kterm;
+  bool kex;
+  key_geom<WS, KS>(d, w, n, ktok, kreg, kterm, kex);
+  load_row8(d.qkv, ktok, ld, d.C + w.head * hd, hd, part, kr);
+  load_row8(d.qkv, ktok, ld, 2 * d.C + w.head * hd, hd, part, vr);
+  f32x16 dq = zero16();
+  // dS dump: [(b, window, head)][query 256][key NK]
+  float* dump = d.workspace + ws.ds_full + ((int64_t)(blockIdx.x / G::NQB) * G::NQ + w.qb * QB) * G::NK;
+  for (int kb = 0; kb < G::NKB; ++kb) {
+    __syncthreads();
+    store_row8(S.Ks, n, part, kr, 1.f);
+    store_row8(S.Vs, n, part, vr, 1.f);
+    if (part == 0) S.kpk[n] = kex ? kterm * 16 + kreg : KEY_NONE;
+    __syncthreads();
+    if (kb + 1 < G::NKB) {
+      key_geom<WS, KS>(d, w, (kb + 1) * QB + n, ktok, kreg, kterm, kex);
+      load_row8(d.qkv, ktok, ld, d.C + w.head * hd, hd, part, kr);
+      load_row8(d.qkv, ktok, ld, 2 * d.C + w.head * hd, hd, part, vr);
+    }
+    recompute_p_ds<G::NBINS, G::SELF>(S, kq, wave, l31, lh);
+    {  // dump this dS tile (rows n, 16 columns per thread) for the bias gradient
+      const float* gr = S.dS + n * PS + part * 16;
+      float* o = dump + (int64_t)n * G::NK + kb * QB + part * 16;
+#pragma unroll
+      for (int c = 0; c < 16; ++c)
+        if (kb * QB + part * 16 + c < G::NK) o[c] = gr[c];
+    }
+    if (wave < 2) dq = mm_ab(dq, S.dS, PS, S.Ks, QS, wave, 0, l31, lh);
+  }
+  if (wave < 2 && l31 < hd) {
+    float* g = d.dqkv + w.head * hd + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      g[(int64_t)S.qtok[32 * wave + (r & 3) + 8 * (r >> 2) + 4 * lh] * ld] = dq[r] * d.scale;
+  }
+}
+
+// (B) one workgroup per (window, head, key block): dK, dV over the 4 query blocks
+template <int WS, int KS>
+__global__ __launch_bounds__(256) void flash_wattn_bwd_dkv_kernel(const neosr_fattn_desc d, const BwdWs ws) {
+  using G = Geo<WS, KS>;
+  __shared__ SharedBwd S;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  Win w = decode(d, blockIdx.x, G::NKB);
+  const int kb = w.qb;  // decode()'s innermost index is the key block here
+  const int hd = d.C / d.heads, ld = 3 * d.C, kq = (hd + 1) & ~1;
+  const int n = tid >> 2, part = tid & 3;
+  const int64_t wh = blockIdx.x / G::NKB;  // (b, window, head)
+  if (tid < QB) {
+    int tok, reg, kterm;
+    bool ex;
+    key_geom<WS, KS>(d, w, kb * QB + tid, tok, reg, kterm, ex);
+    S.ktok[tid] = tok;
+    S.kpk[tid] = ex ? kterm * 16 + reg : KEY_NONE;
+  }
+  for (int k = tid; k < G::NBINS; k += 256) S.tab[k] = d.rpb_table[k * d.heads + w.head];
+  __syncthreads();
+  {
+    float kr[8], vr[8];
+    load_row8(d.qkv, S.ktok[n], ld, d.C + w.head * hd, hd, part, kr);
+    load_row8(d.qkv, S.ktok[n], ld, 2 * d.C + w.head * hd, hd, part, vr);
+    store_row8(S.Ks, n, part, kr, 1.f);
+    store_row8(S.Vs, n, part, vr, 1.f);
+  }
+  f32x16 acc = zero16();  // waves 0,1: dV rows 32 wave..; waves 2,3: dK rows 32 (wave-2)..
+  for (int qb = 0; qb < G::NQB; ++qb) {
+    __syncthreads();  // previous products finished with Qs / Gs / P / dS
+    w.qb = qb;
+    if (tid < QB) {
+      int tok, reg;
+      query_geom<WS>(d, w, qb * QB + tid, tok, reg);
+      S.qtok[tid] = tok;
+      S.qpk[tid] = query_term<WS, KS>(qb * QB + tid) * 16 + reg;
+      S.lse[tid] = d.lse[(wh * G::NQB + qb) * QB + tid];
+      S.dsum[tid] = d.workspace[ws.dsum + (wh * G::NQB + qb) * QB + tid];
+    }
+    __syncthreads();
+    {
+      float q[8], g[8];
+      load_row8(d.qkv, S.qtok[n], ld, w.head * hd, hd, part, q);
+      load_row8(d.dout, S.qtok[n], d.C, w.head * hd, hd, part, g);
+      store_row8(S.Qs, n, part, q, d.scale);
+      store_row8(S.Gs, n, part, g, 1.f);
+    }
+    __syncthreads();
+    recompute_p_ds<G::NBINS, G::SELF>(S, kq, wave, l31, lh);
+    if (wave < 2)
+      acc = mm_atb(acc, S.P, PS, S.Gs, QS, wave, 0, l31, lh);       // dV[j][d] += sum_i P[i][j] dO[i][d]
+    else
+      acc = mm_atb(acc, S.dS, PS, S.Qs, QS, wave - 2, 0, l31, lh);  // dK[j][d] += sum_i dS[i][j] (scale q)[i][d]
+  }
+  if (l31 < hd) {
+    const int which = wave < 2 ? 2 : 1;  // v : k
+    const int jt = wave & 1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int j = 32 * jt + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (G::SELF) {
+        d.dqkv[(int64_t)S.ktok[j] * ld + which * d.C + w.head * hd + l31] = acc[r];
+      } else if (kb * QB + j < G::NK) {
+        const int64_t bwin = wh / d.heads;
+        d.workspace[ws.unf + ((bwin * G::NK + kb * QB + j) * 2 + (which - 1)) * d.C + w.head * hd + l31] = acc[r];
+      }
+    }
+  }
+}
+
+// OCAB: nn.Unfold's adjoint — every pixel sums the k / v gradients of the (up to 4) overlapping
+// windows that contain it, in (Wy, Wx) order
+template <int WS, int KS>
+__global__ __launch_bounds__(256) void fold_dkv_kernel(const neosr_fattn_desc d, const BwdWs ws) {
+  using G = Geo<WS, KS>;
+  const int nWy = d.H / WS, nWx = d.W / WS, C2 = 2 * d.C;
+  const int64_t total = (int64_t)d.B * d.H * d.W * C2;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int c = (int)(e % C2);
+    int64_t p = e / C2;
+    const int x = (int)(p % d.W);
+    p /= d.W;
+    const int y = (int)(p % d.H), b = (int)(p / d.H);
+    float s = 0.f;
+    for (int Wy = max(0, (y - (WS + G::PAD) + WS) / WS); Wy < nWy && Wy * WS - G::PAD <= y; ++Wy) {
+      const int yk = y - Wy * WS + G::PAD;
+      if (yk < 0 || yk >= KS) continue;
+      for (int Wx = max(0, (x - (WS + G::PAD) + WS) / WS); Wx < nWx && Wx * WS - G::PAD <= x; ++Wx) {
+        const int xk = x - Wx * WS + G::PAD;
+        if (xk < 0 || xk >= KS) continue;
+        const int64_t bwin = ((int64_t)b * nWy + Wy) * nWx + Wx;
+        s += d.workspace[ws.unf + ((bwin * G::NK + yk * KS + xk) * 2 + c / d.C) * d.C + c % d.C];
+      }
+    }
+    d.dqkv[((int64_t)(b * d.H + y) * d.W + x) * 3 * d.C + d.C + c] = s;
+  }
+}
+
+// d_table[bin][head] (+)= sum over the (query, key) pairs mapped to `bin` of the dense bias gradient
+template <int WS, int KS>
+__global__ __launch_bounds__(256) void rpb_bins_kernel(const float* __restrict__ dense, float* __restrict__ dtab,
+                                                       int heads, int accumulate) {
+  using G = Geo<WS, KS>;
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= G::NBINS * heads) return;
+  const int bin = e / heads, head = e - bin * heads;
+  // key - query offsets (dy, dx) of this bin
+  int dy, dx;
+  if (G::SELF) {  // bin = (yi - yj + WS-1) L + (xi - xj + WS-1)
+    dy = -(bin / G::L - (WS - 1));
+    dx = -(bin % G::L - (WS - 1));
+  } else {  // unwrap the negative-index wrap-around, then t = (yj-yi+WS-KS+1) L + (xj-xi+WS-KS+1)
+    const int hi = (WS - 1 + WS - KS + 1) * G::L + (WS - 1 + WS - KS + 1) + (KS - WS) * (G::L + 1);  // max t
+    const int t = bin <= hi ? bin : bin - G::NBINS;
+    const int off = KS - 2;  // digits (xj - xi + WS-KS+1) lie in [2-KS, WS-1]: + off -> [0, L)
+    const int u = (t + off * G::L + off) / G::L, v = (t + off * G::L + off) % G::L;
+    dy = u - off - (WS - KS + 1);
+    dx = v - off - (WS - KS + 1);
+  }
+  const float* base = dense + (int64_t)head * G::NQ * G::NK;
+  float s = 0.f;
+  for (int yi = 0; yi < WS; ++yi) {
+    const int yj = yi + dy;
+    if (yj < 0 || yj >= KS) continue;
+    for (int xi = 0; xi < WS; ++xi) {
+      const int xj = xi + dx;
+      if (xj < 0 || xj >= KS) continue;
+      s += base[(int64_t)(yi * WS + xi) * G::NK + yj * KS + xj];
+    }
+  }
+  dtab[e] = accumulate ? dtab[e] + s : s;
+}
+
+template <int WS, int KS>
+int launch_bwd(const neosr_fattn_desc& d, hipStream_t st) {
+  using G = Geo<WS, KS>;
+  const BwdWs ws = bwd_ws(d);
+  const int bw = d.B * (d.H / WS) * (d.W / WS);
+  hipLaunchKernelGGL((flash_wattn_bwd_dq_kernel<WS, KS>), dim3(bw * d.heads * G::NQB), dim3(256), 0, st, d, ws);
+  NEOSR_LAUNCH_CHECK();
+  hipLaunchKernelGGL((flash_wattn_bwd_dkv_kernel<WS, KS>), dim3(bw * d.heads * G::NKB), dim3(256), 0, st, d, ws);
+  NEOSR_LAUNCH_CHECK();
+  if (!G::SELF) {
+    const int64_t total = (int64_t)d.B * d.H * d.W * 2 * d.C;
+    int g = (int)((total + 255) / 256);
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL((fold_dkv_kernel<WS, KS>), dim3(g), dim3(256), 0, st, d, ws);
+    NEOSR_LAUNCH_CHECK();
+  }
+  // bias gradient: sum the dS dump over (batch, window), then gather per table row
+  const int cols = d.heads * G::NQ * G::NK;
+  if (int rc = neosr_colsum(d.workspace + ws.ds_full, d.workspace + ws.dense, d.workspace + ws.stage, bw, cols,
+                            cols, 0, (void*)st))
+    return rc;
+  hipLaunchKernelGGL((rpb_bins_kernel<WS, KS>), dim3(ceil_div(G::NBINS * d.heads, 256)), dim3(256), 0, st,
+                     d.workspace + ws.dense, d.d_rpb_table, d.heads, d.accumulate_rpb);
+  NEOSR_LAUNCH_CHECK();
+  return 0;
+}
+
+int check(const neosr_fattn_desc* d) {
+  NEOSR_CHECK(d && d->qkv && d->rpb_table, "flash_window_attention: null tensor");
+  NEOSR_CHECK(d->B > 0 && d->H > 0 && d->W > 0 && d->C > 0 && d->heads > 0, "flash_window_attention: bad geometry");
+  NEOSR_CHECK(d->ws == 16 && (d->ks == 16 || d->ks == 24),
+              "flash_window_attention: window 16 with key window 16 (self) or 24 (overlapping) only (got %d / %d)",
+              d->ws, d->ks);
+  NEOSR_CHECK(d->H % 16 == 0 && d->W % 16 == 0, "flash_window_attention: H, W must be multiples of 16");
+  NEOSR_CHECK(d->C % d->heads == 0 && d->C / d->heads <= 32, "flash_window_attention: head_dim must be <= 32");
+  NEOSR_CHECK(d->shift >= 0 && d->shift < 16 && (d->ks == 16 || d->shift == 0),
+              "flash_window_attention: bad shift");
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int neosr_flash_window_attention_fwd(const neosr_fattn_desc* d, void* stream) {
+  if (int rc = check(d)) return rc;
+  NEOSR_CHECK(d->out, "flash_window_attention_fwd: out missing");
+  const int nblk = d->B * (d->H / 16) * (d->W / 16) * d->heads * 4;
+  if (d->ks == 16)
+    hipLaunchKernelGGL((flash_wattn_fwd_kernel<16, 16>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, *d);
+  else
+    hipLaunchKernelGGL((flash_wattn_fwd_kernel<16, 24>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, *d);
+  NEOSR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int64_t neosr_flash_window_attention_workspace_bytes(const neosr_fattn_desc* d) {
+  if (!d || d->ws != 16 || (d->ks != 16 && d->ks != 24) || d->B <= 0) return 0;
+  return bwd_ws(*d).total * 4;
+}
+
+extern "C" int neosr_flash_window_attention_bwd(const neosr_fattn_desc* d, void* stream) {
+  if (int rc = check(d)) return rc;
+  NEOSR_CHECK(d->out && d->dout && d->dqkv && d->lse && d->d_rpb_table && d->workspace,
+              "flash_window_attention_bwd: null tensor");
+  return d->ks == 16 ? launch_bwd<16, 16>(*d, (hipStream_t)stream) : launch_bwd<16, 24>(*d, (hipStream_t)stream);
+}
