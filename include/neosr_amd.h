@@ -364,6 +364,28 @@ typedef struct neosr_fattn_desc {
 int64_t neosr_flash_window_attention_workspace_bytes(const neosr_fattn_desc* d);
 int neosr_flash_window_attention_fwd(const neosr_fattn_desc* d, void* stream);
 int neosr_flash_window_attention_bwd(const neosr_fattn_desc* d, void* stream);
+/* HAT Channel Attention Block, non-conv parts (hat_arch.py:15-52) ------------------------------------
+ * exact-erf GELU between the two convs: out = g ? g * GELU'(x) : GELU(x). */
+int neosr_gelu(const float* x, const float* g, float* out, int64_t n, void* stream);
+/* out[b, c] = scale * sum_r x[b, r, c] (* y[b, r, c] if y): AdaptiveAvgPool2d(1) on channels-last data
+ * and the gate gradient; fixed-order two-stage; workspace >= B*32*cols floats. */
+int neosr_batched_colsum(const float* x, const float* y, float* out, float* workspace, int32_t B, int32_t rows,
+                         int32_t cols, float scale, void* stream);
+/* squeeze-excite gate: hidden = relu(W1 pooled + b1) (Cs <= 16), attn = sigmoid(W2 hidden + b2);
+ * W1 (Cs, C), W2 (C, Cs) = the 1x1 conv weights (hat_arch.py:27-33).  bwd: parameter gradients and
+ * d pooled, samples summed in order (deterministic); C <= 512. */
+int neosr_channel_attention_fwd(const float* pooled, const float* w1, const float* b1, const float* w2,
+                                const float* b2, float* hidden, float* attn, int32_t B, int32_t C, int32_t Cs,
+                                void* stream);
+int neosr_channel_attention_bwd(const float* dattn, const float* attn, const float* hidden, const float* pooled,
+                                const float* w1, const float* w2, float* dpooled, float* dw1, float* db1, float* dw2,
+                                float* db2, int32_t B, int32_t C, int32_t Cs, void* stream);
+/* out = res + alpha * y * attn[b, c]  (ChannelAttention's x*y, hat_arch.py:36-37, fused with
+ * `+ conv_x * conv_scale` of HAB.forward :347; res optional);  bwd: dy = alpha g attn + dpooled / rows. */
+int neosr_scale_channels_add(const float* y, const float* attn, const float* res, float* out, int32_t B,
+                             int32_t rows, int32_t C, float alpha, void* stream);
+int neosr_scale_channels_bwd(const float* g, const float* attn, const float* dpooled, float* dy, int32_t B,
+                             int32_t rows, int32_t C, float alpha, void* stream);
 /* nn.PixelShuffle(r) on channels-last tensors (swinir_arch.py:782-783): in (B,H,W,C*r*r) ->
  * out (B,H*r,W*r,C); inverse=1: the adjoint. */
 int neosr_pixel_shuffle_nhwc(const float* in, float* out, int32_t B, int32_t H, int32_t W, int32_t C,

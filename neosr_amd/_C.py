@@ -245,6 +245,12 @@ SIGNATURES: dict[str, tuple] = {
     "neosr_layernorm_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     "neosr_window_attention_fwd": (C.c_int, [C.POINTER(WattnDesc), _vp]),
     "neosr_window_attention_bwd": (C.c_int, [C.POINTER(WattnDesc), _vp]),
+    "neosr_gelu": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
+    "neosr_batched_colsum": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp]),
+    "neosr_channel_attention_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "neosr_channel_attention_bwd": (C.c_int, [_vp] * 11 + [_i32, _i32, _i32, _vp]),
+    "neosr_scale_channels_add": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp]),
+    "neosr_scale_channels_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp]),
     "neosr_flash_window_attention_workspace_bytes": (_i64, [C.POINTER(FattnDesc)]),
     "neosr_flash_window_attention_fwd": (C.c_int, [C.POINTER(FattnDesc), _vp]),
     "neosr_flash_window_attention_bwd": (C.c_int, [C.POINTER(FattnDesc), _vp]),

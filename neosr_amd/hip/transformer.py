@@ -310,3 +310,72 @@ class FlashWindowAttention(torch.autograd.Function):
 
 def flash_window_attention(qkv, table, heads, ks, shift, scale):
     return FlashWindowAttention.apply(qkv, table, heads, ks, shift, scale)
+
+
+class Gelu(torch.autograd.Function):
+    """exact-erf nn.GELU between the two convs of CAB (hat_arch.py:46)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        lib = _C.load()
+        x = _C.require_device(x, "x").contiguous()
+        out = torch.empty_like(x)
+        _C.check(lib.neosr_gelu(x.data_ptr(), None, out.data_ptr(), x.numel(), _st()), "neosr_gelu")
+        ctx.save_for_backward(x)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _C.load()
+        (x,) = ctx.saved_tensors
+        g = g.contiguous()
+        out = torch.empty_like(x)
+        _C.check(lib.neosr_gelu(x.data_ptr(), g.data_ptr(), out.data_ptr(), x.numel(), _st()), "neosr_gelu")
+        return out
+
+
+class ChannelGate(torch.autograd.Function):
+    """out = res + alpha * y * sigmoid(W2 relu(W1 mean_hw(y) + b1) + b2): ChannelAttention
+    (hat_arch.py:15-37) fused with HAB's `+ conv_x * conv_scale` (:347).  y, res: (B, H, W, C)."""
+
+    @staticmethod
+    def forward(ctx, y, w1, b1, w2, b2, res, alpha):
+        lib = _C.load()
+        y = _C.require_device(y, "y").contiguous()
+        B, H, W, C_ = y.shape
+        rows, Cs = H * W, w1.shape[0]
+        w1c, w2c = w1.contiguous(), w2.contiguous()
+        pooled, attn, hidden = _new((B, C_), y), _new((B, C_), y), _new((B, Cs), y)
+        ws = _new((B * 32 * C_,), y)
+        _C.check(lib.neosr_batched_colsum(y.data_ptr(), None, pooled.data_ptr(), ws.data_ptr(), B, rows, C_,
+                                          1.0 / rows, _st()), "neosr_batched_colsum")
+        _C.check(lib.neosr_channel_attention_fwd(pooled.data_ptr(), w1c.data_ptr(), b1.data_ptr(), w2c.data_ptr(),
+                                                 b2.data_ptr(), hidden.data_ptr(), attn.data_ptr(), B, C_, Cs, _st()),
+                 "neosr_channel_attention_fwd")
+        out = torch.empty_like(y)
+        r = None if res is None else res.contiguous()
+        _C.check(lib.neosr_scale_channels_add(y.data_ptr(), attn.data_ptr(), _p(r), out.data_ptr(), B, rows, C_, alpha,
+                                              _st()), "neosr_scale_channels_add")
+        ctx.save_for_backward(y, w1c, w2c, pooled, attn, hidden)
+        ctx.meta = (B, rows, C_, Cs, alpha, res is not None, w1.shape, w2.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _C.load()
+        y, w1, w2, pooled, attn, hidden = ctx.saved_tensors
+        B, rows, C_, Cs, alpha, has_res, s1, s2 = ctx.meta
+        g = g.contiguous()
+        dattn, dpooled = _new((B, C_), y), _new((B, C_), y)
+        ws = _new((B * 32 * C_,), y)
+        _C.check(lib.neosr_batched_colsum(g.data_ptr(), y.data_ptr(), dattn.data_ptr(), ws.data_ptr(), B, rows, C_,
+                                          alpha, _st()), "neosr_batched_colsum")
+        dw1, db1, dw2, db2 = _new((Cs, C_), y), _new((Cs,), y), _new((C_, Cs), y), _new((C_,), y)
+        _C.check(lib.neosr_channel_attention_bwd(dattn.data_ptr(), attn.data_ptr(), hidden.data_ptr(), pooled.data_ptr(),
+                                                 w1.data_ptr(), w2.data_ptr(), dpooled.data_ptr(), dw1.data_ptr(),
+                                                 db1.data_ptr(), dw2.data_ptr(), db2.data_ptr(), B, C_, Cs, _st()),
+                 "neosr_channel_attention_bwd")
+        dy = torch.empty_like(y)
+        _C.check(lib.neosr_scale_channels_bwd(g.data_ptr(), attn.data_ptr(), dpooled.data_ptr(), dy.data_ptr(), B, rows,
+                                              C_, alpha, _st()), "neosr_scale_channels_bwd")
+        return dy, dw1.view(s1), db1, dw2.view(s2), db2, (g if has_res else None), None

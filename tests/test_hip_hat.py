@@ -114,3 +114,106 @@ def test_flash_attention_bwd_is_deterministic():
         (tr.flash_window_attention(a, t, 6, 24, 0, 30 ** -0.5) * r).sum().backward()
         outs.append((a.grad.clone(), t.grad.clone()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+def _nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def test_cab_vs_reference_fixture():
+    from neosr_amd.archs.hat_arch import CAB
+
+    fix = load_golden("hat_prims.npz")
+    cab = CAB(24, 3, 6)
+    cab.load_state_dict(group(fix, "cab/p"))
+    cab = cab.to(DEV)
+    x = _nhwc(T(fix["cab/x"])).to(DEV).requires_grad_(True)
+    y = cab(x, None, 1.0)
+    (y * _nhwc(T(fix["cab/r"])).to(DEV)).sum().backward()
+    assert rel_err(y, _nhwc(T(fix["cab/y"]))) < 1e-4
+    assert rel_err(x.grad, _nhwc(T(fix["cab/gx"]))) < 1e-3
+    named = dict(cab.named_parameters())
+    for k, g in group(fix, "cab/g").items():
+        assert rel_err(named[k].grad, g) < 1e-3, k
+
+
+@pytest.mark.parametrize("pre", ["hab_s0", "hab_s8", "ocab"])
+def test_hab_ocab_blocks_vs_reference_fixture(pre):
+    from neosr_amd.archs.hat_arch import HAB, OCAB
+
+    fix = load_golden("hat_prims.npz")
+    if pre == "ocab":
+        blk = OCAB(24, (32, 48), 16, 0.5, 2, mlp_ratio=2)
+    else:
+        blk = HAB(24, (32, 48), 2, 16, int(pre[-1]), 3, 6, 0.01, 2)
+    blk.load_state_dict(group(fix, f"{pre}/p"))
+    blk = blk.to(DEV).train()
+    x = T(fix[f"{pre}/x"]).view(2, 32, 48, 24).to(DEV).requires_grad_(True)
+    y = blk(x)
+    (y * T(fix[f"{pre}/r"]).view(2, 32, 48, 24).to(DEV)).sum().backward()
+    assert rel_err(y.view(2, -1, 24), T(fix[f"{pre}/y"])) < 1e-4
+    assert rel_err(x.grad.view(2, -1, 24), T(fix[f"{pre}/gx"])) < 1e-3
+    named = dict(blk.named_parameters())
+    worst = max((rel_err(named[k].grad, g), k) for k, g in group(fix, f"{pre}/g").items())
+    assert worst[0] < 1e-3, worst
+
+
+def test_tiny_hat_net_vs_reference_fixture():
+    from neosr_amd.archs.hat_arch import hat
+
+    fix = load_golden("hat_net.npz")
+    net = hat(img_size=32, embed_dim=24, depths=(2,), num_heads=(2,), window_size=16, compress_ratio=3,
+              squeeze_factor=6, mlp_ratio=2, drop_path_rate=0.0, upsampler="pixelshuffle", upscale=4)
+    assert list(net.state_dict().keys()) == [str(k) for k in fix["keys"]]
+    net.load_state_dict(group(fix, "p"), strict=False)
+    net = net.to(DEV).train()
+    x = T(fix["x"]).to(DEV).requires_grad_(True)
+    y = net(x)
+    (y * T(fix["r"]).to(DEV)).sum().backward()
+    assert rel_err(y, T(fix["y"])) < 1e-4
+    assert rel_err(x.grad, T(fix["gx"])) < 1e-3
+    named = dict(net.named_parameters())
+    worst = max((rel_err(named[k].grad, g), k) for k, g in group(fix, "g").items())
+    assert worst[0] < 1e-3, worst
+
+
+def test_hat_l_forward_b1_vs_reference_fixture():
+    """BASELINE configs[4] generator at full size: seeded init identical to the reference, forward at 64x64 LR"""
+    from neosr_amd.archs import hat_arch as A
+    from neosr_amd.utils import options
+
+    fix = load_golden("hat_l_fwd.npz")
+    options.set_global_opt({"manual_seed": 1024, "rank": 0, "scale": 4, "datasets": {"train": {}}})
+    try:
+        torch.manual_seed(1024)
+        net = A.hat_l(upscale=4)
+    finally:
+        options.set_global_opt(None)
+    s = np.array([float(v.double().sum()) for v in net.state_dict().values()])
+    np.testing.assert_allclose(s, fix["init_sum"], rtol=1e-6, atol=1e-6)
+    net = net.to(DEV).eval()
+    with torch.no_grad():
+        y = net(T(fix["x"]).to(DEV))
+    assert rel_err(y, T(fix["y"])) < 1e-4
+
+
+def test_image_model_trajectory_hat_s_vs_reference_fixture():
+    from neosr_amd.models import build_model
+    from neosr_amd.utils.options import parse_options
+    from tests.conftest import GOLDEN, ROOT
+
+    fix = load_golden("step_hat.npz")
+    opt, _ = parse_options(str(ROOT), True, argv=["-opt", str(GOLDEN / "golden_hat.toml")])
+    model = build_model(opt)
+    s = np.array([float(v.double().sum()) for v in model.net_g.state_dict().values()])
+    np.testing.assert_allclose(s, fix["init/sum"], rtol=1e-5, atol=1e-5)
+    for it in (1, 2):
+        model.feed_data({"lq": T(fix[f"it{it}/lq"]), "gt": T(fix[f"it{it}/gt"])})
+        model.optimize_parameters(it)
+        log = model.get_current_log()
+        ref = float(fix[f"it{it}/log/l_g_pix"])
+        assert abs(log["l_g_pix"] - ref) < 1e-4 * ref
+        assert rel_err(model.output, T(fix[f"it{it}/output"])) < 1e-3
+    sd = model.net_g.state_dict()
+    for k in [f for f in fix if f.startswith("final/w/")]:
+        assert rel_err(sd[k[len("final/w/"):]], T(fix[k])) < 1e-3, k
