@@ -47,6 +47,9 @@ def make_opt(batch: int, world: int, rank: int, arch: str) -> dict:
         "compact": {"type": "compact"},
         "swinir_small": {"type": "swinir_small"},
         "swinir_medium": {"type": "swinir_medium"},
+        "hat_s": {"type": "hat_s"},
+        "hat_m": {"type": "hat_m"},
+        "hat_l": {"type": "hat_l"},
     }
     return {
         "name": f"bench_{arch}", "model_type": "image", "scale": 4, "manual_seed": 1024,
@@ -120,10 +123,10 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16, help="per-GPU batch (BASELINE configs[1]: 16)")
-    ap.add_argument("--arch", default="esrgan", choices=["esrgan", "esrgan_small", "compact", "swinir_small", "swinir_medium"])
+    ap.add_argument("--arch", default="esrgan", choices=["esrgan", "esrgan_small", "compact", "swinir_small", "swinir_medium", "hat_s", "hat_m", "hat_l"])
     ap.add_argument("--workload", default="paired_l1", choices=["paired_l1", "otf_gan", "swinir_percep"],
                     help="paired_l1 = BASELINE configs[1] (headline); otf_gan = configs[2]: otf degradation + "
-                         "unet D + VGG perceptual + GAN (use --batch 32); swinir_percep = configs[3]: "
+                         "unet D + VGG perceptual + GAN (use --batch 32; with --arch hat_l --batch 4 = configs[4]); swinir_percep = configs[3]: "
                          "swinir_medium, L1 + VGG perceptual (use --batch 8)")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU-oracle timing (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
@@ -213,7 +216,7 @@ def main() -> None:
     loss = model.get_current_log().get("l_g_pix")
 
     roofline = None
-    if not args.no_roofline and rank == 0 and not args.arch.startswith("swinir"):
+    if not args.no_roofline and rank == 0 and not args.arch.startswith(("swinir", "hat")):
         lib = _C.load()
         lib.neosr_prof_enable(1)
         for _ in range(max(1, min(args.steps, 3))):
@@ -271,12 +274,13 @@ def main() -> None:
         "roofline": roofline,
     }
     if args.workload == "otf_gan":
-        out["config"]["workload"] = (f"{args.arch} RRDB x4 + unet-SN D + VGG19 perceptual (random weights) + GAN, "
-                                     f"otf degradation from 512x512 GT, adan_sf x2 (template), batch={B}/GPU (BASELINE configs[2])")
+        cfg = "configs[4]" if args.arch.startswith("hat") else "configs[2]"
+        out["config"]["workload"] = (f"{args.arch} x4 + unet-SN D + VGG19 perceptual (random weights) + GAN, "
+                                     f"otf degradation from 512x512 GT, adan_sf x2 (template), batch={B}/GPU (BASELINE {cfg})")
     if args.workload == "swinir_percep":
         out["config"]["workload"] = (f"{args.arch} x4, paired 64x64 LR synthetic, L1 + VGG19 perceptual (random weights), "
                                      f"window-attention path, adan_sf (template) + grad-clip + EMA, batch={B}/GPU (BASELINE configs[3])")
-    if world == 1 and args.cpu_budget > 0 and args.workload == "paired_l1" and not args.arch.startswith("swinir"):
+    if world == 1 and args.cpu_budget > 0 and args.workload == "paired_l1" and not args.arch.startswith(("swinir", "hat")):
         out["cpu_baseline"] = cpu_baseline(args.arch, args.cpu_budget)
     else:
         out["cpu_baseline"] = None
