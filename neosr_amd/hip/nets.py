@@ -15,69 +15,102 @@ from neosr_amd import _C
 # --------------------------------------------------------------------------------------------
 # flat arenas
 # --------------------------------------------------------------------------------------------
+ALIGN = 4  # every tensor of an arena starts on a 16-byte boundary (float4 loads in the kernels)
+
+
+def arena_layout(tensors) -> tuple[list[int], int]:
+    """(element offset of each tensor, total elements) of a flat arena holding `tensors` in order,
+    each start rounded up to ALIGN elements.  Identical to a packed layout when every numel is a
+    multiple of ALIGN (esrgan, compact); pads exist e.g. after SwinIR's 225x6 bias tables."""
+    offs, off = [], 0
+    for t in tensors:
+        offs.append(off)
+        off += (t.numel() + ALIGN - 1) // ALIGN * ALIGN
+    return offs, off
+
+
 def flatten_parameters_(module: nn.Module) -> torch.Tensor:
     """Re-home every parameter of ``module`` into one contiguous fp32 arena (in named_parameters
-    order) and make each ``nn.Parameter`` a view of it.  Idempotent; returns the arena."""
+    order, 16-byte aligned starts, zero pads) and make each ``nn.Parameter`` a view of it.
+    Idempotent; returns the arena."""
     params = [p for p in module.parameters()]
     if not params:
         raise ValueError("module has no parameters")
     arena = getattr(module, "_neosr_arena", None)
     if arena is not None and _is_flat(params, arena):
         return arena
-    total = sum(p.numel() for p in params)
-    dev = params[0].device
-    arena = torch.empty(total, device=dev, dtype=torch.float32)
-    off = 0
+    offs, total = arena_layout(params)
+    arena = torch.zeros(total, device=params[0].device, dtype=torch.float32)
     with torch.no_grad():
-        for p in params:
-            n = p.numel()
-            view = arena[off : off + n].view(p.shape)
+        for p, off in zip(params, offs):
+            view = arena[off : off + p.numel()].view(p.shape)
             view.copy_(p.data)
             p.data = view
-            off += n
     module._neosr_arena = arena  # noqa: SLF001
     return arena
 
 
 def _is_flat(tensors, arena: torch.Tensor) -> bool:
-    off = arena.data_ptr()
-    for t in tensors:
-        if t is None or t.data_ptr() != off or not t.is_contiguous():
+    offs, total = arena_layout(tensors)
+    base = arena.data_ptr()
+    for t, off in zip(tensors, offs):
+        if t is None or t.data_ptr() != base + 4 * off or not t.is_contiguous():
             return False
-        off += t.numel() * 4
-    return off == arena.data_ptr() + arena.numel() * 4
+    return total == arena.numel()
 
 
-def flat_grad_of(params) -> torch.Tensor | None:
-    """If all ``p.grad`` sit back-to-back in one buffer (as our backward emits them), return that
-    buffer as a 1-D tensor without copying; else None."""
-    params = list(params)
-    g0 = params[0].grad
-    if g0 is None:
+def flat_view_of(tensors) -> torch.Tensor | None:
+    """If `tensors` sit at their `arena_layout` offsets of one buffer, return that buffer as a 1-D
+    tensor (no copy); else None."""
+    tensors = list(tensors)
+    t0 = tensors[0]
+    if t0 is None:
         return None
-    total = sum(p.numel() for p in params)
-    base = g0.data_ptr()
-    off = base
-    for p in params:
-        g = p.grad
-        if g is None or g.data_ptr() != off or not g.is_contiguous():
+    offs, total = arena_layout(tensors)
+    base = t0.data_ptr()
+    for t, off in zip(tensors, offs):
+        if t is None or t.data_ptr() != base + 4 * off or not t.is_contiguous():
             return None
-        off += g.numel() * 4
-    # rebuild a flat view over the same storage
-    storage_off = g0.storage_offset()
-    flat = torch.empty(0, device=g0.device, dtype=torch.float32)
-    flat.set_(g0.untyped_storage(), storage_off, (total,), (1,))
+    if t0.untyped_storage().nbytes() < (t0.storage_offset() + total) * 4:
+        return None
+    flat = torch.empty(0, device=t0.device, dtype=torch.float32)
+    flat.set_(t0.untyped_storage(), t0.storage_offset(), (total,), (1,))
     return flat
 
 
+def flat_grad_of(params) -> torch.Tensor | None:
+    """If all ``p.grad`` sit in one buffer at the arena layout (as our plans emit them), return that
+    buffer as a 1-D tensor without copying; else None."""
+    return flat_view_of([p.grad for p in params])
+
+
+_PADS: dict = {}
+
+
+def pack_grads(params) -> torch.Tensor:
+    """Gradients produced tensor by tensor (layer-composed networks) -> one flat arena in the
+    parameter layout, zero pads included: a single `cat`."""
+    params = list(params)
+    offs, total = arena_layout(params)
+    parts = []
+    for i, p in enumerate(params):
+        g = p.grad.reshape(-1)
+        parts.append(g)
+        end = offs[i + 1] if i + 1 < len(params) else total
+        pad = end - offs[i] - g.numel()
+        if pad:
+            key = (pad, g.device)
+            if key not in _PADS:
+                _PADS[key] = torch.zeros(pad, device=g.device, dtype=torch.float32)
+            parts.append(_PADS[key])
+    return torch.cat(parts)
+
+
 def _alloc_flat_grads(params):
-    total = sum(p.numel() for p in params)
-    flat = torch.empty(total, device=params[0].device, dtype=torch.float32)
-    views, off = [], 0
-    for p in params:
-        n = p.numel()
-        views.append(flat[off : off + n].view(p.shape))
-        off += n
+    offs, total = arena_layout(params)
+    packed = total == sum(p.numel() for p in params)
+    flat = (torch.empty if packed else torch.zeros)(total, device=params[0].device, dtype=torch.float32)
+    views = [flat[off : off + p.numel()].view(p.shape) for p, off in zip(params, offs)]
     return flat, views
 
 

@@ -24,7 +24,7 @@ import torch
 from torch import Tensor, nn
 
 from neosr_amd.archs import build_network
-from neosr_amd.hip.nets import flat_grad_of, flatten_parameters_
+from neosr_amd.hip.nets import arena_layout, flat_grad_of, flatten_parameters_, pack_grads
 from neosr_amd.losses import build_loss
 from neosr_amd.models.base import allreduce_flat_, base
 from neosr_amd.utils.misc import get_root_logger, tc
@@ -199,11 +199,9 @@ class image(base):
         if self.opt["dist"]:
             flat = flat_grad_of(params)
             if flat is None:
-                flat = torch.cat([p.grad.reshape(-1) for p in params])
-                off = 0
-                for p in params:
+                flat = pack_grads(params)
+                for p, off in zip(params, arena_layout(params)[0]):
                     p.grad = flat[off : off + p.numel()].view_as(p)
-                    off += p.numel()
             allreduce_flat_(flat)
             optimizer.set_grad_scale(1.0 / self.opt["world_size"])
         if self.gradclip:

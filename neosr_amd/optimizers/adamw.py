@@ -16,7 +16,7 @@ import torch
 from torch.optim.optimizer import Optimizer
 
 from neosr_amd import _C
-from neosr_amd.hip.nets import flat_grad_of
+from neosr_amd.hip.nets import arena_layout, flat_grad_of, flat_view_of, pack_grads
 
 
 class AdamW(Optimizer):
@@ -52,18 +52,9 @@ class AdamW(Optimizer):
 
     # -- state ---------------------------------------------------------------------------
     def _group_arena(self, group):
-        """(param_flat, offsets) if the group's params are back-to-back in one buffer."""
+        """(param_flat, params) if the group's params sit in one buffer at the arena layout."""
         params = [p for p in group["params"] if p.requires_grad]
-        base = params[0].data_ptr()
-        off = base
-        for p in params:
-            if p.data_ptr() != off or not p.is_contiguous():
-                return None, params
-            off += p.numel() * 4
-        total = (off - base) // 4
-        flat = torch.empty(0, device=params[0].device, dtype=torch.float32)
-        flat.set_(params[0].untyped_storage(), params[0].storage_offset(), (total,), (1,))
-        return flat, params
+        return flat_view_of([p.data for p in params]), params
 
     def _ensure_state(self, gi, params, total):
         st = self._flat.get(gi)
@@ -71,10 +62,9 @@ class AdamW(Optimizer):
         if st is None or st["exp_avg"].numel() != total or st["exp_avg"].device != dev:
             m = torch.zeros(total, device=dev, dtype=torch.float32)
             v = torch.zeros(total, device=dev, dtype=torch.float32)
-            off = 0
             step0 = 0
             shared_step = torch.zeros((), device="cpu", dtype=torch.float32)  # one host scalar
-            for p in params:
+            for p, off in zip(params, arena_layout(params)[0]):
                 n = p.numel()
                 old = self.state.get(p, {})
                 if "exp_avg" in old:  # resumed from a checkpoint: adopt its moments
@@ -86,7 +76,6 @@ class AdamW(Optimizer):
                     "exp_avg": m[off : off + n].view(p.shape),
                     "exp_avg_sq": v[off : off + n].view(p.shape),
                 }
-                off += n
             shared_step.fill_(step0)
             st = {"exp_avg": m, "exp_avg_sq": v, "step": shared_step, "step_int": step0}
             self._flat[gi] = st
@@ -108,7 +97,7 @@ class AdamW(Optimizer):
             _C.require_device(pflat, "parameter arena")
             gflat = flat_grad_of(params)
             if gflat is None:  # grads produced elsewhere (not by our plans): pack them once
-                gflat = torch.cat([p.grad.reshape(-1) for p in params])
+                gflat = pack_grads(params)
             total = pflat.numel()
             st = self._ensure_state(gi, params, total)
             st["step_int"] += 1

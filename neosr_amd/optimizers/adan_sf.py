@@ -16,7 +16,7 @@ import torch
 from torch.optim.optimizer import Optimizer
 
 from neosr_amd import _C
-from neosr_amd.hip.nets import flat_grad_of
+from neosr_amd.hip.nets import arena_layout, flat_grad_of, flat_view_of, pack_grads
 from neosr_amd.optimizers.adamw import AdamW
 
 _ARENAS = ("exp_avg", "exp_avg_sq", "exp_avg_diff", "z", "neg_pre_grad")
@@ -88,8 +88,7 @@ class adan_sf(AdamW):
         dev = params[0].device
         if st is None or st["exp_avg"].numel() != total or st["exp_avg"].device != dev:
             st = {k: torch.zeros(total, device=dev, dtype=torch.float32) for k in _ARENAS}
-            off = 0
-            for p in params:
+            for p, off in zip(params, arena_layout(params)[0]):
                 n = p.numel()
                 old = self.state.get(p, {})
                 new = {}
@@ -101,7 +100,6 @@ class adan_sf(AdamW):
                         view.copy_(p.detach())  # state["z"] = torch.clone(p)
                     new[k] = view
                 self.state[p] = new
-                off += n
             self._flat[gi] = st
         return st
 
@@ -120,7 +118,7 @@ class adan_sf(AdamW):
             _C.require_device(pflat, "parameter arena")
             gflat = flat_grad_of(params)
             if gflat is None:
-                gflat = torch.cat([p.grad.reshape(-1) for p in params])
+                gflat = pack_grads(params)
             total = pflat.numel()
             st = self._ensure_state(gi, params, total)
             group["step"] = group.get("step", 0) + 1

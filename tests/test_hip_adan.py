@@ -25,12 +25,15 @@ def test_adan_sf_kernel_vs_reference_fixture(tag):
 
     fix = load_golden("adan_sf.npz")
     shapes = [fix[f"{tag}/p0/{i}"].shape for i in range(2)]
-    arena = torch.cat([T(fix[f"{tag}/p0/{i}"]).reshape(-1) for i in range(2)]).to(DEV)
-    ps, off = [], 0
-    for s in shapes:
-        n = int(np.prod(s))
-        ps.append(torch.nn.Parameter(arena[off: off + n].view(*s)))
-        off += n
+    from neosr_amd.hip.nets import arena_layout
+
+    init = [T(fix[f"{tag}/p0/{i}"]) for i in range(2)]
+    offs, total = arena_layout(init)  # 16-byte aligned starts: 35 elements -> the second tensor starts at 36
+    arena = torch.zeros(total, device=DEV)
+    ps = []
+    for t, off in zip(init, offs):
+        arena[off: off + t.numel()].copy_(t.reshape(-1))
+        ps.append(torch.nn.Parameter(arena[off: off + t.numel()].view(t.shape)))
     opt = adan_sf(ps, lr=2e-3, betas=(0.98, 0.92, 0.987), weight_decay=0.02, warmup_steps=3,
                   schedule_free=tag == "sf")
     for step in range(1, 6):
