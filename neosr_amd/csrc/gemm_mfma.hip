@@ -50,6 +50,55 @@ __device__ __forceinline__ f32x4 ld4(const float* p, int vec) {
   return r;
 }
 
+// epilogue shared by all GEMM kernels: lane owns C row m = m0 + 32*wave + l31 and the column quads
+// 32t + 8g + 4lh + {0..3} (D was formed as Bfrag x Afrag)
+template <int MODE>
+__device__ __forceinline__ void epilogue(const GemmArgs& args, const f32x16 (&acc)[2], int m0, int n0, int split) {
+  const neosr_gemm_desc& d = args.d;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const int M = d.M, N = d.N;
+  const int m = m0 + wave * 32 + l31;
+  const bool m_ok = m < M;
+  const int64_t mrow = m_ok ? m : 0;
+  float* Cbase = d.C;
+  if (MODE == 2) Cbase = d.C + (int64_t)split * M * d.ldc;  // split-K partial slab
+  const float rs = (MODE != 2 && d.row_scale && m_ok) ? d.row_scale[m / d.rows_per_scale] : 1.f;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int n = n0 + 32 * t + 8 * g + 4 * lh;
+      const bool ok = m_ok && n < N;
+      float v[4] = {acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
+      if (MODE != 2) {
+        const int ns = n < N ? n : 0;
+        if (d.bias) {
+          const f32x4 b = ld4(d.bias + ns, args.b_vec);
+          v[0] += b[0]; v[1] += b[1]; v[2] += b[2]; v[3] += b[3];
+        }
+        if (d.aux_out)  // keep the pre-activation for the backward pass
+          *reinterpret_cast<float4*>(ok ? d.aux_out + mrow * d.ldaux + n : gm_trash + tid * 4) =
+              make_float4(v[0], v[1], v[2], v[3]);
+        if (d.gelu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = gelu_exact(v[e]);
+        }
+        if (d.aux_in) {  // dz = da * GELU'(z)
+          const float4 z = *reinterpret_cast<const float4*>(ok ? d.aux_in + mrow * d.ldaux + n : gm_zero_page);
+          v[0] *= gelu_grad(z.x); v[1] *= gelu_grad(z.y); v[2] *= gelu_grad(z.z); v[3] *= gelu_grad(z.w);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= rs;
+        if (d.res) {
+          const float4 r = *reinterpret_cast<const float4*>(ok ? d.res + mrow * d.ldres + n : gm_zero_page);
+          v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+        }
+      }
+      *reinterpret_cast<float4*>(ok ? Cbase + mrow * d.ldc + n : gm_trash + tid * 4) =
+          make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
 // MODE 0 = NT, 1 = NN, 2 = TN
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(const GemmArgs args) {
@@ -186,47 +235,78 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(const GemmArgs args) 
     }
   }
 
-  // epilogue: lane owns C row m = m0 + 32*wave + l31 and column quads 32t + 8g + 4lh + {0..3}
-  const int m = m0 + wave * 32 + l31;
-  const bool m_ok = m < M;
-  const int64_t mrow = m_ok ? m : 0;
-  float* Cbase = d.C;
-  if (MODE == 2) Cbase = d.C + (int64_t)split * M * d.ldc;  // split-K partial slab
-  const float rs = (MODE != 2 && d.row_scale && m_ok) ? d.row_scale[m / d.rows_per_scale] : 1.f;
+  epilogue<MODE>(args, acc, m0, n0, split);
+}
+
+// NT GEMM with direct-to-LDS staging (global_load_lds_dwordx4): no staging VGPRs, no ds_write pass, two
+// LDS buffers and ONE barrier per K chunk; MFMA fragments come from 16-byte LDS reads (one ds_read_b128
+// feeds 4 MFMAs).  LDS image per operand: [row][8 quads of 4 k] with quad q of row r stored at slot
+// q ^ (r & 7): a wave's glds instruction still fetches full 128-byte rows (8 lanes per row, permuted
+// within the line), and the 8 lanes of a ds_read_b128 phase hit 8 different 16-byte bank groups.
+// Fragment convention: lanes with lh = 0 read quad 2s, lanes with lh = 1 quad 2s+1; MFMA e of step s then
+// multiplies k = 8s + e (lh 0) and k = 8s + 4 + e (lh 1) — the same pairing for both operands.
+__global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(const GemmArgs args) {
+  const neosr_gemm_desc& d = args.d;
+  __shared__ __attribute__((aligned(1024))) float lds[2 * (BM + BN) * BK];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const int tiles = args.tiles_m * args.tiles_n;
+  const int chunk = gridDim.x >> 3;
+  const int logical = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+  if (logical >= tiles) return;
+  const int m0 = (logical / args.tiles_n) * BM, n0 = (logical % args.tiles_n) * BN;
+  const int K = d.K;
+  // per-lane source rows: instruction i of this wave covers tile rows (4 i + wave) * 8 + lane / 8
+  const int rsub = lane >> 3, slot = lane & 7;
+  auto issue = [&](int k0, int buf) {
+    float* abuf = lds + buf * (BM + BN) * BK;
+    float* bbuf = abuf + BM * BK;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = (4 * i + wave) * 8 + rsub;
+      const int k = k0 + 4 * (slot ^ (r & 7));
+      const float* src = (m0 + r < d.M && k < K) ? d.A + (int64_t)(m0 + r) * d.lda + k : gm_zero_page;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(abuf + (4 * i + wave) * 256), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = (4 * i + wave) * 8 + rsub;
+      const int k = k0 + 4 * (slot ^ (r & 7));
+      const float* src = (n0 + r < d.N && k < K) ? d.B + (int64_t)(n0 + r) * d.ldb + k : gm_zero_page;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(bbuf + (4 * i + wave) * 256), 16, 0, 0);
+    }
+  };
+  f32x16 acc[2];
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int n = n0 + 32 * t + 8 * g + 4 * lh;
-      const bool ok = m_ok && n < N;
-      float v[4] = {acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
-      if (MODE != 2) {
-        const int ns = n < N ? n : 0;
-        if (d.bias) {
-          const f32x4 b = ld4(d.bias + ns, args.b_vec);
-          v[0] += b[0]; v[1] += b[1]; v[2] += b[2]; v[3] += b[3];
-        }
-        if (d.aux_out)  // keep the pre-activation for the backward pass
-          *reinterpret_cast<float4*>(ok ? d.aux_out + mrow * d.ldaux + n : gm_trash + tid * 4) =
-              make_float4(v[0], v[1], v[2], v[3]);
-        if (d.gelu) {
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  const int nchunks = (K + BK - 1) / BK;
+  issue(0, 0);
+  __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
+  __syncthreads();
+  const int arow = wave * 32 + l31;
+  for (int c = 0; c < nchunks; ++c) {
+    if (c + 1 < nchunks) issue((c + 1) * BK, (c + 1) & 1);
+    const float* abuf = lds + (c & 1) * (BM + BN) * BK;
+    const float* bbuf = abuf + BM * BK;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = gelu_exact(v[e]);
-        }
-        if (d.aux_in) {  // dz = da * GELU'(z)
-          const float4 z = *reinterpret_cast<const float4*>(ok ? d.aux_in + mrow * d.ldaux + n : gm_zero_page);
-          v[0] *= gelu_grad(z.x); v[1] *= gelu_grad(z.y); v[2] *= gelu_grad(z.z); v[3] *= gelu_grad(z.w);
-        }
+    for (int s = 0; s < BK / 8; ++s) {
+      const int q = 2 * s + lh;
+      const f32x4 a = *reinterpret_cast<const f32x4*>(abuf + arow * BK + 4 * (q ^ (arow & 7)));
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(bbuf + l31 * BK + 4 * (q ^ (l31 & 7)));
+      const f32x4 b1 = *reinterpret_cast<const f32x4*>(bbuf + (32 + l31) * BK + 4 * (q ^ (l31 & 7)));
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= rs;
-        if (d.res) {
-          const float4 r = *reinterpret_cast<const float4*>(ok ? d.res + mrow * d.ldres + n : gm_zero_page);
-          v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
-        }
+      for (int e = 0; e < 4; ++e) {
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[e], a[e], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b1[e], a[e], acc[1], 0, 0, 0);
       }
-      *reinterpret_cast<float4*>(ok ? Cbase + mrow * d.ldc + n : gm_trash + tid * 4) =
-          make_float4(v[0], v[1], v[2], v[3]);
     }
+    __builtin_amdgcn_s_waitcnt(0x0f70);  // the next chunk has landed ...
+    __syncthreads();                      // ... for every wave, and this buffer is free to overwrite
+  }
+  epilogue<0>(args, acc, m0, n0, 0);
 }
 
 // column sums of a row-major [rows, cols] matrix (bias gradients, LayerNorm / relative-position-bias
@@ -267,6 +347,12 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
 #ifndef TN_TARGET_BLOCKS
 #define TN_TARGET_BLOCKS 768
 #endif
+#ifdef GEMM_NO_GLDS
+constexpr bool g_no_glds = true;
+#else
+constexpr bool g_no_glds = false;
+#endif
+
 int tn_splits(int M, int N, int K) {
   const int tiles = ceil_div(M, BM) * ceil_div(N, BN);
   int s = ceil_div(TN_TARGET_BLOCKS, tiles);
@@ -305,7 +391,9 @@ extern "C" int neosr_gemm(const neosr_gemm_desc* dp, void* stream) {
   a.tiles_m = ceil_div(d.M, BM);
   a.tiles_n = ceil_div(d.N, BN);
   dim3 grid(ceil_div(a.tiles_m * a.tiles_n, 8) * 8, 1, 1);
-  if (d.mode == NEOSR_GEMM_NT) {
+  if (d.mode == NEOSR_GEMM_NT && a.b_vec && !g_no_glds) {
+    hipLaunchKernelGGL(gemm_nt_glds_kernel, grid, dim3(256), 0, st, a);
+  } else if (d.mode == NEOSR_GEMM_NT) {
     hipLaunchKernelGGL(gemm_mfma_kernel<0>, grid, dim3(256), 0, st, a);
   } else if (d.mode == NEOSR_GEMM_NN) {
     hipLaunchKernelGGL(gemm_mfma_kernel<1>, grid, dim3(256), 0, st, a);
