@@ -130,6 +130,8 @@ def main() -> None:
                          "swinir_medium, L1 + VGG perceptual (use --batch 8)")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU-oracle timing (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--augment", action="store_true",
+                    help="also enable the template batch augmentations (options/train_esrgan_otf.toml:17-18)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -172,6 +174,9 @@ def main() -> None:
                                    "schedule_free": True}
         opt["train"]["perceptual_opt"] = {"type": "vgg_perceptual_loss", "loss_weight": 0.5, "criterion": "chc"}
         opt["train"]["gan_opt"] = {"type": "gan_loss", "gan_type": "bce", "loss_weight": 0.3}
+    if args.augment:
+        opt["datasets"]["train"].update({"augmentation": ["none", "mixup", "cutmix", "resizemix", "cutblur"],
+                                         "aug_prob": [0.5, 0.1, 0.1, 0.1, 0.5]})
     set_global_opt(opt)
     torch.manual_seed(1024 + rank)
     model = build_model(opt)

@@ -364,6 +364,20 @@ typedef struct neosr_fattn_desc {
 int64_t neosr_flash_window_attention_workspace_bytes(const neosr_fattn_desc* d);
 int neosr_flash_window_attention_fwd(const neosr_fattn_desc* d, void* stream);
 int neosr_flash_window_attention_bwd(const neosr_fattn_desc* d, void* stream);
+/* batch augmentations (neosr/data/augmentations.py) --------------------------------------
+ * F.interpolate(mode = bilinear | bicubic, antialias=True) on planar NCHW data with ATen's window /
+ * weights (support = interp/2 * max(scale, 1), bicubic a = -0.5, normalised), horizontal then vertical
+ * pass through `tmp` (>= B*C*Hin*Wout floats); the result lands in the box (y0, x0) of an (Hfull, Wfull)
+ * output image, optionally clamped to [0, 1] and optionally reading batch entry perm[b] (resizemix,
+ * augmentations.py:150-170).  Used for the x scale up / down round trip of apply_augment (:258-308). */
+int neosr_resize_aa(const float* in, float* out, float* tmp, const int32_t* perm, int32_t B, int32_t C,
+                    int32_t Hin, int32_t Win, int32_t Hout, int32_t Wout, int32_t Hfull, int32_t Wfull, int32_t y0,
+                    int32_t x0, int32_t mode, int32_t clamp01, void* stream);
+/* out = inside rows [y0,y1) x cols [x0,x1) ? lam * x[b] + (1-lam) * src[perm[b]] : x[b]  (mixup: whole
+ * image; cutmix / cutblur: lam = 0; perm optional).  NCHW. */
+int neosr_box_blend(const float* x, const float* src, const int32_t* perm, float* out, int32_t B, int32_t C,
+                    int32_t H, int32_t W, int32_t y0, int32_t y1, int32_t x0, int32_t x1, float lam, void* stream);
+
 /* HAT Channel Attention Block, non-conv parts (hat_arch.py:15-52) ------------------------------------
  * exact-erf GELU between the two convs: out = g ? g * GELU'(x) : GELU(x). */
 int neosr_gelu(const float* x, const float* g, float* out, int64_t n, void* stream);

@@ -23,7 +23,7 @@ class LiveDraws:
         self.device = torch.device(device)
 
     # python `random`
-    def choices(self, population, weights):
+    def choices(self, population, weights=None):
         return random.choices(population, weights)[0]
 
     def choice(self, seq):
@@ -35,6 +35,12 @@ class LiveDraws:
     # numpy Generator
     def uniform(self, lo: float = 0.0, hi: float = 1.0) -> float:
         return float(self.rng.uniform(lo, hi))
+
+    def random(self) -> float:
+        return float(self.rng.random())
+
+    def integers(self, lo: int, hi: int | None = None) -> int:
+        return int(self.rng.integers(lo, hi))
 
     # torch generator (device draws: no host round trip)
     def rand(self, n: int) -> torch.Tensor:
@@ -74,7 +80,7 @@ class ReplayDraws:
         v = self._next(kind)
         return torch.as_tensor(np.asarray(v)).to(self.device)
 
-    def choices(self, population, weights):
+    def choices(self, population, weights=None):
         return str(self._next("choices"))
 
     def choice(self, seq):
@@ -85,6 +91,12 @@ class ReplayDraws:
 
     def uniform(self, lo: float = 0.0, hi: float = 1.0) -> float:
         return float(self._next("uniform"))
+
+    def random(self) -> float:
+        return float(self._next("random"))
+
+    def integers(self, lo: int, hi: int | None = None) -> int:
+        return int(self._next("integers"))
 
     def rand(self, n: int) -> torch.Tensor:
         return self._t("rand").float()

@@ -9,7 +9,7 @@ and the same `log_dict` keys; the work is re-staged for one MI355X per process:
   logging:   loss scalars stay on the device until `get_current_log()`
 
 Options the reference supports but that are not on the benchmarked path (SAM, ECO, wavelet
-guidance, AMP, match_lq_colors, augmentations) raise `NotImplementedError` instead of silently
+guidance, AMP, match_lq_colors) raise `NotImplementedError` instead of silently
 doing something else.
 """
 
@@ -24,6 +24,8 @@ import torch
 from torch import Tensor, nn
 
 from neosr_amd.archs import build_network
+from neosr_amd.data.augmentations import apply_augment
+from neosr_amd.data.draws import LiveDraws
 from neosr_amd.hip.nets import arena_layout, flat_grad_of, flatten_parameters_, pack_grads
 from neosr_amd.losses import build_loss
 from neosr_amd.models.base import allreduce_flat_, base
@@ -123,8 +125,10 @@ class image(base):
         self.patch_size = ds.get("patch_size")
         self.aug = ds.get("augmentation", None)
         self.aug_prob = ds.get("aug_prob", None)
-        if self.aug is not None and not (len(self.aug) == 1 and "none" in self.aug):
-            raise NotImplementedError("batch augmentations are a 'next' row (SURVEY §8 a9)")
+        if self.aug is not None and self.patch_size % 4 != 0:  # image.py:275-278
+            raise ValueError(f"{tc.red}The patch_size value must be a multiple of 4 while using augmentations.{tc.end}")
+        if not hasattr(self, "draws"):  # python `random` / numpy Generator(manual_seed) / torch, as the reference
+            self.draws = LiveDraws(self.opt.get("manual_seed"), self.device)
         self.use_amp = False
         self.total_iter = train_opt.get("total_iter", 200000)
         self.n_accumulated = 0
@@ -192,6 +196,10 @@ class image(base):
         self.lq = data["lq"].to(self.device, non_blocking=True)
         if "gt" in data:
             self.gt = data["gt"].to(self.device, non_blocking=True)
+        # image.py:381-391
+        if self.is_train and self.aug is not None and not (len(self.aug) == 1 and "none" in self.aug):
+            self.gt, self.lq = apply_augment(self.gt, self.lq, self.draws, scale=self.scale, augs=self.aug,
+                                             prob=self.aug_prob)
 
     def _sync_grads(self, optimizer) -> None:
         """data-parallel exchange + clip request for one network (after its backward)"""

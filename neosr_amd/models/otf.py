@@ -20,6 +20,7 @@ from typing import Any
 
 import torch
 
+from neosr_amd.data.augmentations import apply_augment
 from neosr_amd.data.draws import LiveDraws
 from neosr_amd.hip import degrade as D
 from neosr_amd.models.image import image
@@ -167,5 +168,9 @@ class otf(image):
 
         self._dequeue_and_enqueue()
         self.lq = self.lq.contiguous()
-        if self.aug is not None and not (len(self.aug) == 1 and "none" in self.aug):
-            raise NotImplementedError("batch augmentations are a 'next' row (SURVEY §8 a9)")
+        # otf.py:266-278: with `augmentation` set the batch always goes through apply_augment (its x scale
+        # up / down resize round trip happens even when "none" is drawn)
+        if self.aug is not None:
+            if self.patch_size % 4 != 0:
+                raise ValueError(f"{tc.red}The patch_size value must be a multiple of 4 while using augmentations.{tc.end}")
+            self.gt, self.lq = apply_augment(self.gt, self.lq, d, scale=self.scale, augs=self.aug, prob=self.aug_prob)
