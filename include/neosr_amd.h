@@ -378,6 +378,35 @@ int neosr_resize_aa(const float* in, float* out, float* tmp, const int32_t* perm
 int neosr_box_blend(const float* x, const float* src, const int32_t* perm, float* out, int32_t B, int32_t C,
                     int32_t H, int32_t W, int32_t y0, int32_t y1, int32_t x0, int32_t x1, float lam, void* stream);
 
+/* multi-scale SSIM loss (neosr/losses/ssim_loss.py:11-163) on planar NCHW data -------------
+ * Per scale: neosr_ssim_fwd applies the separable 11-tap Gaussian window (host array `window11`, zero
+ * padding 5) to x, y, x^2, y^2, xy in one pass and writes per-tile partial sums [tile][{cs, ssim}]
+ * (neosr_ssim_tiles(P,H,W) tiles) and, when `dmaps` is given, the three derivative maps
+ * d map/d(G*x), d map/d(G*x^2), d map/d(G*xy) (3*P*H*W floats; map = ssim if want_ssim else cs).
+ * neosr_avgpool2_planes is the F.avg_pool2d(2, 2) between scales.  neosr_msssim_finalize reduces the
+ * partials in a fixed order to loss = loss_weight * (1 - prod_i m_i^w_i) (m = mean cs, mean ssim on the last
+ * scale) and the per-scale pixel gradients gscal[i] = -loss_weight w_i prod / m_i / npix_i (device scalars, no
+ * host sync).  neosr_ssim_bwd: dx = gscal * gout * (G*D0 + 2 x G*D1 + y G*D2) + 0.25 * coarse[y/2, x/2]
+ * (the gradient arriving through the average pool from the next scale; optional). */
+#define NEOSR_MSSSIM_SCALES 5
+typedef struct neosr_msssim_desc {
+  const float* partial[NEOSR_MSSSIM_SCALES];
+  int64_t npix[NEOSR_MSSSIM_SCALES];
+  int32_t nblk[NEOSR_MSSSIM_SCALES];
+  float weights[NEOSR_MSSSIM_SCALES];
+  float loss_weight;
+  int32_t nscales;
+  float* loss;   /* 1 float */
+  float* gscal;  /* nscales floats */
+} neosr_msssim_desc;
+int64_t neosr_ssim_tiles(int32_t P, int32_t H, int32_t W);
+int neosr_ssim_fwd(const float* x, const float* y, const float* window11, float* dmaps, float* partial, int32_t P,
+                   int32_t H, int32_t W, float C1, float C2, int32_t want_ssim, void* stream);
+int neosr_ssim_bwd(const float* dmaps, const float* x, const float* y, const float* window11, const float* gscal,
+                   const float* gout, const float* coarse, float* dx, int32_t P, int32_t H, int32_t W, void* stream);
+int neosr_avgpool2_planes(const float* in, float* out, int32_t P, int32_t H, int32_t W, void* stream);
+int neosr_msssim_finalize(const neosr_msssim_desc* d, void* stream);
+
 /* HAT Channel Attention Block, non-conv parts (hat_arch.py:15-52) ------------------------------------
  * exact-erf GELU between the two convs: out = g ? g * GELU'(x) : GELU(x). */
 int neosr_gelu(const float* x, const float* g, float* out, int64_t n, void* stream);

@@ -181,6 +181,13 @@ class FattnDesc(C.Structure):
     )
 
 
+class MsssimDesc(C.Structure):
+    """neosr_msssim_desc"""
+
+    _fields_ = [("partial", C.c_void_p * 5), ("npix", C.c_int64 * 5), ("nblk", C.c_int32 * 5), ("weights", C.c_float * 5),
+                ("loss_weight", C.c_float), ("nscales", C.c_int32), ("loss", C.c_void_p), ("gscal", C.c_void_p)]
+
+
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_PRELU = 0, 1, 2, 3
 CONV_FWD, CONV_DGRAD = 0, 1
@@ -247,6 +254,11 @@ SIGNATURES: dict[str, tuple] = {
     "neosr_window_attention_bwd": (C.c_int, [C.POINTER(WattnDesc), _vp]),
     "neosr_resize_aa": (C.c_int, [_vp, _vp, _vp, _vp] + [_i32] * 12 + [_vp]),
     "neosr_box_blend": (C.c_int, [_vp, _vp, _vp, _vp] + [_i32] * 8 + [_f32, _vp]),
+    "neosr_ssim_tiles": (_i64, [_i32, _i32, _i32]),
+    "neosr_ssim_fwd": (C.c_int, [_vp, _vp, c_float_p, _vp, _vp, _i32, _i32, _i32, _f32, _f32, _i32, _vp]),
+    "neosr_ssim_bwd": (C.c_int, [_vp, _vp, _vp, c_float_p, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "neosr_avgpool2_planes": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
+    "neosr_msssim_finalize": (C.c_int, [C.POINTER(MsssimDesc), _vp]),
     "neosr_gelu": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
     "neosr_batched_colsum": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp]),
     "neosr_channel_attention_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),

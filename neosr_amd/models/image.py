@@ -64,7 +64,7 @@ class EMAModel(nn.Module):
 
 
 _UNSUPPORTED_TRAIN_FLAGS = ("sam", "eco", "wavelet_guided", "match_lq_colors")
-_UNSUPPORTED_LOSSES = ("mssim_opt", "consistency_opt", "dists_opt", "ldl_opt", "ff_opt", "gw_opt")
+_UNSUPPORTED_LOSSES = ("consistency_opt", "dists_opt", "ldl_opt", "ff_opt", "gw_opt")
 
 
 @MODEL_REGISTRY.register()
@@ -138,12 +138,13 @@ class image(base):
             return build_loss(train_opt[key]).to(self.device) if train_opt.get(key) else None
 
         self.cri_pix = crit("pixel_opt")
+        self.cri_mssim = crit("mssim_opt")
         self.cri_perceptual = crit("perceptual_opt")
         self.cri_gan = crit("gan_opt")
         self.gradclip = train_opt.get("grad_clip", True)
 
         optim_d = train_opt.get("optim_d", None)
-        if self.cri_pix is None and self.cri_perceptual is None:
+        if self.cri_pix is None and self.cri_mssim is None and self.cri_perceptual is None:
             logger.error(f"{tc.red}Both pixel/mssim and perceptual losses are None. "
                          f"Please enable at least one.{tc.end}")
             sys.exit(1)
@@ -234,6 +235,10 @@ class image(base):
             l_g_pix = self.cri_pix(self.output, self.gt)
             l_g_total = l_g_total + l_g_pix
             loss_dict["l_g_pix"] = l_g_pix
+        if self.cri_mssim:  # image.py:478-481
+            l_g_mssim = self.cri_mssim(self.output, self.gt)
+            l_g_total = l_g_total + l_g_mssim
+            loss_dict["l_g_mssim"] = l_g_mssim
         if self.cri_perceptual:
             l_g_percep = self.cri_perceptual(self.output, self.gt)
             l_g_total = l_g_total + l_g_percep
