@@ -130,6 +130,9 @@ def main() -> None:
                          "swinir_medium, L1 + VGG perceptual (use --batch 8)")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU-oracle timing (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--template-losses", action="store_true",
+                    help="otf_gan: the shipped template loss stack (options/train_esrgan_otf.toml:118-141): "
+                         "mssim + consistency + perceptual + gan, no L1")
     ap.add_argument("--augment", action="store_true",
                     help="also enable the template batch augmentations (options/train_esrgan_otf.toml:17-18)")
     args = ap.parse_args()
@@ -174,6 +177,10 @@ def main() -> None:
                                    "schedule_free": True}
         opt["train"]["perceptual_opt"] = {"type": "vgg_perceptual_loss", "loss_weight": 0.5, "criterion": "chc"}
         opt["train"]["gan_opt"] = {"type": "gan_loss", "gan_type": "bce", "loss_weight": 0.3}
+    if args.template_losses:
+        opt["train"].pop("pixel_opt", None)
+        opt["train"]["mssim_opt"] = {"type": "mssim_loss", "loss_weight": 1.0}
+        opt["train"]["consistency_opt"] = {"type": "consistency_loss", "loss_weight": 1.0}
     if args.augment:
         opt["datasets"]["train"].update({"augmentation": ["none", "mixup", "cutmix", "resizemix", "cutblur"],
                                          "aug_prob": [0.5, 0.1, 0.1, 0.1, 0.5]})
@@ -218,7 +225,7 @@ def main() -> None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    loss = model.get_current_log().get("l_g_pix")
+    loss = model.get_current_log().get("l_g_pix", model.get_current_log().get("l_g_total"))
 
     roofline = None
     if not args.no_roofline and rank == 0 and not args.arch.startswith(("swinir", "hat")):

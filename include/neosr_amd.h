@@ -407,6 +407,31 @@ int neosr_ssim_bwd(const float* dmaps, const float* x, const float* y, const flo
 int neosr_avgpool2_planes(const float* in, float* out, int32_t P, int32_t H, int32_t W, void* stream);
 int neosr_msssim_finalize(const neosr_msssim_desc* d, void* stream);
 
+/* consistency_loss pieces (neosr/losses/consistency_loss.py:14-192), planar NCHW ---------
+ * out = g ? g * [lo <= x <= hi] : clamp(x, lo, hi)   (torch.clamp and its backward). */
+int neosr_clamp(const float* x, const float* g, float* out, int64_t n, float lo, float hi, void* stream);
+/* torchvision GaussianBlur: separable `taps` (host array, odd count <= 31) with reflect padding on P planes
+ * of H x W (consistency_loss.py:39,144-145); adjoint = 1: the exact transpose (pad gradients fold back).
+ * tmp >= P*H*W floats. */
+#define NEOSR_BLUR_MAX_TAPS 31
+int neosr_gaussian_blur_reflect(const float* in, float* out, float* tmp, const float* taps, int32_t ntaps,
+                                int32_t P, int32_t H, int32_t W, int32_t adjoint, void* stream);
+/* sRGB (B,3,H,W) -> clamp(CIE L* / 100, 0, 1) * mul as (B,H,W) (consistency_loss.py:106-133);
+ * with g (B,H,W): out = gradient wrt rgb (B,3,H,W). */
+int neosr_rgb_to_luma(const float* rgb, const float* g, float* out, int32_t B, int32_t H, int32_t W, float mul,
+                      void* stream);
+/* sRGB (B,3,H,W) -> clamp(Oklab (a, b) * mul + 0.5, 0, 1) as (B,2,H,W) (consistency_loss.py:63-104,159-165);
+ * with g (B,2,H,W): out = gradient wrt rgb. */
+int neosr_rgb_to_oklab_chroma(const float* rgb, const float* g, float* out, int32_t B, int32_t H, int32_t W,
+                              float mul, void* stream);
+/* out[0] = 1 - mean cos(a, b) over `groups * inner` vectors of length L and stride `inner`
+ * (nn.CosineSimilarity(dim=1) on (groups, L, inner) data; consistency_loss.py:176-178).  stats: 3 floats per
+ * vector kept for backward; partial >= 1024 floats.  bwd: da = gout[0] * d out / d a. */
+int neosr_cosine_dist_fwd(const float* a, const float* b, float* stats, float* partial, float* out, int64_t groups,
+                          int32_t L, int64_t inner, float eps, void* stream);
+int neosr_cosine_dist_bwd(const float* a, const float* b, const float* stats, const float* gout, float* da,
+                          int64_t groups, int32_t L, int64_t inner, float eps, void* stream);
+
 /* HAT Channel Attention Block, non-conv parts (hat_arch.py:15-52) ------------------------------------
  * exact-erf GELU between the two convs: out = g ? g * GELU'(x) : GELU(x). */
 int neosr_gelu(const float* x, const float* g, float* out, int64_t n, void* stream);

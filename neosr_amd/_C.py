@@ -259,6 +259,12 @@ SIGNATURES: dict[str, tuple] = {
     "neosr_ssim_bwd": (C.c_int, [_vp, _vp, _vp, c_float_p, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "neosr_avgpool2_planes": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
     "neosr_msssim_finalize": (C.c_int, [C.POINTER(MsssimDesc), _vp]),
+    "neosr_clamp": (C.c_int, [_vp, _vp, _vp, _i64, _f32, _f32, _vp]),
+    "neosr_gaussian_blur_reflect": (C.c_int, [_vp, _vp, _vp, c_float_p, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "neosr_rgb_to_luma": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp]),
+    "neosr_rgb_to_oklab_chroma": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp]),
+    "neosr_cosine_dist_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _f32, _vp]),
+    "neosr_cosine_dist_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _f32, _vp]),
     "neosr_gelu": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
     "neosr_batched_colsum": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp]),
     "neosr_channel_attention_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),

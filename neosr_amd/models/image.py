@@ -64,7 +64,7 @@ class EMAModel(nn.Module):
 
 
 _UNSUPPORTED_TRAIN_FLAGS = ("sam", "eco", "wavelet_guided", "match_lq_colors")
-_UNSUPPORTED_LOSSES = ("consistency_opt", "dists_opt", "ldl_opt", "ff_opt", "gw_opt")
+_UNSUPPORTED_LOSSES = ("dists_opt", "ldl_opt", "ff_opt", "gw_opt")
 
 
 @MODEL_REGISTRY.register()
@@ -139,6 +139,7 @@ class image(base):
 
         self.cri_pix = crit("pixel_opt")
         self.cri_mssim = crit("mssim_opt")
+        self.cri_consistency = crit("consistency_opt")
         self.cri_perceptual = crit("perceptual_opt")
         self.cri_gan = crit("gan_opt")
         self.gradclip = train_opt.get("grad_clip", True)
@@ -239,6 +240,10 @@ class image(base):
             l_g_mssim = self.cri_mssim(self.output, self.gt)
             l_g_total = l_g_total + l_g_mssim
             loss_dict["l_g_mssim"] = l_g_mssim
+        if self.cri_consistency:  # image.py:483-489 (match_lq_colors is rejected at construction)
+            l_g_consistency = self.cri_consistency(self.output, self.gt)
+            l_g_total = l_g_total + l_g_consistency
+            loss_dict["l_g_consistency"] = l_g_consistency
         if self.cri_perceptual:
             l_g_percep = self.cri_perceptual(self.output, self.gt)
             l_g_total = l_g_total + l_g_percep

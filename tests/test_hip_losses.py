@@ -46,3 +46,29 @@ def test_mssim_loss_full_size_vs_float64_oracle():
     (loss * 0.37).backward()
     assert abs(float(loss) - float(lo.mssim_loss(x0.double(), gt.double()))) < 1e-5
     assert rel_err(x.grad, xr.grad) < 1e-4
+
+
+@pytest.mark.parametrize("tag", ["near", "far"])
+def test_consistency_loss_vs_reference_fixture(tag):
+    """`near`: the cosine term is below 1e-3 and gets added (decided on the device); `far`: it is not"""
+    from neosr_amd.losses import build_loss
+
+    fix = load_golden("consistency.npz")
+    crit = build_loss({"type": "consistency_loss", "saturation": 1.1, "brightness": 0.95, "loss_weight": 0.8})
+    x = T(fix[f"{tag}/x"]).to(DEV).requires_grad_(True)
+    loss = crit(x, T(fix[f"{tag}/gt"]).to(DEV))
+    loss.backward()
+    assert abs(float(loss.detach()) - float(fix[f"{tag}/loss"])) < 1e-4 * abs(float(fix[f"{tag}/loss"]))
+    assert rel_err(x.grad, T(fix[f"{tag}/gx"])) < 1e-3
+
+
+def test_blur_adjoint_identity():
+    """<blur(a), b> == <a, blur^T(b)> for the reflect-padded Gaussian (the backward kernel is the exact transpose)"""
+    from neosr_amd.losses.consistency_loss import _Blur, _gaussian_taps
+
+    g = torch.Generator().manual_seed(5)
+    a, b = torch.randn(2, 3, 40, 33, generator=g).to(DEV), torch.randn(2, 3, 40, 33, generator=g).to(DEV)
+    taps = _gaussian_taps(21, 3.0)
+    lhs = (_Blur._run(a, taps, 21, 0).double() * b.double()).sum()
+    rhs = (a.double() * _Blur._run(b, taps, 21, 1).double()).sum()
+    assert abs(float(lhs - rhs)) < 1e-5 * abs(float(lhs))

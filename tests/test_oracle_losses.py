@@ -22,3 +22,13 @@ def test_mssim_loss_value_and_gradient(tag):
     loss.backward()
     assert abs(float(loss) - float(fix[f"{tag}/loss"])) < 1e-6
     assert rel_err(x.grad, T(fix[f"{tag}/gx"])) < 1e-5
+
+
+@pytest.mark.parametrize("tag", ["near", "far"])
+def test_consistency_loss_value_and_gradient(tag):
+    fix = load_golden("consistency.npz")
+    x = T(fix[f"{tag}/x"]).requires_grad_(True)
+    loss = lo.consistency_loss(x, T(fix[f"{tag}/gt"]), saturation=1.1, brightness=0.95, loss_weight=0.8)
+    loss.backward()
+    assert abs(float(loss) - float(fix[f"{tag}/loss"])) < 1e-6
+    assert rel_err(x.grad, T(fix[f"{tag}/gx"])) < 1e-5
