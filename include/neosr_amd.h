@@ -302,6 +302,8 @@ typedef struct neosr_gemm_desc {
   const float* row_scale;
   float* workspace;
   int32_t M, N, K, lda, ldb, ldc, ldres, ldaux, rows_per_scale, mode, gelu, accumulate;
+  float* colsum_a; /* TN only, optional: colsum_a[m] (+)= sum_k A[k, m] — the bias gradient sum_rows dY,
+                      taken from the A tiles the weight-gradient GEMM stages anyway */
 } neosr_gemm_desc;
 int64_t neosr_gemm_workspace_bytes(const neosr_gemm_desc* d);
 int neosr_gemm(const neosr_gemm_desc* d, void* stream);
@@ -310,7 +312,8 @@ int neosr_colsum(const float* x, float* out, float* workspace, int32_t rows, int
                  int32_t accumulate, void* stream);
 /* nn.LayerNorm(C) over the last dim, eps 1e-5, biased variance (swinir_arch.py:284,297,960,1035).
  * fwd keeps (mean, rstd) per row in `stats` (2*rows floats).  bwd: dx, and dgamma/dbeta (+)= via a
- * fixed-order two-stage column reduction; workspace >= (2*1024 + 256)*C floats.  C <= 512. */
+ * fixed-order two-stage column reduction; workspace >= (2*1024 + 512)*C floats.  C <= 512.  One reduction launch
+ * when dbeta == dgamma + C. */
 int neosr_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stats,
                         int64_t rows, int32_t C, float eps, void* stream);
 int neosr_layernorm_bwd(const float* dy, const float* x, const float* stats, const float* gamma,

@@ -158,7 +158,7 @@ class GemmDesc(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("A", "B", "C", "bias", "res", "aux_in", "aux_out", "row_scale", "workspace")] + [
         (n, C.c_int32)
         for n in ("M", "N", "K", "lda", "ldb", "ldc", "ldres", "ldaux", "rows_per_scale", "mode", "gelu", "accumulate")
-    ]
+    ] + [("colsum_a", C.c_void_p)]
 
 
 class WattnDesc(C.Structure):

@@ -483,6 +483,8 @@ extern "C" int neosr_layernorm_bwd(const float* dy, const float* x, const float*
   // per-workgroup partials [nblk][2][C] -> dgamma | dbeta; the column sums stage through the tail of
   // the workspace (behind the 2*1024*C partials)
   float* stage = workspace + (int64_t)2 * 1024 * C;
+  if (dbeta == dgamma + C)  // adjacent outputs: one reduction over the 2C columns
+    return neosr_colsum(workspace, dgamma, stage, nblk, 2 * C, 2 * C, accumulate, stream);
   if (int rc = neosr_colsum(workspace, dgamma, stage, nblk, C, 2 * C, accumulate, stream)) return rc;
   return neosr_colsum(workspace + C, dbeta, stage, nblk, C, 2 * C, accumulate, stream);
 }

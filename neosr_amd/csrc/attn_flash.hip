@@ -514,12 +514,15 @@ __global__ __launch_bounds__(256) void fold_dkv_kernel(const neosr_fattn_desc d,
   }
 }
 
-// d_table[bin][head] (+)= sum over the (query, key) pairs mapped to `bin` of the dense bias gradient
+// d_table[bin][head] (+)= sum over the (query, key) pairs mapped to `bin` of the dense bias gradient:
+// one wave per (bin, head), each lane takes 4 of the 256 query positions, butterfly-free fixed-order
+// shuffle reduction
 template <int WS, int KS>
 __global__ __launch_bounds__(256) void rpb_bins_kernel(const float* __restrict__ dense, float* __restrict__ dtab,
                                                        int heads, int accumulate) {
   using G = Geo<WS, KS>;
-  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (e >= G::NBINS * heads) return;
   const int bin = e / heads, head = e - bin * heads;
   // key - query offsets (dy, dx) of this bin
@@ -537,16 +540,14 @@ __global__ __launch_bounds__(256) void rpb_bins_kernel(const float* __restrict__
   }
   const float* base = dense + (int64_t)head * G::NQ * G::NK;
   float s = 0.f;
-  for (int yi = 0; yi < WS; ++yi) {
-    const int yj = yi + dy;
-    if (yj < 0 || yj >= KS) continue;
-    for (int xi = 0; xi < WS; ++xi) {
-      const int xj = xi + dx;
-      if (xj < 0 || xj >= KS) continue;
-      s += base[(int64_t)(yi * WS + xi) * G::NK + yj * KS + xj];
-    }
+  for (int q = lane; q < G::NQ; q += 64) {
+    const int yi = q / WS, xi = q % WS;
+    const int yj = yi + dy, xj = xi + dx;
+    if (yj >= 0 && yj < KS && xj >= 0 && xj < KS) s += base[(int64_t)q * G::NK + yj * KS + xj];
   }
-  dtab[e] = accumulate ? dtab[e] + s : s;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+  if (lane == 0) dtab[e] = accumulate ? dtab[e] + s : s;
 }
 
 template <int WS, int KS>
@@ -570,7 +571,7 @@ int launch_bwd(const neosr_fattn_desc& d, hipStream_t st) {
   if (int rc = neosr_colsum(d.workspace + ws.ds_full, d.workspace + ws.dense, d.workspace + ws.stage, bw, cols,
                             cols, 0, (void*)st))
     return rc;
-  hipLaunchKernelGGL((rpb_bins_kernel<WS, KS>), dim3(ceil_div(G::NBINS * d.heads, 256)), dim3(256), 0, st,
+  hipLaunchKernelGGL((rpb_bins_kernel<WS, KS>), dim3(ceil_div(G::NBINS * d.heads, 4)), dim3(256), 0, st,
                      d.workspace + ws.dense, d.d_rpb_table, d.heads, d.accumulate_rpb);
   NEOSR_LAUNCH_CHECK();
   return 0;

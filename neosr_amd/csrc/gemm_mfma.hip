@@ -40,6 +40,7 @@ struct GemmArgs {
   neosr_gemm_desc d;
   int ksplit_len;  // TN: K range per split
   int tiles_m, tiles_n, nsplit;
+  float* colsum_part;  // TN with d.colsum_a: per-split partial column sums of A, [nsplit][M]
   int b_vec;       // B (and bias) 16-byte aligned -> float4 loads; else dword loads (weights that sit
                    // at a 4-byte-aligned offset of a packed parameter arena)
 };
@@ -211,12 +212,19 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(const GemmArgs args) 
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
+  // TN: the n-tile-0 workgroups also sum the columns of their A tile (= the bias gradient sum_rows dY)
+  const bool do_colsum = MODE == 2 && args.colsum_part && n0 == 0 && tid < BM;
+  float csum = 0.f;
   const int nchunks = (k_hi - k_lo + BK - 1) / BK;
   if (nchunks > 0) gload(k_lo);
   for (int c = 0; c < nchunks; ++c) {
     __syncthreads();
     sstore();
     __syncthreads();
+    if (do_colsum) {
+#pragma unroll 8
+      for (int kk = 0; kk < BK; ++kk) csum += As[kk * LDM + tid];
+    }
 #ifndef GEMM_NO_GLOAD
     if (c + 1 < nchunks) gload(k_lo + (c + 1) * BK);
 #endif
@@ -235,6 +243,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(const GemmArgs args) 
     }
   }
 
+  if (do_colsum && m0 + tid < M) args.colsum_part[(int64_t)split * M + m0 + tid] = csum;
   epilogue<MODE>(args, acc, m0, n0, split);
 }
 
@@ -367,7 +376,8 @@ int tn_splits(int M, int N, int K) {
 extern "C" int64_t neosr_gemm_workspace_bytes(const neosr_gemm_desc* d) {
   if (!d || d->mode != NEOSR_GEMM_TN) return 256;
   // split-K slabs + the staging area of the column-sum reduction (<= 16384 + M*N floats)
-  return ((int64_t)(tn_splits(d->M, d->N, d->K) + 1) * d->M * d->N + 16384 + 64) * 4;
+  // ... + per-split column sums of A and their reduction stage (d->colsum_a), 2 x 256 x M
+  return ((int64_t)(tn_splits(d->M, d->N, d->K) + 1) * d->M * d->N + 16384 + 64 + 512 * (int64_t)d->M) * 4;
 }
 
 extern "C" int neosr_gemm(const neosr_gemm_desc* dp, void* stream) {
@@ -387,6 +397,7 @@ extern "C" int neosr_gemm(const neosr_gemm_desc* dp, void* stream) {
   GemmArgs a;
   a.d = d;
   a.ksplit_len = d.K;
+  a.colsum_part = nullptr;
   a.b_vec = al(d.B, d.ldb) && al(d.bias, 0);
   a.tiles_m = ceil_div(d.M, BM);
   a.tiles_n = ceil_div(d.N, BN);
@@ -407,12 +418,17 @@ extern "C" int neosr_gemm(const neosr_gemm_desc* dp, void* stream) {
     NEOSR_CHECK(ldc == d.N, "gemm TN: C must be dense (ldc == N)");
     a.d.C = d.workspace;
     a.nsplit = nsplit;
+    float* stage = d.workspace + (int64_t)nsplit * d.M * d.N;
+    float* cpart = stage + (int64_t)d.M * d.N + 16384 + 64;
+    a.colsum_part = d.colsum_a ? cpart : nullptr;
     grid.x = ceil_div(nsplit, 8) * 8 * a.tiles_m * a.tiles_n;
     hipLaunchKernelGGL(gemm_mfma_kernel<2>, grid, dim3(256), 0, st, a);
     NEOSR_LAUNCH_CHECK();
     // fixed-order reduction of the split-K slabs == column sums of the [nsplit][M*N] partial matrix
-    return neosr_colsum(d.workspace, out, d.workspace + (int64_t)nsplit * d.M * d.N, nsplit, d.M * d.N,
-                        d.M * d.N, d.accumulate, stream);
+    if (int rc = neosr_colsum(d.workspace, out, stage, nsplit, d.M * d.N, d.M * d.N, d.accumulate, stream)) return rc;
+    if (d.colsum_a)
+      return neosr_colsum(cpart, d.colsum_a, cpart + (int64_t)256 * d.M, nsplit, d.M, d.M, d.accumulate, stream);
+    return 0;
   }
   NEOSR_LAUNCH_CHECK();
   return 0;

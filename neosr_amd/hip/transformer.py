@@ -26,8 +26,9 @@ def _new(shape, like):
 
 
 def gemm(mode, A, B, M, N, K, *, out=None, bias=None, res=None, aux_in=None, aux_out=None, row_scale=None,
-         rows_per_scale=0, gelu=False, accumulate=False):
-    """C = op(A) op(B) with the fused epilogue of `neosr_gemm` (include/neosr_amd.h). Dense operands."""
+         rows_per_scale=0, gelu=False, accumulate=False, colsum_a=None):
+    """C = op(A) op(B) with the fused epilogue of `neosr_gemm` (include/neosr_amd.h). Dense operands.
+    TN only: `colsum_a` (M floats) also receives sum_k A[k, :] (the bias gradient)."""
     lib = _C.load()
     if out is None:
         out = _new((M, N), A)
@@ -36,7 +37,7 @@ def gemm(mode, A, B, M, N, K, *, out=None, bias=None, res=None, aux_in=None, aux
     d = _C.GemmDesc(A=A.data_ptr(), B=B.data_ptr(), C=out.data_ptr(), bias=_p(bias), res=_p(res),
                     aux_in=_p(aux_in), aux_out=_p(aux_out), row_scale=_p(row_scale), workspace=None,
                     M=M, N=N, K=K, lda=lda, ldb=ldb, ldc=N, ldres=N, ldaux=N, rows_per_scale=rows_per_scale,
-                    mode=mode, gelu=int(gelu), accumulate=int(accumulate))
+                    mode=mode, gelu=int(gelu), accumulate=int(accumulate), colsum_a=_p(colsum_a))
     ws = None
     if mode == _C.GEMM_TN:
         ws = torch.empty(lib.neosr_gemm_workspace_bytes(d) // 4, device=A.device, dtype=torch.float32)
@@ -95,9 +96,11 @@ class Linear(torch.autograd.Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             gx = gemm(_C.GEMM_NN, gs, w, M, K, N).view(*g.shape[:-1], K)
+        want_b = has_b and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            gw = gemm(_C.GEMM_TN, gs, x2, N, K, M)
-        if has_b and ctx.needs_input_grad[2]:
+            gb = _new((N,), gs) if want_b else None  # bias gradient rides in the weight-gradient GEMM
+            gw = gemm(_C.GEMM_TN, gs, x2, N, K, M, colsum_a=gb)
+        elif want_b:
             gb = colsum(gs)
         return gx, gw, gb, (g if has_res else None), None, None
 
@@ -134,11 +137,10 @@ class Mlp(torch.autograd.Function):
         M, K, Hd, N, rps, has_res = ctx.meta
         g2 = _as2d(g)
         gs = g2 if rs is None else row_scale(g2, rs, rps)
-        gw2 = gemm(_C.GEMM_TN, gs, h, N, Hd, M)
-        gb2 = colsum(gs)
+        gb2, gb1 = _new((N,), gs), _new((Hd,), gs)  # bias gradients ride in the weight-gradient GEMMs
+        gw2 = gemm(_C.GEMM_TN, gs, h, N, Hd, M, colsum_a=gb2)
         gpre = gemm(_C.GEMM_NN, gs, w2, M, Hd, N, aux_in=pre)  # (g W2) * GELU'(pre)
-        gw1 = gemm(_C.GEMM_TN, gpre, x2, Hd, K, M)
-        gb1 = colsum(gpre)
+        gw1 = gemm(_C.GEMM_TN, gpre, x2, Hd, K, M, colsum_a=gb1)
         gx = gemm(_C.GEMM_NN, gpre, w1, M, K, Hd).view(*g.shape[:-1], K) if ctx.needs_input_grad[0] else None
         return gx, gw1, gb1, gw2, gb2, (g if has_res else None), None, None
 
@@ -169,8 +171,9 @@ class LayerNorm(torch.autograd.Function):
         rows, C_ = x2.shape
         g2 = _as2d(g)
         dx = torch.empty_like(x2)
-        dg, db = _new((C_,), x2), _new((C_,), x2)
-        ws = _new(((2 * 1024 + 256) * C_,), x2)
+        dgb = _new((2 * C_,), x2)  # dgamma | dbeta adjacent: one reduction launch
+        dg, db = dgb[:C_], dgb[C_:]
+        ws = _new(((2 * 1024 + 512) * C_,), x2)
         _C.check(lib.neosr_layernorm_bwd(g2.data_ptr(), x2.data_ptr(), stats.data_ptr(), gamma.data_ptr(),
                                          dx.data_ptr(), dg.data_ptr(), db.data_ptr(), ws.data_ptr(), rows, C_, 0,
                                          _st()), "neosr_layernorm_bwd")
