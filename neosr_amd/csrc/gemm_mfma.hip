@@ -40,7 +40,8 @@ struct GemmArgs {
   neosr_gemm_desc d;
   int ksplit_len;  // TN: K range per split
   int tiles_m, tiles_n, nsplit;
-  float* colsum_part;  // TN with d.colsum_a: per-split partial column sums of A, [nsplit][M]
+  float* colsum_part;  // TN with d.colsum_a: per-split partial column sums of A, row stride slab
+  int64_t slab;        // TN: floats per split-K slab (M*N, + M when the column sums ride behind it)
   int b_vec;       // B (and bias) 16-byte aligned -> float4 loads; else dword loads (weights that sit
                    // at a 4-byte-aligned offset of a packed parameter arena)
 };
@@ -62,7 +63,7 @@ __device__ __forceinline__ void epilogue(const GemmArgs& args, const f32x16 (&ac
   const bool m_ok = m < M;
   const int64_t mrow = m_ok ? m : 0;
   float* Cbase = d.C;
-  if (MODE == 2) Cbase = d.C + (int64_t)split * M * d.ldc;  // split-K partial slab
+  if (MODE == 2) Cbase = d.C + (int64_t)split * args.slab;  // split-K partial slab
   const float rs = (MODE != 2 && d.row_scale && m_ok) ? d.row_scale[m / d.rows_per_scale] : 1.f;
 #pragma unroll
   for (int t = 0; t < 2; ++t)
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(const GemmArgs args) 
     }
   }
 
-  if (do_colsum && m0 + tid < M) args.colsum_part[(int64_t)split * M + m0 + tid] = csum;
+  if (do_colsum && m0 + tid < M) args.colsum_part[(int64_t)split * args.slab + m0 + tid] = csum;
   epilogue<MODE>(args, acc, m0, n0, split);
 }
 
@@ -376,8 +377,9 @@ int tn_splits(int M, int N, int K) {
 extern "C" int64_t neosr_gemm_workspace_bytes(const neosr_gemm_desc* d) {
   if (!d || d->mode != NEOSR_GEMM_TN) return 256;
   // split-K slabs + the staging area of the column-sum reduction (<= 16384 + M*N floats)
-  // ... + per-split column sums of A and their reduction stage (d->colsum_a), 2 x 256 x M
-  return ((int64_t)(tn_splits(d->M, d->N, d->K) + 1) * d->M * d->N + 16384 + 64 + 512 * (int64_t)d->M) * 4;
+  // (slabs carry M extra floats for the column sums of A; the stage is sized for <= 256 row slabs of 64 columns)
+  const int64_t slab = (int64_t)d->M * d->N + d->M;
+  return ((int64_t)(tn_splits(d->M, d->N, d->K) + 1) * slab + 16384 + 256 * 64 + 64) * 4;
 }
 
 extern "C" int neosr_gemm(const neosr_gemm_desc* dp, void* stream) {
@@ -398,6 +400,7 @@ extern "C" int neosr_gemm(const neosr_gemm_desc* dp, void* stream) {
   a.d = d;
   a.ksplit_len = d.K;
   a.colsum_part = nullptr;
+  a.slab = 0;
   a.b_vec = al(d.B, d.ldb) && al(d.bias, 0);
   a.tiles_m = ceil_div(d.M, BM);
   a.tiles_n = ceil_div(d.N, BN);
@@ -416,18 +419,22 @@ extern "C" int neosr_gemm(const neosr_gemm_desc* dp, void* stream) {
     float* out = d.C;
     const int ldc = d.ldc;
     NEOSR_CHECK(ldc == d.N, "gemm TN: C must be dense (ldc == N)");
+    // slab = [M*N partial C | M partial column sums of A]: when the caller keeps colsum_a right behind C, ONE
+    // fixed-order column-sum pass over the [nsplit][slab] matrix finishes both
+    const int64_t mn = (int64_t)d.M * d.N;
+    a.slab = mn + (d.colsum_a ? d.M : 0);
     a.d.C = d.workspace;
     a.nsplit = nsplit;
-    float* stage = d.workspace + (int64_t)nsplit * d.M * d.N;
-    float* cpart = stage + (int64_t)d.M * d.N + 16384 + 64;
-    a.colsum_part = d.colsum_a ? cpart : nullptr;
+    a.colsum_part = d.colsum_a ? d.workspace + mn : nullptr;
+    float* stage = d.workspace + (int64_t)nsplit * a.slab;
     grid.x = ceil_div(nsplit, 8) * 8 * a.tiles_m * a.tiles_n;
     hipLaunchKernelGGL(gemm_mfma_kernel<2>, grid, dim3(256), 0, st, a);
     NEOSR_LAUNCH_CHECK();
-    // fixed-order reduction of the split-K slabs == column sums of the [nsplit][M*N] partial matrix
-    if (int rc = neosr_colsum(d.workspace, out, stage, nsplit, d.M * d.N, d.M * d.N, d.accumulate, stream)) return rc;
+    if (d.colsum_a == out + mn)
+      return neosr_colsum(d.workspace, out, stage, nsplit, (int)a.slab, (int)a.slab, d.accumulate, stream);
+    if (int rc = neosr_colsum(d.workspace, out, stage, nsplit, (int)mn, (int)a.slab, d.accumulate, stream)) return rc;
     if (d.colsum_a)
-      return neosr_colsum(cpart, d.colsum_a, cpart + (int64_t)256 * d.M, nsplit, d.M, d.M, d.accumulate, stream);
+      return neosr_colsum(d.workspace + mn, d.colsum_a, stage, nsplit, d.M, (int)a.slab, d.accumulate, stream);
     return 0;
   }
   NEOSR_LAUNCH_CHECK();

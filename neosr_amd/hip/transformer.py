@@ -64,6 +64,13 @@ def row_scale(x2d, scale, rows_per_scale):
     return out
 
 
+def _wgrad_pair(like, n_out: int, k_in: int, want_bias: bool):
+    """(dW (n_out, k_in), db (n_out)) in one buffer, db right behind dW: the TN GEMM then finishes both with a
+    single split-K reduction pass"""
+    buf = _new((n_out * k_in + (n_out if want_bias else 0),), like)
+    return buf[: n_out * k_in].view(n_out, k_in), (buf[n_out * k_in:] if want_bias else None)
+
+
 def _as2d(x):
     x = _C.require_device(x, "x")
     if not x.is_contiguous():
@@ -98,8 +105,8 @@ class Linear(torch.autograd.Function):
             gx = gemm(_C.GEMM_NN, gs, w, M, K, N).view(*g.shape[:-1], K)
         want_b = has_b and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            gb = _new((N,), gs) if want_b else None  # bias gradient rides in the weight-gradient GEMM
-            gw = gemm(_C.GEMM_TN, gs, x2, N, K, M, colsum_a=gb)
+            gw, gb = _wgrad_pair(gs, N, K, want_b)  # bias gradient rides in the weight-gradient GEMM
+            gemm(_C.GEMM_TN, gs, x2, N, K, M, out=gw, colsum_a=gb)
         elif want_b:
             gb = colsum(gs)
         return gx, gw, gb, (g if has_res else None), None, None
@@ -137,10 +144,11 @@ class Mlp(torch.autograd.Function):
         M, K, Hd, N, rps, has_res = ctx.meta
         g2 = _as2d(g)
         gs = g2 if rs is None else row_scale(g2, rs, rps)
-        gb2, gb1 = _new((N,), gs), _new((Hd,), gs)  # bias gradients ride in the weight-gradient GEMMs
-        gw2 = gemm(_C.GEMM_TN, gs, h, N, Hd, M, colsum_a=gb2)
+        gw2, gb2 = _wgrad_pair(gs, N, Hd, True)  # bias gradients ride in the weight-gradient GEMMs
+        gemm(_C.GEMM_TN, gs, h, N, Hd, M, out=gw2, colsum_a=gb2)
         gpre = gemm(_C.GEMM_NN, gs, w2, M, Hd, N, aux_in=pre)  # (g W2) * GELU'(pre)
-        gw1 = gemm(_C.GEMM_TN, gpre, x2, Hd, K, M, colsum_a=gb1)
+        gw1, gb1 = _wgrad_pair(gs, Hd, K, True)
+        gemm(_C.GEMM_TN, gpre, x2, Hd, K, M, out=gw1, colsum_a=gb1)
         gx = gemm(_C.GEMM_NN, gpre, w1, M, K, Hd).view(*g.shape[:-1], K) if ctx.needs_input_grad[0] else None
         return gx, gw1, gb1, gw2, gb2, (g if has_res else None), None, None
 
