@@ -367,6 +367,16 @@ typedef struct neosr_fattn_desc {
 int64_t neosr_flash_window_attention_workspace_bytes(const neosr_fattn_desc* d);
 int neosr_flash_window_attention_fwd(const neosr_fattn_desc* d, void* stream);
 int neosr_flash_window_attention_bwd(const neosr_fattn_desc* d, void* stream);
+/* MSELoss / HuberLoss with reduction = "mean" (neosr/losses/basic_loss.py:57-127: F.mse_loss,
+ * F.huber_loss(delta)): loss = loss_weight * mean(term(pred - target)); workspace >= 1024 floats;
+ * bwd: grad_pred = grad_out[0] * loss_weight / n * term'(pred - target). */
+#define NEOSR_LOSS_MSE 1
+#define NEOSR_LOSS_HUBER 2
+int neosr_pointwise_loss_fwd(const float* pred, const float* target, int64_t n, int32_t kind, float delta,
+                             float loss_weight, float* loss_out, float* workspace, void* stream);
+int neosr_pointwise_loss_bwd(const float* pred, const float* target, const float* grad_out, int64_t n,
+                             int32_t kind, float delta, float loss_weight, float* grad_pred, void* stream);
+
 /* batch augmentations (neosr/data/augmentations.py) --------------------------------------
  * F.interpolate(mode = bilinear | bicubic, antialias=True) on planar NCHW data with ATen's window /
  * weights (support = interp/2 * max(scale, 1), bicubic a = -0.5, normalised), horizontal then vertical

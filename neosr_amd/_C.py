@@ -252,6 +252,8 @@ SIGNATURES: dict[str, tuple] = {
     "neosr_layernorm_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     "neosr_window_attention_fwd": (C.c_int, [C.POINTER(WattnDesc), _vp]),
     "neosr_window_attention_bwd": (C.c_int, [C.POINTER(WattnDesc), _vp]),
+    "neosr_pointwise_loss_fwd": (C.c_int, [_vp, _vp, _i64, _i32, _f32, _f32, _vp, _vp, _vp]),
+    "neosr_pointwise_loss_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _f32, _f32, _vp, _vp]),
     "neosr_resize_aa": (C.c_int, [_vp, _vp, _vp, _vp] + [_i32] * 12 + [_vp]),
     "neosr_box_blend": (C.c_int, [_vp, _vp, _vp, _vp] + [_i32] * 8 + [_f32, _vp]),
     "neosr_ssim_tiles": (_i64, [_i32, _i32, _i32]),

@@ -7,7 +7,10 @@ Other reductions are rejected loudly rather than silently computed elsewhere.
 
 from __future__ import annotations
 
+import torch
 from torch import Tensor, nn
+
+from neosr_amd import _C
 
 from neosr_amd.hip.layers import ChcLoss
 from neosr_amd.hip.nets import L1LossFunction
@@ -59,3 +62,66 @@ class chc_loss(nn.Module):
     def forward(self, pred: Tensor, target: Tensor, **kwargs) -> Tensor:  # noqa: ARG002
         return ChcLoss.apply(pred, target, 1.0, self.criterion == "huber", float(self.clip_min),
                              float(self.clip_max), float(self.loss_weight))
+
+
+class _PointwiseLoss(torch.autograd.Function):
+    """loss_weight * mean(term(pred - target)), term = d^2 (MSE) or Huber(delta); `neosr_pointwise_loss_*`."""
+
+    @staticmethod
+    def forward(ctx, pred, target, kind, delta, loss_weight):
+        lib = _C.load()
+        pred = _C.require_device(pred, "pred").contiguous()
+        target = _C.require_device(target, "target").contiguous()
+        if pred.shape != target.shape:
+            raise _C.NeosrAmdError(f"loss: shape mismatch {tuple(pred.shape)} vs {tuple(target.shape)}")
+        out = torch.empty((), device=pred.device, dtype=torch.float32)
+        ws = torch.empty(1024, device=pred.device, dtype=torch.float32)
+        _C.check(lib.neosr_pointwise_loss_fwd(pred.data_ptr(), target.data_ptr(), pred.numel(), kind, delta,
+                                              loss_weight, out.data_ptr(), ws.data_ptr(), _C.stream_ptr()),
+                 "neosr_pointwise_loss_fwd")
+        ctx.save_for_backward(pred, target)
+        ctx.cfg = (kind, delta, loss_weight)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _C.load()
+        pred, target = ctx.saved_tensors
+        g = g.contiguous().to(torch.float32)
+        gp = torch.empty_like(pred)
+        _C.check(lib.neosr_pointwise_loss_bwd(pred.data_ptr(), target.data_ptr(), g.data_ptr(), pred.numel(), *ctx.cfg,
+                                              gp.data_ptr(), _C.stream_ptr()), "neosr_pointwise_loss_bwd")
+        return gp, (-gp if ctx.needs_input_grad[1] else None), None, None, None
+
+
+def _check_reduction(reduction: str, who: str) -> None:
+    if reduction not in _reduction_modes:
+        raise ValueError(f"Unsupported reduction mode: {reduction}. Supported ones are: {_reduction_modes}")
+    if reduction != "mean":
+        raise NotImplementedError(f"neosr_amd {who}: only reduction='mean' has a HIP kernel")
+
+
+@LOSS_REGISTRY.register()
+class MSELoss(nn.Module):
+    """MSE (L2) loss, `loss_weight * mean((pred - target)^2)` (basic_loss.py:57-86)."""
+
+    def __init__(self, loss_weight: float = 1.0, reduction: str = "mean") -> None:
+        super().__init__()
+        _check_reduction(reduction, "MSELoss")
+        self.loss_weight, self.reduction = loss_weight, reduction
+
+    def forward(self, pred: Tensor, target: Tensor, **kwargs) -> Tensor:  # noqa: ARG002
+        return _PointwiseLoss.apply(pred, target, 1, 1.0, float(self.loss_weight))
+
+
+@LOSS_REGISTRY.register()
+class HuberLoss(nn.Module):
+    """Huber loss with threshold `delta` (basic_loss.py:89-127)."""
+
+    def __init__(self, loss_weight: float = 1.0, reduction: str = "mean", delta: float = 1.0) -> None:
+        super().__init__()
+        _check_reduction(reduction, "HuberLoss")
+        self.loss_weight, self.reduction, self.delta = loss_weight, reduction, delta
+
+    def forward(self, pred: Tensor, target: Tensor, **kwargs) -> Tensor:  # noqa: ARG002
+        return _PointwiseLoss.apply(pred, target, 2, float(self.delta), float(self.loss_weight))

@@ -72,3 +72,25 @@ def test_blur_adjoint_identity():
     lhs = (_Blur._run(a, taps, 21, 0).double() * b.double()).sum()
     rhs = (a.double() * _Blur._run(b, taps, 21, 1).double()).sum()
     assert abs(float(lhs - rhs)) < 1e-5 * abs(float(lhs))
+
+
+@pytest.mark.parametrize("kind", ["MSELoss", "HuberLoss"])
+def test_mse_and_huber_vs_aten(kind):
+    """the reference classes are thin wrappers of F.mse_loss / F.huber_loss (basic_loss.py:57-127)"""
+    import torch.nn.functional as F
+
+    from neosr_amd.losses import build_loss
+
+    g = torch.Generator().manual_seed(3)
+    a, b = torch.randn(2, 3, 37, 41, generator=g), torch.randn(2, 3, 37, 41, generator=g)
+    opt = {"type": kind, "loss_weight": 0.7}
+    if kind == "HuberLoss":
+        opt["delta"] = 0.6
+    x = a.to(DEV).requires_grad_(True)
+    loss = build_loss(opt)(x, b.to(DEV))
+    (loss * 1.3).backward()
+    xr = a.double().requires_grad_(True)
+    ref = 0.7 * (F.mse_loss(xr, b.double()) if kind == "MSELoss" else F.huber_loss(xr, b.double(), delta=0.6))
+    (ref * 1.3).backward()
+    assert abs(float(loss.detach()) - float(ref)) < 1e-5 * abs(float(ref))
+    assert rel_err(x.grad, xr.grad) < 1e-5
