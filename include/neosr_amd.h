@@ -505,6 +505,38 @@ int neosr_adan_sf_step(const neosr_adan_desc* d, void* stream);
 /* p = torch.lerp(p, end, weight) elementwise: adan_sf.train() / .eval() (adan_sf.py:112-136). */
 int neosr_lerp(float* p, const float* end, int64_t n, float weight, void* stream);
 
+/* The remaining optimizers of base.get_optimizer (neosr/models/base.py:151-172) as one fused elementwise
+ * step on flat arenas, with the model-level clip (max_norm) and the EMA update fused as in
+ * neosr_adamw_step.  The host computes every scalar coefficient in double (as the Python originals do):
+ *   ADAM      torch.optim.Adam          s0 m, s1 v              c = b1, b2, eps, wd, lr/bc1, sqrt(bc2)
+ *   NADAM     torch.optim.NAdam         s0 m, s1 v              c = b1, b2, eps, wd, lr(1-mu)/(1-muprod), sqrt(bc2),
+ *                                                                   lr mu_next/(1-muprod mu_next)
+ *   ADAN      optimizers/adan.py        s0 m, s1 n, s2 diff, s3 neg_pre_grad   c = b1, b2, b3, eps, lr wd,
+ *                                       lr/bc1, lr b2/bc2, sqrt(bc3), no_prox;  flags bit 0 = first step
+ *   ADAMW_SF  optimizers/adamw_sf.py    s0 exp_avg_sq, s1 z     c = b2, eps, decay, ckp1, lr_t, lr_t (b1 (1-ckp1) - 1)
+ *   ADAMW_WIN optimizers/adamw_win.py   s0 m, s1 v, s2 x, s3 y  c = b1, b2, eps, wd, lr, bc1, sqrt(bc2), beta3, beta4;
+ *                                       flags 0 = plain AdamW, 1 = win, 2 = win2 */
+#define NEOSR_OPT_ADAM 1
+#define NEOSR_OPT_NADAM 2
+#define NEOSR_OPT_ADAN 3
+#define NEOSR_OPT_ADAMW_SF 4
+#define NEOSR_OPT_ADAMW_WIN 5
+typedef struct neosr_optim_desc {
+  float* param;
+  const float* grad;
+  float* s0;
+  float* s1;
+  float* s2;
+  float* s3;
+  float* ema;      /* optional */
+  float* norm_ws;  /* >= 4200 floats when max_norm > 0 */
+  int64_t n;
+  float c[12];
+  float max_norm, ema_decay, grad_scale;
+  int32_t kind, flags;
+} neosr_optim_desc;
+int neosr_optim_step(const neosr_optim_desc* d, void* stream);
+
 /* opt-in profiler ------------------------------------------------------------------------------
  * HIP events around every conv-class launch on the launch stream (classes: 0 conv fwd, 1 conv
  * dgrad, 2 conv wgrad, 3 wgrad reduce).  Used by bench.py's roofline pass only.  collect()

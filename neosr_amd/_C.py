@@ -119,6 +119,20 @@ class AdanDesc(C.Structure):
     )
 
 
+class OptimDesc(C.Structure):
+    """neosr_optim_desc"""
+
+    _fields_ = (
+        [(n, C.c_void_p) for n in ("param", "grad", "s0", "s1", "s2", "s3", "ema", "norm_ws")]
+        + [("n", C.c_int64), ("c", C.c_float * 12)]
+        + [(n, C.c_float) for n in ("max_norm", "ema_decay", "grad_scale")]
+        + [("kind", C.c_int32), ("flags", C.c_int32)]
+    )
+
+
+OPT_ADAM, OPT_NADAM, OPT_ADAN, OPT_ADAMW_SF, OPT_ADAMW_WIN = 1, 2, 3, 4, 5
+
+
 class RRDBNetCfg(C.Structure):
     """neosr_rrdbnet_cfg"""
 
@@ -281,6 +295,7 @@ SIGNATURES: dict[str, tuple] = {
     "neosr_row_scale": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     "neosr_adan_sf_step": (C.c_int, [C.POINTER(AdanDesc), _vp]),
     "neosr_lerp": (C.c_int, [_vp, _vp, _i64, _f32, _vp]),
+    "neosr_optim_step": (C.c_int, [C.POINTER(OptimDesc), _vp]),
     "neosr_prof_enable": (C.c_int, [C.c_int]),
     "neosr_prof_collect": (
         C.c_int,

@@ -118,3 +118,129 @@ extern "C" int neosr_lerp(float* p, const float* end, int64_t n, float weight, v
   NEOSR_LAUNCH_CHECK();
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// The other optimizers of base.get_optimizer (neosr/models/base.py:151-172) as ONE elementwise kernel:
+// torch.optim.Adam / NAdam, adan (neosr/optimizers/adan.py), adamw_sf (adamw_sf.py), adamw_win
+// (adamw_win.py).  All scalar coefficients are computed by the host in double (as the Python originals
+// do) and passed in c[]; the model-level clip and the EMA update are fused exactly as in adamw / adan_sf.
+namespace {
+
+__global__ __launch_bounds__(256) void optim_kernel(const neosr_optim_desc d) {
+  float clip = d.grad_scale;
+  if (d.max_norm > 0.f) clip *= fminf(d.max_norm / (d.norm_ws[0] + 1e-6f), 1.f);
+  const float* c = d.c;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < d.n; i += (int64_t)gridDim.x * 256) {
+    float p = d.param[i];
+    float g = d.grad[i] * clip;
+    switch (d.kind) {
+      case NEOSR_OPT_ADAM:     // c: b1, b2, eps, wd, lr/bc1, sqrt(bc2)
+      case NEOSR_OPT_NADAM: {  // c: b1, b2, eps, wd, cg, sqrt(bc2), cm
+        g += c[3] * p;
+        float m = d.s0[i], v = d.s1[i];
+        m = m + (g - m) * (1.f - c[0]);
+        v = v * c[1] + (1.f - c[1]) * g * g;
+        const float denom = sqrtf(v) / c[5] + c[2];
+        if (d.kind == NEOSR_OPT_ADAM) {
+          p -= c[4] * (m / denom);
+        } else {
+          p -= c[4] * (g / denom);
+          p -= c[6] * (m / denom);
+        }
+        d.s0[i] = m;
+        d.s1[i] = v;
+        break;
+      }
+      case NEOSR_OPT_ADAN: {  // s0 m, s1 n, s2 diff, s3 neg_pre_grad; c: b1,b2,b3,eps, lr*wd, ss, ssd, sqrt(bc3), no_prox
+        float m = d.s0[i], n = d.s1[i], df = d.s2[i], npg = d.s3[i];
+        if (d.flags & 1) npg = -g;  // first step
+        npg += g;
+        m = m * c[0] + g * (1.f - c[0]);
+        df = df * c[1] + npg * (1.f - c[1]);
+        npg = npg * c[1] + g;
+        n = n * c[2] + (1.f - c[2]) * npg * npg;
+        const float denom = sqrtf(n) / c[7] + c[3];
+        if (c[8] != 0.f) {
+          p *= 1.f - c[4];
+          p -= c[5] * (m / denom);
+          p -= c[6] * (df / denom);
+        } else {
+          p -= c[5] * (m / denom);
+          p -= c[6] * (df / denom);
+          p /= 1.f + c[4];
+        }
+        d.s0[i] = m;
+        d.s1[i] = n;
+        d.s2[i] = df;
+        d.s3[i] = -g;
+        break;
+      }
+      case NEOSR_OPT_ADAMW_SF: {  // s0 exp_avg_sq, s1 z; c: b2, eps, decay, ckp1, lr_t, lr_t*(b1*(1-ckp1)-1)
+        float v = d.s0[i], z = d.s1[i];
+        v = v * c[0] + (1.f - c[0]) * g * g;
+        float gn = g / (sqrtf(v) + c[1]);
+        if (c[2] != 0.f) gn += c[2] * p;
+        p = lerp_aten(p, z, c[3]);
+        p += c[5] * gn;
+        z -= c[4] * gn;
+        d.s0[i] = v;
+        d.s1[i] = z;
+        break;
+      }
+      default: {  // NEOSR_OPT_ADAMW_WIN: s0 m, s1 v, s2 x, s3 y; c: b1,b2,eps,wd,lr,bc1,sqrt(bc2),beta3,beta4; flags: 0 none 1 win 2 win2
+        float m = d.s0[i], v = d.s1[i];
+        m = m * c[0] + g * (1.f - c[0]);
+        v = v * c[1] + (1.f - c[1]) * g * g;
+        const float denom = sqrtf(v) / c[6] + c[2];
+        if (d.flags == 0) {
+          p *= 1.f - c[4] * c[3];
+          p -= (c[4] / c[5]) * (m / denom);
+        } else {
+          const float upd = (m / denom) / c[5];
+          const float lr_x = c[4], lr_y = c[7] * c[4];
+          float x = d.s2[i];
+          x = (x - lr_x * upd) * (1.f / (1.f + lr_x * c[3]));
+          float gamma = 1.f / (1.f + lr_y / lr_x + lr_y * c[3]);
+          if (d.flags == 1) {
+            p = p * gamma + (lr_y / lr_x) * gamma * x - lr_y * gamma * upd;
+          } else {
+            float y = d.s3[i];
+            y = y * gamma + (lr_y / lr_x) * gamma * x - lr_y * gamma * upd;
+            const float lr_z = c[8] * c[4];
+            gamma = 1.f / (1.f + lr_z / lr_x + lr_z / lr_y + lr_z * c[3]);
+            p = p * gamma - lr_z * gamma * upd;
+            p = p + (lr_z / lr_x) * gamma * x + (lr_z / lr_y) * gamma * y;
+            d.s3[i] = y;
+          }
+          d.s2[i] = x;
+        }
+        d.s0[i] = m;
+        d.s1[i] = v;
+      }
+    }
+    d.param[i] = p;
+    if (d.ema) {
+      const float e = d.ema[i];
+      d.ema[i] = d.ema_decay < 0.f ? p : e + (p - e) * (1.f - d.ema_decay);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int neosr_optim_step(const neosr_optim_desc* dp, void* stream) {
+  NEOSR_CHECK(dp, "optim_step: null descriptor");
+  const neosr_optim_desc& d = *dp;
+  NEOSR_CHECK(d.param && d.grad && d.s0 && d.s1 && d.n > 0, "optim_step: bad args");
+  NEOSR_CHECK(d.kind >= NEOSR_OPT_ADAM && d.kind <= NEOSR_OPT_ADAMW_WIN, "optim_step: unknown kind %d", d.kind);
+  NEOSR_CHECK(d.kind != NEOSR_OPT_ADAN || (d.s2 && d.s3), "optim_step: adan needs 4 state arenas");
+  NEOSR_CHECK(d.kind != NEOSR_OPT_ADAMW_WIN || d.flags == 0 || (d.s2 && (d.flags == 1 || d.s3)),
+              "optim_step: adamw_win needs the x (and y) arenas");
+  if (d.max_norm > 0.f) {
+    NEOSR_CHECK(d.norm_ws, "optim_step: clipping needs norm_ws");
+    if (int rc = neosr_grad_norm(d.grad, d.n, d.grad_scale, d.norm_ws, stream)) return rc;
+  }
+  hipLaunchKernelGGL(optim_kernel, dim3(grid_for(d.n)), dim3(256), 0, (hipStream_t)stream, d);
+  NEOSR_LAUNCH_CHECK();
+  return 0;
+}

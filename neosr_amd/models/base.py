@@ -127,9 +127,18 @@ class base:
             return optimizers.AdamW(params, lr, **kwargs)
         if optim_type in {"Adan_SF", "adan_sf"}:
             return optimizers.adan_sf(params, lr, **kwargs)
+        if optim_type in {"Adam", "adam"}:
+            return optimizers.Adam(params, lr, **kwargs)
+        if optim_type in {"NAdam", "nadam"}:
+            return optimizers.NAdam(params, lr, **kwargs)
+        if optim_type in {"Adan", "adan"}:
+            return optimizers.adan(params, lr, **kwargs)
+        if optim_type in {"AdamW_Win", "adamw_win"}:
+            return optimizers.adamw_win(params, lr, **kwargs)
+        if optim_type in {"AdamW_SF", "adamw_sf"}:
+            return optimizers.adamw_sf(params, lr, **kwargs)
         logger = get_root_logger()
-        logger.error(f"{tc.red}Optimizer {optim_type} has no HIP implementation yet "
-                     f"(available: adamw, adan_sf).{tc.end}")
+        logger.error(f"{tc.red}Optimizer {optim_type} is not supported yet.{tc.end}")
         sys.exit(1)
 
     def setup_schedulers(self) -> None:
