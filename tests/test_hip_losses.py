@@ -94,3 +94,26 @@ def test_mse_and_huber_vs_aten(kind):
     (ref * 1.3).backward()
     assert abs(float(loss.detach()) - float(ref)) < 1e-5 * abs(float(ref))
     assert rel_err(x.grad, xr.grad) < 1e-5
+
+
+@pytest.mark.parametrize("gan_type", ["mse", "huber"])
+def test_gan_loss_mse_huber_vs_torch(gan_type):
+    import torch.nn.functional as F
+
+    from neosr_amd.losses import build_loss
+
+    g = torch.Generator().manual_seed(4)
+    logits = torch.randn(2, 1, 32, 48, generator=g) * 2
+    crit = build_loss({"type": "gan_loss", "gan_type": gan_type, "loss_weight": 0.3})
+    fn = F.mse_loss if gan_type == "mse" else F.huber_loss
+    for real in (True, False):
+        for disc in (True, False):
+            x = logits.to(DEV).requires_grad_(True)
+            loss = crit(x, real, is_disc=disc)
+            loss.backward()
+            xr = logits.double().requires_grad_(True)
+            ref = fn(xr, torch.full_like(xr, 1.0 if real else 0.0)) * (1.0 if disc else 0.3)
+            ref.backward()
+            assert abs(float(loss.detach()) - float(ref)) < 1e-5 * abs(float(ref))
+            assert rel_err(x.grad, xr.grad) < 1e-5
+            assert abs(float(crit.last_mean) - float(logits.mean())) < 1e-5
