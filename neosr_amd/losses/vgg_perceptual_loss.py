@@ -10,6 +10,8 @@ from torch import Tensor, nn
 
 from neosr_amd.archs.vgg_arch import VGGFeatureExtractor
 from neosr_amd.hip.layers import ChcLoss
+from neosr_amd.hip.nets import L1LossFunction
+from neosr_amd.losses.basic_loss import _PointwiseLoss
 from neosr_amd.utils.registry import LOSS_REGISTRY
 
 
@@ -24,8 +26,9 @@ class vgg_perceptual_loss(nn.Module):
             raise ValueError("Please enable PatchLoss to use IPK.")
         if patchloss:
             raise NotImplementedError("PatchLoss / IPK are off by default and outside the hot path")
-        if criterion != "chc":
-            raise NotImplementedError(f"criterion '{criterion}': only 'chc' (the default) has a HIP kernel")
+        if criterion not in ("l1", "l2", "huber", "chc"):
+            raise NotImplementedError(f"{criterion} criterion not supported.")
+        self.criterion_type = criterion
         self.loss_weight = loss_weight
         self.layer_weights = layer_weights if layer_weights is not None else {
             "conv1_2": 0.1, "conv2_2": 0.1, "conv3_4": 1.0, "conv4_4": 1.0, "conv5_4": 1.0}
@@ -38,7 +41,15 @@ class vgg_perceptual_loss(nn.Module):
             fg = self.vgg.features_nhwc(gt.detach())
         total = None
         for k in fx:
-            # chc_loss(loss_lambda=0, clip_min=0, clip_max=1, criterion="huber") on features / 10
-            term = ChcLoss.apply(fx[k], fg[k], 0.1, True, 0.0, 1.0, float(self.layer_weights[k]))
+            w = float(self.layer_weights[k])
+            if self.criterion_type == "chc":
+                # chc_loss(loss_lambda=0, clip_min=0, clip_max=1, criterion="huber") on features / 10
+                term = ChcLoss.apply(fx[k], fg[k], 0.1, True, 0.0, 1.0, w)
+            elif self.criterion_type == "l1":  # criterion(f/10, g/10): the 1/10 folds into the weight
+                term = L1LossFunction.apply(fx[k], fg[k], w / 10)
+            elif self.criterion_type == "l2":
+                term = _PointwiseLoss.apply(fx[k], fg[k], 1, 1.0, w / 100)
+            else:  # huber(d/10, delta 1) == huber(d, delta 10) / 100
+                term = _PointwiseLoss.apply(fx[k], fg[k], 2, 10.0, w / 100)
             total = term if total is None else total + term
         return total * self.loss_weight

@@ -153,3 +153,29 @@ def test_image_model_gan_trajectory_vs_reference_fixture():
     assert max(rel_err(gsd[k], v) for k, v in group(fix, "final_g").items()) < 1e-3
     worst = {k: rel_err(dsd[k], v) for k, v in group(fix, "final_d").items()}
     assert max(worst.values()) < 1e-3, max(worst, key=worst.get)
+
+
+@pytest.mark.parametrize("criterion", ["l1", "l2", "huber"])
+def test_perceptual_loss_other_criteria_vs_oracle(prims, criterion):
+    """criterion(f(x)/10, f(gt)/10) with nn.L1Loss / nn.MSELoss / nn.HuberLoss (vgg_perceptual_loss.py:135-141,232-236)"""
+    import torch.nn.functional as F
+
+    from neosr_amd.losses import build_loss
+    from oracle import gan_oracle as gorc
+
+    pl = build_loss({"type": "vgg_perceptual_loss", "loss_weight": 0.5, "criterion": criterion})
+    _load_vgg(pl.vgg)
+    pl = pl.to(DEV)
+    x = G(prims["vgg_x"]).requires_grad_(True)
+    v = pl(x, G(prims["vgg_gt"]))
+    v.backward()
+    vggP = gorc.vgg_seeded_weights()
+    xr = torch.from_numpy(prims["vgg_x"]).requires_grad_(True)
+    fx = gorc.vgg_features(vggP, xr)
+    with torch.no_grad():
+        fg = gorc.vgg_features(vggP, torch.from_numpy(prims["vgg_gt"]))
+    fn = {"l1": F.l1_loss, "l2": F.mse_loss, "huber": F.huber_loss}[criterion]
+    ref = sum(fn(fx[k] / 10, fg[k] / 10) * w for k, w in gorc.DEFAULT_LAYER_WEIGHTS.items()) * 0.5
+    ref.backward()
+    assert abs(v.item() - float(ref)) < 1e-4 * float(ref)
+    assert rel_err(x.grad, xr.grad) < 1e-3
