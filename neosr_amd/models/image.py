@@ -9,7 +9,7 @@ and the same `log_dict` keys; the work is re-staged for one MI355X per process:
   logging:   loss scalars stay on the device until `get_current_log()`
 
 Options the reference supports but that are not on the benchmarked path (SAM, ECO, wavelet
-guidance, AMP, match_lq_colors) raise `NotImplementedError` instead of silently
+guidance, AMP) raise `NotImplementedError` instead of silently
 doing something else.
 """
 
@@ -24,10 +24,11 @@ import torch
 from torch import Tensor, nn
 
 from neosr_amd.archs import build_network
-from neosr_amd.data.augmentations import apply_augment
+from neosr_amd.data.augmentations import apply_augment, resize_aa
 from neosr_amd.data.draws import LiveDraws
 from neosr_amd.hip.nets import arena_layout, flat_grad_of, flatten_parameters_, pack_grads
 from neosr_amd.losses import build_loss
+from neosr_amd.losses.consistency_loss import _Clamp
 from neosr_amd.models.base import allreduce_flat_, base
 from neosr_amd.utils.misc import get_root_logger, tc
 from neosr_amd.utils.registry import MODEL_REGISTRY
@@ -63,7 +64,7 @@ class EMAModel(nn.Module):
         return self._count == 0
 
 
-_UNSUPPORTED_TRAIN_FLAGS = ("sam", "eco", "wavelet_guided", "match_lq_colors")
+_UNSUPPORTED_TRAIN_FLAGS = ("sam", "eco", "wavelet_guided")
 _UNSUPPORTED_LOSSES = ("dists_opt", "ldl_opt", "ff_opt", "gw_opt")
 
 
@@ -240,8 +241,14 @@ class image(base):
             l_g_mssim = self.cri_mssim(self.output, self.gt)
             l_g_total = l_g_total + l_g_mssim
             loss_dict["l_g_mssim"] = l_g_mssim
-        if self.cri_consistency:  # image.py:483-489 (match_lq_colors is rejected at construction)
-            l_g_consistency = self.cri_consistency(self.output, self.gt)
+        if self.cri_consistency:  # image.py:451-462,483-489
+            target = self.gt
+            if self.opt["train"].get("match_lq_colors", False):
+                with torch.no_grad():  # clamp(bicubic-antialias upsample of the LQ, 1/255, 1)
+                    up = resize_aa(self.lq, self.lq.shape[2] * self.scale, self.lq.shape[3] * self.scale, "bicubic",
+                                   clamp=False)
+                    target = _Clamp.apply(up, 1 / 255, 1.0)
+            l_g_consistency = self.cri_consistency(self.output, target)
             l_g_total = l_g_total + l_g_consistency
             loss_dict["l_g_consistency"] = l_g_consistency
         if self.cri_perceptual:
