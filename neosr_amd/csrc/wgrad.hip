@@ -264,8 +264,18 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_reduce_kernel(const WgradMu
   const int co = ntile * 32 + i, ci = kt * 32 + j;
   if (co < d.N && ci < d.K) {
     const float* p = args.part + (int64_t)pair * args.nsplit * WG_TILE + r;
-    float sum = 0.f;
-    for (int s = 0; s < args.nsplit; ++s) sum += p[(int64_t)s * WG_TILE];
+    // four independent partial sums keep four loads in flight (the splits are ~20 dependent-latency
+    // round trips otherwise); the combination order is fixed -> still run-to-run deterministic
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int s = 0;
+    for (; s + 3 < args.nsplit; s += 4) {
+      s0 += p[(int64_t)s * WG_TILE];
+      s1 += p[(int64_t)(s + 1) * WG_TILE];
+      s2 += p[(int64_t)(s + 2) * WG_TILE];
+      s3 += p[(int64_t)(s + 3) * WG_TILE];
+    }
+    for (; s < args.nsplit; ++s) s0 += p[(int64_t)s * WG_TILE];
+    float sum = (s0 + s1) + (s2 + s3);
     sum *= d.scale;
     float* o = d.dw + ((int64_t)co * d.K + ci) * 9 + tap;
     *o = d.accumulate ? (*o + sum) : sum;
