@@ -50,7 +50,17 @@ int neosr_abi_version(void);
  *   in' = in (optionally nearest-upsampled x2, PReLU'd on load, or multiplied by the
  *         activation derivative mask: in * (mask > 0 ? 1 : mask_slope[_c]))
  *   epilogue: v = act(acc + bias[n]);  v = v*alpha + res1 (n < res1_nch);
- *             v = v*alpha2 + res2 (n < res2_nch);  out = accumulate ? out + v : v
+ *             v = v*alpha2 + res2 (n < res2_nch);  v = accumulate ? out + v : v;
+ *             out = out_mask ? v * (out_mask[p, n] > 0 ? 1 : out_mask_slope) : v
+ *             (out_mask = the forward activation whose derivative gates this gradient slice: lets a
+ *              gather-form backward store d(loss)/d(pre-activation) directly)
+ *
+ * w_pack (optional): the same weights re-laid by neosr_conv3x3_pack_weights() for `mode`.  When given
+ * (and in/out/res are 16-byte aligned, K % 4 == 0, no in_mask / in_prelu) the launch takes the
+ * direct-to-LDS kernel: chunks of 16 reduction channels go global -> LDS with
+ * global_load_lds_dwordx4 into two buffers, one barrier per chunk, 16-byte LDS fragment reads.  With
+ * w_pack the reduction runs over the first K channels of the PACKED image, whose rows may concatenate
+ * several convolutions (see neosr_rrdbnet_backward), so `w`, w_cout, w_cin are not consulted.
  */
 typedef struct neosr_conv_desc {
   const float* in;          /* (B, Hin, Win, in_cs); Hin = ups ? H/2 : H */
@@ -70,9 +80,20 @@ typedef struct neosr_conv_desc {
   int32_t res1_nch, res2_nch;
   int32_t mode, ups, act, accumulate;
   float mask_slope, slope, alpha, alpha2;
+  const float* w_pack;      /* optional packed weights, see above */
+  const float* out_mask;    /* optional (B, H, W, out_mask_cs), first N channels */
+  int32_t out_mask_cs;
+  float out_mask_slope;
 } neosr_conv_desc;
 
 int neosr_conv3x3(const neosr_conv_desc* d, void* stream);
+/* Packed weight image for the direct-to-LDS kernel: [ceil(N/32)][ceil(K/16)][tap 9][k quad 4][n 32][4]
+ * floats (each (n-block, chunk) slab is the 18 KB LDS image, so staging is eighteen contiguous 1 KB
+ * wave loads), zero padded.  mode FWD: N = w_cout, K = w_cin, element = w[n, k, tap];
+ * mode DGRAD: N = w_cin, K = w_cout, element = w[k, n, 8 - tap]. */
+int64_t neosr_conv3x3_pack_bytes(int32_t N, int32_t K);
+int neosr_conv3x3_pack_weights(const float* w, int32_t w_cout, int32_t w_cin, int32_t mode,
+                               float* dst, void* stream);
 /* Debug aid: device buffer (4 x 64 uint64) that NEOSR_TIMELINE builds of the conv kernel fill with
  * per-wave clock stamps of workgroup 0; NULL (default) disables.  No effect in normal builds. */
 int neosr_debug_set_timeline(void* dev_buf);

@@ -53,6 +53,10 @@ class ConvDesc(C.Structure):
         ("slope", C.c_float),
         ("alpha", C.c_float),
         ("alpha2", C.c_float),
+        ("w_pack", C.c_void_p),
+        ("out_mask", C.c_void_p),
+        ("out_mask_cs", C.c_int32),
+        ("out_mask_slope", C.c_float),
     ]
 
 
@@ -213,6 +217,8 @@ SIGNATURES: dict[str, tuple] = {
     "neosr_build_info": (C.c_char_p, []),
     "neosr_abi_version": (C.c_int, []),
     "neosr_conv3x3": (C.c_int, [C.POINTER(ConvDesc), _vp]),
+    "neosr_conv3x3_pack_bytes": (_i64, [_i32, _i32]),
+    "neosr_conv3x3_pack_weights": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp]),
     "neosr_debug_set_timeline": (C.c_int, [_vp]),
     "neosr_conv3x3_wgrad_workspace_bytes": (_i64, [_i32, _i32, _i32, _i32, _i32]),
     "neosr_conv3x3_wgrad": (C.c_int, [C.POINTER(WgradDesc), _vp]),

@@ -16,8 +16,10 @@
 //
 // Reference call sites replaced: neosr/archs/esrgan_arch.py:109-116,137-142,196-214;
 // neosr/archs/compact_arch.py:76-79 (see include/neosr_amd.h).
+#include <cstring>
 #include "common.h"
 #include "prof.h"
+#include "conv_pack.h"
 #include "../../include/neosr_amd.h"
 
 #ifndef NEOSR_INTERLEAVE
@@ -109,6 +111,71 @@ __device__ __forceinline__ float4 ld4_generic(const float* p, int c, int C, floa
   if (c + 2 < C) v.z = p[2];
   if (c + 3 < C) v.w = p[3];
   return v;
+}
+
+// FAST-path epilogue of one 32-channel tile, in two halves so that a kernel can issue the loads
+// (bias, slopes, residuals, accumulate-in, derivative mask) ahead of its last chunk of MFMAs.
+// D layout (D = W * X^T): lane holds pixel lane&31 and channels nbase + 8g + 4*(lane>>5) + {0..3} in
+// acc[4g..4g+3].  Straight-line code: invalid lanes are redirected on the address side.
+struct EpiRegs {
+  float4 bias[4], sl[4], a0[4], a1[4], a2[4], mk[4];
+};
+
+__device__ __forceinline__ void epi_load(const neosr_conv_desc& d, int nbase, int64_t pix, bool pix_ok,
+                                         int lh, float s_uni, bool extra, EpiRegs& R) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int chq = nbase + 8 * g + 4 * lh;
+    const bool ok = pix_ok && chq < d.N;
+    const int cs0 = chq < d.N ? chq : 0;
+    R.bias[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+    R.sl[g] = make_float4(s_uni, s_uni, s_uni, s_uni);
+    R.a0[g] = R.a1[g] = R.a2[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+    R.mk[g] = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (d.bias) R.bias[g] = *reinterpret_cast<const float4*>(d.bias + cs0);
+    if (d.act == ACT_PRELU) R.sl[g] = *reinterpret_cast<const float4*>(d.prelu + cs0);
+    if (extra) {
+      R.a1[g] = *reinterpret_cast<const float4*>(
+          (ok && d.res1 && chq < d.res1_nch) ? d.res1 + pix * d.res1_cs + chq : g_zero_page);
+      R.a2[g] = *reinterpret_cast<const float4*>(
+          (ok && d.res2 && chq < d.res2_nch) ? d.res2 + pix * d.res2_cs + chq : g_zero_page);
+      R.a0[g] = *reinterpret_cast<const float4*>(
+          (ok && d.accumulate) ? d.out + pix * d.out_cs + chq : g_zero_page);
+    }
+    if (d.out_mask)  // invalid lanes read zeros -> scaled garbage goes to the trash slot
+      R.mk[g] = *reinterpret_cast<const float4*>(ok ? d.out_mask + pix * d.out_mask_cs + chq : g_zero_page);
+  }
+}
+
+__device__ __forceinline__ void epi_store(const neosr_conv_desc& d, const f32x16& acc, int nbase,
+                                          int64_t pix, bool pix_ok, int lh, int tid, const EpiRegs& R) {
+  float4 o[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const float bb[4] = {R.bias[g].x, R.bias[g].y, R.bias[g].z, R.bias[g].w};
+    const float ss[4] = {R.sl[g].x, R.sl[g].y, R.sl[g].z, R.sl[g].w};
+    const float r1[4] = {R.a1[g].x, R.a1[g].y, R.a1[g].z, R.a1[g].w};
+    const float r2[4] = {R.a2[g].x, R.a2[g].y, R.a2[g].z, R.a2[g].w};
+    const float r0[4] = {R.a0[g].x, R.a0[g].y, R.a0[g].z, R.a0[g].w};
+    const float mm[4] = {R.mk[g].x, R.mk[g].y, R.mk[g].z, R.mk[g].w};
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float t = acc[4 * g + e] + bb[e];
+      t = t > 0.f ? t : t * ss[e];
+      t = t * d.alpha + r1[e];
+      t = t * d.alpha2 + r2[e];
+      t += r0[e];
+      v[e] = mm[e] > 0.f ? t : t * d.out_mask_slope;
+    }
+    o[g] = make_float4(v[0], v[1], v[2], v[3]);
+  }
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int chq = nbase + 8 * g + 4 * lh;
+    const bool ok = pix_ok && chq < d.N;
+    *reinterpret_cast<float4*>(ok ? d.out + pix * d.out_cs + chq : g_trash + tid * 4) = o[g];
+  }
 }
 
 // staging loads are issued early in the chunk so they have >= 3 taps of MFMAs to land:
@@ -322,53 +389,9 @@ __global__ __launch_bounds__(256, GENERIC ? 2 : NEOSR_CONV_WPS) void conv3x3_mfm
   for (int nt = 0; nt < NT; ++nt) {
     if (nt >= ntv) break;
     if (!GENERIC) {
-      // phase 1: every load of this 32-channel tile is issued before any arithmetic or store
-      float4 bias[4], sl[4], a0[4], a1[4], a2[4];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int chq = n0 + nt * 32 + 8 * g + 4 * lh;
-        const bool ok = pix_ok && chq < d.N;
-        const int cs0 = chq < d.N ? chq : 0;
-        bias[g] = make_float4(0.f, 0.f, 0.f, 0.f);
-        sl[g] = make_float4(s_uni, s_uni, s_uni, s_uni);
-        a0[g] = a1[g] = a2[g] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (d.bias) bias[g] = *reinterpret_cast<const float4*>(d.bias + cs0);
-        if (d.act == ACT_PRELU) sl[g] = *reinterpret_cast<const float4*>(d.prelu + cs0);
-        if (extra) {
-          a1[g] = *reinterpret_cast<const float4*>(
-              (ok && d.res1 && chq < d.res1_nch) ? d.res1 + pix * d.res1_cs + chq : g_zero_page);
-          a2[g] = *reinterpret_cast<const float4*>(
-              (ok && d.res2 && chq < d.res2_nch) ? d.res2 + pix * d.res2_cs + chq : g_zero_page);
-          a0[g] = *reinterpret_cast<const float4*>(
-              (ok && d.accumulate) ? d.out + pix * d.out_cs + chq : g_zero_page);
-        }
-      }
-      // phase 2: arithmetic; phase 3: four 16-byte stores back to back
-      float4 o[4];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float bb[4] = {bias[g].x, bias[g].y, bias[g].z, bias[g].w};
-        const float ss[4] = {sl[g].x, sl[g].y, sl[g].z, sl[g].w};
-        const float r1[4] = {a1[g].x, a1[g].y, a1[g].z, a1[g].w};
-        const float r2[4] = {a2[g].x, a2[g].y, a2[g].z, a2[g].w};
-        const float r0[4] = {a0[g].x, a0[g].y, a0[g].z, a0[g].w};
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float t = acc[nt][4 * g + e] + bb[e];
-          t = t > 0.f ? t : t * ss[e];
-          t = t * d.alpha + r1[e];
-          t = t * d.alpha2 + r2[e];
-          v[e] = t + r0[e];
-        }
-        o[g] = make_float4(v[0], v[1], v[2], v[3]);
-      }
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int chq = n0 + nt * 32 + 8 * g + 4 * lh;
-        const bool ok = pix_ok && chq < d.N;
-        *reinterpret_cast<float4*>(ok ? d.out + pix * d.out_cs + chq : g_trash + tid * 4) = o[g];
-      }
+      EpiRegs R;
+      epi_load(d, n0 + nt * 32, pix, pix_ok, lh, s_uni, extra, R);
+      epi_store(d, acc[nt], n0 + nt * 32, pix, pix_ok, lh, tid, R);
     } else {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -388,12 +411,177 @@ __global__ __launch_bounds__(256, GENERIC ? 2 : NEOSR_CONV_WPS) void conv3x3_mfm
           t = t > 0.f ? t : t * sl;
           t = t * d.alpha + a1;
           t = t * d.alpha2 + a2;
-          *(ok ? op : g_trash + tid * 4 + e) = t + a0;
+          t += a0;
+          if (d.out_mask) {
+            const float m = *(ok ? d.out_mask + pix * d.out_mask_cs + ch : g_zero_page);
+            t = m > 0.f ? t : t * d.out_mask_slope;
+          }
+          *(ok ? op : g_trash + tid * 4 + e) = t;
         }
       }
     }
   }
   TL_MARK(63);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Direct-to-LDS variant (needs d.w_pack).  One workgroup = 4 rows x 32 pixels x 32 output channels;
+// chunks of 16 reduction channels; two LDS buffers of 31 KB (input halo 13 KB + weight slab 18 KB) so
+// two workgroups share a CU.  Per chunk a wave issues 7-8 global_load_lds_dwordx4 (no staging VGPRs,
+// no ds_write pass) and the workgroup meets at ONE barrier.
+//   input image : granule (16 B) index = p*4 + (kq ^ ((p >> 2) & 3)), p = halo pixel (6 x 34), kq =
+//                 channel quad; the permutation is applied on the (per-lane) global address, so 4
+//                 lanes still fetch one pixel's 64 contiguous bytes, and the 16 lanes of a
+//                 ds_read_b128 phase (consecutive pixels, same kq) land in 16 different bank groups
+//   weight image: [tap][kq][n 32] granules — already the order of neosr_conv3x3_pack_weights()
+// Fragments: lanes lh = 0 read quad 2s, lanes lh = 1 quad 2s+1; MFMA e of step s multiplies channel
+// 8s + 4lh + e on both operands.
+constexpr int GL_IN_GRAN = 13 * 64;                    // 816 used
+constexpr int GL_W_GRAN = 9 * 4 * 32;                  // 1152 = 18 wave loads
+constexpr int GL_BUF = (GL_IN_GRAN + GL_W_GRAN) * 4;   // floats per buffer (31 744 B)
+
+__device__ __forceinline__ void glds16(const float* src, float* lds_dst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+__global__ __launch_bounds__(256, 2) void conv3x3_glds_kernel(const ConvArgs args) {
+  const neosr_conv_desc& d = args.d;
+  __shared__ __attribute__((aligned(1024))) float lds[2 * GL_BUF];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  TL_MARK(0);
+
+  int bid = blockIdx.x;
+  const int tx = bid % args.tiles_x;
+  bid /= args.tiles_x;
+  const int ty = bid % args.tiles_y;
+  const int b = bid / args.tiles_y;
+  const int x0 = tx * TW, y0 = ty * TH;
+  const int n0 = blockIdx.y * 32;
+  const int H = d.H, W = d.W, K = d.K;
+  const int Hin = d.ups ? (H >> 1) : H, Win = d.ups ? (W >> 1) : W;
+  const float* __restrict__ inb = d.in + (int64_t)b * Hin * Win * d.in_cs;
+  const int nchunks = (K + CK - 1) / CK;
+  const float* __restrict__ wp = d.w_pack + (int64_t)blockIdx.y * nchunks * (GL_W_GRAN * 4) + lane * 4;
+
+  // input granule of this thread in wave-load i: g = i*256 + tid -> pixel i*64 + tid/4, slot tid&3;
+  // the slot holds channel quad (tid & 3) ^ ((p >> 2) & 3), and (p >> 2) & 3 == (tid >> 4) & 3 for all i
+  const int q4 = ((tid & 3) ^ ((tid >> 4) & 3)) << 2;
+  int in_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int pix = (tid >> 2) + i * 64;
+    in_off[i] = -1;
+    if (pix < IN_PIX) {
+      const int py = pix / HALO_W, px = pix - py * HALO_W;
+      const int gy = y0 + py - 1, gx = x0 + px - 1;
+      if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+        const int sy = d.ups ? (gy >> 1) : gy, sx = d.ups ? (gx >> 1) : gx;
+        in_off[i] = (sy * Win + sx) * d.in_cs + q4;
+      }
+    }
+  }
+
+  auto issue = [&](int c, int buf) {
+    float* ibuf = lds + buf * GL_BUF;
+    float* wbuf = ibuf + GL_IN_GRAN * 4;
+    const int c0 = c * CK;
+    const bool kq_ok = c0 + q4 < K;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (i == 3 && wave != 0) break;
+      const float* src = (in_off[i] >= 0 && kq_ok) ? inb + in_off[i] + c0 : g_zero_page;
+      glds16(src, ibuf + (i * 4 + wave) * 256);
+    }
+    const float* ws = wp + (int64_t)c * (GL_W_GRAN * 4);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int j = (3 - wave) + 4 * i;  // 18 slab loads dealt so that every wave issues 7-8 in total
+      if (j < 18) glds16(ws + j * 256, wbuf + j * 256);
+    }
+  };
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  auto compute = [&](int buf) {
+    const float* ibuf = lds + buf * GL_BUF;
+    const float* wbuf = ibuf + GL_IN_GRAN * 4 + (lh * 32 + l31) * 4;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int p = (wave + tap / 3) * HALO_W + l31 + tap % 3;
+      const int sw = (p >> 2) & 3;
+      const float* ap = ibuf + p * 16;
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(ap + ((lh ^ sw) << 2));
+      const f32x4 a1 = *reinterpret_cast<const f32x4*>(ap + (((2 + lh) ^ sw) << 2));
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(wbuf + (tap * 4) * 128);
+      const f32x4 b1 = *reinterpret_cast<const f32x4*>(wbuf + (tap * 4 + 2) * 128);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[e], a0[e], acc, 0, 0, 0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b1[e], a1[e], acc, 0, 0, 0);
+    }
+  };
+
+  issue(0, 0);
+  const int y = y0 + wave, x = x0 + l31;
+  const bool pix_ok = y < H && x < W;
+  const int64_t pix = pix_ok ? ((int64_t)b * H + y) * W + x : 0;
+  float s_uni = 1.f;
+  if (d.act == ACT_LRELU) s_uni = d.slope;
+  else if (d.act == ACT_RELU) s_uni = 0.f;
+  const bool extra = d.res1 || d.res2 || d.accumulate;
+  __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
+  __syncthreads();
+  TL_MARK(1);
+  for (int c = 0; c + 1 < nchunks; ++c) {
+    issue(c + 1, (c + 1) & 1);
+    TL_MARK(2 + c * 4);
+    compute(c & 1);
+    TL_MARK(3 + c * 4);
+    __builtin_amdgcn_s_waitcnt(0x0f70);  // chunk c+1 has landed ...
+    __syncthreads();                      // ... for every wave, and buffer c&1 is free again
+    TL_MARK(4 + c * 4);
+  }
+  EpiRegs R;
+  epi_load(d, n0, pix, pix_ok, lh, s_uni, extra, R);  // in flight under the last 72 MFMAs
+  compute((nchunks - 1) & 1);
+  TL_MARK(62);
+  epi_store(d, acc, n0, pix, pix_ok, lh, tid, R);
+  TL_MARK(63);
+}
+
+// weight repack (see conv_pack.h): one thread per 16-byte granule of the destination image
+__global__ __launch_bounds__(256) void conv_pack_kernel(const neosr_pack::Batch batch) {
+  const neosr_pack::Image& im = batch.im[blockIdx.y];
+  const int nch = (im.K + 15) >> 4, nblk = (im.N + 31) >> 5;
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= nblk * nch * GL_W_GRAN) return;
+  const int n32 = g & 31, kq = (g >> 5) & 3;
+  int rest = g >> 7;
+  const int tap = rest % 9;
+  rest /= 9;
+  const int chunk = rest % nch, nb = rest / nch;
+  const int n = nb * 32 + n32, k0 = chunk * 16 + kq * 4;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  if (n < im.N && k0 < im.K) {
+    for (int s = 0; s < im.nseg; ++s) {
+      const neosr_pack::Seg& sg = im.seg[s];
+      if (k0 < sg.k_lo || k0 >= sg.k_lo + sg.k_cnt) continue;
+      const int kk = k0 - sg.k_lo;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (kk + e >= sg.k_cnt) break;
+        v[e] = im.mode == NEOSR_CONV_FWD
+                   ? sg.w[((int64_t)(sg.n_lo + n) * sg.w_cin + kk + e) * 9 + tap]
+                   : sg.w[((int64_t)(kk + e) * sg.w_cin + sg.n_lo + n) * 9 + (8 - tap)];
+      }
+    }
+  }
+  *reinterpret_cast<float4*>(im.dst + (int64_t)g * 4) = make_float4(v[0], v[1], v[2], v[3]);
 }
 
 unsigned long long* g_timeline = nullptr;
@@ -408,10 +596,12 @@ extern "C" int neosr_debug_set_timeline(void* dev_buf) {
 
 extern "C" int neosr_conv3x3(const neosr_conv_desc* dp, void* stream) {
   const neosr_conv_desc& d = *dp;
-  NEOSR_CHECK(d.in && d.w && d.out, "conv3x3: null tensor");
+  NEOSR_CHECK(d.in && (d.w || d.w_pack) && d.out, "conv3x3: null tensor");
   NEOSR_CHECK(d.B > 0 && d.H > 0 && d.W > 0 && d.K > 0 && d.N > 0, "conv3x3: bad geometry");
   NEOSR_CHECK(d.mode == NEOSR_CONV_FWD || d.mode == NEOSR_CONV_DGRAD, "conv3x3: bad mode");
-  if (d.mode == NEOSR_CONV_FWD)
+  if (!d.w) {
+    // packed image only: geometry was fixed when it was built
+  } else if (d.mode == NEOSR_CONV_FWD)
     NEOSR_CHECK(d.K == d.w_cin && d.N <= d.w_cout, "conv3x3 fwd: K=%d N=%d vs w (%d,%d)", d.K, d.N,
                 d.w_cout, d.w_cin);
   else
@@ -431,11 +621,17 @@ extern "C" int neosr_conv3x3(const neosr_conv_desc* dp, void* stream) {
   auto al16 = [](const void* p, int cs) { return !p || (((uintptr_t)p % 16 == 0) && (cs % 4 == 0)); };
   const bool al_ep = al16(d.out, d.out_cs) && al16(d.res1, d.res1_cs) && al16(d.res2, d.res2_cs) &&
                      al16(d.bias, 0) && al16(d.prelu, 0) && (d.res1_nch % 4 == 0) &&
-                     (d.res2_nch % 4 == 0);
+                     (d.res2_nch % 4 == 0) && al16(d.out_mask, d.out_mask_cs);
   const bool fast = al_in && al_mk && al_w && al_ep && (d.K % 4 == 0) && (d.N % 4 == 0) &&
                     !d.in_prelu && !d.mask_slopes;
   dim3 grid(a.tiles_x * a.tiles_y * d.B, ceil_div(d.N, NB));
   hipStream_t st = (hipStream_t)stream;
+  // the direct-to-LDS kernel needs 16-byte granules everywhere; otherwise the staged kernel serves the
+  // launch from the canonical weights (a gather-form launch has none and is refused)
+  const bool use_pack = d.w_pack && al_in && al_ep && (d.K % 4 == 0) && (d.N % 4 == 0) && !d.in_mask &&
+                        !d.in_prelu && ((uintptr_t)d.w_pack % 16 == 0);
+  NEOSR_CHECK(use_pack || d.w, "conv3x3: w_pack launch needs 16-byte aligned tensors, K,N %% 4 == 0");
+  if (use_pack) grid.y = ceil_div(d.N, 32);
   const bool prof = neosr_prof_on();
   if (prof) {
     const double px = (double)d.B * d.H * d.W;
@@ -444,7 +640,9 @@ extern "C" int neosr_conv3x3(const neosr_conv_desc* dp, void* stream) {
                      2.0 * px * d.K * d.N * 9.0,
                      4.0 * (px / (d.ups ? 4.0 : 1.0) * d.K + px * d.N + 9.0 * d.K * d.N));
   }
-  if (d.mode == NEOSR_CONV_FWD) {
+  if (use_pack) {
+    hipLaunchKernelGGL(conv3x3_glds_kernel, grid, dim3(256), 0, st, a);
+  } else if (d.mode == NEOSR_CONV_FWD) {
     if (!fast)
       hipLaunchKernelGGL((conv3x3_mfma_kernel<false, false, true>), grid, dim3(256), 0, st, a);
     else if (d.in_mask)
@@ -462,4 +660,48 @@ extern "C" int neosr_conv3x3(const neosr_conv_desc* dp, void* stream) {
   if (prof) neosr_prof_end(stream);
   NEOSR_LAUNCH_CHECK();
   return 0;
+}
+
+int neosr_pack::launch(const Image* images, int n, void* stream) {
+  NEOSR_CHECK(images && n > 0, "conv pack: bad arguments");
+  for (int i0 = 0; i0 < n; i0 += BATCH) {
+    const int cnt = n - i0 < BATCH ? n - i0 : BATCH;
+    Batch bt;
+    memset(&bt, 0, sizeof(bt));
+    int64_t gran = 0;
+    for (int i = 0; i < cnt; ++i) {
+      bt.im[i] = images[i0 + i];
+      const int64_t g = image_floats(bt.im[i].N, bt.im[i].K) / 4;
+      gran = g > gran ? g : gran;
+    }
+    dim3 grid((unsigned)((gran + 255) / 256), cnt);
+    hipLaunchKernelGGL(conv_pack_kernel, grid, dim3(256), 0, (hipStream_t)stream, bt);
+  }
+  NEOSR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int64_t neosr_conv3x3_pack_bytes(int32_t N, int32_t K) {
+  if (N <= 0 || K <= 0) return -1;
+  return neosr_pack::image_floats(N, K) * 4;
+}
+
+extern "C" int neosr_conv3x3_pack_weights(const float* w, int32_t w_cout, int32_t w_cin, int32_t mode,
+                                          float* dst, void* stream) {
+  NEOSR_CHECK(w && dst && w_cout > 0 && w_cin > 0, "conv3x3_pack_weights: bad arguments");
+  NEOSR_CHECK(mode == NEOSR_CONV_FWD || mode == NEOSR_CONV_DGRAD, "conv3x3_pack_weights: bad mode");
+  NEOSR_CHECK((uintptr_t)dst % 16 == 0, "conv3x3_pack_weights: dst must be 16-byte aligned");
+  neosr_pack::Image im;
+  memset(&im, 0, sizeof(im));
+  im.dst = dst;
+  im.mode = mode;
+  im.N = mode == NEOSR_CONV_FWD ? w_cout : w_cin;
+  im.K = mode == NEOSR_CONV_FWD ? w_cin : w_cout;
+  im.nseg = 1;
+  im.seg[0].w = w;
+  im.seg[0].w_cin = w_cin;
+  im.seg[0].k_lo = 0;
+  im.seg[0].k_cnt = im.K;
+  im.seg[0].n_lo = 0;
+  return neosr_pack::launch(&im, 1, stream);
 }

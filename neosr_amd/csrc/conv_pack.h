@@ -1,0 +1,38 @@
+// conv_pack.h — packed weight images for the direct-to-LDS 3x3 kernel (internal to libneosr_amd).
+#pragma once
+#include <cstdint>
+
+namespace neosr_pack {
+
+constexpr int IMG_FLOATS = 9 * 4 * 32 * 4;  // one (32-n block, 16-k chunk) slab: 4608 floats = 18 KB
+constexpr int MAX_SEG = 5;
+
+// One source convolution contributing the reduction rows [k_lo, k_lo + k_cnt) of an image.
+struct Seg {
+  const float* w;  // canonical (w_cout, w_cin, 3, 3)
+  int32_t w_cin;
+  int32_t k_lo, k_cnt;
+  int32_t n_lo;  // image column n reads source row/column n_lo + n
+};
+
+// dst[nblk][chunk][tap][kq][n32][4]; mode FWD: element = w[n_lo + n, k - k_lo, tap];
+// mode DGRAD: element = w[k - k_lo, n_lo + n, 8 - tap].
+struct Image {
+  float* dst;
+  int32_t N, K, mode, nseg;
+  Seg seg[MAX_SEG];
+};
+
+inline int64_t image_floats(int N, int K) {
+  return (int64_t)((N + 31) / 32) * ((K + 15) / 16) * IMG_FLOATS;
+}
+
+constexpr int BATCH = 24;  // images per launch (passed by value as kernel arguments: 3.4 KB)
+struct Batch {
+  Image im[BATCH];
+};
+
+// `images` is a HOST array; ceil(n / BATCH) launches, nothing is copied to the device.
+int launch(const Image* images, int n, void* stream);
+
+}  // namespace neosr_pack

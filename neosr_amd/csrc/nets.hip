@@ -7,6 +7,7 @@
 // esrgan.forward) and neosr/archs/compact_arch.py:11-85 (compact.forward), plus their autograd
 // backward.
 #include "common.h"
+#include "conv_pack.h"
 #include "../../include/neosr_amd.h"
 #include <string.h>
 #include <vector>
@@ -69,6 +70,10 @@ struct RrdbLayout {
   float *gy_nhwc, *g_hr, *g_u2, *g_up2in, *g_u1, *g_up1in, *g_fea, *g_trunk, *gx_nhwc;
   float* gb[4];
   float* wg_ws;
+  // packed weight images of the RDB convs (conv_pack.h): forward = one image per conv; backward = one
+  // image per gradient slice of the concat buffer, rows concatenating every conv that consumes it
+  float *wpack_f, *wpack_d;
+  int64_t pf_off[5], pd_off[5], pf_total, pd_total;
   int64_t total;
 };
 
@@ -128,6 +133,23 @@ RrdbLayout rrdb_layout(const neosr_rrdbnet_cfg& c, void* ws) {
     w = max64(w, neosr_conv3x3_wgrad_workspace_bytes(B, 4 * H, 4 * W, F, L.Cout));
     L.wg_ws = b.take(w / 4 + 64);
   }
+  {
+    const int F = L.F, G = L.G;
+    int64_t o = 0;
+    for (int k = 0; k < 5; ++k) {
+      L.pf_off[k] = o;
+      o += neosr_pack::image_floats(k < 4 ? G : F, F + k * G);
+    }
+    L.pf_total = o;
+    o = 0;
+    for (int j = 0; j < 5; ++j) {  // slice 0 = x (F channels, all five convs); slice j = x_j
+      L.pd_off[j] = o;
+      o += neosr_pack::image_floats(j == 0 ? F : G, F + (j == 0 ? 4 : 4 - j) * G);
+    }
+    L.pd_total = o;
+    L.wpack_f = b.take(3 * L.NB * L.pf_total);
+    L.wpack_d = c.training ? b.take(3 * L.NB * L.pd_total) : nullptr;
+  }
   L.total = ((b.off + 255) & ~(int64_t)255);
   return L;
 }
@@ -152,6 +174,56 @@ inline int act_idx(const RrdbLayout& L, int i) {
 inline int p_first() { return 0; }
 inline int p_rdb(int n, int r, int k) { return 2 + ((n * 3 + r) * 5 + k) * 2; }
 inline int p_tail(const RrdbLayout& L, int i) { return 2 + L.NB * 30 + 2 * i; }  // body,up1,up2,hr,last
+
+// Gradient buffer of one RDB (CC channels, "G order"): [g5 (F) | g4 (G) | g3 | g2 | g1], g_m = gradient
+// wrt the pre-activation output of conv m in units of the RDB's residual scale.  Every slice of the
+// concat buffer is then consumed by a PREFIX of it: x_j (j = 1..4) by conv5..conv(j+1) = channels
+// [0, F + (4-j) G), x by all five.
+inline int g_off(int F, int G, int m) { return m == 5 ? 0 : F + (4 - m) * G; }
+
+int rrdb_pack_fwd(const RrdbLayout& L, const float* const* P, void* st) {
+  std::vector<neosr_pack::Image> imgs(3 * L.NB * 5);
+  memset(imgs.data(), 0, imgs.size() * sizeof(neosr_pack::Image));
+  for (int i = 0; i < 3 * L.NB; ++i)
+    for (int k = 0; k < 5; ++k) {
+      neosr_pack::Image& im = imgs[i * 5 + k];
+      im.dst = L.wpack_f + i * L.pf_total + L.pf_off[k];
+      im.N = k < 4 ? L.G : L.F;
+      im.K = L.F + k * L.G;
+      im.mode = NEOSR_CONV_FWD;
+      im.nseg = 1;
+      im.seg[0].w = P[p_rdb(i / 3, i % 3, k)];
+      im.seg[0].w_cin = im.K;
+      im.seg[0].k_cnt = im.K;
+    }
+  return neosr_pack::launch(imgs.data(), (int)imgs.size(), st);
+}
+
+int rrdb_pack_dgrad(const RrdbLayout& L, const float* const* P, void* st) {
+  const int F = L.F, G = L.G;
+  std::vector<neosr_pack::Image> imgs(3 * L.NB * 5);
+  memset(imgs.data(), 0, imgs.size() * sizeof(neosr_pack::Image));
+  for (int i = 0; i < 3 * L.NB; ++i)
+    for (int j = 0; j < 5; ++j) {
+      neosr_pack::Image& im = imgs[i * 5 + j];
+      im.dst = L.wpack_d + i * L.pd_total + L.pd_off[j];
+      im.N = j == 0 ? F : G;
+      im.K = F + (j == 0 ? 4 : 4 - j) * G;
+      im.mode = NEOSR_CONV_DGRAD;
+      const int n_lo = j == 0 ? 0 : F + (j - 1) * G;
+      int ns = 0;
+      for (int m = 5; m > j && m >= 1; --m) {  // consumers of this slice, in G order
+        neosr_pack::Seg& sg = im.seg[ns++];
+        sg.w = P[p_rdb(i / 3, i % 3, m - 1)];
+        sg.w_cin = F + (m - 1) * G;
+        sg.k_lo = g_off(F, G, m);
+        sg.k_cnt = m == 5 ? F : G;
+        sg.n_lo = n_lo;
+      }
+      im.nseg = ns;
+    }
+  return neosr_pack::launch(imgs.data(), (int)imgs.size(), st);
+}
 
 }  // namespace
 
@@ -178,13 +250,16 @@ extern "C" int neosr_rrdbnet_forward(const neosr_rrdbnet_cfg* c, const float* co
     d.out = L.act[0]; d.out_cs = CC; d.N = F;
     RUN(neosr_conv3x3(&d, st));
   }
+  RUN(rrdb_pack_fwd(L, P, st));
   for (int n = 0; n < L.NB; ++n) {
     for (int r = 0; r < 3; ++r) {
       float* A = L.act[act_idx(L, 3 * n + r)];
+      const float* pk = L.wpack_f + (int64_t)(3 * n + r) * L.pf_total;
       for (int k = 0; k < 4; ++k) {
         neosr_conv_desc d = conv_base(B, H, W);
         d.in = A; d.in_cs = CC; d.K = F + k * G;
         d.w = P[p_rdb(n, r, k)]; d.bias = P[p_rdb(n, r, k) + 1]; d.w_cout = G; d.w_cin = F + k * G;
+        d.w_pack = pk + L.pf_off[k];
         d.out = A + F + k * G; d.out_cs = CC; d.N = G;
         d.act = NEOSR_ACT_LRELU; d.slope = 0.2f;
         RUN(neosr_conv3x3(&d, st));
@@ -192,6 +267,7 @@ extern "C" int neosr_rrdbnet_forward(const neosr_rrdbnet_cfg* c, const float* co
       neosr_conv_desc d = conv_base(B, H, W);
       d.in = A; d.in_cs = CC; d.K = CC;
       d.w = P[p_rdb(n, r, 4)]; d.bias = P[p_rdb(n, r, 4) + 1]; d.w_cout = F; d.w_cin = CC;
+      d.w_pack = pk + L.pf_off[4];
       const bool last = (n == L.NB - 1 && r == 2);
       d.out = last ? L.trunk : L.act[act_idx(L, 3 * n + r + 1)];
       d.out_cs = last ? F : CC;
@@ -316,59 +392,58 @@ extern "C" int neosr_rrdbnet_backward(const neosr_rrdbnet_cfg* c, const float* c
     d.mode = NEOSR_CONV_DGRAD;
     d.in = L.g_fea; d.in_cs = F; d.K = F;
     d.w = P[p_tail(L, 0)]; d.w_cout = F; d.w_cin = F;
-    d.out = L.g_trunk; d.out_cs = F; d.N = F;
+    d.out = L.gb[0]; d.out_cs = CC; d.N = F;  // = g5 of the last RDB
     RUN(neosr_conv3x3(&d, st));
   }
   // trunk: 23 x RRDB, reversed
-  const float* dOut = L.g_trunk;
-  int dOut_cs = F;
+  // Gather form: each gradient slice of the concat buffer is produced ONCE, by a forward-shaped
+  // convolution over a prefix of the RDB's gradient buffer (see g_off), with the LeakyReLU derivative
+  // of that slice applied in the epilogue -> no read-modify-write, no masks on load, K = 64..192.
+  RUN(rrdb_pack_dgrad(L, P, st));
   int gbi = 0;
+  const float* dOut = nullptr;  // gradient wrt the output of the current RRDB (g5 slot of its last RDB)
   float* prev = nullptr;
   for (int n = L.NB - 1; n >= 0; --n) {
     for (int r = 2; r >= 0; --r) {
       const float* A = L.act[3 * n + r];
       float* GB = L.gb[gbi];
-      neosr_wgrad_desc wd[5];
-      const float* dO = (r == 2) ? dOut : prev;
-      const int dO_cs = (r == 2) ? dOut_cs : CC;
-      {  // conv5: x5*0.2 + x  (and RRDB-level *0.2 + x for r==2)
-        neosr_wgrad_desc w = wgrad_base(B, H, W);
-        w.in = A; w.in_cs = CC; w.K = CC; w.g = dO; w.g_cs = dO_cs; w.N = F;
-        w.scale = (r == 2) ? 0.04f : 0.2f;
-        w.dw = Gp[p_rdb(n, r, 4)]; w.db = Gp[p_rdb(n, r, 4) + 1];
-        wd[4] = w;
+      float* NG = L.gb[(gbi + 1) & 3];
+      if (r == 2) dOut = GB;
+      const float* pk = L.wpack_d + (int64_t)(3 * n + r) * L.pd_total;
+      for (int j = 4; j >= 1; --j) {  // g_j = lrelu'(x_j) * sum over conv5..conv(j+1)
         neosr_conv_desc d = conv_base(B, H, W);
         d.mode = NEOSR_CONV_DGRAD;
-        d.in = dO; d.in_cs = dO_cs; d.K = F;
-        d.w = P[p_rdb(n, r, 4)]; d.w_cout = F; d.w_cin = CC;
-        d.out = GB; d.out_cs = CC; d.N = CC;
-        d.alpha = 0.2f; d.res1 = dO; d.res1_cs = dO_cs; d.res1_nch = F;
+        d.in = GB; d.in_cs = CC; d.K = F + (4 - j) * G;
+        d.w_pack = pk + L.pd_off[j];
+        d.out = GB + g_off(F, G, j); d.out_cs = CC; d.N = G;
+        d.out_mask = A + F + (j - 1) * G; d.out_mask_cs = CC; d.out_mask_slope = 0.2f;
+        RUN(neosr_conv3x3(&d, st));
+      }
+      {  // gradient wrt the RDB input -> g5 slot of the next RDB's buffer
+        neosr_conv_desc d = conv_base(B, H, W);
+        d.mode = NEOSR_CONV_DGRAD;
+        d.in = GB; d.in_cs = CC; d.K = CC;
+        d.w_pack = pk + L.pd_off[0];
+        d.out = NG; d.out_cs = CC; d.N = F;
+        d.alpha = 0.2f; d.res1 = GB; d.res1_cs = CC; d.res1_nch = F;
         if (r == 2) d.alpha2 = 0.2f;
-        if (r == 0) { d.res2 = dOut; d.res2_cs = dOut_cs; d.res2_nch = F; }
+        if (r == 0) { d.res2 = dOut; d.res2_cs = CC; d.res2_nch = F; }
         RUN(neosr_conv3x3(&d, st));
       }
-      for (int k = 3; k >= 0; --k) {
-        const int Kin = F + k * G;
+      neosr_wgrad_desc wd[5];
+      for (int m = 1; m <= 5; ++m) {
         neosr_wgrad_desc w = wgrad_base(B, H, W);
-        w.in = A; w.in_cs = CC; w.K = Kin; w.g = GB + Kin; w.g_cs = CC; w.N = G;
-        w.g_mask = A + Kin; w.mask_cs = CC; w.mask_slope = 0.2f;
-        w.dw = Gp[p_rdb(n, r, k)]; w.db = Gp[p_rdb(n, r, k) + 1];
-        wd[k] = w;
-        neosr_conv_desc d = conv_base(B, H, W);
-        d.mode = NEOSR_CONV_DGRAD;
-        d.in = GB + Kin; d.in_cs = CC; d.K = G;
-        d.in_mask = A + Kin; d.mask_cs = CC; d.mask_slope = 0.2f;
-        d.w = P[p_rdb(n, r, k)]; d.w_cout = G; d.w_cin = Kin;
-        d.out = GB; d.out_cs = CC; d.N = Kin; d.accumulate = 1;
-        RUN(neosr_conv3x3(&d, st));
+        w.in = A; w.in_cs = CC; w.K = F + (m - 1) * G;
+        w.g = GB + g_off(F, G, m); w.g_cs = CC; w.N = m == 5 ? F : G;
+        w.scale = (r == 2) ? 0.04f : 0.2f;
+        w.dw = Gp[p_rdb(n, r, m - 1)]; w.db = Gp[p_rdb(n, r, m - 1) + 1];
+        wd[m - 1] = w;
       }
-      // all five weight gradients of this RDB in one launch (g slices are final, A untouched)
+      // all five weight gradients of this RDB in one launch
       RUN(neosr_conv3x3_wgrad_multi(wd, 5, L.wg_ws, st));
-      prev = GB;
+      prev = NG;
       gbi = (gbi + 1) & 3;
     }
-    dOut = prev;
-    dOut_cs = CC;
   }
   // skip connection feat + body_feat, then conv_first
   RUN(neosr_axpy_slice(prev, L.g_fea, L.np1, F, CC, F, 1.0f, st));

@@ -30,7 +30,7 @@ def _cs(t: torch.Tensor) -> int:
 def conv3x3(x, w, bias=None, *, out=None, n_out=None, mode=CONV_FWD, ups=False, act=ACT_NONE,
             slope=0.0, prelu=None, alpha=1.0, res1=None, res1_nch=None, alpha2=1.0, res2=None,
             res2_nch=None, accumulate=False, in_mask=None, mask_slope=1.0, mask_slopes=None,
-            in_prelu=None, k_in=None):
+            in_prelu=None, k_in=None, w_pack=None, out_mask=None, out_mask_slope=1.0):
     """out = epilogue(conv3x3(x', w)).  See ``neosr_conv3x3`` in include/neosr_amd.h."""
     lib = _C.load()
     _C.require_device(x, "x")
@@ -73,8 +73,27 @@ def conv3x3(x, w, bias=None, *, out=None, n_out=None, mode=CONV_FWD, ups=False, 
     d.w_cout, d.w_cin = w_cout, w_cin
     d.mode, d.ups, d.act, d.accumulate = mode, int(ups), act, int(accumulate)
     d.mask_slope, d.slope, d.alpha, d.alpha2 = mask_slope, slope, alpha, alpha2
+    d.w_pack = _ptr(w_pack)
+    if out_mask is not None:
+        d.out_mask = out_mask.data_ptr()
+        d.out_mask_cs = _cs(out_mask)
+        d.out_mask_slope = out_mask_slope
     _C.check(lib.neosr_conv3x3(C.byref(d), _C.stream_ptr()), "neosr_conv3x3")
     return out
+
+
+def conv3x3_pack_weights(w, mode=CONV_FWD):
+    """Packed image of ``w`` for the direct-to-LDS kernel (``neosr_conv3x3_pack_weights``)."""
+    lib = _C.load()
+    _C.require_device(w, "w")
+    assert w.is_contiguous() and w.shape[2:] == (3, 3)
+    cout, cin = w.shape[0], w.shape[1]
+    N, K = (cout, cin) if mode == CONV_FWD else (cin, cout)
+    nbytes = lib.neosr_conv3x3_pack_bytes(N, K)
+    dst = torch.empty(nbytes // 4, device=w.device, dtype=torch.float32)
+    _C.check(lib.neosr_conv3x3_pack_weights(w.data_ptr(), cout, cin, mode, dst.data_ptr(), _C.stream_ptr()),
+             "neosr_conv3x3_pack_weights")
+    return dst
 
 
 def conv3x3_wgrad(x, g, n_out, k_in, *, ups=False, g_mask=None, mask_slope=1.0, mask_slopes=None,

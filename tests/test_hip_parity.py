@@ -122,6 +122,66 @@ def test_conv3x3_dgrad_and_wgrad_vs_autograd(B, H, W, K, N):
     assert rel_err(db.cpu(), b.grad) < 1e-5
 
 
+PACK_CASES = [
+    # B, H, W, K, N  (K, N multiples of 4: the direct-to-LDS kernel moves 16-byte granules)
+    (2, 12, 20, 16, 8),
+    (1, 9, 37, 20, 44),     # ragged tile edges, K not a multiple of 16, N not a multiple of 32
+    (1, 64, 64, 64, 32),    # RDB conv1
+    (2, 32, 32, 192, 64),   # RDB conv5: 12 chunks, two n-blocks
+    (1, 16, 16, 160, 32),
+]
+
+
+@pytest.mark.parametrize("B,H,W,K,N", PACK_CASES)
+def test_conv3x3_packed_fwd_and_dgrad(B, H, W, K, N):
+    """direct-to-LDS kernel (w_pack) against autograd, both modes, with the gather-form epilogue:
+    g_in = lrelu'(a) * (dgrad + residual)."""
+    from neosr_amd.hip import ops
+
+    g = torch.Generator().manual_seed(B * 31 + K + N)
+    x = torch.randn(B, K, H, W, generator=g).requires_grad_(True)
+    w = (torch.randn(N, K, 3, 3, generator=g) * 0.1)
+    b = torch.randn(N, generator=g)
+    r = torch.randn(B, N, H, W, generator=g)
+    pre = F.conv2d(x, w, b, padding=1)
+    ref = F.leaky_relu(pre, 0.2) * 0.2 + r
+    wd = w.to(DEV)
+    out = ops.conv3x3(_nhwc(x.detach()), wd, b.to(DEV), act=ops.ACT_LRELU, slope=0.2, alpha=0.2,
+                      res1=_nhwc(r), w_pack=ops.conv3x3_pack_weights(wd, ops.CONV_FWD))
+    torch.cuda.synchronize()
+    assert rel_err(_nchw(out), ref.detach()) < 1e-5
+    # backward-data of the plain conv, then gated by the derivative of a LeakyReLU fed by `a`
+    gy = torch.randn(B, N, H, W, generator=g)
+    a = torch.randn(B, K, H, W, generator=g)
+    (dx,) = torch.autograd.grad(F.conv2d(x, w, None, padding=1), x, gy)
+    ref_g = torch.where(a > 0, dx, dx * 0.2)
+    gin = ops.conv3x3(_nhwc(gy), wd, None, mode=ops.CONV_DGRAD, out_mask=_nhwc(a), out_mask_slope=0.2,
+                      w_pack=ops.conv3x3_pack_weights(wd, ops.CONV_DGRAD))
+    torch.cuda.synchronize()
+    assert rel_err(_nchw(gin), ref_g) < 1e-5
+
+
+def test_conv3x3_packed_matches_staged_kernel_on_slices():
+    """same launch through both kernels: prefix-K read of a wide buffer, slice write, two residuals"""
+    from neosr_amd.hip import ops
+
+    g = torch.Generator().manual_seed(21)
+    B, H, W, CC, K, N = 2, 20, 36, 96, 64, 32
+    buf = _nhwc(torch.randn(B, CC, H, W, generator=g))
+    w = (torch.randn(N, K, 3, 3, generator=g) * 0.1).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    r2 = _nhwc(torch.randn(B, N, H, W, generator=g))
+    outs = []
+    for pack in (None, ops.conv3x3_pack_weights(w, ops.CONV_FWD)):
+        o = buf.clone()
+        ops.conv3x3(o[..., :K], w, b, out=o[..., K:K + N], alpha=0.2, res1=o[..., :N], alpha2=0.5,
+                    res2=r2, w_pack=pack)
+        outs.append(o)
+    torch.cuda.synchronize()
+    assert rel_err(outs[1].cpu(), outs[0].cpu()) < 1e-6
+    assert torch.equal(outs[1][..., :K], buf[..., :K])
+
+
 def test_conv3x3_dgrad_accumulate_into_slice():
     from neosr_amd.hip import ops
 
