@@ -75,9 +75,10 @@ def pmc_traffic(kernel_class: str) -> dict | None:
     if not files:
         return None
     summ = json.loads(files[-1].read_text())
-    want = {"conv3x3_mfma_kernel<fwd>": "conv3x3_mfma_kernel<false, false, false>",
-            "conv3x3_mfma_kernel<dgrad>": "conv3x3_mfma_kernel<true, true, false>",
-            "conv3x3_wgrad_kernel": "conv3x3_wgrad_multi_kernel"}[kernel_class]
+    # forward and backward-data launches of the RDB trunk are the same kernel symbol (gather form)
+    want = {"conv3x3 forward launches": "conv3x3_glds_kernel",
+            "conv3x3 backward-data launches": "conv3x3_glds_kernel",
+            "conv3x3_wgrad_multi_kernel": "conv3x3_wgrad_multi_kernel"}[kernel_class]
     for name, d in summ.items():
         if want in name and "FETCH_SIZE_per_dispatch" in d:
             rd = 2.0 * d["FETCH_SIZE_per_dispatch"] * 1024
@@ -230,8 +231,12 @@ def main() -> None:
     roofline = None
     if not args.no_roofline and rank == 0 and not args.arch.startswith(("swinir", "hat")):
         lib = _C.load()
+        # per-kernel durations are only meaningful without overlap: the trunk's launch chains are put
+        # back on one stream for this pass (the timed region above ran the default, two chains)
+        prev_streams = lib.neosr_set_num_streams(1)
         lib.neosr_prof_enable(1)
-        for _ in range(max(1, min(args.steps, 3))):
+        nprof = max(1, min(args.steps, 3))
+        for _ in range(nprof):
             it += 1
             step(it)
         ms = (C.c_double * 4)()
@@ -240,7 +245,8 @@ def main() -> None:
         by = (C.c_double * 4)()
         _C.check(lib.neosr_prof_collect(ms, ln, fl, by), "neosr_prof_collect")
         lib.neosr_prof_enable(0)
-        names = ["conv3x3_mfma_kernel<fwd>", "conv3x3_mfma_kernel<dgrad>", "conv3x3_wgrad_kernel",
+        lib.neosr_set_num_streams(prev_streams)
+        names = ["conv3x3 forward launches", "conv3x3 backward-data launches", "conv3x3_wgrad_multi_kernel",
                  "conv3x3_wgrad_reduce_kernel"]
         kern = {}
         for i, nm in enumerate(names):
@@ -261,10 +267,15 @@ def main() -> None:
                     "algo_bytes_per_launch": round(by[dom] / max(1, ln[dom])),
                     "avg_launch_us": round(1e3 * ms[dom] / max(1, ln[dom]), 2),
                     "all_conv_tflops": round(allfl / (allms * 1e9), 2) if allms > 0 else None,
+                    # whole step as timed (two launch chains, loss + optimizer included)
+                    "step_tflops": round(allfl / nprof / (elapsed / args.steps * 1e12), 2),
+                    "step_frac": round(allfl / nprof / (elapsed / args.steps * 1e12) / PEAK_F32_MFMA_TFLOPS, 4),
                     "hbm_algo_frac_of_8TBps": round((by[dom] / (ms[dom] * 1e6)) / PEAK_HBM_GBS, 4) if ms[dom] > 0 else None,
                     "kernels": kern,
-                    "method": "HIP events around every launch of the class on the launch stream, "
-                              "separate profiled pass after the timed region"}
+                    "method": "HIP events around every launch of the class on the launch stream, separate "
+                              "profiled pass after the timed region with the trunk on ONE stream "
+                              "(neosr_set_num_streams(1)); profiles/r01_bench_kernel_stats.csv is rocprofv3 of "
+                              "`NEOSR_AMD_STREAMS=1 python bench.py`, ..._2chains.csv of the default run"}
 
     if rank != 0:
         return

@@ -589,6 +589,10 @@ int neosr_rrdbnet_forward(const neosr_rrdbnet_cfg* cfg, const float* const* para
 int neosr_rrdbnet_backward(const neosr_rrdbnet_cfg* cfg, const float* const* params,
                            float* const* grads, const float* gy, float* gx, void* workspace,
                            void* stream);
+/* The RRDB trunk runs the two halves of the batch as independent launch chains on the caller's stream
+ * and one internal stream (fork / join by events; results do not depend on the setting).  n = 1
+ * keeps everything on the caller's stream (used for per-kernel timing); returns the previous n. */
+int neosr_set_num_streams(int n);
 
 /*
  * SRVGGNetCompact ("compact", neosr/archs/compact_arch.py:11-85), act_type prelu|relu|leakyrelu.

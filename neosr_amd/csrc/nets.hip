@@ -9,7 +9,9 @@
 #include "common.h"
 #include "conv_pack.h"
 #include "../../include/neosr_amd.h"
+#include <stdlib.h>
 #include <string.h>
+#include <mutex>
 #include <vector>
 
 extern "C" int neosr_fill(float* p, int64_t n, float v, void* stream);
@@ -69,7 +71,7 @@ struct RrdbLayout {
   float *trunk, *fea, *u1, *u2, *hr, *y_nhwc;
   float *gy_nhwc, *g_hr, *g_u2, *g_up2in, *g_u1, *g_up1in, *g_fea, *g_trunk, *gx_nhwc;
   float* gb[4];
-  float* wg_ws;
+  float *wg_ws, *wg_ws2;
   // packed weight images of the RDB convs (conv_pack.h): forward = one image per conv; backward = one
   // image per gradient slice of the concat buffer, rows concatenating every conv that consumes it
   float *wpack_f, *wpack_d;
@@ -132,6 +134,7 @@ RrdbLayout rrdb_layout(const neosr_rrdbnet_cfg& c, void* ws) {
     w = max64(w, neosr_conv3x3_wgrad_workspace_bytes(B, 4 * H, 4 * W, F, F));
     w = max64(w, neosr_conv3x3_wgrad_workspace_bytes(B, 4 * H, 4 * W, F, L.Cout));
     L.wg_ws = b.take(w / 4 + 64);
+    L.wg_ws2 = b.take(w / 4 + 64);  // second half-batch chain
   }
   {
     const int F = L.F, G = L.G;
@@ -174,6 +177,40 @@ inline int act_idx(const RrdbLayout& L, int i) {
 inline int p_first() { return 0; }
 inline int p_rdb(int n, int r, int k) { return 2 + ((n * 3 + r) * 5 + k) * 2; }
 inline int p_tail(const RrdbLayout& L, int i) { return 2 + L.NB * 30 + 2 * i; }  // body,up1,up2,hr,last
+
+// Second stream for the RRDB trunk: at B = 16 a 64x64 conv is ONE round of 512 workgroups, so every
+// launch pays its fill / drain / first-load latency in full (~8 us of 30-60).  Running the two halves of
+// the batch as independent launch chains on two streams lets one chain's matrix work cover the other's
+// launch gap (measured on the forward chain: 110 -> 121 TFLOP/s).  Fork / join with events only.
+struct Aux {
+  hipStream_t s2 = nullptr, s3 = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+  std::vector<hipEvent_t> ev;
+};
+int g_num_streams = -1;  // -1: read NEOSR_AMD_STREAMS on first use (default 2)
+
+Aux* aux_get(int nev) {
+  static Aux a;
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lk(mu);
+  if (g_num_streams < 0) {
+    const char* e = getenv("NEOSR_AMD_STREAMS");
+    g_num_streams = (e && atoi(e) == 1) ? 1 : 2;
+  }
+  if (g_num_streams < 2) return nullptr;
+  if (!a.s2) {
+    if (hipStreamCreateWithFlags(&a.s2, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    if (hipStreamCreateWithFlags(&a.s3, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&a.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&a.join, hipEventDisableTiming) != hipSuccess) return nullptr;
+  }
+  while ((int)a.ev.size() < nev) {
+    hipEvent_t e;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+    a.ev.push_back(e);
+  }
+  return &a;
+}
 
 // Gradient buffer of one RDB (CC channels, "G order"): [g5 (F) | g4 (G) | g3 | g2 | g1], g_m = gradient
 // wrt the pre-activation output of conv m in units of the RDB's residual scale.  Every slice of the
@@ -251,33 +288,49 @@ extern "C" int neosr_rrdbnet_forward(const neosr_rrdbnet_cfg* c, const float* co
     RUN(neosr_conv3x3(&d, st));
   }
   RUN(rrdb_pack_fwd(L, P, st));
+  // trunk: the two halves of the batch are independent launch chains (see Aux)
+  Aux* ax = B >= 2 ? aux_get(0) : nullptr;
+  const int nhalf = ax ? 2 : 1;
+  if (ax) {
+    NEOSR_HIP(hipEventRecord(ax->fork, (hipStream_t)st));
+    NEOSR_HIP(hipStreamWaitEvent(ax->s2, ax->fork, 0));
+  }
   for (int n = 0; n < L.NB; ++n) {
     for (int r = 0; r < 3; ++r) {
-      float* A = L.act[act_idx(L, 3 * n + r)];
       const float* pk = L.wpack_f + (int64_t)(3 * n + r) * L.pf_total;
-      for (int k = 0; k < 4; ++k) {
-        neosr_conv_desc d = conv_base(B, H, W);
-        d.in = A; d.in_cs = CC; d.K = F + k * G;
-        d.w = P[p_rdb(n, r, k)]; d.bias = P[p_rdb(n, r, k) + 1]; d.w_cout = G; d.w_cin = F + k * G;
-        d.w_pack = pk + L.pf_off[k];
-        d.out = A + F + k * G; d.out_cs = CC; d.N = G;
-        d.act = NEOSR_ACT_LRELU; d.slope = 0.2f;
-        RUN(neosr_conv3x3(&d, st));
+      for (int h = 0; h < nhalf; ++h) {
+        const int b0 = h ? B / 2 : 0, nb = ax ? (h ? B - B / 2 : B / 2) : B;
+        void* sh = h ? (void*)ax->s2 : st;
+        const int64_t po = (int64_t)b0 * H * W;  // pixel offset of this half
+        float* A = L.act[act_idx(L, 3 * n + r)] + po * CC;
+        for (int k = 0; k < 4; ++k) {
+          neosr_conv_desc d = conv_base(nb, H, W);
+          d.in = A; d.in_cs = CC; d.K = F + k * G;
+          d.w = P[p_rdb(n, r, k)]; d.bias = P[p_rdb(n, r, k) + 1]; d.w_cout = G; d.w_cin = F + k * G;
+          d.w_pack = pk + L.pf_off[k];
+          d.out = A + F + k * G; d.out_cs = CC; d.N = G;
+          d.act = NEOSR_ACT_LRELU; d.slope = 0.2f;
+          RUN(neosr_conv3x3(&d, sh));
+        }
+        neosr_conv_desc d = conv_base(nb, H, W);
+        d.in = A; d.in_cs = CC; d.K = CC;
+        d.w = P[p_rdb(n, r, 4)]; d.bias = P[p_rdb(n, r, 4) + 1]; d.w_cout = F; d.w_cin = CC;
+        d.w_pack = pk + L.pf_off[4];
+        const bool last = (n == L.NB - 1 && r == 2);
+        d.out = last ? L.trunk + po * F : L.act[act_idx(L, 3 * n + r + 1)] + po * CC;
+        d.out_cs = last ? F : CC;
+        d.N = F;
+        d.alpha = 0.2f; d.res1 = A; d.res1_cs = CC; d.res1_nch = F;
+        if (r == 2) {
+          d.alpha2 = 0.2f; d.res2 = L.act[act_idx(L, 3 * n)] + po * CC; d.res2_cs = CC; d.res2_nch = F;
+        }
+        RUN(neosr_conv3x3(&d, sh));
       }
-      neosr_conv_desc d = conv_base(B, H, W);
-      d.in = A; d.in_cs = CC; d.K = CC;
-      d.w = P[p_rdb(n, r, 4)]; d.bias = P[p_rdb(n, r, 4) + 1]; d.w_cout = F; d.w_cin = CC;
-      d.w_pack = pk + L.pf_off[4];
-      const bool last = (n == L.NB - 1 && r == 2);
-      d.out = last ? L.trunk : L.act[act_idx(L, 3 * n + r + 1)];
-      d.out_cs = last ? F : CC;
-      d.N = F;
-      d.alpha = 0.2f; d.res1 = A; d.res1_cs = CC; d.res1_nch = F;
-      if (r == 2) {
-        d.alpha2 = 0.2f; d.res2 = L.act[act_idx(L, 3 * n)]; d.res2_cs = CC; d.res2_nch = F;
-      }
-      RUN(neosr_conv3x3(&d, st));
     }
+  }
+  if (ax) {
+    NEOSR_HIP(hipEventRecord(ax->join, ax->s2));
+    NEOSR_HIP(hipStreamWaitEvent((hipStream_t)st, ax->join, 0));
   }
   {  // conv_body + skip
     neosr_conv_desc d = conv_base(B, H, W);
@@ -400,50 +453,80 @@ extern "C" int neosr_rrdbnet_backward(const neosr_rrdbnet_cfg* c, const float* c
   // convolution over a prefix of the RDB's gradient buffer (see g_off), with the LeakyReLU derivative
   // of that slice applied in the epilogue -> no read-modify-write, no masks on load, K = 64..192.
   RUN(rrdb_pack_dgrad(L, P, st));
-  int gbi = 0;
+  // Two launch chains again (see Aux) for the data gradients; the weight gradients (one full-batch
+  // launch per RDB, independent of the chain that follows) run on a third stream behind them.  The ring
+  // of four gradient buffers bounds how far the chains may run ahead: RDB t+3 overwrites the g5 slot of
+  // the buffer RDB t's weight gradient reads.
+  const int NR = 3 * L.NB;
+  Aux* ax = B >= 2 ? aux_get(3 * NR) : nullptr;
+  const int nhalf = ax ? 2 : 1;
+  void* sw = ax ? (void*)ax->s3 : st;  // weight-gradient stream
+  if (ax) {
+    NEOSR_HIP(hipEventRecord(ax->fork, (hipStream_t)st));
+    NEOSR_HIP(hipStreamWaitEvent(ax->s2, ax->fork, 0));
+    NEOSR_HIP(hipStreamWaitEvent(ax->s3, ax->fork, 0));
+  }
+  int gbi = 0, t = 0;
   const float* dOut = nullptr;  // gradient wrt the output of the current RRDB (g5 slot of its last RDB)
   float* prev = nullptr;
   for (int n = L.NB - 1; n >= 0; --n) {
-    for (int r = 2; r >= 0; --r) {
-      const float* A = L.act[3 * n + r];
-      float* GB = L.gb[gbi];
-      float* NG = L.gb[(gbi + 1) & 3];
-      if (r == 2) dOut = GB;
+    for (int r = 2; r >= 0; --r, ++t) {
+      if (r == 2) dOut = L.gb[gbi];
       const float* pk = L.wpack_d + (int64_t)(3 * n + r) * L.pd_total;
-      for (int j = 4; j >= 1; --j) {  // g_j = lrelu'(x_j) * sum over conv5..conv(j+1)
-        neosr_conv_desc d = conv_base(B, H, W);
-        d.mode = NEOSR_CONV_DGRAD;
-        d.in = GB; d.in_cs = CC; d.K = F + (4 - j) * G;
-        d.w_pack = pk + L.pd_off[j];
-        d.out = GB + g_off(F, G, j); d.out_cs = CC; d.N = G;
-        d.out_mask = A + F + (j - 1) * G; d.out_mask_cs = CC; d.out_mask_slope = 0.2f;
-        RUN(neosr_conv3x3(&d, st));
-      }
-      {  // gradient wrt the RDB input -> g5 slot of the next RDB's buffer
-        neosr_conv_desc d = conv_base(B, H, W);
-        d.mode = NEOSR_CONV_DGRAD;
-        d.in = GB; d.in_cs = CC; d.K = CC;
-        d.w_pack = pk + L.pd_off[0];
-        d.out = NG; d.out_cs = CC; d.N = F;
-        d.alpha = 0.2f; d.res1 = GB; d.res1_cs = CC; d.res1_nch = F;
-        if (r == 2) d.alpha2 = 0.2f;
-        if (r == 0) { d.res2 = dOut; d.res2_cs = CC; d.res2_nch = F; }
-        RUN(neosr_conv3x3(&d, st));
+      for (int h = 0; h < nhalf; ++h) {
+        const int b0 = h ? B / 2 : 0, nb = ax ? (h ? B - B / 2 : B / 2) : B;
+        void* sh = h ? (void*)ax->s2 : st;
+        const int64_t po = (int64_t)b0 * H * W * CC;
+        const float* A = L.act[3 * n + r] + po;
+        float* GB = L.gb[gbi] + po;
+        float* NG = L.gb[(gbi + 1) & 3] + po;
+        for (int j = 4; j >= 1; --j) {  // g_j = lrelu'(x_j) * sum over conv5..conv(j+1)
+          neosr_conv_desc d = conv_base(nb, H, W);
+          d.mode = NEOSR_CONV_DGRAD;
+          d.in = GB; d.in_cs = CC; d.K = F + (4 - j) * G;
+          d.w_pack = pk + L.pd_off[j];
+          d.out = GB + g_off(F, G, j); d.out_cs = CC; d.N = G;
+          d.out_mask = A + F + (j - 1) * G; d.out_mask_cs = CC; d.out_mask_slope = 0.2f;
+          RUN(neosr_conv3x3(&d, sh));
+        }
+        {  // gradient wrt the RDB input -> g5 slot of the next RDB's buffer
+          if (ax && t >= 3) NEOSR_HIP(hipStreamWaitEvent((hipStream_t)sh, ax->ev[2 * NR + t - 3], 0));
+          neosr_conv_desc d = conv_base(nb, H, W);
+          d.mode = NEOSR_CONV_DGRAD;
+          d.in = GB; d.in_cs = CC; d.K = CC;
+          d.w_pack = pk + L.pd_off[0];
+          d.out = NG; d.out_cs = CC; d.N = F;
+          d.alpha = 0.2f; d.res1 = GB; d.res1_cs = CC; d.res1_nch = F;
+          if (r == 2) d.alpha2 = 0.2f;
+          if (r == 0) { d.res2 = dOut + po; d.res2_cs = CC; d.res2_nch = F; }
+          RUN(neosr_conv3x3(&d, sh));
+        }
+        if (ax) {
+          NEOSR_HIP(hipEventRecord(ax->ev[h * NR + t], (hipStream_t)sh));
+          NEOSR_HIP(hipStreamWaitEvent(ax->s3, ax->ev[h * NR + t], 0));
+        }
       }
       neosr_wgrad_desc wd[5];
       for (int m = 1; m <= 5; ++m) {
         neosr_wgrad_desc w = wgrad_base(B, H, W);
-        w.in = A; w.in_cs = CC; w.K = F + (m - 1) * G;
-        w.g = GB + g_off(F, G, m); w.g_cs = CC; w.N = m == 5 ? F : G;
+        w.in = L.act[3 * n + r]; w.in_cs = CC; w.K = F + (m - 1) * G;
+        w.g = L.gb[gbi] + g_off(F, G, m); w.g_cs = CC; w.N = m == 5 ? F : G;
         w.scale = (r == 2) ? 0.04f : 0.2f;
         w.dw = Gp[p_rdb(n, r, m - 1)]; w.db = Gp[p_rdb(n, r, m - 1) + 1];
         wd[m - 1] = w;
       }
       // all five weight gradients of this RDB in one launch
-      RUN(neosr_conv3x3_wgrad_multi(wd, 5, L.wg_ws, st));
-      prev = NG;
+      RUN(neosr_conv3x3_wgrad_multi(wd, 5, L.wg_ws, sw));
+      if (ax) NEOSR_HIP(hipEventRecord(ax->ev[2 * NR + t], ax->s3));
+      prev = L.gb[(gbi + 1) & 3];
       gbi = (gbi + 1) & 3;
     }
+  }
+  if (ax) {
+    NEOSR_HIP(hipEventRecord(ax->join, ax->s2));
+    NEOSR_HIP(hipStreamWaitEvent((hipStream_t)st, ax->join, 0));
+    NEOSR_HIP(hipEventRecord(ax->fork, ax->s3));
+    NEOSR_HIP(hipStreamWaitEvent((hipStream_t)st, ax->fork, 0));
   }
   // skip connection feat + body_feat, then conv_first
   RUN(neosr_axpy_slice(prev, L.g_fea, L.np1, F, CC, F, 1.0f, st));
@@ -623,4 +706,13 @@ extern "C" int neosr_compact_backward(const neosr_compact_cfg* c, const float* c
     }
   }
   return 0;
+}
+
+// 1 = the RRDB trunk runs on the caller's stream only, 2 (default) = batch halves on two streams.
+// Returns the previous setting.  Env NEOSR_AMD_STREAMS=1 selects 1 at start-up.
+extern "C" int neosr_set_num_streams(int n) {
+  aux_get(0);  // resolve the default
+  const int prev = g_num_streams;
+  g_num_streams = n >= 2 ? 2 : 1;
+  return prev;
 }

@@ -40,7 +40,39 @@ def run(name, H, W, K, N, CC, B=16, dgrad=False):
         print(f" wave{wv}: " + " ".join(row))
 
 
+def run_glds(name, H, W, K, N, CC, B=16):
+    """direct-to-LDS kernel: marks = start, first barrier, per chunk (issued, computed, barrier), epilogue"""
+    lib = _C.load()
+    x = torch.randn(B, H, W, CC, device="cuda")
+    w = torch.randn(N, K, 3, 3, device="cuda") * 0.05
+    pack = ops.conv3x3_pack_weights(w)
+    out = torch.empty(B, H, W, N, device="cuda")
+    tl = torch.zeros(4 * 64, dtype=torch.int64, device="cuda")
+    for _ in range(3):
+        ops.conv3x3(x, w, None, out=out, k_in=K, w_pack=pack)
+    torch.cuda.synchronize()
+    lib.neosr_debug_set_timeline(tl.data_ptr())
+    ops.conv3x3(x, w, None, out=out, k_in=K, w_pack=pack)
+    torch.cuda.synchronize()
+    lib.neosr_debug_set_timeline(None)
+    t = tl.cpu().view(4, 64)
+    nchunks = (K + 15) // 16
+    print(f"== glds {name}: K={K} N={N} chunks={nchunks}")
+    for wv in range(4):
+        r = t[wv]
+        base = int(r[0])
+        row = [f"first_bar@{int(r[1]) - base}"]
+        for c in range(nchunks - 1):
+            i, cp, bar = (int(r[2 + 4 * c + j]) - base for j in range(3))
+            row.append(f"[c{c} issued@{i} comp_end@{cp} (comp {cp - i}) bar@{bar} (wait {bar - cp})]")
+        row.append(f"last_comp_end@{int(r[62]) - base} end@{int(r[63]) - base}")
+        print(f" wave{wv}: " + " ".join(row))
+
+
 if __name__ == "__main__":
+    run_glds("rdb.conv1", 64, 64, 64, 32, 192)
+    run_glds("rdb.conv4", 64, 64, 160, 32, 192)
+    run_glds("rdb.conv5", 64, 64, 192, 64, 192)
     run("rdb.conv1", 64, 64, 64, 32, 192)
     run("rdb.conv5", 64, 64, 192, 64, 192)
     run("conv_hr@256", 256, 256, 64, 64, 64)
