@@ -558,6 +558,23 @@ typedef struct neosr_optim_desc {
 } neosr_optim_desc;
 int neosr_optim_step(const neosr_optim_desc* d, void* stream);
 
+/* Friendly SAM, first half of the step (neosr/optimizers/fsam.py:36-66) on flat arenas, two launches:
+ *   g' = first ? g : g - sigma * momentum;  momentum = first ? g : lmbda * momentum + (1 - lmbda) * g
+ *   (g = grad * grad_scale; g' is written over grad);  norm = || (adaptive ? |w| : 1) * g' ||_2  -> norm_ws[0];
+ *   old_p = w;  w += (adaptive ? w^2 : 1) * g' * rho / (norm + 1e-12).
+ * The second half (fsam.py:68-79) is a copy old_p -> w followed by the base optimizer's step. */
+typedef struct neosr_fsam_desc {
+  float* param;
+  float* grad;
+  float* momentum;
+  float* old_p;
+  float* norm_ws; /* >= 4 + 1024 floats */
+  int64_t n;
+  float rho, sigma, lmbda, grad_scale;
+  int32_t first, adaptive;
+} neosr_fsam_desc;
+int neosr_fsam_first_step(const neosr_fsam_desc* d, void* stream);
+
 /* opt-in profiler ------------------------------------------------------------------------------
  * HIP events around every conv-class launch on the launch stream (classes: 0 conv fwd, 1 conv
  * dgrad, 2 conv wgrad, 3 wgrad reduce).  Used by bench.py's roofline pass only.  collect()

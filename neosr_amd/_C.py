@@ -134,6 +134,17 @@ class OptimDesc(C.Structure):
     )
 
 
+class FsamDesc(C.Structure):
+    """neosr_fsam_desc"""
+
+    _fields_ = (
+        [(n, C.c_void_p) for n in ("param", "grad", "momentum", "old_p", "norm_ws")]
+        + [("n", C.c_int64)]
+        + [(n, C.c_float) for n in ("rho", "sigma", "lmbda", "grad_scale")]
+        + [("first", C.c_int32), ("adaptive", C.c_int32)]
+    )
+
+
 OPT_ADAM, OPT_NADAM, OPT_ADAN, OPT_ADAMW_SF, OPT_ADAMW_WIN = 1, 2, 3, 4, 5
 
 
@@ -303,6 +314,7 @@ SIGNATURES: dict[str, tuple] = {
     "neosr_adan_sf_step": (C.c_int, [C.POINTER(AdanDesc), _vp]),
     "neosr_lerp": (C.c_int, [_vp, _vp, _i64, _f32, _vp]),
     "neosr_optim_step": (C.c_int, [C.POINTER(OptimDesc), _vp]),
+    "neosr_fsam_first_step": (C.c_int, [C.POINTER(FsamDesc), _vp]),
     "neosr_prof_enable": (C.c_int, [C.c_int]),
     "neosr_prof_collect": (
         C.c_int,

@@ -244,3 +244,72 @@ extern "C" int neosr_optim_step(const neosr_optim_desc* dp, void* stream) {
   NEOSR_LAUNCH_CHECK();
   return 0;
 }
+
+// ------------------------------------------------------------------------------- Friendly SAM
+namespace {
+
+constexpr int FSAM_BLOCKS = 1024;
+
+// pass 1: g' = g - sigma * m (not on the first call), m <- lmbda * m + (1 - lmbda) * g, g' written over
+// the gradient; per-workgroup partial of sum (|w| g')^2 (adaptive) in a fixed order
+__global__ __launch_bounds__(256) void fsam_momentum_kernel(const neosr_fsam_desc d) {
+  __shared__ float red[256];
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < d.n; i += (int64_t)gridDim.x * 256) {
+    const float g = d.grad[i] * d.grad_scale;
+    float gp = g, m = g;
+    if (!d.first) {
+      const float m0 = d.momentum[i];
+      gp = g - m0 * d.sigma;
+      m = m0 * d.lmbda + g * (1.f - d.lmbda);
+    }
+    d.momentum[i] = m;
+    d.grad[i] = gp;
+    const float t = d.adaptive ? fabsf(d.param[i]) * gp : gp;
+    acc += t * t;
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) d.norm_ws[4 + blockIdx.x] = red[0];
+}
+
+// pass 2: every workgroup re-sums the partials in the same order (identical scale everywhere), keeps w
+// in old_p and climbs to w + rho * w^2 * g' / (norm + 1e-12)
+__global__ __launch_bounds__(256) void fsam_perturb_kernel(const neosr_fsam_desc d, int nparts) {
+  __shared__ float red[256];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < nparts; i += 256) acc += d.norm_ws[4 + i];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  const float norm = sqrtf(red[0]);
+  if (blockIdx.x == 0 && threadIdx.x == 0) d.norm_ws[0] = norm;
+  const float scale = d.rho / (norm + 1e-12f);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < d.n; i += (int64_t)gridDim.x * 256) {
+    const float w = d.param[i];
+    d.old_p[i] = w;
+    d.param[i] = w + (d.adaptive ? w * w : 1.f) * d.grad[i] * scale;
+  }
+}
+
+}  // namespace
+
+extern "C" int neosr_fsam_first_step(const neosr_fsam_desc* dp, void* stream) {
+  NEOSR_CHECK(dp, "fsam_first_step: null descriptor");
+  const neosr_fsam_desc& d = *dp;
+  NEOSR_CHECK(d.param && d.grad && d.momentum && d.old_p && d.norm_ws && d.n > 0, "fsam_first_step: bad args");
+  NEOSR_CHECK(d.rho >= 0.f, "fsam_first_step: rho must be non-negative");
+  int nb = (int)((d.n + 255) / 256);
+  if (nb > FSAM_BLOCKS) nb = FSAM_BLOCKS;
+  hipLaunchKernelGGL(fsam_momentum_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, d);
+  hipLaunchKernelGGL(fsam_perturb_kernel, dim3(grid_for(d.n)), dim3(256), 0, (hipStream_t)stream, d, nb);
+  NEOSR_LAUNCH_CHECK();
+  return 0;
+}

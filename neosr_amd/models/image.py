@@ -23,6 +23,7 @@ from typing import Any
 import torch
 from torch import Tensor, nn
 
+from neosr_amd import optimizers
 from neosr_amd.archs import build_network
 from neosr_amd.data.augmentations import apply_augment, resize_aa
 from neosr_amd.data.draws import LiveDraws
@@ -64,7 +65,7 @@ class EMAModel(nn.Module):
         return self._count == 0
 
 
-_UNSUPPORTED_TRAIN_FLAGS = ("sam", "eco", "wavelet_guided")
+_UNSUPPORTED_TRAIN_FLAGS = ("eco", "wavelet_guided")
 _UNSUPPORTED_LOSSES = ("dists_opt", "ldl_opt", "ff_opt", "gw_opt")
 
 
@@ -109,7 +110,13 @@ class image(base):
             self.net_g_ema = EMAModel(self.net_g, self.ema)
             self.net_g_ema.arena()
             logger.info("Using exponential-moving average.")
-        self.sam = None
+        # sharpness-aware minimization (image.py:90-91,232-257)
+        self.sam = train_opt.get("sam", None)
+        self.sam_init = train_opt.get("sam_init", -1)
+        if self.sam is not None:
+            logger.info("Sharpness-Aware Minimization enabled.")
+            if (self.opt["datasets"]["train"].get("accumulate", 1) or 1) > 1:
+                raise NotImplementedError(f"{tc.red}SAM can't be used with gradient accumulation yet.{tc.end}")
 
         self.setup_optimizers()
         self.setup_schedulers()
@@ -133,6 +140,7 @@ class image(base):
         self.use_amp = False
         self.total_iter = train_opt.get("total_iter", 200000)
         self.n_accumulated = 0
+        self._sam_now = False
         self.accum_iters = ds.get("accumulate", 1) or 1
 
         def crit(key):
@@ -182,6 +190,17 @@ class image(base):
             og.pop("schedule_free", None)
         self.optimizer_g = self.get_optimizer(optim_type, optim_params, **og)
         self.optimizers.append(self.optimizer_g)
+        if self.sam is not None:  # image.py:322-352: a second instance of the base optimizer inside fsam
+            bases = {"adamw": optimizers.AdamW, "adan": optimizers.adan, "adamw_sf": optimizers.adamw_sf,
+                     "adan_sf": optimizers.adan_sf}
+            if optim_type.lower() not in bases:
+                logger.error(f"{tc.red}SAM not supported by optimizer {optim_type} yet.{tc.end}")
+                sys.exit(1)
+            if self.sam not in {"FSAM", "fsam"}:
+                logger.error(f"{tc.red}SAM type {self.sam} not supported yet.{tc.end}")
+                sys.exit(1)
+            self.sam_optimizer_g = optimizers.fsam(optim_params, bases[optim_type.lower()], rho=0.5, sigma=1,
+                                                   lmbda=0.9, adaptive=True, **og)
         if self.net_d is not None:
             od = dict(train_opt["optim_d"])
             optim_type = od.pop("type")
@@ -215,7 +234,7 @@ class image(base):
                     p.grad = flat[off : off + p.numel()].view_as(p)
             allreduce_flat_(flat)
             optimizer.set_grad_scale(1.0 / self.opt["world_size"])
-        if self.gradclip:
+        if self.gradclip and not self._sam_now:  # image.py:533-544,597-609: no clipping under SAM
             optimizer.set_clip(1.0)
 
     def closure(self, current_iter: int):  # noqa: ARG002
@@ -264,7 +283,7 @@ class image(base):
         l_g_total = l_g_total / self.accum_iters
         l_g_total.backward()
         if step_now:
-            self._sync_grads(self.optimizer_g)
+            self._sync_grads(self.sam_optimizer_g if self._sam_now else self.optimizer_g)
 
         if self.net_d is not None:
             for p in self.net_d.parameters():
@@ -292,14 +311,19 @@ class image(base):
         self.n_accumulated += 1
         if self.n_accumulated >= self.accum_iters:
             self.n_accumulated = 0
+        self._sam_now = self.sam is not None and current_iter >= self.sam_init
         self.closure(current_iter)
         if self.n_accumulated % self.accum_iters == 0:
+            opt_g = self.sam_optimizer_g if self._sam_now else self.optimizer_g
             if self.ema > 0:
-                self.optimizer_g.set_ema(self.net_g_ema.arena(), self.ema, self.net_g_ema.first)
-            self.optimizer_g.step()
+                opt_g.set_ema(self.net_g_ema.arena(), self.ema, self.net_g_ema.first)
+            if self._sam_now:  # image.py:639-640: first_step, closure at w + e(w), second_step
+                self.sam_optimizer_g.step(self.closure, current_iter)
+            else:
+                self.optimizer_g.step()
             if self.net_d is not None:
                 self.optimizer_d.step()
-            self.optimizer_g.zero_grad(set_to_none=True)
+            opt_g.zero_grad(set_to_none=True)
             if self.net_d is not None:
                 self.optimizer_d.zero_grad(set_to_none=True)
             if self.ema > 0:

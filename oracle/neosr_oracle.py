@@ -307,3 +307,81 @@ class AdanImageTrainer(ImageTrainer):
                 ema_update(self.ema, list(self.P.values()), self.ema_decay, first=self.step == 1)
         self.output = out.detach()
         self.log = {"l_g_pix": float(l_pix.detach()), "l_g_total": float(l_total.detach())}
+
+
+# --------------------------------------------------------------------------------------------
+# Friendly SAM (neosr/optimizers/fsam.py) — functional restatement
+# --------------------------------------------------------------------------------------------
+class FSAM:
+    """`fsam.first_step` / `second_step` (optimizers/fsam.py:36-95) around an AdamW base optimizer that owns
+    its state (the reference builds a SECOND optimizer instance for SAM, image.py:322-347)."""
+
+    def __init__(self, params: list[torch.Tensor], lr: float, betas=(0.9, 0.999), eps: float = 1e-8,
+                 weight_decay: float = 0.01, rho: float = 0.5, sigma: float = 1.0, lmbda: float = 0.9,
+                 adaptive: bool = True) -> None:
+        self.params = params
+        self.rho, self.sigma, self.lmbda, self.adaptive = rho, sigma, lmbda, adaptive
+        self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
+        self.momentum: list[torch.Tensor] | None = None
+        self.old_p: list[torch.Tensor] = []
+        self.m = [torch.zeros_like(p) for p in params]
+        self.v = [torch.zeros_like(p) for p in params]
+        self.t = 0
+
+    @torch.no_grad()
+    def first_step(self, grads: list[torch.Tensor]) -> None:
+        """fsam.py:36-66: g' = g - sigma * momentum (not on the first call), momentum <- EMA of the raw
+        gradient, then climb to w + rho * w^2 * g' / || |w| * g' ||."""
+        if self.momentum is None:
+            self.momentum = [g.clone() for g in grads]
+        else:
+            for i, g in enumerate(grads):
+                raw = g.clone()
+                g.sub_(self.momentum[i] * self.sigma)
+                self.momentum[i] = self.momentum[i] * self.lmbda + raw * (1 - self.lmbda)
+        norms = [((p.abs() if self.adaptive else 1.0) * g).norm(p=2) for p, g in zip(self.params, grads)]
+        scale = self.rho / (torch.norm(torch.stack(norms), p=2) + 1e-12)
+        self.old_p = [p.detach().clone() for p in self.params]
+        for p, g in zip(self.params, grads):
+            p.add_((torch.pow(p, 2) if self.adaptive else 1.0) * g * scale)
+
+    @torch.no_grad()
+    def second_step(self, grads: list[torch.Tensor]) -> None:
+        """fsam.py:68-79: back to w, then the base optimizer steps with the gradient taken at w + e(w)."""
+        for p, o in zip(self.params, self.old_p):
+            p.copy_(o)
+        self.t += 1
+        adamw_step(self.params, grads, self.m, self.v, self.t, self.lr, self.betas, self.eps, self.wd)
+
+
+class FsamImageTrainer(ImageTrainer):
+    """ImageTrainer with `train.sam = "fsam"`, `train.sam_init` (models/image.py:528-544,627-662): from
+    iteration `sam_init` on there is no clipping, the closure runs twice and the SAM optimizer's own AdamW
+    takes the step; before that the plain path."""
+
+    def __init__(self, forward_fn, params, lr: float, betas=(0.9, 0.999), weight_decay: float = 0.01,
+                 sam_init: int = -1, ema: float = 0.999, grad_clip: bool = True, loss_weight: float = 1.0) -> None:
+        super().__init__(forward_fn, params, lr, betas, weight_decay, 1e-8, ema, grad_clip, loss_weight)
+        self.sam_init = sam_init
+        self.sam = FSAM(list(self.P.values()), lr, betas, 1e-8, weight_decay)
+        self.iters = 0
+
+    def _closure(self):
+        out = self.forward_fn(self.P, self.lq)
+        l_pix = l1_loss(out, self.gt, self.loss_weight)
+        l_total = torch.zeros(1) + l_pix
+        grads = [g.clone() for g in torch.autograd.grad(l_total.sum(), list(self.P.values()))]
+        self.output = out.detach()
+        self.log = {"l_g_pix": float(l_pix.detach()), "l_g_total": float(l_total.detach())}
+        return grads
+
+    def optimize_parameters(self, current_iter: int) -> None:  # type: ignore[override]
+        if current_iter < self.sam_init:
+            super().optimize_parameters()
+        else:
+            self.sam.first_step(self._closure())
+            self.sam.second_step(self._closure())
+            with torch.no_grad():
+                if self.ema_decay > 0:
+                    ema_update(self.ema, list(self.P.values()), self.ema_decay, first=self.iters == 0)
+        self.iters += 1
