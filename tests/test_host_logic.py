@@ -140,7 +140,12 @@ def test_unsupported_options_fail_loudly():
             self.opt = opt
             self.is_train = True
 
-    opt = {"train": {"sam": "fsam", "optim_g": {"type": "adamw", "lr": 1e-4}}, "datasets": {"train": {}},
+    opt = {"train": {"eco": True, "optim_g": {"type": "adamw", "lr": 1e-4}}, "datasets": {"train": {}},
            "scale": 4}
-    with pytest.raises(NotImplementedError, match="sam"):
+    with pytest.raises(NotImplementedError, match="eco"):
+        Dummy(opt).init_training_settings()
+    # SAM is supported, but not together with gradient accumulation (image.py:251-257)
+    opt = {"train": {"sam": "fsam", "optim_g": {"type": "adamw", "lr": 1e-4}},
+           "datasets": {"train": {"accumulate": 2}}, "scale": 4}
+    with pytest.raises(NotImplementedError, match="accumulation"):
         Dummy(opt).init_training_settings()
