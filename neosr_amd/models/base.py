@@ -57,6 +57,7 @@ class base:
         if self.is_train:
             self.sf_optim_g = opt["train"]["optim_g"].get("schedule_free", False)
             self.net_d = opt.get("network_d")
+            self.sf_optim_d = None  # the reference leaves it unset here and only reads it when net_d exists
             if self.net_d is not None:
                 self.sf_optim_d = opt["train"]["optim_d"].get("schedule_free", False)
         else:
@@ -227,11 +228,21 @@ class base:
         state = {"epoch": epoch, "iter": current_iter,
                  "optimizers": [o.state_dict() for o in self.optimizers],
                  "schedulers": [s.state_dict() for s in self.schedulers]}
-        path = Path(self.opt["path"]["training_states"]) / f"{current_iter}.state"
+        path = Path(self.opt["path"]["training_states"]) / f"{int(current_iter)}.state"
         path.parent.mkdir(parents=True, exist_ok=True)
+        # base.py:446-470: the same schedule-free eval()/train() round trip as around save_network (the
+        # state dicts were taken before it, so the file holds train-mode groups)
+        sf = [o for o, on in ((getattr(self, "optimizer_g", None), self.sf_optim_g),
+                              (getattr(self, "optimizer_d", None), self.sf_optim_d)) if o is not None and on and self.is_train]
+        for o in sf:
+            o.eval()
         torch.save(state, path)
+        for o in sf:
+            o.train()
 
     def resume_training(self, resume_state) -> None:
+        assert len(resume_state["optimizers"]) == len(self.optimizers), "Wrong lengths of optimizers"
+        assert len(resume_state["schedulers"]) == len(self.schedulers), "Wrong lengths of schedulers"
         for i, o in enumerate(resume_state["optimizers"]):
             self.optimizers[i].load_state_dict(o)
         for i, s in enumerate(resume_state["schedulers"]):

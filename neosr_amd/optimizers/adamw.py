@@ -24,7 +24,7 @@ class AdamW(Optimizer):
                  weight_decay: float = 1e-2, **kwargs) -> None:  # noqa: ARG002
         if lr < 0.0:
             raise ValueError(f"Invalid learning rate: {lr}")
-        defaults = {"lr": lr, "betas": tuple(betas), "eps": eps, "weight_decay": weight_decay}
+        defaults = {"lr": lr, "betas": betas, "eps": eps, "weight_decay": weight_decay}
         super().__init__(params, defaults)
         self._pending_clip: float = 0.0
         self._grad_scale: float = 1.0

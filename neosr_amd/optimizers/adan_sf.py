@@ -38,7 +38,7 @@ class adan_sf(AdamW):
         for i in range(3):
             if not 0.0 <= betas[i] < 1.0:
                 raise ValueError(f"Invalid beta parameter at index {i}: {betas[i]}")
-        defaults = {"lr": lr, "betas": tuple(betas), "eps": eps, "r": r, "weight_decay": weight_decay,
+        defaults = {"lr": lr, "betas": betas, "eps": eps, "r": r, "weight_decay": weight_decay,
                     "max_grad_norm": max_grad_norm, "warmup_steps": warmup_steps, "train_mode": True,
                     "weight_sum": 0.0, "lr_max": -1.0, "weight_lr_power": weight_lr_power,
                     "schedule_free": schedule_free}

@@ -119,7 +119,7 @@ class Adam(_FlatOptimizer):
         _check_basic(lr, eps, betas)
         if amsgrad:
             raise NotImplementedError("Adam: amsgrad has no HIP path")
-        self._init_common(params, {"lr": lr, "betas": tuple(betas), "eps": eps, "weight_decay": weight_decay})
+        self._init_common(params, {"lr": lr, "betas": betas, "eps": eps, "weight_decay": weight_decay})
 
     def _coefficients(self, group):
         group["step"] = group.get("step", 0) + 1
@@ -137,7 +137,7 @@ class NAdam(_FlatOptimizer):
         _check_basic(lr, eps, betas)
         if decoupled_weight_decay:
             raise NotImplementedError("NAdam: decoupled_weight_decay has no HIP path")
-        self._init_common(params, {"lr": lr, "betas": tuple(betas), "eps": eps, "weight_decay": weight_decay,
+        self._init_common(params, {"lr": lr, "betas": betas, "eps": eps, "weight_decay": weight_decay,
                                    "momentum_decay": momentum_decay, "mu_product": 1.0})
 
     def _coefficients(self, group):
@@ -163,7 +163,7 @@ class adan(_FlatOptimizer):
             raise ValueError(f"Invalid Max grad norm: {max_grad_norm}")
         if max_grad_norm > 0.0:
             raise NotImplementedError("adan: max_grad_norm > 0 has no HIP path; the model-level grad_clip is fused")
-        self._init_common(params, {"lr": lr, "betas": tuple(betas), "eps": eps, "weight_decay": weight_decay,
+        self._init_common(params, {"lr": lr, "betas": betas, "eps": eps, "weight_decay": weight_decay,
                                    "max_grad_norm": max_grad_norm, "no_prox": no_prox, "foreach": foreach})
 
     def _coefficients(self, group):
@@ -181,7 +181,7 @@ class adamw_sf(_FlatOptimizer):
 
     def __init__(self, params, lr=0.0025, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, warmup_steps=0, r=0.0,
                  weight_lr_power=2.0, foreach=True, schedule_free=True, **kwargs):  # noqa: ARG002
-        self._init_common(params, {"lr": lr, "betas": tuple(betas), "eps": eps, "r": r, "k": 0,
+        self._init_common(params, {"lr": lr, "betas": betas, "eps": eps, "r": r, "k": 0,
                                    "warmup_steps": warmup_steps, "train_mode": True, "weight_sum": 0.0, "lr_max": -1.0,
                                    "weight_lr_power": weight_lr_power, "weight_decay": weight_decay, "foreach": foreach})
 
@@ -245,7 +245,7 @@ class adamw_win(_FlatOptimizer):
             raise ValueError(f"Invalid reckless_steps parameter: {reckless_steps}")
         if amsgrad or max_grad_norm > 1e-8:
             raise NotImplementedError("adamw_win: amsgrad / max_grad_norm have no HIP path (model-level grad_clip is fused)")
-        self._init_common(params, {"lr": lr, "betas": tuple(betas), "reckless_steps": tuple(reckless_steps), "eps": eps,
+        self._init_common(params, {"lr": lr, "betas": betas, "reckless_steps": tuple(reckless_steps), "eps": eps,
                                    "weight_decay": weight_decay, "amsgrad": amsgrad, "max_grad_norm": max_grad_norm,
                                    "acceleration_mode": acceleration_mode})
 

@@ -149,3 +149,27 @@ def test_unsupported_options_fail_loudly():
            "datasets": {"train": {"accumulate": 2}}, "scale": 4}
     with pytest.raises(NotImplementedError, match="accumulation"):
         Dummy(opt).init_training_settings()
+
+
+def test_check_resume_rewrites_pretrain_paths_like_the_reference():
+    """misc.check_resume (reference neosr/utils/misc.py:131-165) + train.load_resume_state on the
+    reference-written state file (tests/golden/ckpt/2.state)."""
+    from neosr_amd.utils.misc import check_resume, load_resume_state
+
+    opt = {"name": "x", "network_g": {}, "network_d": {}, "auto_resume": False,
+           "path": {"models": "/m", "resume_state": str(GOLDEN / "ckpt" / "2.state"),
+                    "pretrain_network_g": "/old.pth", "param_key_g": "params_ema", "param_key_d": "params",
+                    "ignore_resume_networks": ["network_d"]}}
+    state = load_resume_state(opt)
+    assert state["iter"] == 2 and state["epoch"] == 0 and len(state["optimizers"]) == 1
+    assert opt["path"]["pretrain_network_g"] == Path("/m/net_g_2.pth")
+    assert "pretrain_network_d" not in opt["path"]          # listed in ignore_resume_networks
+    assert opt["path"]["param_key_g"] == "params" and opt["path"]["param_key_d"] == "params"
+    opt2 = {"network_g": {}, "path": {"models": "/m"}}
+    check_resume(opt2, 5)                                     # no resume_state: untouched
+    assert opt2["path"] == {"models": "/m"}
+    assert load_resume_state({"auto_resume": False, "path": {}}) is None
+    # the state file holds what torch.optim / the reference's adan_sf put there
+    g = state["optimizers"][0]["param_groups"][0]
+    assert g["train_mode"] is True and g["betas"] == [0.98, 0.92, 0.987] and g["step"] == 2
+    assert state["schedulers"][0]["milestones"] == {1: 1, 3: 1} and state["schedulers"][0]["last_epoch"] == 2
