@@ -31,6 +31,7 @@ from neosr_amd.hip.nets import arena_layout, flat_grad_of, flatten_parameters_, 
 from neosr_amd.losses import build_loss
 from neosr_amd.losses.consistency_loss import _Clamp
 from neosr_amd.models.base import allreduce_flat_, base
+from neosr_amd.models.tiling import tiled_inference
 from neosr_amd.utils.misc import get_root_logger, tc
 from neosr_amd.utils.registry import MODEL_REGISTRY
 
@@ -328,6 +329,43 @@ class image(base):
                 self.optimizer_d.zero_grad(set_to_none=True)
             if self.ema > 0:
                 self.net_g_ema.mark_updated()
+
+    # ------------------------------------------------------------------------------------
+    def _eval_net(self):
+        """which weights `test()` runs (image.py:672-680,741-760): the EMA copy while training with EMA"""
+        if self.is_train and getattr(self, "ema", -1) > 0:
+            return self.net_g_ema
+        return self.net_g
+
+    def test(self) -> None:
+        """image.py:664-783: inference on `self.lq`, whole image (`val.tile = -1`) or partitioned into
+        (h // tile + 1) x (w // tile + 1) bands with 16-pixel overlaps and mirror padding."""
+        tile = self.opt["val"].get("tile", -1)
+        scale = self.opt["scale"]
+        sf = bool(self.sf_optim_g) and self.is_train
+        if sf:
+            self.optimizer_g.eval()  # schedule-free: evaluate at the averaged weights
+        net = self._eval_net()
+        net.eval()
+        with torch.inference_mode():
+            if tile == -1:
+                # (image.py:672-676 leaves `output` untouched when training without EMA; we run net_g)
+                self.output = net(self.lq)
+            else:
+                C = 1 if self.opt.get("color", None) == "y" else None
+                self.output = tiled_inference(net, self.lq, tile, scale, C)
+        self.net_g.train()
+        if sf:
+            self.optimizer_g.train()
+
+    def get_current_visuals(self) -> OrderedDict:
+        """image.py:924-930"""
+        out = OrderedDict()
+        out["lq"] = self.lq.detach().cpu()
+        out["result"] = self.output.detach().cpu()
+        if hasattr(self, "gt"):
+            out["gt"] = self.gt.detach().cpu()
+        return out
 
     # ------------------------------------------------------------------------------------
     def save(self, epoch: int, current_iter: int) -> None:

@@ -1,0 +1,33 @@
+"""GPU: `image.test()` (validation-time inference, whole image and partitioned) against
+the reference's outputs on the same inputs and EMA weights (tests/golden/val.npz)."""
+
+from __future__ import annotations
+
+import numpy as np
+import pytest
+import torch
+
+from tests.conftest import GOLDEN, ROOT, group, load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name,tile", [("whole", -1), ("tiled", 24), ("tiled_small", 24)])
+def test_image_test_vs_reference_fixture(name, tile):
+    from neosr_amd.models import build_model
+    from neosr_amd.utils.options import parse_options
+
+    fix = load_golden("val.npz")
+    opt, _ = parse_options(str(ROOT), True, argv=["-opt", str(GOLDEN / "golden_val.toml")])
+    model = build_model(opt)
+    model.net_g.load_state_dict(group(fix, "init"))
+    model.net_g_ema.load_state_dict(group(fix, "ema"))
+    model.opt["val"]["tile"] = tile
+    model.feed_data({"lq": torch.from_numpy(np.array(fix[f"{name}/lq"]))})
+    model.test()
+    ref = torch.from_numpy(np.array(fix[f"{name}/out"]))
+    assert model.output.shape == ref.shape
+    assert rel_err(model.output, ref) < 1e-3
+    assert model.net_g.training
+    vis = model.get_current_visuals()
+    assert set(vis) == {"lq", "result"} and vis["result"].device.type == "cpu"
