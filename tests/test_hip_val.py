@@ -31,3 +31,18 @@ def test_image_test_vs_reference_fixture(name, tile):
     assert model.net_g.training
     vis = model.get_current_visuals()
     assert set(vis) == {"lq", "result"} and vis["result"].device.type == "cpu"
+
+
+def test_device_prefetcher_stages_batches_in_order():
+    from neosr_amd.data.prefetch_dataloader import CUDAPrefetcher, DevicePrefetcher
+
+    assert CUDAPrefetcher is DevicePrefetcher
+    data = [{"lq": torch.full((3, 8, 8), float(i)).pin_memory(), "path": f"im{i}"} for i in range(5)]
+    pf = DevicePrefetcher(data, {})
+    for rnd in range(2):
+        seen = []
+        while (b := pf.next()) is not None:
+            assert b["lq"].is_cuda and isinstance(b["path"], str)
+            seen.append(int(b["lq"].mean().item()))
+        assert seen == list(range(5))
+        pf.reset()
