@@ -148,7 +148,9 @@ def main() -> None:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl")
+        # "nccl" is RCCL on ROCm; NEOSR_BENCH_BACKEND=gloo lets the control flow be exercised with several
+        # ranks on ONE device (RCCL refuses duplicate GPUs)
+        dist.init_process_group(os.environ.get("NEOSR_BENCH_BACKEND", "nccl"))
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from neosr_amd import _C
@@ -229,7 +231,8 @@ def main() -> None:
     loss = model.get_current_log().get("l_g_pix", model.get_current_log().get("l_g_total"))
 
     roofline = None
-    if not args.no_roofline and rank == 0 and not args.arch.startswith(("swinir", "hat")):
+    # every rank runs the profiled steps (they contain the gradient all-reduce); rank 0 reports
+    if not args.no_roofline and not args.arch.startswith(("swinir", "hat")):
         lib = _C.load()
         # per-kernel durations are only meaningful without overlap: the trunk's launch chains are put
         # back on one stream for this pass (the timed region above ran the default, two chains)
@@ -277,6 +280,11 @@ def main() -> None:
                               "(neosr_set_num_streams(1)); profiles/r01_bench_kernel_stats.csv is rocprofv3 of "
                               "`NEOSR_AMD_STREAMS=1 python bench.py`, ..._2chains.csv of the default run"}
 
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        if rank != 0:
+            dist.destroy_process_group()
     if rank != 0:
         return
     patches = world * B * args.steps
@@ -308,6 +316,9 @@ def main() -> None:
     else:
         out["cpu_baseline"] = None
     print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

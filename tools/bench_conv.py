@@ -1,12 +1,12 @@
 """Per-shape timing of the two 3x3 kernels (register-staged vs direct-to-LDS) on the RDB shapes.
-usage: python tools/bench_conv.py [B]"""
+usage: python tools/bench_conv.py [B] [H]"""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
 from neosr_amd.hip import ops
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
-H = W = 64
+H = W = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 dev = "cuda"
 buf = torch.randn(B, H, W, 192, device=dev)
 out = torch.empty(B, H, W, 192, device=dev)
@@ -25,7 +25,7 @@ def timeit(fn, n=30):
     return a.elapsed_time(b) / n * 1e3
 
 
-for K, N in [(64, 32), (96, 32), (128, 32), (160, 32), (192, 64)]:
+for K, N in ([(64, 32), (96, 32), (128, 32), (160, 32), (192, 64)] if H <= 64 else [(64, 64)]):
     w = torch.randn(N, K, 3, 3, device=dev) * 0.05
     bias = torch.randn(N, device=dev)
     pack = ops.conv3x3_pack_weights(w)
