@@ -339,6 +339,34 @@ def test_esrgan_full_size_vs_oracle():
     assert errs[worst] < 1e-3, (worst, errs[worst])
 
 
+def test_esrgan_launch_chains_do_not_change_results():
+    """`neosr_set_num_streams`: the two batch-half chains (+ the weight-gradient stream) give bit-identical
+    outputs and gradients to the single-stream schedule, run after run (odd batch: halves of 1 and 2)."""
+    from neosr_amd import _C
+    from neosr_amd.archs import build_network
+
+    lib = _C.load()
+    torch.manual_seed(3)
+    net = build_network({"type": "esrgan", "num_feat": 32, "num_block": 2, "num_grow_ch": 16, "scale": 4}).to(DEV).train()
+    x = torch.rand(3, 3, 24, 40, device=DEV)
+    gy = torch.randn(3, 3, 96, 160, device=DEV)
+    runs = []
+    prev = lib.neosr_set_num_streams(2)
+    try:
+        for ns in (1, 2, 2):
+            lib.neosr_set_num_streams(ns)
+            net.zero_grad(set_to_none=True)
+            y = net(x)
+            y.backward(gy)
+            torch.cuda.synchronize()
+            runs.append((y.detach().clone(), [p.grad.clone() for p in net.parameters()]))
+    finally:
+        lib.neosr_set_num_streams(prev)
+    for y, grads in runs[1:]:
+        assert torch.equal(y, runs[0][0])
+        assert all(torch.equal(a, b) for a, b in zip(grads, runs[0][1]))
+
+
 def test_adamw_clip_ema_step_vs_oracle():
     from neosr_amd.hip.nets import arena_layout, flatten_parameters_
     from neosr_amd.optimizers import AdamW
