@@ -182,8 +182,9 @@ __device__ __forceinline__ void epi_store(const neosr_conv_desc& d, const f32x16
 // input quads i (0..3) in pieces 0,0,1,1; weight quads rr (0..8) in pieces 1,2,2,3,3,4,4,5,5
 __device__ __forceinline__ constexpr int w_piece(int rr) { return 1 + ((rr + 1) >> 1); }
 
-// FAST path preconditions (checked on the host): in/mask/w 16-byte aligned, in_cs, mask_cs, K,
-// w_cin, N multiples of 4, no PReLU-on-load, no per-channel mask slopes.
+// FAST path preconditions (checked on the host): in/mask/w (and the per-channel slope vector of a
+// PReLU-on-load or PReLU-derivative mask, at most one of the two) 16-byte aligned, in_cs, mask_cs, K,
+// w_cin, N multiples of 4.
 template <bool DGRAD, bool MASK, bool GENERIC>
 __global__ __launch_bounds__(256, GENERIC ? 2 : NEOSR_CONV_WPS) void conv3x3_mfma_kernel(const ConvArgs args) {
   const neosr_conv_desc& d = args.d;
@@ -242,10 +243,16 @@ __global__ __launch_bounds__(256, GENERIC ? 2 : NEOSR_CONV_WPS) void conv3x3_mfm
   float4 rin[IN_F4];
   float4 rmk[(MASK || GENERIC) ? IN_F4 : 1];
   float4 rw[W_F4];
+  float4 rsl = make_float4(1.f, 1.f, 1.f, 1.f);  // FAST: per-channel slopes of this thread's quad (PReLU on
+                                                 // load / PReLU derivative mask), fetched with the chunk
 
   // piece p (0..8) of the staging loads of the chunk starting at channel c0; p < 0 = all pieces
   auto gload = [&](int c0, int piece) {
     const int c = c0 + q4;
+    if (!GENERIC && piece <= 0) {
+      const float* sp = d.in_prelu ? d.in_prelu : d.mask_slopes;  // wave-uniform
+      if (sp) rsl = *reinterpret_cast<const float4*>(c < K ? sp + c : g_zero_page);
+    }
 #pragma unroll
     for (int i = 0; i < IN_F4; ++i) {
       if (piece >= 0 && piece != (i >> 1)) continue;
@@ -297,6 +304,12 @@ __global__ __launch_bounds__(256, GENERIC ? 2 : NEOSR_CONV_WPS) void conv3x3_mfm
       const int pix = (tid >> 2) + i * 64;
       if (pix < IN_PIX) {
         float4 v = rin[i];
+        if (!GENERIC && d.in_prelu) {
+          v.x = v.x > 0.f ? v.x : v.x * rsl.x;
+          v.y = v.y > 0.f ? v.y : v.y * rsl.y;
+          v.z = v.z > 0.f ? v.z : v.z * rsl.z;
+          v.w = v.w > 0.f ? v.w : v.w * rsl.w;
+        }
         if (GENERIC && d.in_prelu) {
           const int c = c0 + q4;
           const float4 s = ld4_generic(d.in_prelu + c, c, K, 1.f);
@@ -308,6 +321,7 @@ __global__ __launch_bounds__(256, GENERIC ? 2 : NEOSR_CONV_WPS) void conv3x3_mfm
         if (has_mask) {
           const float4 m = rmk[i];
           float4 s = make_float4(d.mask_slope, d.mask_slope, d.mask_slope, d.mask_slope);
+          if (!GENERIC && d.mask_slopes) s = rsl;
           if (GENERIC && d.mask_slopes) {
             const int c = c0 + q4;
             s = ld4_generic(d.mask_slopes + c, c, K, 1.f);
@@ -622,8 +636,9 @@ extern "C" int neosr_conv3x3(const neosr_conv_desc* dp, void* stream) {
   const bool al_ep = al16(d.out, d.out_cs) && al16(d.res1, d.res1_cs) && al16(d.res2, d.res2_cs) &&
                      al16(d.bias, 0) && al16(d.prelu, 0) && (d.res1_nch % 4 == 0) &&
                      (d.res2_nch % 4 == 0) && al16(d.out_mask, d.out_mask_cs);
+  // per-channel slopes ride along as one 16-byte load per chunk; both at once is not a fused case
   const bool fast = al_in && al_mk && al_w && al_ep && (d.K % 4 == 0) && (d.N % 4 == 0) &&
-                    !d.in_prelu && !d.mask_slopes;
+                    al16(d.in_prelu, 0) && al16(d.mask_slopes, 0) && !(d.in_prelu && d.mask_slopes);
   dim3 grid(a.tiles_x * a.tiles_y * d.B, ceil_div(d.N, NB));
   hipStream_t st = (hipStream_t)stream;
   // the direct-to-LDS kernel needs 16-byte granules everywhere; otherwise the staged kernel serves the

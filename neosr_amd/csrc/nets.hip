@@ -183,6 +183,7 @@ inline int p_tail(const RrdbLayout& L, int i) { return 2 + L.NB * 30 + 2 * i; } 
 // the batch as independent launch chains on two streams lets one chain's matrix work cover the other's
 // launch gap (measured on the forward chain: 110 -> 121 TFLOP/s).  Fork / join with events only.
 struct Aux {
+  int dev = -1;
   hipStream_t s2 = nullptr, s3 = nullptr;
   hipEvent_t fork = nullptr, join = nullptr;
   std::vector<hipEvent_t> ev;
@@ -198,6 +199,12 @@ Aux* aux_get(int nev) {
     g_num_streams = (e && atoi(e) == 1) ? 1 : 2;
   }
   if (g_num_streams < 2) return nullptr;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  if (a.s2 && a.dev != dev) {  // streams / events belong to the device they were created on
+    a = Aux();
+  }
+  a.dev = dev;
   if (!a.s2) {
     if (hipStreamCreateWithFlags(&a.s2, hipStreamNonBlocking) != hipSuccess) return nullptr;
     if (hipStreamCreateWithFlags(&a.s3, hipStreamNonBlocking) != hipSuccess) return nullptr;
