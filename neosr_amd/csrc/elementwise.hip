@@ -154,14 +154,31 @@ __global__ __launch_bounds__(256) void prelu_dslope_stage1(const float* __restri
   }
 }
 
+// stage 2: 64 channels per workgroup, four block lanes walk the partial rows k = lane, lane + 4, ...
+// (fixed combination order)
 __global__ __launch_bounds__(256) void prelu_dslope_stage2(const float* __restrict__ part,
                                                            float* __restrict__ dslope, int nblk,
                                                            int C, int accumulate) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  float s = 0.f;
-  for (int k = 0; k < nblk; ++k) s += part[(int64_t)k * C + c];
-  dslope[c] = accumulate ? dslope[c] + s : s;
+  __shared__ float red[4][64];
+  const int o = threadIdx.x & 63, kl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + o;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < C) {
+    int k = kl;
+    for (; k + 12 < nblk; k += 16) {
+      s0 += part[(int64_t)k * C + c];
+      s1 += part[(int64_t)(k + 4) * C + c];
+      s2 += part[(int64_t)(k + 8) * C + c];
+      s3 += part[(int64_t)(k + 12) * C + c];
+    }
+    for (; k < nblk; k += 4) s0 += part[(int64_t)k * C + c];
+  }
+  red[kl][o] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (kl == 0 && c < C) {
+    const float s = ((red[0][o] + red[1][o]) + red[2][o]) + red[3][o];
+    dslope[c] = accumulate ? dslope[c] + s : s;
+  }
 }
 
 // ---------------------------------------------------------------- L1 loss
@@ -413,7 +430,7 @@ extern "C" int neosr_prelu_dslope(const float* dA, const float* z, float* dslope
   hipLaunchKernelGGL(prelu_dslope_stage1, dim3(nblk), dim3(256), 0, (hipStream_t)stream, dA, z,
                      workspace, npix, C, da_cs, z_cs, ppb);
   NEOSR_LAUNCH_CHECK();
-  hipLaunchKernelGGL(prelu_dslope_stage2, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(prelu_dslope_stage2, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream,
                      workspace, dslope, nblk, C, accumulate);
   NEOSR_LAUNCH_CHECK();
   return 0;

@@ -248,8 +248,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_multi_kernel(const Wgrad
   }
 }
 
-// stage 2: sum partials over splits in index order, scatter into canonical (N,K,3,3)
+// stage 2: sum partials over splits, scatter into canonical (N,K,3,3).  A workgroup owns 64 outputs;
+// four split lanes walk the partials s = lane, lane + 4, ... and are combined through LDS in a fixed order
+// (run-to-run deterministic); launches with few tile pairs carry > 100 splits, which one thread per
+// output would walk as a serial chain of dependent-latency loads.
 __global__ __launch_bounds__(256) void conv3x3_wgrad_reduce_kernel(const WgradMultiArgs args) {
+  __shared__ float red[4][64];
   const int pair = blockIdx.y;
   int di = 0;
 #pragma unroll
@@ -259,26 +263,32 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_reduce_kernel(const WgradMu
   const int local = pair - args.pair_start[di];
   const int nkt = args.nkt[di];
   const int ntile = local / nkt, kt = local - ntile * nkt;
-  const int r = blockIdx.x * 256 + threadIdx.x;  // < WG_TILE
+  const int o = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int r = blockIdx.x * 64 + o;  // < WG_TILE
   const int tap = r >> 10, i = (r >> 5) & 31, j = r & 31;
   const int co = ntile * 32 + i, ci = kt * 32 + j;
-  if (co < d.N && ci < d.K) {
+  const bool live = co < d.N && ci < d.K;
+  {
     const float* p = args.part + (int64_t)pair * args.nsplit * WG_TILE + r;
-    // four independent partial sums keep four loads in flight (the splits are ~20 dependent-latency
-    // round trips otherwise); the combination order is fixed -> still run-to-run deterministic
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int s = 0;
-    for (; s + 3 < args.nsplit; s += 4) {
-      s0 += p[(int64_t)s * WG_TILE];
-      s1 += p[(int64_t)(s + 1) * WG_TILE];
-      s2 += p[(int64_t)(s + 2) * WG_TILE];
-      s3 += p[(int64_t)(s + 3) * WG_TILE];
+    int s = sl;
+    if (live) {
+      for (; s + 12 < args.nsplit; s += 16) {
+        s0 += p[(int64_t)s * WG_TILE];
+        s1 += p[(int64_t)(s + 4) * WG_TILE];
+        s2 += p[(int64_t)(s + 8) * WG_TILE];
+        s3 += p[(int64_t)(s + 12) * WG_TILE];
+      }
+      for (; s < args.nsplit; s += 4) s0 += p[(int64_t)s * WG_TILE];
     }
-    for (; s < args.nsplit; ++s) s0 += p[(int64_t)s * WG_TILE];
-    float sum = (s0 + s1) + (s2 + s3);
+    red[sl][o] = (s0 + s1) + (s2 + s3);
+  }
+  __syncthreads();
+  if (sl == 0 && live) {
+    float sum = ((red[0][o] + red[1][o]) + red[2][o]) + red[3][o];
     sum *= d.scale;
-    float* o = d.dw + ((int64_t)co * d.K + ci) * 9 + tap;
-    *o = d.accumulate ? (*o + sum) : sum;
+    float* q = d.dw + ((int64_t)co * d.K + ci) * 9 + tap;
+    *q = d.accumulate ? (*q + sum) : sum;
   }
   if (d.db && kt == 0 && blockIdx.x == 0 && threadIdx.x < 32) {
     const int cb = ntile * 32 + threadIdx.x;
@@ -370,7 +380,7 @@ extern "C" int neosr_conv3x3_wgrad_multi(const neosr_wgrad_desc* ds, int32_t n, 
   if (prof) neosr_prof_end(stream);
   NEOSR_LAUNCH_CHECK();
   if (prof) neosr_prof_begin(NEOSR_PROF_WGRAD_REDUCE, stream, 0.0, 0.0);
-  hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3(WG_TILE / 256, a.pair_start[MAXD]),
+  hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3(WG_TILE / 64, a.pair_start[MAXD]),
                      dim3(256), 0, st, a);
   if (prof) neosr_prof_end(stream);
   NEOSR_LAUNCH_CHECK();
