@@ -20,8 +20,9 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-def _nhwc(t):  # (B,C,H,W) cpu -> (B,H,W,C) contiguous on device
-    return t.permute(0, 2, 3, 1).contiguous().to(DEV)
+def _nhwc(t):  # (B,C,H,W) cpu -> (B,H,W,C) contiguous on device (canonical strides also when C == 1)
+    B, C, H, W = t.shape
+    return torch.empty(B, H, W, C).copy_(t.permute(0, 2, 3, 1)).to(DEV)
 
 
 def _nchw(t):  # (B,H,W,C) device -> (B,C,H,W) cpu
@@ -36,6 +37,10 @@ CONV_CASES = [
     (1, 64, 64, 64, 32),    # RDB conv1 shape
     (1, 32, 32, 192, 64),   # RDB conv5 shape (12 chunks)
     (1, 9, 33, 20, 70),     # 3 N tiles across 2 workgroups, ragged everything
+    (2, 40, 70, 3, 64),     # thin-K forward (conv_first / VGG conv1_1), thin-N backward-data
+    (2, 40, 70, 64, 3),     # thin-N forward (conv_last), thin-K backward-data
+    (1, 33, 65, 64, 1),     # U-Net conv9: one output channel
+    (1, 21, 130, 4, 180),   # swinir conv_first-like: 3 n-blocks
 ]
 
 
