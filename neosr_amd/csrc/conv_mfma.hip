@@ -579,7 +579,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_glds_kernel(const ConvArgs arg
 constexpr int TK_INS = 5;               // LDS pixel stride (odd -> conflict-free b32 reads)
 constexpr int TK_WROW = 37;             // weight row stride (36 + 1)
 
-__global__ __launch_bounds__(256, 2) void conv3x3_thin_k_kernel(const ConvArgs args) {
+__global__ __launch_bounds__(256, 3) void conv3x3_thin_k_kernel(const ConvArgs args) {
   const neosr_conv_desc& d = args.d;
   __shared__ float lin[IN_PIX * TK_INS];
   __shared__ float lw[NB * TK_WROW];
@@ -610,13 +610,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_thin_k_kernel(const ConvArgs a
     q[2] = K > 2 ? v.z : 0.f;
     q[3] = K > 3 ? v.w : 0.f;
   }
-  for (int e = tid; e < NB * 36; e += 256) {
-    const int n = e / 36, kp = e - n * 36, tap = kp >> 2, ch = kp & 3;
-    float v = 0.f;
-    if (n < nvalid && ch < K)
-      v = dgrad ? d.w[((int64_t)ch * d.w_cin + n0 + n) * 9 + (8 - tap)]
-                : d.w[((int64_t)(n0 + n) * d.w_cin + ch) * 9 + tap];
-    lw[n * TK_WROW + kp] = v;
+  {  // 64 x 36 slab = 9 elements per thread, all loads in flight before the first LDS store
+    float wv[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+      const int e = j * 256 + tid;
+      const int n = e / 36, kp = e - n * 36, tap = kp >> 2, ch = kp & 3;
+      const bool ok = n < nvalid && ch < K;
+      const float* src = dgrad ? d.w + ((int64_t)ch * d.w_cin + n0 + n) * 9 + (8 - tap)
+                               : d.w + ((int64_t)(n0 + n) * d.w_cin + ch) * 9 + tap;
+      wv[j] = *(ok ? src : g_zero_page);
+    }
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+      const int e = j * 256 + tid;
+      const int n = e / 36;
+      lw[n * TK_WROW + (e - n * 36)] = wv[j];
+    }
   }
   const int y = y0 + wave, x = x0 + l31;
   const bool pix_ok = y < H && x < W;
@@ -625,10 +635,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_thin_k_kernel(const ConvArgs a
   if (d.act == ACT_LRELU) s_uni = d.slope;
   else if (d.act == ACT_RELU) s_uni = 0.f;
   const bool extra = d.res1 || d.res2 || d.accumulate;
-  EpiRegs R[NT];
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt)
-    if (nt < ntv) epi_load(d, n0 + nt * 32, pix, pix_ok, lh, s_uni, extra, R[nt]);
   __syncthreads();
 
   f32x16 acc[NT];
@@ -648,9 +654,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_thin_k_kernel(const ConvArgs a
       acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv, a, acc[nt], 0, 0, 0);
     }
   }
+  // memory-bound kernel: registers are spent on resident waves (latency hiding), not on hoisted loads
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt)
-    if (nt < ntv) epi_store(d, acc[nt], n0 + nt * 32, pix, pix_ok, lh, tid, R[nt]);
+    if (nt < ntv) {
+      EpiRegs R;
+      epi_load(d, n0 + nt * 32, pix, pix_ok, lh, s_uni, extra, R);
+      epi_store(d, acc[nt], n0 + nt * 32, pix, pix_ok, lh, tid, R);
+    }
 }
 
 // (2) N <= 4 output channels (64 -> 3 forward, 3 <- 64 backward-data): v_mfma_f32_4x4x1_16b_f32, whose 16

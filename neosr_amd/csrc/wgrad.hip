@@ -248,6 +248,174 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_multi_kernel(const Wgrad
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Thin layers (3 or 1 channels on one side: conv_first / conv_last, U-Net conv0 / conv9): the 32 x 32
+// tile above would compute 10x zeros.  Here v_mfma_f32_4x4x1_16b_f32 takes ONE pixel per instruction:
+// the 4 rows of every 4x4 block are the thin side's channels t, the 64 columns (16 blocks x 4) are 64
+// channels c of the wide side -> lane = wide channel (coalesced 256-byte row loads straight from
+// global, no LDS), 9 accumulators of 4 registers = D[tap][t] for channel c.  XWIDE: wide = input x
+// (shifted by the tap), thin = g (conv_last, N <= 4); else wide = g, thin = x shifted (conv_first, K <= 4).
+// Waves stride over 64-pixel row segments; a workgroup sums its 4 waves through LDS in a fixed order and
+// writes one partial; conv3x3_wgrad_thin_reduce_kernel sums the partials in index order.
+constexpr int THIN_WGS = 512;
+constexpr int THIN_PART = 9 * 4 * 64;  // floats per (workgroup, 64-channel group)
+constexpr int THIN_UNROLL = 4;
+
+struct ThinArgs {
+  neosr_wgrad_desc d;
+  int xwide;        // 1: wide = x (K channels), thin = g (N <= 4);  0: wide = g (N), thin = x (K <= 4)
+  int wide_c, thin_c;
+  int segs_per_row, nseg;
+  float* part;      // [group][THIN_WGS][THIN_PART]
+  float* bpart;     // [THIN_WGS][64 * groups] (wide = g) or [THIN_WGS][4] (thin = g)
+  int groups;
+};
+
+template <bool XWIDE>
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_thin_kernel(const ThinArgs a) {
+  __shared__ float red[THIN_PART];
+  __shared__ float bred[4][64];
+  const neosr_wgrad_desc& d = a.d;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = blockIdx.y;
+  const int c = grp * 64 + lane;            // wide channel of this lane
+  const int t = lane & 3;                   // thin channel this lane feeds as the A operand
+  const bool c_ok = c < a.wide_c, t_ok = t < a.thin_c;
+  const int H = d.H, W = d.W;
+  const float* __restrict__ wide = XWIDE ? d.in : d.g;
+  const float* __restrict__ thin = XWIDE ? d.g : d.in;
+  const int wide_cs = XWIDE ? d.in_cs : d.g_cs, thin_cs = XWIDE ? d.g_cs : d.in_cs;
+  const bool masked = !XWIDE && d.g_mask != nullptr;
+
+  f32x4 acc[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
+
+  const int nwaves = gridDim.x * 4;
+  for (int seg = blockIdx.x * 4 + wave; seg < a.nseg; seg += nwaves) {
+    const int xs = seg % a.segs_per_row;
+    const int r = seg / a.segs_per_row;
+    const int y = r % H, b = r / H;
+    const int x_lo = xs * 64, x_hi = min(W, x_lo + 64);
+    // 32-bit element offsets from clamped coordinates (tensors < 2^31 floats, checked on the host);
+    // out-of-image taps are zeroed on the value: one multiply-add per address instead of 64-bit chains
+    const unsigned cw = c_ok ? c : 0, tw = t_ok ? t : 0;
+    unsigned shrow[3];   // row offsets of the SHIFTED operand (x), per ky
+    bool rowok[3];
+    const unsigned sh_cs = XWIDE ? wide_cs : thin_cs, sh_ch = XWIDE ? cw : tw;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int yy = y + ky - 1;
+      rowok[ky] = yy >= 0 && yy < H;
+      shrow[ky] = (unsigned)((b * H + min(max(yy, 0), H - 1)) * W) * sh_cs + sh_ch;
+    }
+    const unsigned fxrow = (unsigned)((b * H + y) * W) * (XWIDE ? thin_cs : wide_cs) + (XWIDE ? tw : cw);
+    const float* __restrict__ shp = XWIDE ? wide : thin;   // shifted operand = the layer input x
+    const float* __restrict__ fxp = XWIDE ? thin : wide;   // unshifted operand = g
+    const bool sh_lane_ok = XWIDE ? c_ok : t_ok, fx_lane_ok = XWIDE ? t_ok : c_ok;
+    for (int x = x_lo; x < x_hi; x += THIN_UNROLL) {
+      float wv[THIN_UNROLL][9], tv[THIN_UNROLL][9];
+      // every load of the batch of pixels first (global latency >> 72 cycles of MFMA per pixel)
+#pragma unroll
+      for (int u = 0; u < THIN_UNROLL; ++u) {
+        const int xx = x + u;
+        const bool in_seg = xx < x_hi;
+        const unsigned xc = (unsigned)min(xx, W - 1);
+        float fx = fxp[fxrow + xc * (XWIDE ? thin_cs : wide_cs)];
+        if (masked) {
+          const float m = d.g_mask[(unsigned)((b * H + y) * W + xc) * d.mask_cs + cw];
+          fx = m > 0.f ? fx : fx * d.mask_slope;
+        }
+        fx = (in_seg && fx_lane_ok) ? fx : 0.f;
+        // the nine shifted loads are unconditional (clamped coordinates -> finite image data, no select
+        // behind a load); an out-of-image tap is cancelled on the OTHER operand, which was loaded once
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+          const int xq = xx + k % 3 - 1;
+          const float v = shp[shrow[k / 3] + (unsigned)min(max(xq, 0), W - 1) * sh_cs];
+          const float f = (rowok[k / 3] && xq >= 0 && xq < W) ? fx : 0.f;
+          wv[u][k] = XWIDE ? v : f;
+          tv[u][k] = XWIDE ? f : v;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < THIN_UNROLL; ++u) {
+        bsum += XWIDE ? tv[u][4] : wv[u][4];  // centre tap: always inside the image
+#pragma unroll
+        for (int k = 0; k < 9; ++k) acc[k] = __builtin_amdgcn_mfma_f32_4x4x1f32(tv[u][k], wv[u][k], acc[k], 0, 0, 0);
+      }
+    }
+  }
+  // fixed-order sum of the 4 waves: red[(tap*4 + t)*64 + lane]
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          float* p = red + (k * 4 + v) * 64 + lane;
+          *p = (w == 0) ? acc[k][v] : (*p + acc[k][v]);
+        }
+    }
+    __syncthreads();
+  }
+  float* part = a.part + ((int64_t)grp * gridDim.x + blockIdx.x) * THIN_PART;
+  for (int e = tid; e < THIN_PART; e += 256) part[e] = red[e];
+  if (d.db) {
+    bred[wave][lane] = bsum;
+    __syncthreads();
+    if (wave == 0) {
+      const float v = ((bred[0][lane] + bred[1][lane]) + bred[2][lane]) + bred[3][lane];
+      if (XWIDE) {
+        if (grp == 0 && lane < 4) a.bpart[(int64_t)blockIdx.x * 4 + lane] = v;   // lanes 0..3 hold t = 0..3
+      } else {
+        a.bpart[(int64_t)blockIdx.x * (64 * a.groups) + c] = v;
+      }
+    }
+  }
+}
+
+// dw[n][k][tap] (+)= scale * sum over workgroups; one thread per weight, four-lane split of the partials
+__global__ __launch_bounds__(256) void conv3x3_wgrad_thin_reduce_kernel(const ThinArgs a, int nwg) {
+  __shared__ float red[4][64];
+  const neosr_wgrad_desc& d = a.d;
+  const int o = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int idx = blockIdx.x * 64 + o;
+  const int total = d.N * d.K * 9;
+  float s0 = 0.f, s1 = 0.f;
+  int n = 0, k = 0, tap = 0;
+  const bool live = idx < total;
+  if (live) {
+    tap = idx % 9;
+    k = (idx / 9) % d.K;
+    n = idx / (9 * d.K);
+    const int cw = a.xwide ? k : n, tt = a.xwide ? n : k;   // wide channel, thin channel
+    const float* p = a.part + (int64_t)(cw >> 6) * nwg * THIN_PART + (tap * 4 + tt) * 64 + (cw & 63);
+    int w = sl;
+    for (; w + 4 < nwg; w += 8) {
+      s0 += p[(int64_t)w * THIN_PART];
+      s1 += p[(int64_t)(w + 4) * THIN_PART];
+    }
+    for (; w < nwg; w += 4) s0 += p[(int64_t)w * THIN_PART];
+  }
+  red[sl][o] = s0 + s1;
+  __syncthreads();
+  if (sl == 0 && live) {
+    const float sum = (((red[0][o] + red[1][o]) + red[2][o]) + red[3][o]) * d.scale;
+    float* q = d.dw + ((int64_t)n * d.K + k) * 9 + tap;
+    *q = d.accumulate ? (*q + sum) : sum;
+  }
+  if (d.db && blockIdx.x == 0 && (int)threadIdx.x < d.N) {
+    const int nb = threadIdx.x;
+    const int stride = a.xwide ? 4 : 64 * a.groups;
+    float sum = 0.f;
+    for (int w = 0; w < nwg; ++w) sum += a.bpart[(int64_t)w * stride + nb];
+    sum *= d.scale;
+    d.db[nb] = d.accumulate ? (d.db[nb] + sum) : sum;
+  }
+}
+
 // stage 2: sum partials over splits, scatter into canonical (N,K,3,3).  A workgroup owns 64 outputs;
 // four split lanes walk the partials s = lane, lane + 4, ... and are combined through LDS in a fixed order
 // (run-to-run deterministic); launches with few tile pairs carry > 100 splits, which one thread per
@@ -337,8 +505,32 @@ int plan(const neosr_wgrad_desc* ds, int n, WgradMultiArgs& a) {
   return 0;
 }
 
+// single thin layer without PReLU-on-load / per-channel slopes / upsampling: the 4x4x1 path
+bool thin_ok(const neosr_wgrad_desc* ds, int n) {
+  if (n != 1) return false;
+  const neosr_wgrad_desc& d = ds[0];
+  if (d.ups || d.in_prelu || d.mask_slopes) return false;
+  const int64_t px = (int64_t)d.B * d.H * d.W;  // the kernel addresses with 32-bit element offsets
+  if (px * d.in_cs >= (1ll << 31) || px * d.g_cs >= (1ll << 31) || px * (d.g_mask ? d.mask_cs : 0) >= (1ll << 31))
+    return false;
+  if (d.N <= 4 && d.K > 4) return !d.g_mask;   // thin = g
+  if (d.K <= 4 && d.N > 4) return true;        // thin = x (a scalar-slope mask on g is handled)
+  return false;
+}
+
+int64_t thin_ws_floats(const neosr_wgrad_desc& d) {
+  const int wide = d.N <= 4 ? d.K : d.N;
+  const int groups = ceil_div(wide, 64);
+  return (int64_t)groups * THIN_WGS * THIN_PART + (int64_t)THIN_WGS * 64 * groups + 64;
+}
+
 int64_t ws_floats(const WgradMultiArgs& a) {
-  return (int64_t)a.pair_start[MAXD] * a.nsplit * WG_TILE + (int64_t)a.btile_start[MAXD] * a.nsplit * 32 + 64;
+  int64_t w = (int64_t)a.pair_start[MAXD] * a.nsplit * WG_TILE + (int64_t)a.btile_start[MAXD] * a.nsplit * 32 + 64;
+  if (thin_ok(a.d, a.ndesc)) {
+    const int64_t t = thin_ws_floats(a.d[0]);
+    if (t > w) w = t;
+  }
+  return w;
 }
 
 }  // namespace
@@ -366,6 +558,31 @@ extern "C" int neosr_conv3x3_wgrad_multi(const neosr_wgrad_desc* ds, int32_t n, 
       by += 4.0 * (px * ds[i].N + px / (a.ups ? 4.0 : 1.0) * ds[i].K + 9.0 * ds[i].K * ds[i].N);
     }
     neosr_prof_begin(NEOSR_PROF_CONV_WGRAD, stream, fl, by);
+  }
+  if (thin_ok(ds, n)) {
+    ThinArgs t;
+    memset(&t, 0, sizeof(t));
+    t.d = ds[0];
+    t.xwide = ds[0].N <= 4;
+    t.wide_c = t.xwide ? ds[0].K : ds[0].N;
+    t.thin_c = t.xwide ? ds[0].N : ds[0].K;
+    t.groups = ceil_div(t.wide_c, 64);
+    t.segs_per_row = ceil_div(a.W, 64);
+    t.nseg = t.segs_per_row * a.H * a.B;
+    int nwg = ceil_div(t.nseg, 4);
+    if (nwg > THIN_WGS) nwg = THIN_WGS;
+    t.part = workspace;
+    t.bpart = workspace + (int64_t)t.groups * THIN_WGS * THIN_PART;
+    if (t.xwide)
+      hipLaunchKernelGGL(conv3x3_wgrad_thin_kernel<true>, dim3(nwg, t.groups), dim3(256), 0, st, t);
+    else
+      hipLaunchKernelGGL(conv3x3_wgrad_thin_kernel<false>, dim3(nwg, t.groups), dim3(256), 0, st, t);
+    if (prof) neosr_prof_end(stream);
+    NEOSR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(conv3x3_wgrad_thin_reduce_kernel, dim3(ceil_div(ds[0].N * ds[0].K * 9, 64)), dim3(256), 0, st,
+                       t, nwg);
+    NEOSR_LAUNCH_CHECK();
+    return 0;
   }
   bool fast = true;
   for (int i = 0; i < n; ++i)

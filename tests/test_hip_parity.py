@@ -202,6 +202,26 @@ def test_conv3x3_dgrad_accumulate_into_slice():
     assert rel_err(_nchw(dgb), ref) < 1e-5
 
 
+@pytest.mark.parametrize("B,H,W,K,N", [(2, 40, 70, 64, 3), (1, 33, 65, 64, 1), (2, 40, 70, 3, 64),
+                                       (1, 21, 130, 4, 180), (1, 17, 200, 96, 3)])
+def test_wgrad_thin_layers_vs_autograd(B, H, W, K, N):
+    """first / last layers (3 or 1 channels on one side): the 4x4x1-MFMA weight-gradient path, no mask"""
+    from neosr_amd.hip import ops
+
+    g = torch.Generator().manual_seed(K * 7 + N)
+    x = torch.randn(B, K, H, W, generator=g)
+    w = (torch.randn(N, K, 3, 3, generator=g) * 0.1).requires_grad_(True)
+    b = torch.randn(N, generator=g).requires_grad_(True)
+    gy = torch.randn(B, N, H, W, generator=g)
+    F.conv2d(x, w, b, padding=1).backward(gy)
+    dw, db = ops.conv3x3_wgrad(_nhwc(x), _nhwc(gy), N, K)
+    dw2, db2 = ops.conv3x3_wgrad(_nhwc(x), _nhwc(gy), N, K)
+    torch.cuda.synchronize()
+    assert rel_err(dw.cpu(), w.grad) < 1e-5
+    assert rel_err(db.cpu(), b.grad) < 1e-5
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)  # fixed-order reductions
+
+
 def test_wgrad_upsampled_input():
     from neosr_amd.hip import ops
 
