@@ -376,43 +376,49 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_thin_kernel(const ThinAr
   }
 }
 
-// dw[n][k][tap] (+)= scale * sum over workgroups; one thread per weight, four-lane split of the partials
+// dw[n][k][tap] (+)= scale * sum over workgroups, db[n] likewise (outputs N*K*9 .. N*K*9 + N - 1): 16 outputs
+// per workgroup, 16 split lanes each walking every 16th partial, combined through LDS in a fixed order
 __global__ __launch_bounds__(256) void conv3x3_wgrad_thin_reduce_kernel(const ThinArgs a, int nwg) {
-  __shared__ float red[4][64];
+  __shared__ float red[16][17];
   const neosr_wgrad_desc& d = a.d;
-  const int o = threadIdx.x & 63, sl = threadIdx.x >> 6;
-  const int idx = blockIdx.x * 64 + o;
+  const int o = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int idx = blockIdx.x * 16 + o;
   const int total = d.N * d.K * 9;
-  float s0 = 0.f, s1 = 0.f;
-  int n = 0, k = 0, tap = 0;
-  const bool live = idx < total;
-  if (live) {
-    tap = idx % 9;
-    k = (idx / 9) % d.K;
-    n = idx / (9 * d.K);
+  const bool is_w = idx < total, is_b = !is_w && d.db && idx < total + d.N;
+  const float* p = nullptr;
+  int64_t stride = 0;
+  float* q = nullptr;
+  if (is_w) {
+    const int tap = idx % 9, k = (idx / 9) % d.K, n = idx / (9 * d.K);
     const int cw = a.xwide ? k : n, tt = a.xwide ? n : k;   // wide channel, thin channel
-    const float* p = a.part + (int64_t)(cw >> 6) * nwg * THIN_PART + (tap * 4 + tt) * 64 + (cw & 63);
+    p = a.part + (int64_t)(cw >> 6) * nwg * THIN_PART + (tap * 4 + tt) * 64 + (cw & 63);
+    stride = THIN_PART;
+    q = d.dw + idx;  // canonical (N, K, 3, 3) is exactly n*K*9 + k*9 + tap
+  } else if (is_b) {
+    const int nb = idx - total;
+    stride = a.xwide ? 4 : 64 * a.groups;
+    p = a.bpart + nb;
+    q = d.db + nb;
+  }
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (p) {
     int w = sl;
-    for (; w + 4 < nwg; w += 8) {
-      s0 += p[(int64_t)w * THIN_PART];
-      s1 += p[(int64_t)(w + 4) * THIN_PART];
+    for (; w + 48 < nwg; w += 64) {
+      s0 += p[(int64_t)w * stride];
+      s1 += p[(int64_t)(w + 16) * stride];
+      s2 += p[(int64_t)(w + 32) * stride];
+      s3 += p[(int64_t)(w + 48) * stride];
     }
-    for (; w < nwg; w += 4) s0 += p[(int64_t)w * THIN_PART];
+    for (; w < nwg; w += 16) s0 += p[(int64_t)w * stride];
   }
-  red[sl][o] = s0 + s1;
+  red[sl][o] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  if (sl == 0 && live) {
-    const float sum = (((red[0][o] + red[1][o]) + red[2][o]) + red[3][o]) * d.scale;
-    float* q = d.dw + ((int64_t)n * d.K + k) * 9 + tap;
-    *q = d.accumulate ? (*q + sum) : sum;
-  }
-  if (d.db && blockIdx.x == 0 && (int)threadIdx.x < d.N) {
-    const int nb = threadIdx.x;
-    const int stride = a.xwide ? 4 : 64 * a.groups;
+  if (sl == 0 && p) {
     float sum = 0.f;
-    for (int w = 0; w < nwg; ++w) sum += a.bpart[(int64_t)w * stride + nb];
+#pragma unroll
+    for (int l = 0; l < 16; ++l) sum += red[l][o];
     sum *= d.scale;
-    d.db[nb] = d.accumulate ? (d.db[nb] + sum) : sum;
+    *q = d.accumulate ? (*q + sum) : sum;
   }
 }
 
@@ -458,14 +464,21 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_reduce_kernel(const WgradMu
     float* q = d.dw + ((int64_t)co * d.K + ci) * 9 + tap;
     *q = d.accumulate ? (*q + sum) : sum;
   }
-  if (d.db && kt == 0 && blockIdx.x == 0 && threadIdx.x < 32) {
-    const int cb = ntile * 32 + threadIdx.x;
-    if (cb < d.N) {
-      const float* bp = args.bpart + (int64_t)(args.btile_start[di] + ntile) * args.nsplit * 32 + threadIdx.x;
-      float sum = 0.f;
-      for (int s = 0; s < args.nsplit; ++s) sum += bp[(int64_t)s * 32];
-      sum *= d.scale;
-      d.db[cb] = d.accumulate ? (d.db[cb] + sum) : sum;
+  if (d.db && kt == 0 && blockIdx.x == 0) {  // bias gradient of this cout tile: 32 outputs x 8 split lanes
+    __shared__ float bred[8][33];
+    const int cbl = threadIdx.x & 31, bl = threadIdx.x >> 5;
+    const float* bp = args.bpart + (int64_t)(args.btile_start[di] + ntile) * args.nsplit * 32 + cbl;
+    float sum = 0.f;
+    for (int s = bl; s < args.nsplit; s += 8) sum += bp[(int64_t)s * 32];
+    bred[bl][cbl] = sum;
+    __syncthreads();
+    const int cb = ntile * 32 + cbl;
+    if (bl == 0 && cb < d.N) {
+      float tot = 0.f;
+#pragma unroll
+      for (int l = 0; l < 8; ++l) tot += bred[l][cbl];
+      tot *= d.scale;
+      d.db[cb] = d.accumulate ? (d.db[cb] + tot) : tot;
     }
   }
 }
@@ -579,7 +592,7 @@ extern "C" int neosr_conv3x3_wgrad_multi(const neosr_wgrad_desc* ds, int32_t n, 
       hipLaunchKernelGGL(conv3x3_wgrad_thin_kernel<false>, dim3(nwg, t.groups), dim3(256), 0, st, t);
     if (prof) neosr_prof_end(stream);
     NEOSR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(conv3x3_wgrad_thin_reduce_kernel, dim3(ceil_div(ds[0].N * ds[0].K * 9, 64)), dim3(256), 0, st,
+    hipLaunchKernelGGL(conv3x3_wgrad_thin_reduce_kernel, dim3(ceil_div(ds[0].N * ds[0].K * 9 + ds[0].N, 16)), dim3(256), 0, st,
                        t, nwg);
     NEOSR_LAUNCH_CHECK();
     return 0;
