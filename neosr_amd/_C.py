@@ -338,6 +338,17 @@ SIGNATURES: dict[str, tuple] = {
 
 _lib = None
 
+# Bumped by everything that rewrites parameters through raw device pointers (the fused optimizer steps,
+# schedule-free eval()/train() lerps, SAM's climb / restore): derived per-weight data cached on the Python
+# side (packed convolution weights, neosr_amd/hip/layers.py) is keyed on it.  In-place torch ops are
+# covered by the tensors' own `_version`.
+WEIGHTS_EPOCH = 0
+
+
+def params_changed() -> None:
+    global WEIGHTS_EPOCH
+    WEIGHTS_EPOCH += 1
+
 
 class NeosrAmdError(RuntimeError):
     pass

@@ -76,6 +76,24 @@ class VGGInput(torch.autograd.Function):
 # --------------------------------------------------------------------------------------------
 # convolution
 # --------------------------------------------------------------------------------------------
+def packed_weights(w: torch.Tensor, mode: int):
+    """Packed image of `w` for the direct-to-LDS kernel (`neosr_conv3x3_pack_weights`), cached ON the weight
+    tensor object and rebuilt when the weights changed: torch in-place ops move `w._version`, the fused
+    optimizer kernels (raw pointers) move `_C.WEIGHTS_EPOCH`, re-homing (flatten_parameters_) moves
+    `data_ptr()`.  Frozen networks (VGG) are packed once; temporaries (spectral-normalised weights) carry
+    no cache.  Thin layers have their own kernels and are not packed."""
+    if min(w.shape[0], w.shape[1]) <= 4 or w.shape[0] % 4 or w.shape[1] % 4:
+        return None
+    key = (w._version, _C.WEIGHTS_EPOCH, w.data_ptr())
+    cache = w.__dict__.setdefault("_neosr_packs", {}) if hasattr(w, "__dict__") else {}
+    hit = cache.get(mode)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    pack = ops.conv3x3_pack_weights(w, mode)
+    cache[mode] = (key, pack)
+    return pack
+
+
 class Conv3x3(torch.autograd.Function):
     """y = act(conv3x3(x'[..., :K], w) + b) (+ res), fused bias/activation/residual; x' = x or its
     nearest x2 upsampling (`ups`, folded into the conv loader).  backward = MFMA dgrad (activation
@@ -85,7 +103,8 @@ class Conv3x3(torch.autograd.Function):
     def forward(ctx, x, w, b, act, slope, ups, res):
         _C.require_device(x, "x")
         w = _C.require_device(w, "weight").contiguous()
-        y = ops.conv3x3(x, w, b, act=act, slope=slope, k_in=w.shape[1], ups=ups, res1=res)
+        y = ops.conv3x3(x, w, b, act=act, slope=slope, k_in=w.shape[1], ups=ups, res1=res,
+                        w_pack=packed_weights(w, ops.CONV_FWD))
         ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
         ctx.act, ctx.slope, ctx.has_bias, ctx.ups, ctx.has_res = act, slope, b is not None, ups, res is not None
         if act != ACT_NONE and res is not None:
@@ -99,7 +118,8 @@ class Conv3x3(torch.autograd.Function):
         slope = ctx.slope if ctx.act == ACT_LRELU else 0.0
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = ops.conv3x3(g, w, None, mode=ops.CONV_DGRAD, in_mask=y, mask_slope=slope)
+            gx = ops.conv3x3(g, w, None, mode=ops.CONV_DGRAD, in_mask=y, mask_slope=slope,
+                             w_pack=packed_weights(w, ops.CONV_DGRAD) if y is None else None)
             if ctx.ups:
                 gx = ops.pool2x2_sum(gx)
             if x.shape[3] > gx.shape[3]:  # conv read a channel prefix of a wider buffer

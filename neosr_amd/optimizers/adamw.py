@@ -124,6 +124,7 @@ class AdamW(Optimizer):
                 d.ema = ema_arena.data_ptr()
                 d.ema_decay = -1.0 if first else decay
             _C.check(lib.neosr_adamw_step(C.byref(d), _C.stream_ptr()), "neosr_adamw_step")
+            _C.params_changed()
             if self._pending_clip > 0:
                 self.last_grad_norm = self._norm_ws[0]
         self._pending_clip = 0.0

@@ -65,6 +65,7 @@ class adan_sf(AdamW):
             pflat, _ = self._group_arena(group)
             _C.check(lib.neosr_lerp(pflat.data_ptr(), st["z"].data_ptr(), pflat.numel(),
                                     weight_of_beta1(group["betas"][0]), _C.stream_ptr()), "neosr_lerp")
+            _C.params_changed()
 
     @torch.no_grad()
     def eval(self) -> None:
@@ -155,6 +156,7 @@ class adan_sf(AdamW):
                 d.ema = ema_arena.data_ptr()
                 d.ema_decay = -1.0 if first else decay
             _C.check(lib.neosr_adan_sf_step(C.byref(d), _C.stream_ptr()), "neosr_adan_sf_step")
+            _C.params_changed()
             if self._pending_clip > 0:
                 self.last_grad_norm = self._norm_ws[0]
         self._pending_clip = 0.0

@@ -95,6 +95,7 @@ class fsam(Optimizer):
                             rho=group["rho"], sigma=self.sigma, lmbda=self.lmbda, grad_scale=self._grad_scale,
                             first=int(st["first"]), adaptive=int(bool(group["adaptive"])))
             _C.check(lib.neosr_fsam_first_step(C.byref(d), _C.stream_ptr()), "neosr_fsam_first_step")
+            _C.params_changed()
             st["first"] = False
             self.last_grad_norm = self._norm_ws[0]
         if zero_grad:
@@ -109,6 +110,7 @@ class fsam(Optimizer):
             params = [p for p in group["params"] if p.requires_grad]
             pflat = flat_view_of([p.data for p in params])
             pflat.copy_(st["old_p"])  # back to "w" from "w + e(w)"
+            _C.params_changed()
         self.base_optimizer.step()  # the actual sharpness-aware update
         if zero_grad:
             self.zero_grad(set_to_none=True)
