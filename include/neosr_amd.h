@@ -84,6 +84,12 @@ typedef struct neosr_conv_desc {
   const float* out_mask;    /* optional (B, H, W, out_mask_cs), first N channels */
   int32_t out_mask_cs;
   float out_mask_slope;
+  int32_t s2d_c;            /* > 0: the input (FWD: K side, DGRAD: N side) is a space-to-depth tensor with
+                               s2d_c channels per sub-pixel and `w` is the 3x3 expansion of a 4x4 / stride-2
+                               / pad-1 kernel (nn.Conv2d(C, N, 4, 2, 1), unet_arch.py:20-22): 20 of its 36
+                               (tap, sub-pixel) blocks are structurally zero and are skipped (4 taps per
+                               sub-pixel instead of 9) */
+  int32_t reserved0;
 } neosr_conv_desc;
 
 int neosr_conv3x3(const neosr_conv_desc* d, void* stream);
@@ -119,6 +125,8 @@ typedef struct neosr_wgrad_desc {
   int32_t in_cs, g_cs, mask_cs;
   int32_t ups, accumulate;
   float mask_slope, scale;
+  int32_t s2d_c;            /* as in neosr_conv_desc (K side): only the 4 live taps per sub-pixel are computed */
+  int32_t reserved0;
 } neosr_wgrad_desc;
 
 int64_t neosr_conv3x3_wgrad_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t K, int32_t N);

@@ -57,6 +57,8 @@ class ConvDesc(C.Structure):
         ("out_mask", C.c_void_p),
         ("out_mask_cs", C.c_int32),
         ("out_mask_slope", C.c_float),
+        ("s2d_c", C.c_int32),
+        ("reserved0", C.c_int32),
     ]
 
 
@@ -84,6 +86,8 @@ class WgradDesc(C.Structure):
         ("accumulate", C.c_int32),
         ("mask_slope", C.c_float),
         ("scale", C.c_float),
+        ("s2d_c", C.c_int32),
+        ("reserved0", C.c_int32),
     ]
 
 

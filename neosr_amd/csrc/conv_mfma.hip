@@ -63,10 +63,20 @@ struct ConvArgs {
 #define TL_MARK(slot) do {} while (0)
 #endif
 
+// 4x4 / stride-2 kernels run as a 3x3 over the space-to-depth tensor (neosr_conv_desc.s2d_c): a channel
+// of sub-pixel (dy, dx) only meets block taps by in {1, dy ? 0 : 2}, bx in {1, dx ? 0 : 2}.  Returns the 9-bit
+// mask of live taps in LOOP order (backward-data walks the taps flipped).
+__device__ __forceinline__ int s2d_tap_mask(int sub, bool dgrad) {
+  const int dy = (sub >> 1) & 1, dx = sub & 1;
+  int r1 = dy ? 0 : 2, c1 = dx ? 0 : 2;
+  if (dgrad) { r1 = 2 - r1; c1 = 2 - c1; }
+  return (1 << 4) | (1 << (3 + c1)) | (1 << (r1 * 3 + 1)) | (1 << (r1 * 3 + c1));
+}
+
 template <bool DGRAD, int NTV, class Hook>
 __device__ __forceinline__ void compute_chunk(const float* __restrict__ lin,
                                               const float* __restrict__ lw, int wave, int l31,
-                                              int lh, f32x16 (&acc)[NT], Hook&& hook) {
+                                              int lh, f32x16 (&acc)[NT], Hook&& hook, int tapmask) {
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap) {
     // per-tap hook: issues a slice of the next chunk's global loads so that the 13 loads of a
@@ -75,6 +85,7 @@ __device__ __forceinline__ void compute_chunk(const float* __restrict__ lin,
 #if NEOSR_INTERLEAVE
     __builtin_amdgcn_sched_barrier(0);
 #endif
+    if (!((tapmask >> tap) & 1)) continue;  // wave-uniform (all taps unless s2d_c)
     const int ty = tap / 3, tx = tap % 3;
     const float* ap = lin + ((wave + ty) * HALO_W + l31 + tx) * INS + lh;
 #pragma unroll
@@ -365,23 +376,28 @@ __global__ __launch_bounds__(256, GENERIC ? 2 : NEOSR_CONV_WPS) void conv3x3_mfm
     __syncthreads();
     TL_MARK(3 + c * 4);
     const int cn = (c + 1) * CK;
+    int tapmask = 0x1ff;
+    if (d.s2d_c > 0) {  // FWD: this chunk's channels, DGRAD: this workgroup's output channels, in one sub-pixel
+      if (!DGRAD && d.s2d_c % CK == 0) tapmask = s2d_tap_mask((c * CK) / d.s2d_c, false);
+      if (DGRAD && d.s2d_c % NB == 0) tapmask = s2d_tap_mask(n0 / d.s2d_c, true);
+    }
 #if NEOSR_INTERLEAVE
     TL_MARK(4 + c * 4);
     if (c + 1 < nchunks) {
       auto hook = [&](int tap) { gload(cn, tap); };
-      if (ntv == 2) compute_chunk<DGRAD, 2>(lin, lw, wave, l31, lh, acc, hook);
-      else compute_chunk<DGRAD, 1>(lin, lw, wave, l31, lh, acc, hook);
+      if (ntv == 2) compute_chunk<DGRAD, 2>(lin, lw, wave, l31, lh, acc, hook, tapmask);
+      else compute_chunk<DGRAD, 1>(lin, lw, wave, l31, lh, acc, hook, tapmask);
     } else {
       auto hook = [](int) {};
-      if (ntv == 2) compute_chunk<DGRAD, 2>(lin, lw, wave, l31, lh, acc, hook);
-      else compute_chunk<DGRAD, 1>(lin, lw, wave, l31, lh, acc, hook);
+      if (ntv == 2) compute_chunk<DGRAD, 2>(lin, lw, wave, l31, lh, acc, hook, tapmask);
+      else compute_chunk<DGRAD, 1>(lin, lw, wave, l31, lh, acc, hook, tapmask);
     }
 #else
     if (c + 1 < nchunks) gload(cn, -1);
     TL_MARK(4 + c * 4);
     auto hook = [](int) {};
-    if (ntv == 2) compute_chunk<DGRAD, 2>(lin, lw, wave, l31, lh, acc, hook);
-    else compute_chunk<DGRAD, 1>(lin, lw, wave, l31, lh, acc, hook);
+    if (ntv == 2) compute_chunk<DGRAD, 2>(lin, lw, wave, l31, lh, acc, hook, tapmask);
+    else compute_chunk<DGRAD, 1>(lin, lw, wave, l31, lh, acc, hook, tapmask);
 #endif
     TL_MARK(5 + c * 4);
   }
@@ -521,11 +537,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_glds_kernel(const ConvArgs arg
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-  auto compute = [&](int buf) {
+  const bool dg = d.mode == NEOSR_CONV_DGRAD;
+  const int s2d_dgrad_mask = (d.s2d_c > 0 && dg && d.s2d_c % 32 == 0) ? s2d_tap_mask(n0 / d.s2d_c, true) : 0x1ff;
+  auto compute = [&](int buf, int tapmask) {
     const float* ibuf = lds + buf * GL_BUF;
     const float* wbuf = ibuf + GL_IN_GRAN * 4 + (lh * 32 + l31) * 4;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
+      if (!((tapmask >> tap) & 1)) continue;  // wave-uniform (all taps unless s2d_c)
       const int p = (wave + tap / 3) * HALO_W + l31 + tap % 3;
       const int sw = (p >> 2) & 3;
       const float* ap = ibuf + p * 16;
@@ -540,6 +559,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_glds_kernel(const ConvArgs arg
     }
   };
 
+  auto chunk_mask = [&](int c) {
+    if (d.s2d_c > 0 && !dg && d.s2d_c % CK == 0) return s2d_tap_mask((c * CK) / d.s2d_c, false);
+    return s2d_dgrad_mask;
+  };
   issue(0, 0);
   const int y = y0 + wave, x = x0 + l31;
   const bool pix_ok = y < H && x < W;
@@ -554,7 +577,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_glds_kernel(const ConvArgs arg
   for (int c = 0; c + 1 < nchunks; ++c) {
     issue(c + 1, (c + 1) & 1);
     TL_MARK(2 + c * 4);
-    compute(c & 1);
+    compute(c & 1, chunk_mask(c));
     TL_MARK(3 + c * 4);
     __builtin_amdgcn_s_waitcnt(0x0f70);  // chunk c+1 has landed ...
     __syncthreads();                      // ... for every wave, and buffer c&1 is free again
@@ -562,7 +585,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_glds_kernel(const ConvArgs arg
   }
   EpiRegs R;
   epi_load(d, n0, pix, pix_ok, lh, s_uni, extra, R);  // in flight under the last 72 MFMAs
-  compute((nchunks - 1) & 1);
+  compute((nchunks - 1) & 1, chunk_mask(nchunks - 1));
   TL_MARK(62);
   epi_store(d, acc, n0, pix, pix_ok, lh, tid, R);
   TL_MARK(63);

@@ -193,6 +193,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_multi_kernel(const Wgrad
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   float bsum = 0.f;
+  // 4x4 / stride-2 kernel as a 3x3 over the space-to-depth input: this cin tile lies in one sub-pixel
+  // (dy, dx) and only meets block taps by in {1, dy ? 0 : 2}, bx in {1, dx ? 0 : 2}
+  int tapmask = 0x1ff;
+  if (d.s2d_c > 0 && d.s2d_c % 32 == 0) {
+    const int sub = ci0 / d.s2d_c, r1 = (sub & 2) ? 0 : 2, c1 = (sub & 1) ? 0 : 2;
+    tapmask = (1 << 4) | (1 << (3 + c1)) | (1 << (r1 * 3 + 1)) | (1 << (r1 * 3 + c1));
+  }
 
   if (t_lo < t_hi) gload(t_lo);
   for (int t = t_lo; t < t_hi; ++t) {
@@ -211,6 +218,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_multi_kernel(const Wgrad
       for (int ty = 0; ty < 3; ++ty)
 #pragma unroll
         for (int tx = 0; tx < 3; ++tx) {
+          if (!((tapmask >> (ty * 3 + tx)) & 1)) continue;  // workgroup-uniform (all taps unless s2d_c)
           const float bv = xb[(ty * HALO_W + ks * 2 + tx) * 32];
           acc[ty * 3 + tx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[ty * 3 + tx], 0, 0, 0);
         }

@@ -100,11 +100,12 @@ class Conv3x3(torch.autograd.Function):
     derivative applied on load; 2x2 sum-pool after it for `ups`) + multi-conv wgrad kernel."""
 
     @staticmethod
-    def forward(ctx, x, w, b, act, slope, ups, res):
+    def forward(ctx, x, w, b, act, slope, ups, res, s2d_c=0):
         _C.require_device(x, "x")
         w = _C.require_device(w, "weight").contiguous()
         y = ops.conv3x3(x, w, b, act=act, slope=slope, k_in=w.shape[1], ups=ups, res1=res,
-                        w_pack=packed_weights(w, ops.CONV_FWD))
+                        w_pack=packed_weights(w, ops.CONV_FWD), s2d_c=s2d_c)
+        ctx.s2d_c = s2d_c
         ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
         ctx.act, ctx.slope, ctx.has_bias, ctx.ups, ctx.has_res = act, slope, b is not None, ups, res is not None
         if act != ACT_NONE and res is not None:
@@ -119,7 +120,7 @@ class Conv3x3(torch.autograd.Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             gx = ops.conv3x3(g, w, None, mode=ops.CONV_DGRAD, in_mask=y, mask_slope=slope,
-                             w_pack=packed_weights(w, ops.CONV_DGRAD) if y is None else None)
+                             w_pack=packed_weights(w, ops.CONV_DGRAD) if y is None else None, s2d_c=ctx.s2d_c)
             if ctx.ups:
                 gx = ops.pool2x2_sum(gx)
             if x.shape[3] > gx.shape[3]:  # conv read a channel prefix of a wider buffer
@@ -127,12 +128,12 @@ class Conv3x3(torch.autograd.Function):
                 gx = torch.cat((gx, pad), 3)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             gw, gb = ops.conv3x3_wgrad(x, g, w.shape[0], w.shape[1], g_mask=y, mask_slope=slope,
-                                       want_bias=ctx.has_bias, ups=ctx.ups)
-        return gx, gw, gb, None, None, None, (g if ctx.has_res else None)
+                                       want_bias=ctx.has_bias, ups=ctx.ups, s2d_c=ctx.s2d_c)
+        return gx, gw, gb, None, None, None, (g if ctx.has_res else None), None
 
 
-def conv3x3(x, w, b=None, act=ACT_NONE, slope=0.0, ups=False, res=None):
-    return Conv3x3.apply(x, w, b, act, slope, ups, res)
+def conv3x3(x, w, b=None, act=ACT_NONE, slope=0.0, ups=False, res=None, s2d_c=0):
+    return Conv3x3.apply(x, w, b, act, slope, ups, res, s2d_c)
 
 
 class SpaceToDepth2(torch.autograd.Function):
@@ -207,7 +208,7 @@ class _Expand4x4s2(torch.autograd.Function):
 
 def conv4x4s2(x, w, b=None, act=ACT_NONE, slope=0.0):
     """nn.Conv2d(C, N, 4, 2, 1) on channels-last x, as space-to-depth + the MFMA 3x3 kernel."""
-    return conv3x3(SpaceToDepth2.apply(x), expand_4x4s2_weight(w), b, act, slope)
+    return conv3x3(SpaceToDepth2.apply(x), expand_4x4s2_weight(w), b, act, slope, s2d_c=x.shape[3])
 
 
 # --------------------------------------------------------------------------------------------

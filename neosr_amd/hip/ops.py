@@ -30,7 +30,7 @@ def _cs(t: torch.Tensor) -> int:
 def conv3x3(x, w, bias=None, *, out=None, n_out=None, mode=CONV_FWD, ups=False, act=ACT_NONE,
             slope=0.0, prelu=None, alpha=1.0, res1=None, res1_nch=None, alpha2=1.0, res2=None,
             res2_nch=None, accumulate=False, in_mask=None, mask_slope=1.0, mask_slopes=None,
-            in_prelu=None, k_in=None, w_pack=None, out_mask=None, out_mask_slope=1.0):
+            in_prelu=None, k_in=None, w_pack=None, out_mask=None, out_mask_slope=1.0, s2d_c=0):
     """out = epilogue(conv3x3(x', w)).  See ``neosr_conv3x3`` in include/neosr_amd.h."""
     lib = _C.load()
     _C.require_device(x, "x")
@@ -74,6 +74,7 @@ def conv3x3(x, w, bias=None, *, out=None, n_out=None, mode=CONV_FWD, ups=False, 
     d.mode, d.ups, d.act, d.accumulate = mode, int(ups), act, int(accumulate)
     d.mask_slope, d.slope, d.alpha, d.alpha2 = mask_slope, slope, alpha, alpha2
     d.w_pack = _ptr(w_pack)
+    d.s2d_c = int(s2d_c)
     if out_mask is not None:
         d.out_mask = out_mask.data_ptr()
         d.out_mask_cs = _cs(out_mask)
@@ -97,7 +98,7 @@ def conv3x3_pack_weights(w, mode=CONV_FWD):
 
 
 def conv3x3_wgrad(x, g, n_out, k_in, *, ups=False, g_mask=None, mask_slope=1.0, mask_slopes=None,
-                  in_prelu=None, scale=1.0, dw=None, db=None, want_bias=True, accumulate=False):
+                  in_prelu=None, scale=1.0, dw=None, db=None, want_bias=True, accumulate=False, s2d_c=0):
     """(dw, db) of the 3x3 conv.  See ``neosr_conv3x3_wgrad``."""
     lib = _C.load()
     _C.require_device(x, "x")
@@ -125,6 +126,7 @@ def conv3x3_wgrad(x, g, n_out, k_in, *, ups=False, g_mask=None, mask_slope=1.0, 
     d.B, d.H, d.W, d.K, d.N = B, H, W, k_in, n_out
     d.ups, d.accumulate = int(ups), int(accumulate)
     d.mask_slope, d.scale = mask_slope, scale
+    d.s2d_c = int(s2d_c)
     _C.check(lib.neosr_conv3x3_wgrad(C.byref(d), _C.stream_ptr()), "neosr_conv3x3_wgrad")
     return dw, db
 
