@@ -50,6 +50,7 @@ constexpr int W_F4 = (NB * CK * 9) / (256 * 4);                                 
 struct ConvArgs {
   neosr_conv_desc d;
   int tiles_x, tiles_y;
+  int scalar_in;                 // thin-K kernel: the input's channel stride / base is not 16-byte friendly
   unsigned long long* timeline;  // debug only (NEOSR_TIMELINE builds)
 };
 
@@ -625,8 +626,16 @@ __global__ __launch_bounds__(256, 3) void conv3x3_thin_k_kernel(const ConvArgs a
     const int py = tid / HALO_W, px = tid - py * HALO_W;
     const int gy = y0 + py - 1, gx = x0 + px - 1;
     const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
-    const float4 v = *reinterpret_cast<const float4*>(
-        ok ? d.in + (((int64_t)b * H + gy) * W + gx) * d.in_cs : g_zero_page);
+    const float* src = ok ? d.in + (((int64_t)b * H + gy) * W + gx) * d.in_cs : g_zero_page;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (args.scalar_in) {  // channel stride not a multiple of 4 / unaligned base: K scalar loads
+      v.x = src[0];
+      if (K > 1) v.y = src[1];
+      if (K > 2) v.z = src[2];
+      if (K > 3) v.w = src[3];
+    } else {
+      v = *reinterpret_cast<const float4*>(src);
+    }
     float* q = lin + tid * TK_INS;  // channels >= K of the quad are padding of the buffer: never used
     q[0] = v.x;
     q[1] = K > 1 ? v.y : 0.f;
@@ -869,6 +878,7 @@ extern "C" int neosr_conv3x3(const neosr_conv_desc* dp, void* stream) {
   a.d = d;
   a.tiles_x = ceil_div(d.W, TW);
   a.tiles_y = ceil_div(d.H, TH);
+  a.scalar_in = 0;
   a.timeline = g_timeline;
   const bool al_in = (d.in_cs % 4 == 0) && ((uintptr_t)d.in % 16 == 0);
   const bool al_mk = !d.in_mask || ((d.mask_cs % 4 == 0) && ((uintptr_t)d.in_mask % 16 == 0));
@@ -898,7 +908,9 @@ extern "C" int neosr_conv3x3(const neosr_conv_desc* dp, void* stream) {
   }
   // thin layers (see conv3x3_thin_*_kernel)
   const bool plain_in = d.w && al_in && !d.ups && !d.in_prelu && !d.mask_slopes;
-  const bool thin_k = plain_in && d.K <= 4 && !d.in_mask && al_ep && (d.N % 4 == 0);
+  const bool thin_k = d.w && !d.ups && !d.in_prelu && !d.mask_slopes && d.K <= 4 && !d.in_mask && al_ep &&
+                      (d.N % 4 == 0);
+  a.scalar_in = thin_k && !al_in;
   const bool thin_n = plain_in && d.N <= 4 && d.K >= 8 && (d.K % 4 == 0) && al_mk && !d.res1 && !d.res2 &&
                       !d.accumulate && !d.out_mask && d.act != NEOSR_ACT_PRELU;
   if (use_pack) {

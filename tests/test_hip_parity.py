@@ -41,6 +41,7 @@ CONV_CASES = [
     (2, 40, 70, 64, 3),     # thin-N forward (conv_last), thin-K backward-data
     (1, 33, 65, 64, 1),     # U-Net conv9: one output channel
     (1, 21, 130, 4, 180),   # swinir conv_first-like: 3 n-blocks
+    (2, 24, 40, 1, 64),     # one input channel (backward-data of U-Net conv9): channel stride 1
 ]
 
 
