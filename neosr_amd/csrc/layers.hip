@@ -37,13 +37,15 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restri
 
 // ------------------------------------------------------------------ space-to-depth (r = 2), NHWC
 // out[b, Y, X, (dy*2+dx)*C + c] = in[b, 2Y+dy, 2X+dx, c]   (dir = 0), inverse for dir = 1
+template <int V>
 __global__ __launch_bounds__(256) void s2d_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                   int B, int H2, int W2, int C, int dir) {
-  const int64_t total = (int64_t)B * H2 * W2 * 4 * C;  // H2, W2 = low-res size
+  const int Cv = C / V;
+  const int64_t total = (int64_t)B * H2 * W2 * 4 * Cv;  // H2, W2 = low-res size
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total;
        e += (int64_t)gridDim.x * 256) {
-    const int c = (int)(e % C);
-    int64_t t = e / C;
+    const int c = (int)(e % Cv) * V;
+    int64_t t = e / Cv;
     const int q = (int)(t & 3);
     t >>= 2;
     const int X = (int)(t % W2);
@@ -51,8 +53,10 @@ __global__ __launch_bounds__(256) void s2d_kernel(const float* __restrict__ in, 
     const int Y = (int)(t % H2);
     const int b = (int)(t / H2);
     const int64_t hi = (((int64_t)b * 2 * H2 + 2 * Y + (q >> 1)) * 2 * W2 + 2 * X + (q & 1)) * C + c;
-    if (dir == 0) out[e] = in[hi];
-    else out[hi] = in[e];
+    const int64_t lo = e * V;
+    const int64_t src = dir == 0 ? hi : lo, dst = dir == 0 ? lo : hi;
+    if (V == 4) *reinterpret_cast<float4*>(out + dst) = *reinterpret_cast<const float4*>(in + src);
+    else out[dst] = in[src];
   }
 }
 
@@ -66,15 +70,36 @@ __device__ __forceinline__ void bil_tap(int o, int n_in, int& i0, int& i1, float
   l = s - i0;
 }
 
+// V = 4: one thread per channel quad (16-byte accesses; C % 4 == 0 and 16-byte aligned buffers), else V = 1
+template <int V>
+struct VecF {
+  float v[V];
+  __device__ __forceinline__ static VecF load(const float* p) {
+    VecF r;
+    if (V == 4) {
+      const float4 t = *reinterpret_cast<const float4*>(p);
+      r.v[0] = t.x; r.v[1 % V] = t.y; r.v[2 % V] = t.z; r.v[3 % V] = t.w;
+    } else {
+      r.v[0] = *p;
+    }
+    return r;
+  }
+  __device__ __forceinline__ void store(float* p) const {
+    if (V == 4) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1 % V], v[2 % V], v[3 % V]);
+    else *p = v[0];
+  }
+};
+
+template <int V>
 __global__ __launch_bounds__(256) void bilinear_up2_kernel(const float* __restrict__ in,
                                                            float* __restrict__ out, int B, int H,
                                                            int W, int C) {
-  const int Ho = 2 * H, Wo = 2 * W;
-  const int64_t total = (int64_t)B * Ho * Wo * C;
+  const int Ho = 2 * H, Wo = 2 * W, Cv = C / V;
+  const int64_t total = (int64_t)B * Ho * Wo * Cv;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total;
        e += (int64_t)gridDim.x * 256) {
-    const int c = (int)(e % C);
-    int64_t t = e / C;
+    const int c = (int)(e % Cv) * V;
+    int64_t t = e / Cv;
     const int ox = (int)(t % Wo);
     t /= Wo;
     const int oy = (int)(t % Ho);
@@ -85,27 +110,35 @@ __global__ __launch_bounds__(256) void bilinear_up2_kernel(const float* __restri
     bil_tap(ox, W, x0, x1, lx);
     const float* s = in + (int64_t)b * H * W * C + c;
     const float hy = 1.f - ly, hx = 1.f - lx;
-    out[e] = hy * (hx * s[((int64_t)y0 * W + x0) * C] + lx * s[((int64_t)y0 * W + x1) * C]) +
-             ly * (hx * s[((int64_t)y1 * W + x0) * C] + lx * s[((int64_t)y1 * W + x1) * C]);
+    const VecF<V> a00 = VecF<V>::load(s + ((int64_t)y0 * W + x0) * C), a01 = VecF<V>::load(s + ((int64_t)y0 * W + x1) * C);
+    const VecF<V> a10 = VecF<V>::load(s + ((int64_t)y1 * W + x0) * C), a11 = VecF<V>::load(s + ((int64_t)y1 * W + x1) * C);
+    VecF<V> o;
+#pragma unroll
+    for (int k = 0; k < V; ++k)
+      o.v[k] = hy * (hx * a00.v[k] + lx * a01.v[k]) + ly * (hx * a10.v[k] + lx * a11.v[k]);
+    o.store(out + e * V);
   }
 }
 
 // adjoint, gather form (deterministic): each input pixel sums the <= 4x4 outputs that read it
+template <int V>
 __global__ __launch_bounds__(256) void bilinear_up2_bwd_kernel(const float* __restrict__ gout,
                                                                float* __restrict__ gin, int B, int H,
                                                                int W, int C) {
-  const int Ho = 2 * H, Wo = 2 * W;
-  const int64_t total = (int64_t)B * H * W * C;
+  const int Ho = 2 * H, Wo = 2 * W, Cv = C / V;
+  const int64_t total = (int64_t)B * H * W * Cv;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total;
        e += (int64_t)gridDim.x * 256) {
-    const int c = (int)(e % C);
-    int64_t t = e / C;
+    const int c = (int)(e % Cv) * V;
+    int64_t t = e / Cv;
     const int x = (int)(t % W);
     t /= W;
     const int y = (int)(t % H);
     const int b = (int)(t / H);
     const float* g = gout + (int64_t)b * Ho * Wo * C + c;
-    float acc = 0.f;
+    VecF<V> acc;
+#pragma unroll
+    for (int k = 0; k < V; ++k) acc.v[k] = 0.f;
     for (int oy = max(2 * y - 2, 0); oy <= min(2 * y + 2, Ho - 1); ++oy) {
       int y0, y1;
       float ly;
@@ -117,10 +150,14 @@ __global__ __launch_bounds__(256) void bilinear_up2_bwd_kernel(const float* __re
         float lx;
         bil_tap(ox, W, x0, x1, lx);
         const float wx = (x0 == x ? 1.f - lx : 0.f) + (x1 == x ? lx : 0.f);
-        if (wx != 0.f) acc += wy * wx * g[((int64_t)oy * Wo + ox) * C];
+        if (wx != 0.f) {
+          const VecF<V> gv = VecF<V>::load(g + ((int64_t)oy * Wo + ox) * C);
+#pragma unroll
+          for (int k = 0; k < V; ++k) acc.v[k] += wy * wx * gv.v[k];
+        }
       }
     }
-    gin[e] = acc;
+    acc.store(gin + e * V);
   }
 }
 
@@ -368,8 +405,12 @@ __global__ __launch_bounds__(256) void sn_bwd_kernel(const float* __restrict__ g
 extern "C" int neosr_space_to_depth2(const float* in, float* out, int32_t B, int32_t Hlo,
                                      int32_t Wlo, int32_t C, int32_t inverse, void* stream) {
   NEOSR_CHECK(in && out && B > 0 && Hlo > 0 && Wlo > 0 && C > 0, "space_to_depth2: bad args");
-  hipLaunchKernelGGL(s2d_kernel, dim3(grid_for((int64_t)B * Hlo * Wlo * 4 * C)), dim3(256), 0, ST,
-                     in, out, B, Hlo, Wlo, C, inverse);
+  if (C % 4 == 0 && (uintptr_t)in % 16 == 0 && (uintptr_t)out % 16 == 0)
+    hipLaunchKernelGGL(s2d_kernel<4>, dim3(grid_for((int64_t)B * Hlo * Wlo * C)), dim3(256), 0, ST, in, out, B,
+                       Hlo, Wlo, C, inverse);
+  else
+    hipLaunchKernelGGL(s2d_kernel<1>, dim3(grid_for((int64_t)B * Hlo * Wlo * 4 * C)), dim3(256), 0, ST, in, out,
+                       B, Hlo, Wlo, C, inverse);
   NEOSR_LAUNCH_CHECK();
   return 0;
 }
@@ -377,12 +418,14 @@ extern "C" int neosr_space_to_depth2(const float* in, float* out, int32_t B, int
 extern "C" int neosr_bilinear_up2(const float* in, float* out, int32_t B, int32_t H, int32_t W,
                                   int32_t C, int32_t backward, void* stream) {
   NEOSR_CHECK(in && out && B > 0 && H > 0 && W > 0 && C > 0, "bilinear_up2: bad args");
-  if (!backward)
-    hipLaunchKernelGGL(bilinear_up2_kernel, dim3(grid_for((int64_t)B * 4 * H * W * C)), dim3(256), 0,
-                       ST, in, out, B, H, W, C);
-  else
-    hipLaunchKernelGGL(bilinear_up2_bwd_kernel, dim3(grid_for((int64_t)B * H * W * C)), dim3(256), 0,
-                       ST, in, out, B, H, W, C);
+  const bool v4 = (C % 4 == 0) && ((uintptr_t)in % 16 == 0) && ((uintptr_t)out % 16 == 0);
+  if (!backward) {
+    if (v4) hipLaunchKernelGGL(bilinear_up2_kernel<4>, dim3(grid_for((int64_t)B * H * W * C)), dim3(256), 0, ST, in, out, B, H, W, C);
+    else hipLaunchKernelGGL(bilinear_up2_kernel<1>, dim3(grid_for((int64_t)B * 4 * H * W * C)), dim3(256), 0, ST, in, out, B, H, W, C);
+  } else {
+    if (v4) hipLaunchKernelGGL(bilinear_up2_bwd_kernel<4>, dim3(grid_for((int64_t)B * H * W * C / 4)), dim3(256), 0, ST, in, out, B, H, W, C);
+    else hipLaunchKernelGGL(bilinear_up2_bwd_kernel<1>, dim3(grid_for((int64_t)B * H * W * C)), dim3(256), 0, ST, in, out, B, H, W, C);
+  }
   NEOSR_LAUNCH_CHECK();
   return 0;
 }
