@@ -242,6 +242,10 @@ int neosr_poisson_rate(const float* img, uint32_t* levels_ws, float* vals, float
 int neosr_poisson_noise(const float* img, const float* P, const float* vals, const float* P_gray,
                         const float* vals_gray, const float* scale, const float* gray, float* out,
                         int32_t B, int32_t H, int32_t W, void* stream);
+/* P ~ Poisson(rate) elementwise — the `torch.poisson(rate)` draw of generate_poisson_noise_pt
+ * (degradations.py:782-785) — from a counter-based Philox4x32-10 stream keyed by (seed, offset, element):
+ * Knuth's product method below rate 10, Hoermann's PTRS rejection above (exact in distribution). */
+int neosr_poisson_sample(const float* rate, float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream);
 /* DiffJPEG(differentiable=False)(x, quality) (neosr/utils/diffjpeg.py:514-555): pad to x16 with
  * zeros, RGB*255 -> YCbCr, 2x2 chroma mean, 8x8 DCT, quantise with the (transposed-as-stored)
  * tables * quality_to_factor(quality[b]) and round-half-even, dequantise, IDCT, chroma repeat,

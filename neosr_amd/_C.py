@@ -264,6 +264,7 @@ SIGNATURES: dict[str, tuple] = {
     "neosr_gaussian_noise": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "neosr_poisson_rate": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "neosr_poisson_noise": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "neosr_poisson_sample": (C.c_int, [_vp, _vp, _i64, C.c_uint64, C.c_uint64, _vp]),
     "neosr_diffjpeg": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "neosr_quantize_u8": (C.c_int, [_vp, _vp, _i64, _vp]),
     "neosr_clamp01": (C.c_int, [_vp, _vp, _i64, _vp]),

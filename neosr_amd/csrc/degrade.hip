@@ -517,3 +517,87 @@ extern "C" int neosr_gather_rows(const float* src, const int64_t* idx, float* ds
   NEOSR_LAUNCH_CHECK();
   return 0;
 }
+
+// ------------------------------------------------------------------ Poisson sampling (replaces torch.poisson)
+// Counter-based Philox4x32-10 (Salmon et al. 2011): element e owns the counter stream (e, draw#, offset) under
+// key = seed, so the field is a pure function of (seed, offset, rate) — no generator state, no host sync.
+// Small rates: Knuth's product of uniforms; rate >= 10: Hoermann's PTRS transformed rejection (the
+// algorithm behind numpy / ATen's CPU sampler), exact in distribution.
+namespace {
+
+struct Philox {
+  uint32_t k0, k1, c0, c1, c2, c3;
+  uint32_t out[4];
+  int have = 0;
+  uint32_t draw = 0;
+  __device__ Philox(uint64_t seed, uint64_t offset, uint64_t elem)
+      : k0((uint32_t)seed), k1((uint32_t)(seed >> 32)), c0((uint32_t)elem), c1((uint32_t)(elem >> 32)),
+        c2((uint32_t)offset), c3((uint32_t)(offset >> 32)) {}
+  __device__ void refill() {
+    uint32_t a = c0, b = c1 ^ draw, c = c2, d = c3;  // the draw index perturbs the counter
+    uint32_t x0 = k0, x1 = k1;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+      const uint32_t hi0 = __umulhi(0xD2511F53u, a), lo0 = 0xD2511F53u * a;
+      const uint32_t hi1 = __umulhi(0xCD9E8D57u, c), lo1 = 0xCD9E8D57u * c;
+      a = hi1 ^ b ^ x0;
+      b = lo1;
+      c = hi0 ^ d ^ x1;
+      d = lo0;
+      x0 += 0x9E3779B9u;
+      x1 += 0xBB67AE85u;
+    }
+    out[0] = a; out[1] = b; out[2] = c; out[3] = d;
+    have = 4;
+    ++draw;
+  }
+  __device__ float uniform() {  // (0, 1)
+    if (!have) refill();
+    const uint32_t x = out[--have];
+    return ((x >> 8) + 0.5f) * (1.0f / 16777216.0f);
+  }
+};
+
+__global__ __launch_bounds__(256) void poisson_sample_kernel(const float* __restrict__ rate,
+                                                             float* __restrict__ out, int64_t n,
+                                                             uint64_t seed, uint64_t offset) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+    const float lam = rate[e];
+    Philox rng(seed, offset, (uint64_t)e);
+    float k = 0.f;
+    if (!(lam > 0.f)) {
+      k = 0.f;
+    } else if (lam < 10.f) {
+      const float L = expf(-lam);
+      float p = rng.uniform();
+      while (p > L) {
+        k += 1.f;
+        p *= rng.uniform();
+      }
+    } else {
+      const float slam = sqrtf(lam), loglam = logf(lam);
+      const float b = 0.931f + 2.53f * slam, a = -0.059f + 0.02483f * b;
+      const float invalpha = 1.1239f + 1.1328f / (b - 3.4f), vr = 0.9277f - 3.6224f / (b - 2.f);
+      for (;;) {
+        const float U = rng.uniform() - 0.5f, V = rng.uniform();
+        const float us = 0.5f - fabsf(U);
+        k = floorf((2.f * a / us + b) * U + lam + 0.43f);
+        if (us >= 0.07f && V <= vr) break;
+        if (k < 0.f || (us < 0.013f && V > us)) continue;
+        if (logf(V) + logf(invalpha) - logf(a / (us * us) + b) <= -lam + k * loglam - lgammaf(k + 1.f)) break;
+      }
+    }
+    out[e] = k;
+  }
+}
+
+}  // namespace
+
+extern "C" int neosr_poisson_sample(const float* rate, float* out, int64_t n, uint64_t seed, uint64_t offset,
+                                    void* stream) {
+  NEOSR_CHECK(rate && out && n > 0, "poisson_sample: bad args");
+  hipLaunchKernelGGL(poisson_sample_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, rate, out, n,
+                     seed, offset);
+  NEOSR_LAUNCH_CHECK();
+  return 0;
+}

@@ -50,7 +50,18 @@ class LiveDraws:
         return torch.randn(*shape, dtype=torch.float32, device=self.device)
 
     def poisson(self, rate: torch.Tensor) -> torch.Tensor:
-        return torch.poisson(rate)
+        """`torch.poisson(rate)` (degradations.py:782-785).  On a HIP device the field comes from our own
+        counter-based sampler, keyed by the device generator's (seed, offset) — which is advanced like a
+        generator draw would — so `torch.manual_seed` still fixes the run."""
+        if not rate.is_cuda:
+            return torch.poisson(rate)
+        from neosr_amd.hip import degrade as D
+
+        gen = torch.cuda.default_generators[rate.device.index if rate.device.index is not None
+                                            else torch.cuda.current_device()]
+        seed, offset = gen.initial_seed(), gen.get_offset()
+        gen.set_offset(offset + 4 * ((rate.numel() + 3) // 4))
+        return D.poisson_sample(rate, seed, offset)
 
     def uniform_tensor(self, n: int, lo: float, hi: float) -> torch.Tensor:
         return torch.empty(n, dtype=torch.float32, device=self.device).uniform_(lo, hi)

@@ -88,6 +88,16 @@ def poisson_rate(img: torch.Tensor, gray: bool) -> tuple[torch.Tensor, torch.Ten
     return rate, vals
 
 
+def poisson_sample(rate: torch.Tensor, seed: int, offset: int) -> torch.Tensor:
+    """P ~ Poisson(rate), a pure function of (seed, offset, rate): `neosr_poisson_sample`."""
+    lib = _C.load()
+    rate = _C.require_device(rate, "rate").contiguous()
+    out = torch.empty_like(rate)
+    _C.check(lib.neosr_poisson_sample(rate.data_ptr(), out.data_ptr(), rate.numel(), seed & (2**64 - 1),
+                                      offset & (2**64 - 1), _C.stream_ptr()), "neosr_poisson_sample")
+    return out
+
+
 def poisson_noise(img, P, vals, P_gray, vals_gray, scale, gray) -> torch.Tensor:
     lib = _C.load()
     img = _img(img)

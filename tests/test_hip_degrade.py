@@ -155,3 +155,40 @@ def test_otf_feed_data_replaying_reference_draws():
         assert torch.equal(model.gt.cpu(), torch.from_numpy(fix[f"it{it}/gt_out"]))
     model.optimize_parameters(1)  # the degraded pair feeds the HIP training step
     assert np.isfinite(model.get_current_log()["l_g_pix"])
+
+
+@pytest.mark.parametrize("lam", [0.3, 3.0, 9.9, 10.1, 50.0, 800.0])
+def test_poisson_sample_distribution(lam):
+    """`neosr_poisson_sample` against the Poisson pmf (scipy): mean / variance and a chi-square over the
+    central bins; pure function of (seed, offset)."""
+    from scipy import stats
+
+    from neosr_amd.hip import degrade as D
+
+    n = 1 << 20
+    rate = torch.full((n,), lam, device="cuda")
+    a = D.poisson_sample(rate, 1234, 0)
+    b = D.poisson_sample(rate, 1234, 0)
+    c = D.poisson_sample(rate, 1234, 4 * n)
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    x = a.cpu().numpy().astype(np.int64)
+    assert x.min() >= 0
+    assert abs(x.mean() - lam) < 5 * np.sqrt(lam / n)
+    assert abs(x.var() - lam) < 8 * lam * np.sqrt(2.0 / n) + 5 * np.sqrt(lam / n)
+    lo, hi = int(stats.poisson.ppf(1e-4, lam)), int(stats.poisson.ppf(1 - 1e-4, lam))
+    ks = np.arange(lo, hi + 1)
+    exp = stats.poisson.pmf(ks, lam) * n
+    obs = np.array([(x == k).sum() for k in ks], dtype=np.float64)
+    keep = exp > 20
+    chi2 = ((obs[keep] - exp[keep]) ** 2 / exp[keep]).sum()
+    dof = keep.sum() - 1
+    assert chi2 < dof + 6 * np.sqrt(2 * dof) + 10, (chi2, dof)
+
+
+def test_poisson_sample_mixed_rates_and_zero():
+    from neosr_amd.hip import degrade as D
+
+    rate = torch.tensor([0.0, 0.0, 1e-6, 5.0, 20.0, 3000.0], device="cuda").repeat(4096)
+    p = D.poisson_sample(rate, 7, 0).view(4096, 6).cpu()
+    assert (p[:, :2] == 0).all() and (p >= 0).all() and torch.equal(p, p.round())
+    assert abs(p[:, 3].mean() - 5.0) < 0.2 and abs(p[:, 4].mean() - 20.0) < 0.4 and abs(p[:, 5].mean() - 3000.0) < 5
