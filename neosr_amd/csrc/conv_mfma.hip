@@ -17,6 +17,7 @@
 // Reference call sites replaced: neosr/archs/esrgan_arch.py:109-116,137-142,196-214;
 // neosr/archs/compact_arch.py:76-79 (see include/neosr_amd.h).
 #include <cstring>
+#include <type_traits>
 #include "common.h"
 #include "prof.h"
 #include "conv_pack.h"
@@ -74,7 +75,9 @@ __device__ __forceinline__ int s2d_tap_mask(int sub, bool dgrad) {
   return (1 << 4) | (1 << (3 + c1)) | (1 << (r1 * 3 + 1)) | (1 << (r1 * 3 + c1));
 }
 
-template <bool DGRAD, int NTV, class Hook>
+// MASKED = false keeps the tap loop free of branches (the compiler software-pipelines the LDS reads across
+// taps); the s2d_c launches pay a wave-uniform branch per tap instead.
+template <bool DGRAD, int NTV, bool MASKED, class Hook>
 __device__ __forceinline__ void compute_chunk(const float* __restrict__ lin,
                                               const float* __restrict__ lw, int wave, int l31,
                                               int lh, f32x16 (&acc)[NT], Hook&& hook, int tapmask) {
@@ -86,7 +89,7 @@ __device__ __forceinline__ void compute_chunk(const float* __restrict__ lin,
 #if NEOSR_INTERLEAVE
     __builtin_amdgcn_sched_barrier(0);
 #endif
-    if (!((tapmask >> tap) & 1)) continue;  // wave-uniform (all taps unless s2d_c)
+    if (MASKED && !((tapmask >> tap) & 1)) continue;  // wave-uniform
     const int ty = tap / 3, tx = tap % 3;
     const float* ap = lin + ((wave + ty) * HALO_W + l31 + tx) * INS + lh;
 #pragma unroll
@@ -197,7 +200,7 @@ __device__ __forceinline__ constexpr int w_piece(int rr) { return 1 + ((rr + 1) 
 // FAST path preconditions (checked on the host): in/mask/w (and the per-channel slope vector of a
 // PReLU-on-load or PReLU-derivative mask, at most one of the two) 16-byte aligned, in_cs, mask_cs, K,
 // w_cin, N multiples of 4.
-template <bool DGRAD, bool MASK, bool GENERIC>
+template <bool DGRAD, bool MASK, bool GENERIC, bool S2D = false>
 __global__ __launch_bounds__(256, GENERIC ? 2 : NEOSR_CONV_WPS) void conv3x3_mfma_kernel(const ConvArgs args) {
   const neosr_conv_desc& d = args.d;
   __shared__ float lds[IN_LDS + W_LDS];
@@ -377,8 +380,9 @@ __global__ __launch_bounds__(256, GENERIC ? 2 : NEOSR_CONV_WPS) void conv3x3_mfm
     __syncthreads();
     TL_MARK(3 + c * 4);
     const int cn = (c + 1) * CK;
+#define CHUNK(NTV_) compute_chunk<DGRAD, NTV_, S2D>(lin, lw, wave, l31, lh, acc, hook, tapmask)
     int tapmask = 0x1ff;
-    if (d.s2d_c > 0) {  // FWD: this chunk's channels, DGRAD: this workgroup's output channels, in one sub-pixel
+    if (S2D) {  // FWD: this chunk's channels, DGRAD: this workgroup's output channels, in one sub-pixel
       if (!DGRAD && d.s2d_c % CK == 0) tapmask = s2d_tap_mask((c * CK) / d.s2d_c, false);
       if (DGRAD && d.s2d_c % NB == 0) tapmask = s2d_tap_mask(n0 / d.s2d_c, true);
     }
@@ -386,19 +390,19 @@ __global__ __launch_bounds__(256, GENERIC ? 2 : NEOSR_CONV_WPS) void conv3x3_mfm
     TL_MARK(4 + c * 4);
     if (c + 1 < nchunks) {
       auto hook = [&](int tap) { gload(cn, tap); };
-      if (ntv == 2) compute_chunk<DGRAD, 2>(lin, lw, wave, l31, lh, acc, hook, tapmask);
-      else compute_chunk<DGRAD, 1>(lin, lw, wave, l31, lh, acc, hook, tapmask);
+      if (ntv == 2) CHUNK(2);
+      else CHUNK(1);
     } else {
       auto hook = [](int) {};
-      if (ntv == 2) compute_chunk<DGRAD, 2>(lin, lw, wave, l31, lh, acc, hook, tapmask);
-      else compute_chunk<DGRAD, 1>(lin, lw, wave, l31, lh, acc, hook, tapmask);
+      if (ntv == 2) CHUNK(2);
+      else CHUNK(1);
     }
 #else
     if (c + 1 < nchunks) gload(cn, -1);
     TL_MARK(4 + c * 4);
     auto hook = [](int) {};
-    if (ntv == 2) compute_chunk<DGRAD, 2>(lin, lw, wave, l31, lh, acc, hook, tapmask);
-    else compute_chunk<DGRAD, 1>(lin, lw, wave, l31, lh, acc, hook, tapmask);
+    if (ntv == 2) CHUNK(2);
+    else CHUNK(1);
 #endif
     TL_MARK(5 + c * 4);
   }
@@ -476,6 +480,7 @@ __device__ __forceinline__ void glds16(const float* src, float* lds_dst) {
                                    (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
+template <bool S2D>
 __global__ __launch_bounds__(256, 2) void conv3x3_glds_kernel(const ConvArgs args) {
   const neosr_conv_desc& d = args.d;
   __shared__ __attribute__((aligned(1024))) float lds[2 * GL_BUF];
@@ -540,12 +545,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_glds_kernel(const ConvArgs arg
 
   const bool dg = d.mode == NEOSR_CONV_DGRAD;
   const int s2d_dgrad_mask = (d.s2d_c > 0 && dg && d.s2d_c % 32 == 0) ? s2d_tap_mask(n0 / d.s2d_c, true) : 0x1ff;
+  // S2D = false keeps the tap loop branch-free (the compiler software-pipelines the LDS reads across
+  // taps); s2d_c launches pay a wave-uniform branch per tap
   auto compute = [&](int buf, int tapmask) {
     const float* ibuf = lds + buf * GL_BUF;
     const float* wbuf = ibuf + GL_IN_GRAN * 4 + (lh * 32 + l31) * 4;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-      if (!((tapmask >> tap) & 1)) continue;  // wave-uniform (all taps unless s2d_c)
+      if (S2D && !((tapmask >> tap) & 1)) continue;  // wave-uniform
       const int p = (wave + tap / 3) * HALO_W + l31 + tap % 3;
       const int sw = (p >> 2) & 3;
       const float* ap = ibuf + p * 16;
@@ -914,7 +921,8 @@ extern "C" int neosr_conv3x3(const neosr_conv_desc* dp, void* stream) {
   const bool thin_n = plain_in && d.N <= 4 && d.K >= 8 && (d.K % 4 == 0) && al_mk && !d.res1 && !d.res2 &&
                       !d.accumulate && !d.out_mask && d.act != NEOSR_ACT_PRELU;
   if (use_pack) {
-    hipLaunchKernelGGL(conv3x3_glds_kernel, grid, dim3(256), 0, st, a);
+    if (d.s2d_c > 0) hipLaunchKernelGGL(conv3x3_glds_kernel<true>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(conv3x3_glds_kernel<false>, grid, dim3(256), 0, st, a);
   } else if (thin_k) {
     hipLaunchKernelGGL(conv3x3_thin_k_kernel, grid, dim3(256), 0, st, a);
   } else if (thin_n) {
@@ -927,13 +935,19 @@ extern "C" int neosr_conv3x3(const neosr_conv_desc* dp, void* stream) {
       hipLaunchKernelGGL((conv3x3_mfma_kernel<false, false, true>), grid, dim3(256), 0, st, a);
     else if (d.in_mask)
       hipLaunchKernelGGL((conv3x3_mfma_kernel<false, true, false>), grid, dim3(256), 0, st, a);
+    else if (d.s2d_c > 0)
+      hipLaunchKernelGGL((conv3x3_mfma_kernel<false, false, false, true>), grid, dim3(256), 0, st, a);
     else
       hipLaunchKernelGGL((conv3x3_mfma_kernel<false, false, false>), grid, dim3(256), 0, st, a);
   } else {
     if (!fast)
       hipLaunchKernelGGL((conv3x3_mfma_kernel<true, false, true>), grid, dim3(256), 0, st, a);
+    else if (d.in_mask && d.s2d_c > 0)
+      hipLaunchKernelGGL((conv3x3_mfma_kernel<true, true, false, true>), grid, dim3(256), 0, st, a);
     else if (d.in_mask)
       hipLaunchKernelGGL((conv3x3_mfma_kernel<true, true, false>), grid, dim3(256), 0, st, a);
+    else if (d.s2d_c > 0)
+      hipLaunchKernelGGL((conv3x3_mfma_kernel<true, false, false, true>), grid, dim3(256), 0, st, a);
     else
       hipLaunchKernelGGL((conv3x3_mfma_kernel<true, false, false>), grid, dim3(256), 0, st, a);
   }

@@ -18,6 +18,7 @@
 #include "common.h"
 #include "prof.h"
 #include <string.h>
+#include <type_traits>
 #include "../../include/neosr_amd.h"
 
 namespace {
@@ -60,7 +61,7 @@ __device__ __forceinline__ float4 ld4(const float* p, bool vec, int c, int C) {
 __device__ __attribute__((aligned(256))) float wg_zero_page[64];
 
 // FAST: every descriptor has 16-byte aligned tensors, channel strides / K / N multiples of 4.
-template <bool FAST>
+template <bool FAST, bool S2D = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_multi_kernel(const WgradMultiArgs args) {
   __shared__ __attribute__((aligned(16))) float lds[G_LDS + X_LDS];  // 42.5 KB (>= WG_TILE)
   __shared__ float bred[4 * 32];
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_multi_kernel(const Wgrad
   // 4x4 / stride-2 kernel as a 3x3 over the space-to-depth input: this cin tile lies in one sub-pixel
   // (dy, dx) and only meets block taps by in {1, dy ? 0 : 2}, bx in {1, dx ? 0 : 2}
   int tapmask = 0x1ff;
-  if (d.s2d_c > 0 && d.s2d_c % 32 == 0) {
+  if (S2D && d.s2d_c > 0 && d.s2d_c % 32 == 0) {
     const int sub = ci0 / d.s2d_c, r1 = (sub & 2) ? 0 : 2, c1 = (sub & 1) ? 0 : 2;
     tapmask = (1 << 4) | (1 << (3 + c1)) | (1 << (r1 * 3 + 1)) | (1 << (r1 * 3 + c1));
   }
@@ -218,7 +219,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_multi_kernel(const Wgrad
       for (int ty = 0; ty < 3; ++ty)
 #pragma unroll
         for (int tx = 0; tx < 3; ++tx) {
-          if (!((tapmask >> (ty * 3 + tx)) & 1)) continue;  // workgroup-uniform (all taps unless s2d_c)
+          if (S2D && !((tapmask >> (ty * 3 + tx)) & 1)) continue;  // workgroup-uniform; dense loop is branch-free
           const float bv = xb[(ty * HALO_W + ks * 2 + tx) * 32];
           acc[ty * 3 + tx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[ty * 3 + tx], 0, 0, 0);
         }
@@ -609,7 +610,12 @@ extern "C" int neosr_conv3x3_wgrad_multi(const neosr_wgrad_desc* ds, int32_t n, 
   for (int i = 0; i < n; ++i)
     fast = fast && a.vec_in[i] && a.vec_g[i] && (!ds[i].g_mask || a.vec_m[i]) &&
            (ds[i].K % 4 == 0) && (ds[i].N % 4 == 0);
-  if (fast)
+  bool s2d = false;
+  for (int i = 0; i < n; ++i) s2d = s2d || ds[i].s2d_c > 0;
+  if (fast && s2d)
+    hipLaunchKernelGGL((conv3x3_wgrad_multi_kernel<true, true>), dim3(a.pair_start[MAXD], a.nsplit),
+                       dim3(256), 0, st, a);
+  else if (fast)
     hipLaunchKernelGGL(conv3x3_wgrad_multi_kernel<true>, dim3(a.pair_start[MAXD], a.nsplit),
                        dim3(256), 0, st, a);
   else
