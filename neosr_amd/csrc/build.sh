@@ -7,7 +7,7 @@ mkdir -p "$OUT"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
 OBJS=""
-for f in api prof conv_mfma wgrad elementwise degrade layers gemm_mfma attn attn_flash cab augment ssim color losses optim nets; do
+for f in api prof conv_mfma conv_glds conv_thin wgrad elementwise degrade layers gemm_mfma attn attn_flash cab augment ssim color losses optim nets; do
   "$HIPCC" $FLAGS -c "$HERE/$f.hip" -o "$OUT/$f.o" "$@" &
   OBJS="$OBJS $OUT/$f.o"
 done
