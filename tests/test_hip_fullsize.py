@@ -1,0 +1,59 @@
+"""GPU: the benchmarked configuration itself (esrgan 23 x RRDB, batch 16, 64x64 LR — BASELINE configs[1]),
+checked through size-independent properties, where the CPU oracle would take minutes:
+batch independence (bit-exact), run-to-run determinism (bit-exact) and linearity of the backward pass."""
+
+from __future__ import annotations
+
+import pytest
+import torch
+
+from tests.conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def net():
+    from neosr_amd.archs import build_network
+
+    torch.manual_seed(1024)
+    return build_network({"type": "esrgan", "scale": 4}).to(DEV).train()
+
+
+def _fwd_bwd(net, x, gy):
+    net.zero_grad(set_to_none=True)
+    y = net(x)
+    y.backward(gy)
+    torch.cuda.synchronize()
+    return y.detach(), [p.grad.detach().clone() for p in net.parameters()]
+
+
+def test_full_size_batch_independence_and_determinism(net):
+    g = torch.Generator().manual_seed(7)
+    x = torch.rand(16, 3, 64, 64, generator=g).to(DEV)
+    gy = (torch.randn(16, 3, 256, 256, generator=g) * 1e-3).to(DEV)
+    y, grads = _fwd_bwd(net, x, gy)
+    y2, grads2 = _fwd_bwd(net, x, gy)
+    assert torch.equal(y, y2) and all(torch.equal(a, b) for a, b in zip(grads, grads2))   # three streams, fixed order
+    # every sample's output depends on that sample alone: two half batches reproduce the full batch bit for bit
+    with torch.no_grad():
+        ya, yb = net(x[:8].contiguous()), net(x[8:].contiguous())
+    assert torch.equal(torch.cat((ya, yb)), y)
+    # and the parameter gradient is the sum over samples (re-association only)
+    _, ga = _fwd_bwd(net, x[:8].contiguous(), gy[:8].contiguous())
+    _, gb = _fwd_bwd(net, x[8:].contiguous(), gy[8:].contiguous())
+    worst = max(rel_err(a + b, c) for a, b, c in zip(ga, gb, grads))
+    assert worst < 1e-4, worst
+
+
+def test_full_size_backward_is_linear_in_the_upstream_gradient(net):
+    g = torch.Generator().manual_seed(11)
+    x = torch.rand(16, 3, 64, 64, generator=g).to(DEV)
+    g1 = (torch.randn(16, 3, 256, 256, generator=g) * 1e-3).to(DEV)
+    g2 = (torch.randn(16, 3, 256, 256, generator=g) * 1e-3).to(DEV)
+    _, a = _fwd_bwd(net, x, g1)
+    _, b = _fwd_bwd(net, x, g2)
+    _, c = _fwd_bwd(net, x, 0.5 * g1 - 2.0 * g2)
+    worst = max(rel_err(0.5 * p - 2.0 * q, r) for p, q, r in zip(a, b, c))
+    assert worst < 1e-4, worst
