@@ -64,7 +64,10 @@ __device__ __forceinline__ float4 ld4(const float* p, bool vec, int c, int C) {
 __device__ __attribute__((aligned(256))) float wg_zero_page[64];
 
 // FAST: every descriptor has 16-byte aligned tensors, channel strides / K / N multiples of 4.
-template <bool FAST, bool S2D = false>
+// PLAIN: no descriptor has a derivative mask or a PReLU on load (the gather-form RDB backward): the mask
+// staging registers and the per-channel slope code disappear, which leaves the allocator room to keep the
+// next k-step's LDS fragments in flight.
+template <bool FAST, bool S2D = false, bool PLAIN = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_multi_kernel(const WgradMultiArgs args) {
   __shared__ __attribute__((aligned(16))) float lds[G_LDS + X_LDS];  // 42.5 KB (>= WG_TILE)
   __shared__ float bred[4 * 32];
@@ -97,7 +100,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_multi_kernel(const Wgrad
 
   // staging slots: (pixel, 4-channel quad) per thread
   const int q4 = (tid & 7) << 2;  // channel quad within the 32-wide tile
-  float4 rg[G_F4], rm[G_F4], rx[X_F4];
+  float4 rg[G_F4], rm[PLAIN ? 1 : G_F4], rx[X_F4];
 
   auto gload = [&](int t) {
     const int txi = t % args.tiles_x;
@@ -116,7 +119,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_multi_kernel(const Wgrad
         const bool ok = gy < H && gx < W && co0 + q4 < d.N;
         const int64_t p = ok ? ((int64_t)b * H + gy) * W + gx : 0;
         v = *reinterpret_cast<const float4*>(ok ? d.g + p * d.g_cs + co0 + q4 : wg_zero_page);
-        if (d.g_mask)
+        if (!PLAIN && d.g_mask)
           m = *reinterpret_cast<const float4*>(ok ? d.g_mask + p * d.mask_cs + co0 + q4 : wg_zero_page);
       } else if (gy < H && gx < W) {
         const int64_t p = ((int64_t)b * H + gy) * W + gx;
@@ -124,7 +127,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_multi_kernel(const Wgrad
         if (d.g_mask) m = ld4(d.g_mask + p * d.mask_cs + co0 + q4, vec_m, co0 + q4, d.N);
       }
       rg[i] = v;
-      rm[i] = m;
+      if (!PLAIN) rm[i] = m;
     }
 #pragma unroll
     for (int i = 0; i < X_F4; ++i) {
@@ -165,8 +168,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_multi_kernel(const Wgrad
 #pragma unroll
     for (int i = 0; i < G_F4; ++i) {
       float4 v = rg[i];
-      if (d.g_mask) {
-        const float4 m = rm[i];
+      if (!PLAIN && d.g_mask) {
+        const float4 m = rm[PLAIN ? 0 : i];
         v.x = m.x > 0.f ? v.x : v.x * ms[0];
         v.y = m.y > 0.f ? v.y : v.y * ms[1];
         v.z = m.z > 0.f ? v.z : v.z * ms[2];
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_multi_kernel(const Wgrad
       const int idx = tid + i * 256;
       if (idx < X_PIX * 8) {
         float4 v = rx[i];
-        if (d.in_prelu) {
+        if (!PLAIN && d.in_prelu) {
           v.x = v.x > 0.f ? v.x : v.x * ps[0];
           v.y = v.y > 0.f ? v.y : v.y * ps[1];
           v.z = v.z > 0.f ? v.z : v.z * ps[2];
@@ -613,10 +616,16 @@ extern "C" int neosr_conv3x3_wgrad_multi(const neosr_wgrad_desc* ds, int32_t n, 
   for (int i = 0; i < n; ++i)
     fast = fast && a.vec_in[i] && a.vec_g[i] && (!ds[i].g_mask || a.vec_m[i]) &&
            (ds[i].K % 4 == 0) && (ds[i].N % 4 == 0);
-  bool s2d = false;
-  for (int i = 0; i < n; ++i) s2d = s2d || ds[i].s2d_c > 0;
+  bool s2d = false, plain = true;
+  for (int i = 0; i < n; ++i) {
+    s2d = s2d || ds[i].s2d_c > 0;
+    plain = plain && !ds[i].g_mask && !ds[i].in_prelu && !ds[i].mask_slopes;
+  }
   if (fast && s2d)
     hipLaunchKernelGGL((conv3x3_wgrad_multi_kernel<true, true>), dim3(a.pair_start[MAXD], a.nsplit),
+                       dim3(256), 0, st, a);
+  else if (fast && plain)
+    hipLaunchKernelGGL((conv3x3_wgrad_multi_kernel<true, false, true>), dim3(a.pair_start[MAXD], a.nsplit),
                        dim3(256), 0, st, a);
   else if (fast)
     hipLaunchKernelGGL(conv3x3_wgrad_multi_kernel<true>, dim3(a.pair_start[MAXD], a.nsplit),
