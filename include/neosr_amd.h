@@ -588,9 +588,10 @@ typedef struct neosr_fsam_desc {
 int neosr_fsam_first_step(const neosr_fsam_desc* d, void* stream);
 
 /* opt-in profiler ------------------------------------------------------------------------------
- * HIP events around every conv-class launch on the launch stream (classes: 0 conv fwd, 1 conv
- * dgrad, 2 conv wgrad, 3 wgrad reduce).  Used by bench.py's roofline pass only.  collect()
- * synchronises the device and fills 4-element arrays. */
+ * HIP events around every conv-class launch on the launch stream (classes: 0 / 1 forward / backward-data
+ * launches of conv3x3_glds_kernel, 2 weight gradient, 3 its reduce, 4 / 5 forward / backward-data launches
+ * of the staged and thin kernels).  Used by bench.py's roofline pass only.  collect() synchronises the
+ * device and fills 6-element arrays. */
 int neosr_prof_enable(int on);
 int neosr_prof_collect(double* ms, long long* launches, double* flops, double* bytes);
 

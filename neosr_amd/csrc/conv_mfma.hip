@@ -389,7 +389,7 @@ extern "C" int neosr_conv3x3(const neosr_conv_desc* dp, void* stream) {
   if (prof) {
     const double px = (double)d.B * d.H * d.W;
     // algorithmic traffic: read |x| + |W|, write |y| (fp32)
-    neosr_prof_begin(d.mode == NEOSR_CONV_FWD ? NEOSR_PROF_CONV_FWD : NEOSR_PROF_CONV_DGRAD, stream,
+    neosr_prof_begin((d.mode == NEOSR_CONV_FWD ? NEOSR_PROF_CONV_FWD : NEOSR_PROF_CONV_DGRAD) + (use_pack ? 0 : 4), stream,
                      2.0 * px * d.K * d.N * 9.0,
                      4.0 * (px / (d.ups ? 4.0 : 1.0) * d.K + px * d.N + 9.0 * d.K * d.N));
   }

@@ -1,11 +1,13 @@
 // prof.h — kernel classes for the opt-in HIP-event profiler (see prof.hip)
 #pragma once
 enum : int {
-  NEOSR_PROF_CONV_FWD = 0,
-  NEOSR_PROF_CONV_DGRAD = 1,
-  NEOSR_PROF_CONV_WGRAD = 2,
+  NEOSR_PROF_CONV_FWD = 0,        // conv3x3_glds_kernel, forward launches (packed weights)
+  NEOSR_PROF_CONV_DGRAD = 1,      // conv3x3_glds_kernel, backward-data launches
+  NEOSR_PROF_CONV_WGRAD = 2,      // conv3x3_wgrad_multi_kernel (+ thin weight gradients)
   NEOSR_PROF_WGRAD_REDUCE = 3,
-  NEOSR_PROF_NCLASS = 4
+  NEOSR_PROF_CONV_FWD_OTHER = 4,  // staged / thin kernels, forward
+  NEOSR_PROF_CONV_DGRAD_OTHER = 5,
+  NEOSR_PROF_NCLASS = 6
 };
 bool neosr_prof_on();
 void neosr_prof_begin(int cls, void* stream, double flops, double bytes);
