@@ -365,6 +365,34 @@ def test_esrgan_full_size_vs_oracle():
     assert errs[worst] < 1e-3, (worst, errs[worst])
 
 
+@pytest.mark.parametrize("scale", [2, 1])
+def test_esrgan_scale_2_and_1_vs_oracle(scale):
+    """esrgan with `scale` 2 / 1: pixel-unshuffled input (12 / 48 channels into conv_first, esrgan_arch.py:
+    197-200), output + all gradients incl. the input gradient against the CPU oracle."""
+    from neosr_amd.archs import build_network
+    from oracle import neosr_oracle as orc
+
+    torch.manual_seed(5)
+    net = build_network({"type": "esrgan", "num_feat": 32, "num_block": 2, "num_grow_ch": 16, "scale": scale})
+    P = {k: v.detach().clone().requires_grad_(True) for k, v in net.state_dict().items()}
+    x = torch.rand(2, 3, 32, 48).requires_grad_(True)
+    y_ref = orc.rrdbnet_forward(P, x, scale)
+    gt = torch.rand_like(y_ref)
+    orc.l1_loss(y_ref, gt).backward()
+    net = net.to(DEV).train()
+    xd = x.detach().to(DEV).requires_grad_(True)
+    y = net(xd)
+    assert y.shape == y_ref.shape == (2, 3, 32 * scale, 48 * scale)
+    F.l1_loss(y, gt.to(DEV)).backward()
+    torch.cuda.synchronize()
+    assert rel_err(y, y_ref) < 1e-4
+    assert rel_err(xd.grad, x.grad) < 1e-3
+    named = dict(net.named_parameters())
+    errs = {k: rel_err(named[k].grad, P[k].grad) for k in P}
+    worst = max(errs, key=errs.get)
+    assert errs[worst] < 1e-3, (worst, errs[worst])
+
+
 def test_esrgan_launch_chains_do_not_change_results():
     """`neosr_set_num_streams`: the two batch-half chains (+ the weight-gradient stream) give bit-identical
     outputs and gradients to the single-stream schedule, run after run (odd batch: halves of 1 and 2)."""
