@@ -393,6 +393,30 @@ def test_esrgan_scale_2_and_1_vs_oracle(scale):
     assert errs[worst] < 1e-3, (worst, errs[worst])
 
 
+@pytest.mark.parametrize("upscale,act", [(2, "prelu"), (3, "leakyrelu"), (1, "relu")])
+def test_compact_other_scales_vs_oracle(upscale, act):
+    """compact with upscale 1 / 2 / 3 (PixelShuffle factor, nearest-upsampled residual; compact_arch.py:56-85)."""
+    from neosr_amd.archs import build_network
+    from oracle import neosr_oracle as orc
+
+    torch.manual_seed(9)
+    net = build_network({"type": "compact", "num_feat": 16, "num_conv": 3, "upscale": upscale, "act_type": act})
+    P = {k: v.detach().clone().requires_grad_(True) for k, v in net.state_dict().items()}
+    x = torch.rand(2, 3, 20, 36)
+    y_ref = orc.compact_forward(P, x, upscale, act)
+    gt = torch.rand_like(y_ref)
+    orc.l1_loss(y_ref, gt).backward()
+    net = net.to(DEV).train()
+    y = net(x.to(DEV))
+    F.l1_loss(y, gt.to(DEV)).backward()
+    torch.cuda.synchronize()
+    assert y.shape == y_ref.shape and rel_err(y, y_ref) < 1e-4
+    named = dict(net.named_parameters())
+    errs = {k: rel_err(named[k].grad, P[k].grad) for k in P}
+    worst = max(errs, key=errs.get)
+    assert errs[worst] < 1e-3, (worst, errs[worst])
+
+
 def test_esrgan_launch_chains_do_not_change_results():
     """`neosr_set_num_streams`: the two batch-half chains (+ the weight-gradient stream) give bit-identical
     outputs and gradients to the single-stream schedule, run after run (odd batch: halves of 1 and 2)."""
