@@ -1,21 +1,30 @@
 #!/usr/bin/env python
 """bench.py — LR-patches/sec of one full training iteration on the hot path (BASELINE.json metric).
 
-Workload at N GPUs (weak scaling, one process per GPU, RCCL all-reduce of the flat grad arena):
-BASELINE.json configs[1] = "esrgan RRDB x4, paired 64^2 LR synthetic, L1 only, batch=16" per GPU:
-`feed_data` (inputs already resident in HBM) + `optimize_parameters` (RRDBNet fwd + L1 + bwd +
-grad-clip + AdamW + EMA) through the same `image` model plugin a neosr TOML would build.
+The workload is an option file under options/ (neosr TOML schema, read through
+`neosr_amd.utils.options.parse_options` exactly like `train.py -opt <file>` would):
 
-    python bench.py --gpus 1 --steps 10 --warmup 3
+    bench_esrgan          BASELINE configs[1]  esrgan RRDB x4, paired, L1, B=16/GPU            (default, headline)
+    bench_compact         BASELINE configs[0]  compact x4, paired, L1, B=2
+    bench_esrgan_otf_gan  BASELINE configs[2]  esrgan + U-Net-SN D + VGG19 perceptual + GAN, otf degradation, B=32/GPU
+    bench_swinir_medium   BASELINE configs[3]  swinir_medium x4, L1 + VGG19 perceptual, B=8/GPU
+    bench_hat_l_otf_gan   BASELINE configs[4]  hat_l + U-Net-SN D + VGG19 perceptual + GAN, otf degradation, B=4/GPU
+
+A "step" = `feed_data` (inputs already resident in HBM; for otf configs this is the whole degradation
+pipeline) + `optimize_parameters` (G fwd, losses, bwd, [D phase], grad clip, optimizer step(s), EMA).
+
+    python bench.py                                   # N=1, headline config
+    python bench.py --gpus 8                          # re-executes itself under torch.distributed.run (8 ranks, RCCL)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W     # what the driver runs; same thing
 
-Prints ONE JSON line on rank 0.  Extra objects:
-  roofline     — dominant conv kernel class: algorithmic FLOPs / HIP-event time of its launches,
-                 measured in a dedicated profiled pass of the same K steps (events on the launch
-                 stream, collected inside libneosr_amd), against the dense fp32 MFMA peak.
-  cpu_baseline — the CPU oracle (oracle/neosr_oracle.py, a pure-PyTorch port of the same
-                 iteration) timed on this host's cores on a bounded sample (rank 0, N=1 only).
+Weak scaling: one process per GPU, per-GPU batch fixed, RCCL all-reduce of the flat gradient arena
+(overlapped with the backward of the RRDB trunk), no other exchange.  Rank 0 prints ONE JSON line.  Extra objects:
+  roofline     — the kernel class with the most time in the step: algorithmic FLOPs / HIP-event time of its launches,
+                 measured in a dedicated profiled pass after the timed region (events on the launch stream,
+                 collected inside libneosr_amd), against the dense fp32 MFMA peak.
+  cpu_baseline — the CPU oracle (oracle/step_oracle.py: the same iteration restated on PyTorch-CPU fp32) timed on
+                 this host's cores on a bounded sample (rank 0, N=1 only).
 """
 
 from __future__ import annotations
@@ -24,98 +33,189 @@ import argparse
 import ctypes as C
 import json
 import os
+import socket
 import sys
 import time
 from pathlib import Path
-
-import torch
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X dense fp32 MFMA = fp32 vector peak (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
-# SURVEY §8(d) / BASELINE.md §3: esrgan fwd+bwd per LR patch
-GFLOP_PER_PATCH = 440.56
-ALGO_MB_PER_PATCH = 2852.8
+# algorithmic GFLOP per LR patch (fwd + bwd) of the generator / of one D fwd + full bwd / VGG taps
+GFLOP_G = {"compact": 15.20, "esrgan": 440.56, "swinir_medium": 321.30, "hat_l": 1217.89}
+GFLOP_UNET_FWD_BWD = 155.30
+GFLOP_VGG = 153.0
+ALGO_MB_PER_PATCH = {"esrgan": 2852.8}
+
+ALIASES = {"paired_l1": "bench_esrgan", "otf_gan": "bench_esrgan_otf_gan", "swinir_percep": "bench_swinir_medium"}
+
+CLASS_NAMES = [
+    "conv3x3_glds_kernel (forward launches)", "conv3x3_glds_kernel (backward-data launches)",
+    "conv3x3_wgrad_multi_kernel", "conv3x3_wgrad_reduce_kernel",
+    "staged + thin conv kernels (forward)", "staged + thin conv kernels (backward-data)",
+    "gemm NT (nn.Linear forward)", "gemm NN (nn.Linear backward-data)", "gemm TN (nn.Linear backward-weight)",
+    "window attention forward", "window attention backward",
+]
+# rocprofv3 symbol a class is launched as (for the PMC traffic lookup / the profiles cross-check)
+CLASS_SYMBOL = ["conv3x3_glds_kernel", "conv3x3_glds_kernel", "conv3x3_wgrad_multi_kernel", "conv3x3_wgrad_reduce_kernel",
+                "conv3x3_mfma_kernel", "conv3x3_mfma_kernel", "gemm_nt_glds_kernel", "gemm_mfma_kernel<1>",
+                "gemm_mfma_kernel<2>", "attention_fwd", "attention_bwd"]
+COMPUTE_CLASSES = (0, 1, 2, 4, 5, 6, 7, 8, 9, 10)
 
 
-def make_opt(batch: int, world: int, rank: int, arch: str) -> dict:
-    nets = {
-        "esrgan": {"type": "esrgan"},
-        "esrgan_small": {"type": "esrgan", "num_block": 2, "num_feat": 32, "num_grow_ch": 16},
-        "compact": {"type": "compact"},
-        "swinir_small": {"type": "swinir_small"},
-        "swinir_medium": {"type": "swinir_medium"},
-        "hat_s": {"type": "hat_s"},
-        "hat_m": {"type": "hat_m"},
-        "hat_l": {"type": "hat_l"},
-    }
-    return {
-        "name": f"bench_{arch}", "model_type": "image", "scale": 4, "manual_seed": 1024,
-        "is_train": True, "dist": world > 1, "rank": rank, "world_size": world, "num_gpu": world,
-        "datasets": {"train": {"type": "paired", "patch_size": 64, "batch_size": batch,
-                               "phase": "train", "scale": 4}},
-        "path": {},
-        "network_g": nets[arch],
-        "train": {"ema": 0.999, "grad_clip": True,
-                  "optim_g": {"type": "adamw", "lr": 1e-4, "betas": [0.9, 0.99], "weight_decay": 0.0},
-                  "pixel_opt": {"type": "L1Loss", "loss_weight": 1.0}},
-        "logger": {"total_iter": 1000000, "print_freq": 100, "save_checkpoint_freq": 100000,
-                   "use_tb_logger": False},
-    }
+def free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
 
 
-def pmc_traffic(kernel_class: str) -> dict | None:
-    """HBM traffic per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (tools/profile_round.sh -> profiles/*_pmc_summary.json; bench.py cannot drive rocprofv3 on
-    itself).  FETCH_SIZE is doubled as MI355X_MICROARCH.md §HBM prescribes for gfx950 (it counts
-    128-B requests at 64 B); both counters are in KiB."""
-    files = sorted((ROOT / "profiles").glob("r*_bench_pmc_summary.json"))
+def self_launch(n: int) -> None:
+    """`python bench.py --gpus N` with no launcher around it: become N ranks (one per GPU) under
+    torch.distributed.run on this node."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), str(Path(__file__).resolve()),
+           *sys.argv[1:]]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.execv(sys.executable, cmd)
+
+
+def load_opt(args, world: int, rank: int) -> dict:
+    """options/<config>.toml through parse_options (the boundary train.py uses), then the command-line
+    overrides (--batch / --arch) and the launcher facts (dist / rank / world_size)."""
+    from neosr_amd.utils.options import parse_options, set_global_opt
+
+    path = Path(args.config)
+    if not path.suffix:
+        path = ROOT / "options" / f"{args.config}.toml"
+    opt, _ = parse_options(str(ROOT), True, argv=["-opt", str(path)])
+    # the launcher is ours (torch.distributed.run env), not parse_options' `--launcher pytorch`
+    opt["dist"], opt["rank"], opt["world_size"], opt["num_gpu"] = world > 1, rank, world, world
+    if args.batch:
+        opt["datasets"]["train"]["batch_size"] = args.batch
+    if args.arch:
+        opt["network_g"] = {"esrgan_small": {"type": "esrgan", "num_block": 2, "num_feat": 32, "num_grow_ch": 16}}.get(
+            args.arch, {"type": args.arch})
+    if args.template_losses:  # the shipped template's loss stack (reference options/train_esrgan_otf.toml:118-141)
+        opt["train"].pop("pixel_opt", None)
+        opt["train"]["mssim_opt"] = {"type": "mssim_loss", "loss_weight": 1.0}
+        opt["train"]["consistency_opt"] = {"type": "consistency_loss", "loss_weight": 1.0}
+    if args.augment:  # reference options/train_esrgan_otf.toml:17-18
+        opt["datasets"]["train"].update({"augmentation": ["none", "mixup", "cutmix", "resizemix", "cutblur"],
+                                         "aug_prob": [0.5, 0.1, 0.1, 0.1, 0.5]})
+    if opt["model_type"] == "otf":  # train.py:69-70
+        opt["datasets"]["train"].update(opt.get("degradations", {}))
+    set_global_opt(opt)
+    return opt
+
+
+def describe(opt: dict) -> tuple[str, float | None]:
+    """(workload sentence, algorithmic GFLOP per LR patch of the whole iteration or None)"""
+    tr, ds = opt["train"], opt["datasets"]["train"]
+    g = opt["network_g"]["type"]
+    extra = {k: v for k, v in opt["network_g"].items() if k != "type"}
+    losses = [n for k, n in (("pixel_opt", "L1"), ("mssim_opt", "mssim"), ("consistency_opt", "consistency"),
+                             ("perceptual_opt", "VGG19 perceptual (seeded-random weights)"), ("gan_opt", "GAN (bce)"))
+              if tr.get(k)]
+    s = f"{g}{extra or ''} x{opt['scale']}, "
+    s += ("otf degradation from 512x512 GT (options/train_esrgan_otf.toml [degradations]) -> 64x64 LR"
+          if opt["model_type"] == "otf" else "paired 64x64 LR synthetic (U[0,1))")
+    s += ", " + " + ".join(losses)
+    if opt.get("network_d"):
+        s += f", {opt['network_d']['type']} (spectral norm) discriminator"
+    s += f", {tr['optim_g']['type']} + grad-clip + EMA, batch={ds['batch_size']}/GPU"
+    gf = GFLOP_G.get(g) if not extra else None
+    if gf is not None:
+        if tr.get("perceptual_opt"):
+            gf += GFLOP_VGG
+        if opt.get("network_d"):  # G phase: D fwd + data-gradient; D phase: 2 x (fwd + full bwd)
+            gf += GFLOP_UNET_FWD_BWD * (2.0 / 3.0 + 2.0)
+    return s, gf
+
+
+def pmc_traffic(cfg_name: str, symbol: str) -> dict | None:
+    """HBM traffic per launch of a kernel from the committed rocprofv3 PMC passes of THIS config
+    (tools/profile_round.sh -> profiles/rNN_<config>_pmc_summary.json; bench.py cannot drive rocprofv3 on
+    itself, so this is a citation of the latest committed measurement, named in `source`).  FETCH_SIZE is doubled
+    as MI355X_MICROARCH.md §HBM prescribes for gfx950 (it counts 128-B requests at 64 B); both counters are in KiB."""
+    files = sorted((ROOT / "profiles").glob(f"r*_{cfg_name}_pmc_summary.json"))
+    if not files and cfg_name == "bench_esrgan":
+        files = sorted((ROOT / "profiles").glob("r*_bench_pmc_summary.json"))
     if not files:
         return None
     summ = json.loads(files[-1].read_text())
-    # forward and backward-data launches of the RDB trunk are the same kernel symbol (gather form)
-    want = "conv3x3_wgrad_multi_kernel" if "wgrad" in kernel_class else "conv3x3_glds_kernel"
     hits = [(d.get("dispatches_fetch", 0), name, d) for name, d in summ.items()
-            if want in name and "FETCH_SIZE_per_dispatch" in d]
+            if symbol in name and "FETCH_SIZE_per_dispatch" in d]
     if not hits:
         return None
-    _, name, d = max(hits, key=lambda h: h[0])  # the instantiation the RDB trunk launches
+    _, name, d = max(hits, key=lambda h: h[0])  # the instantiation launched most
     rd = 2.0 * d["FETCH_SIZE_per_dispatch"] * 1024
     wr = d.get("WRITE_SIZE_per_dispatch", 0.0) * 1024
     return {"bytes_per_launch": round(rd + wr), "read": round(rd), "write": round(wr),
             "source": files[-1].name, "kernel": name[:96]}
 
 
-def cpu_baseline(arch: str, budget_s: float) -> dict:
-    """Time the CPU oracle on a bounded sample of the same workload (B=1 batches of the same shapes)."""
-    from oracle import neosr_oracle as orc
-    from neosr_amd.archs import build_network
+def make_batch(opt: dict, dev, rank: int) -> dict:
+    import torch
 
+    B = opt["datasets"]["train"]["batch_size"]
+    if opt["model_type"] == "otf":
+        import random
+
+        import numpy as np
+
+        from neosr_amd.data.degradations import KernelSampler
+        random.seed(1024 + rank)
+        ks = KernelSampler(np.random.default_rng(1024 + rank)).otf_kernel_batch(opt["datasets"]["train"], B)
+        return {"gt": torch.rand(B, 3, 512, 512, device=dev), **{k: v.to(dev) for k, v in ks.items()}}
+    return {"lq": torch.rand(B, 3, 64, 64, device=dev), "gt": torch.rand(B, 3, 256, 256, device=dev)}
+
+
+def cpu_baseline(opt: dict, budget_s: float) -> dict:
+    """Time the CPU oracle (oracle/step_oracle.py) on a bounded sample of the same workload: the same iteration
+    (same nets, losses, optimizers, otf degradation) at a CPU-feasible batch."""
+    import copy
+
+    import torch
+
+    from neosr_amd.archs import build_network
+    from neosr_amd.data.draws import LiveDraws
+    from oracle import gan_oracle as gorc
+    from oracle.step_oracle import ConfigTrainer
+
+    g = opt["network_g"]["type"]
+    b = 2 if g in ("esrgan", "compact") and not opt.get("network_d") else 1
+    o = copy.deepcopy(opt)
+    o["datasets"]["train"]["batch_size"] = b
+    o["datasets"]["train"]["queue_size"] = b  # the pair pool never changes the work per iteration
     torch.manual_seed(1024)
-    net = build_network({"type": arch} if arch != "esrgan_small" else
-                        {"type": "esrgan", "num_block": 2, "num_feat": 32, "num_grow_ch": 16})
-    params = {k: v.detach().clone() for k, v in net.state_dict().items()}
-    fwd = (lambda P, x: orc.compact_forward(P, x, 4, "prelu")) if arch == "compact" else (
-        lambda P, x: orc.rrdbnet_forward(P, x, 4))
-    tr = orc.ImageTrainer(fwd, params, lr=1e-4, betas=(0.9, 0.99), weight_decay=0.0, ema=0.999)
-    b = 2
-    lq, gt = torch.rand(b, 3, 64, 64), torch.rand(b, 3, 256, 256)
-    tr.feed_data(lq, gt)
+    net = build_network(dict(opt["network_g"]))
+    gp = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    dp = None
+    if opt.get("network_d"):
+        dp = {k: v.detach().clone() for k, v in build_network(dict(opt["network_d"])).state_dict().items()}
+    vgg = gorc.vgg_seeded_weights() if opt["train"].get("perceptual_opt") else None
+    tr = ConfigTrainer(o, gp, dp, vgg, draws=LiveDraws(1024, "cpu"))
+    batch = {k: v[:b].cpu() for k, v in make_batch(o, "cpu", 0).items()}
+    t0 = time.perf_counter()
+    tr.feed_data(batch)
     tr.optimize_parameters()  # warm-up
+    warm = time.perf_counter() - t0
     n, t0 = 0, time.perf_counter()
     while True:
-        tr.feed_data(lq, gt)
+        tr.feed_data(batch)
         tr.optimize_parameters()
         n += 1
         el = time.perf_counter() - t0
-        if el > budget_s or n >= 6:
+        if el > budget_s or el + warm > 1.5 * budget_s or n >= 6:
             break
     return {"value": round(n * b / el, 4), "unit": "LR-patches/s", "cores": torch.get_num_threads(),
             "kind": "port",
-            "sample": f"{n} iterations of the same training step at batch {b} (64x64 LR -> 256x256), "
-                      f"torch {torch.__version__} CPU fp32, after 1 warm-up; host has {os.cpu_count()} logical cpus"}
+            "sample": f"{n} iteration(s) of the same training step at batch {b} (64x64 LR -> 256x256"
+                      f"{', incl. the otf degradation of 512x512 GT' if opt['model_type'] == 'otf' else ''}), "
+                      f"oracle/step_oracle.py on torch {torch.__version__} CPU fp32, after 1 warm-up; "
+                      f"host has {os.cpu_count()} logical cpus"}
 
 
 def main() -> None:
@@ -123,84 +223,66 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=16, help="per-GPU batch (BASELINE configs[1]: 16)")
-    ap.add_argument("--arch", default="esrgan", choices=["esrgan", "esrgan_small", "compact", "swinir_small", "swinir_medium", "hat_s", "hat_m", "hat_l"])
-    ap.add_argument("--workload", default="paired_l1", choices=["paired_l1", "otf_gan", "swinir_percep"],
-                    help="paired_l1 = BASELINE configs[1] (headline); otf_gan = configs[2]: otf degradation + "
-                         "unet D + VGG perceptual + GAN (use --batch 32; with --arch hat_l --batch 4 = configs[4]); swinir_percep = configs[3]: "
-                         "swinir_medium, L1 + VGG perceptual (use --batch 8)")
+    ap.add_argument("--config", default=None,
+                    help="option file: a name under options/ (bench_esrgan [default], bench_compact, bench_esrgan_otf_gan, "
+                         "bench_swinir_medium, bench_hat_l_otf_gan) or a path to a neosr TOML")
+    ap.add_argument("--workload", default=None, choices=list(ALIASES), help="round-1 spelling of --config")
+    ap.add_argument("--batch", type=int, default=0, help="override datasets.train.batch_size (per GPU)")
+    ap.add_argument("--arch", default=None, help="override network_g.type (not the named config any more)")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU-oracle timing (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--template-losses", action="store_true",
-                    help="otf_gan: the shipped template loss stack (options/train_esrgan_otf.toml:118-141): "
-                         "mssim + consistency + perceptual + gan, no L1")
-    ap.add_argument("--augment", action="store_true",
-                    help="also enable the template batch augmentations (options/train_esrgan_otf.toml:17-18)")
+                    help="the shipped template loss stack instead of L1: mssim + consistency (+ perceptual + gan)")
+    ap.add_argument("--augment", action="store_true", help="also enable the template batch augmentations")
     args = ap.parse_args()
+    if args.config is None:
+        args.config = ALIASES.get(args.workload, "bench_esrgan")
+        if args.workload == "otf_gan" and (args.arch or "").startswith("hat_l"):
+            args.config, args.arch = "bench_hat_l_otf_gan", None
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus)  # does not return
+
+    import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (MI355X); there is no CPU fallback")
-    torch.cuda.set_device(local % torch.cuda.device_count())
+    backend = os.environ.get("NEOSR_BENCH_BACKEND", "nccl")  # "nccl" IS RCCL on ROCm
+    ndev = torch.cuda.device_count()
+    if world > 1 and backend == "nccl" and ndev < world:
+        raise SystemExit(f"bench.py: {world} ranks need {world} GPUs, {ndev} visible "
+                         "(NEOSR_BENCH_BACKEND=gloo shares one device for a control-flow smoke test)")
+    torch.cuda.set_device(local % ndev)
+    dev = torch.device("cuda", local % ndev)
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # "nccl" is RCCL on ROCm; NEOSR_BENCH_BACKEND=gloo lets the control flow be exercised with several
-        # ranks on ONE device (RCCL refuses duplicate GPUs)
-        dist.init_process_group(os.environ.get("NEOSR_BENCH_BACKEND", "nccl"))
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+        dist.init_process_group(backend)
+        assert dist.get_world_size() == args.gpus
+        mine = f"rank{rank}:cuda:{local % ndev}:{torch.cuda.get_device_name(dev)}"
+        devices: list = [None] * world
+        dist.all_gather_object(devices, mine)
+    else:
+        devices = [f"rank0:cuda:{local % ndev}:{torch.cuda.get_device_name(dev)}"]
 
     from neosr_amd import _C
     from neosr_amd.models import build_model
-    from neosr_amd.utils.options import set_global_opt
 
     import logging
     logging.getLogger("neosr").setLevel(logging.WARNING)
 
-    if args.workload == "swinir_percep" and not args.arch.startswith("swinir"):
-        args.arch = "swinir_medium"
-    opt = make_opt(args.batch, world, rank, args.arch)
-    if args.workload == "swinir_percep":
-        opt["train"]["perceptual_opt"] = {"type": "vgg_perceptual_loss", "loss_weight": 1.0, "criterion": "chc"}
-        opt["train"]["optim_g"] = {"type": "adan_sf", "lr": 1e-3, "betas": [0.98, 0.92, 0.987], "weight_decay": 0.02,
-                                   "schedule_free": True, "warmup_steps": 1600}
-    if args.workload == "otf_gan":
-        from tools.bench_degrade import DEG_TABLE
-        opt["model_type"] = "otf"
-        opt["degradations"] = dict(DEG_TABLE)
-        opt["datasets"]["train"].update({"type": "otf", "queue_size": 180})
-        opt["network_d"] = {"type": "unet"}
-        # template optimizers (options/train_esrgan_otf.toml:103-117)
-        opt["train"]["optim_g"] = {"type": "adan_sf", "lr": 8e-4, "betas": [0.98, 0.92, 0.987], "weight_decay": 0.02,
-                                   "schedule_free": True, "warmup_steps": 1600}
-        opt["train"]["optim_d"] = {"type": "adan_sf", "lr": 5e-4, "betas": [0.98, 0.92, 0.99], "weight_decay": 0.02,
-                                   "schedule_free": True}
-        opt["train"]["perceptual_opt"] = {"type": "vgg_perceptual_loss", "loss_weight": 0.5, "criterion": "chc"}
-        opt["train"]["gan_opt"] = {"type": "gan_loss", "gan_type": "bce", "loss_weight": 0.3}
-    if args.template_losses:
-        opt["train"].pop("pixel_opt", None)
-        opt["train"]["mssim_opt"] = {"type": "mssim_loss", "loss_weight": 1.0}
-        opt["train"]["consistency_opt"] = {"type": "consistency_loss", "loss_weight": 1.0}
-    if args.augment:
-        opt["datasets"]["train"].update({"augmentation": ["none", "mixup", "cutmix", "resizemix", "cutblur"],
-                                         "aug_prob": [0.5, 0.1, 0.1, 0.1, 0.5]})
-    set_global_opt(opt)
+    opt = load_opt(args, world, rank)
+    cfg_name = Path(args.config).stem
     torch.manual_seed(1024 + rank)
     model = build_model(opt)
-    dev = torch.device("cuda")
-    B = args.batch
-    if args.workload == "otf_gan":
-        import random
-        import numpy as np
-        from neosr_amd.data.degradations import KernelSampler
-        random.seed(1024 + rank)
-        ks = KernelSampler(np.random.default_rng(1024 + rank)).otf_kernel_batch(opt["degradations"], B)
-        batch = {"gt": torch.rand(B, 3, 512, 512, device=dev), **{k: v.to(dev) for k, v in ks.items()}}
-    else:
-        batch = {"lq": torch.rand(B, 3, 64, 64, device=dev), "gt": torch.rand(B, 3, 256, 256, device=dev)}
+    B = opt["datasets"]["train"]["batch_size"]
+    batch = make_batch(opt, dev, rank)
 
     def step(it: int) -> None:
         model.feed_data(batch)
@@ -208,7 +290,6 @@ def main() -> None:
 
     def barrier() -> None:
         if world > 1:
-            import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -224,15 +305,16 @@ def main() -> None:
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        import torch.distributed as dist
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    loss = model.get_current_log().get("l_g_pix", model.get_current_log().get("l_g_total"))
+    log = model.get_current_log()
+    loss = log.get("l_g_pix", log.get("l_g_total"))
 
+    workload, gflop_patch = describe(opt)
     roofline = None
     # every rank runs the profiled steps (they contain the gradient all-reduce); rank 0 reports
-    if not args.no_roofline and not args.arch.startswith(("swinir", "hat")):
+    if not args.no_roofline:
         lib = _C.load()
         # per-kernel durations are only meaningful without overlap: the trunk's launch chains are put
         # back on one stream for this pass (the timed region above ran the default, two chains)
@@ -242,52 +324,46 @@ def main() -> None:
         for _ in range(nprof):
             it += 1
             step(it)
-        ms = (C.c_double * 6)()
-        ln = (C.c_longlong * 6)()
-        fl = (C.c_double * 6)()
-        by = (C.c_double * 6)()
+        nc = lib.neosr_prof_num_classes()
+        ms, ln, fl, by = (C.c_double * nc)(), (C.c_longlong * nc)(), (C.c_double * nc)(), (C.c_double * nc)()
         _C.check(lib.neosr_prof_collect(ms, ln, fl, by), "neosr_prof_collect")
         lib.neosr_prof_enable(0)
         lib.neosr_set_num_streams(prev_streams)
-        # classes 0 / 1 are the two uses of ONE kernel symbol (the gather-form backward-data is a forward-shaped
-        # launch); 4 / 5 are the few staged / thin launches outside the RDB trunk
-        names = ["conv3x3_glds_kernel (forward launches)", "conv3x3_glds_kernel (backward-data launches)",
-                 "conv3x3_wgrad_multi_kernel", "conv3x3_wgrad_reduce_kernel",
-                 "staged + thin conv kernels (forward)", "staged + thin conv kernels (backward-data)"]
         kern = {}
-        for i, nm in enumerate(names):
+        for i in range(nc):
             if ln[i]:
-                kern[nm] = {"launches": int(ln[i]), "avg_us": round(1e3 * ms[i] / ln[i], 2),
-                            "total_ms": round(ms[i], 3),
-                            "tflops": round(fl[i] / (ms[i] * 1e9), 2) if ms[i] > 0 else None,
-                            "algo_GBps": round(by[i] / (ms[i] * 1e6), 1) if ms[i] > 0 else None}
-        dom = max(range(3), key=lambda i: ms[i])
+                kern[CLASS_NAMES[i]] = {"launches": int(ln[i]), "avg_us": round(1e3 * ms[i] / ln[i], 2),
+                                        "total_ms": round(ms[i], 3),
+                                        "tflops": round(fl[i] / (ms[i] * 1e9), 2) if ms[i] > 0 and fl[i] else None,
+                                        "algo_GBps": round(by[i] / (ms[i] * 1e6), 1) if ms[i] > 0 and by[i] else None}
+        dom = max(COMPUTE_CLASSES, key=lambda i: ms[i])
         ach = fl[dom] / (ms[dom] * 1e9) if ms[dom] > 0 else 0.0
-        allms = sum(ms[i] for i in (0, 1, 2, 4, 5))
-        allfl = sum(fl[i] for i in (0, 1, 2, 4, 5))
-        glds_avg = 1e3 * (ms[0] + ms[1]) / max(1, ln[0] + ln[1])
-        tr = pmc_traffic(names[dom]) if args.arch == "esrgan" and B == 16 else None
-        roofline = {"bound": "mfma", "kernel": names[dom], "achieved": round(ach, 2),
+        allms = sum(ms[i] for i in COMPUTE_CLASSES)
+        allfl = sum(fl[i] for i in COMPUTE_CLASSES)
+        tr = pmc_traffic(cfg_name, CLASS_SYMBOL[dom]) if not (args.batch or args.arch) else None
+        step_s = elapsed / args.steps
+        roofline = {"bound": "mfma", "kernel": CLASS_NAMES[dom], "achieved": round(ach, 2),
                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
                     "traffic": tr["bytes_per_launch"] if tr else None, "traffic_detail": tr,
                     "algo_bytes_per_launch": round(by[dom] / max(1, ln[dom])),
                     "avg_launch_us": round(1e3 * ms[dom] / max(1, ln[dom]), 2),
-                    # all launches of the symbol, directly comparable with the rocprofv3 row of conv3x3_glds_kernel
-                    "conv3x3_glds_kernel_avg_us": round(glds_avg, 2),
-                    "all_conv_tflops": round(allfl / (allms * 1e9), 2) if allms > 0 else None,
-                    # whole step as timed (two launch chains, loss + optimizer included)
-                    "step_tflops": round(allfl / nprof / (elapsed / args.steps * 1e12), 2),
-                    "step_frac": round(allfl / nprof / (elapsed / args.steps * 1e12) / PEAK_F32_MFMA_TFLOPS, 4),
+                    "all_mfma_kernels_tflops": round(allfl / (allms * 1e9), 2) if allms > 0 else None,
+                    "mfma_kernel_share_of_profiled_step": round(allms / nprof / (step_s * 1e3), 4),
+                    # whole step as timed (launch chains, losses, optimizer, all-reduce included); FLOPs = the MFMA
+                    # kernels' algorithmic FLOPs as counted at their launches
+                    "step_tflops": round(allfl / nprof / (step_s * 1e12), 2),
+                    "step_frac": round(allfl / nprof / (step_s * 1e12) / PEAK_F32_MFMA_TFLOPS, 4),
                     "hbm_algo_frac_of_8TBps": round((by[dom] / (ms[dom] * 1e6)) / PEAK_HBM_GBS, 4) if ms[dom] > 0 else None,
                     "kernels": kern,
                     "method": "HIP events around every launch of the class on the launch stream, separate "
                               "profiled pass after the timed region with the trunk on ONE stream "
-                              "(neosr_set_num_streams(1)); profiles/r01_bench_kernel_stats.csv is rocprofv3 of "
-                              "`NEOSR_AMD_STREAMS=1 python bench.py`, ..._2chains.csv of the default run"}
+                              "(neosr_set_num_streams(1)); profiles/r02_<config>_kernel_stats.csv is rocprofv3 "
+                              "--kernel-trace --stats of `NEOSR_AMD_STREAMS=1 python bench.py --config <config>`"}
+        if ms[0] + ms[1] > 0:  # all launches of the symbol, directly comparable with its rocprofv3 row
+            roofline["conv3x3_glds_kernel_avg_us"] = round(1e3 * (ms[0] + ms[1]) / max(1, ln[0] + ln[1]), 2)
 
     if world > 1:
-        import torch.distributed as dist
         dist.barrier()
         if rank != 0:
             dist.destroy_process_group()
@@ -295,36 +371,34 @@ def main() -> None:
         return
     patches = world * B * args.steps
     value = patches / elapsed
+    named = not (args.batch or args.arch or args.template_losses or args.augment)
     out = {
         "metric": "LR-patches/sec (64x64 -> 256x256 x4) fwd+bwd+optimizer step",
         "value": round(value, 3), "unit": "LR-patches/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": f"{args.arch} RRDB x4, paired 64x64 LR synthetic (U[0,1)), L1 only, "
-                               f"AdamW + grad-clip + EMA, batch={B}/GPU (BASELINE configs[1])"
-                   if args.arch == "esrgan" else f"{args.arch} x4 L1 batch={B}/GPU (not the headline config)",
-                   "global_batch": B * world, "parallelism": f"dp{world}",
-                   "gflop_per_patch": GFLOP_PER_PATCH if args.arch == "esrgan" else None},
-        "whole_step_tflops": round(value * GFLOP_PER_PATCH / 1e3, 2) if args.arch == "esrgan" else None,
-        "final_l_g_pix": loss,
+        "config": {"workload": workload + (f" ({opt_doc(cfg_name)})" if named else " (NOT a named BASELINE config)"),
+                   "options_file": f"options/{cfg_name}.toml" if (ROOT / "options" / f"{cfg_name}.toml").exists() else args.config,
+                   "global_batch": B * world, "parallelism": f"dp{world}", "ranks": world, "backend": backend if world > 1 else None,
+                   "devices": devices, "gflop_per_patch": gflop_patch},
+        "whole_step_tflops": round(value / world * gflop_patch / 1e3, 2) if gflop_patch else None,
+        "final_loss": loss,
         "roofline": roofline,
     }
-    if args.workload == "otf_gan":
-        cfg = "configs[4]" if args.arch.startswith("hat") else "configs[2]"
-        out["config"]["workload"] = (f"{args.arch} x4 + unet-SN D + VGG19 perceptual (random weights) + GAN, "
-                                     f"otf degradation from 512x512 GT, adan_sf x2 (template), batch={B}/GPU (BASELINE {cfg})")
-    if args.workload == "swinir_percep":
-        out["config"]["workload"] = (f"{args.arch} x4, paired 64x64 LR synthetic, L1 + VGG19 perceptual (random weights), "
-                                     f"window-attention path, adan_sf (template) + grad-clip + EMA, batch={B}/GPU (BASELINE configs[3])")
-    if world == 1 and args.cpu_budget > 0 and args.workload == "paired_l1" and not args.arch.startswith(("swinir", "hat")):
-        out["cpu_baseline"] = cpu_baseline(args.arch, args.cpu_budget)
+    if world == 1 and args.cpu_budget > 0:
+        out["cpu_baseline"] = cpu_baseline(opt, args.cpu_budget)
     else:
         out["cpu_baseline"] = None
     print(json.dumps(out))
     if world > 1:
-        import torch.distributed as dist
         dist.destroy_process_group()
+
+
+def opt_doc(cfg_name: str) -> str:
+    return {"bench_compact": "BASELINE configs[0]", "bench_esrgan": "BASELINE configs[1]",
+            "bench_esrgan_otf_gan": "BASELINE configs[2]", "bench_swinir_medium": "BASELINE configs[3]",
+            "bench_hat_l_otf_gan": "BASELINE configs[4]"}.get(cfg_name, cfg_name)
 
 
 if __name__ == "__main__":

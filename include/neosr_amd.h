@@ -590,8 +590,10 @@ int neosr_fsam_first_step(const neosr_fsam_desc* d, void* stream);
 /* opt-in profiler ------------------------------------------------------------------------------
  * HIP events around every conv-class launch on the launch stream (classes: 0 / 1 forward / backward-data
  * launches of conv3x3_glds_kernel, 2 weight gradient, 3 its reduce, 4 / 5 forward / backward-data launches
- * of the staged and thin kernels).  Used by bench.py's roofline pass only.  collect() synchronises the
- * device and fills 6-element arrays. */
+ * of the staged and thin kernels, 6 / 7 / 8 nn.Linear forward / backward-data / backward-weight GEMMs, 9 / 10
+ * window-attention forward / backward kernels).  Used by bench.py's roofline pass only.  collect()
+ * synchronises the device and fills neosr_prof_num_classes()-element arrays. */
+int neosr_prof_num_classes(void);
 int neosr_prof_enable(int on);
 int neosr_prof_collect(double* ms, long long* launches, double* flops, double* bytes);
 
@@ -619,6 +621,17 @@ int neosr_rrdbnet_forward(const neosr_rrdbnet_cfg* cfg, const float* const* para
 int neosr_rrdbnet_backward(const neosr_rrdbnet_cfg* cfg, const float* const* params,
                            float* const* grads, const float* gy, float* gx, void* workspace,
                            void* stream);
+/* The same backward with gradient marks for the data-parallel path (the reference gets this from
+ * DistributedDataParallel's bucketed all-reduce during backward, neosr/models/base.py:140-146): backward walks
+ * the parameters from the end of the arena to its start, so after RRDB `mark_block[i]` the gradients of
+ * body.<mark_block[i]>.* and of every parameter behind it (later RRDBs, conv_body .. conv_last) are final.
+ * mark_event[i] is a caller-owned hipEvent_t that the plan records at that point on the stream that writes the
+ * weight gradients; the caller makes its communication stream wait on it and reduces that suffix of the flat
+ * gradient arena while the earlier RRDBs are still in backward.  n_marks = 0 is neosr_rrdbnet_backward. */
+int neosr_rrdbnet_backward_marked(const neosr_rrdbnet_cfg* cfg, const float* const* params,
+                                  float* const* grads, const float* gy, float* gx, void* workspace,
+                                  void* stream, int32_t n_marks, const int32_t* mark_block,
+                                  void* const* mark_event);
 /* The RRDB trunk runs the two halves of the batch as independent launch chains on the caller's stream
  * and one internal stream (fork / join by events; results do not depend on the setting).  n = 1
  * keeps everything on the caller's stream (used for per-kernel timing); returns the previous n. */

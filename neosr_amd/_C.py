@@ -320,6 +320,7 @@ SIGNATURES: dict[str, tuple] = {
     "neosr_lerp": (C.c_int, [_vp, _vp, _i64, _f32, _vp]),
     "neosr_optim_step": (C.c_int, [C.POINTER(OptimDesc), _vp]),
     "neosr_fsam_first_step": (C.c_int, [C.POINTER(FsamDesc), _vp]),
+    "neosr_prof_num_classes": (C.c_int, []),
     "neosr_prof_enable": (C.c_int, [C.c_int]),
     "neosr_prof_collect": (
         C.c_int,
@@ -331,6 +332,10 @@ SIGNATURES: dict[str, tuple] = {
     "neosr_rrdbnet_backward": (
         C.c_int,
         [C.POINTER(RRDBNetCfg), c_void_pp, c_void_pp, _vp, _vp, _vp, _vp],
+    ),
+    "neosr_rrdbnet_backward_marked": (
+        C.c_int,
+        [C.POINTER(RRDBNetCfg), c_void_pp, c_void_pp, _vp, _vp, _vp, _vp, _i32, C.POINTER(C.c_int32), c_void_pp],
     ),
     "neosr_compact_workspace_bytes": (_i64, [C.POINTER(CompactCfg)]),
     "neosr_compact_num_params": (_i32, [C.POINTER(CompactCfg)]),

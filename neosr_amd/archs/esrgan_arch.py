@@ -74,5 +74,6 @@ class esrgan(HipNet):
             feat = pixel_unshuffle(x, scale=4)
         else:
             feat = x
-        hp = dict(self._hp, training=self.training)
+        # `_neosr_grad_sync`: set by the model on data-parallel runs (overlapped all-reduce of the gradient arena)
+        hp = dict(self._hp, training=self.training, sync=getattr(self, "_neosr_grad_sync", None))
         return RRDBNetFunction.apply(feat, hp, *self._plan_params())

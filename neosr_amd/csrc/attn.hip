@@ -12,6 +12,7 @@
 // Softmax statistics (log-sum-exp per row) are the only thing kept for backward; P is recomputed.
 #include "common.h"
 #include "../../include/neosr_amd.h"
+#include "prof.h"
 
 namespace {
 
@@ -493,7 +494,11 @@ extern "C" int neosr_window_attention_fwd(const neosr_wattn_desc* d, void* strea
   if (int rc = wattn_check(d)) return rc;
   NEOSR_CHECK(d->out, "window_attention_fwd: out missing");
   const int nblk = d->B * (d->H / WS) * (d->W / WS) * d->heads;
+  const bool prof = neosr_prof_on();
+  const double tok = (double)d->B * d->H * d->W;  // Q.K^T + P.V: 4 * 64 * head_dim FLOP per (token, head)
+  if (prof) neosr_prof_begin(NEOSR_PROF_ATTN_FWD, stream, 4.0 * WS * WS * tok * d->C, 4.0 * tok * 4 * d->C);
   hipLaunchKernelGGL(window_attention_fwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, *d);
+  if (prof) neosr_prof_end(stream);
   NEOSR_LAUNCH_CHECK();
   return 0;
 }
@@ -502,7 +507,11 @@ extern "C" int neosr_window_attention_bwd(const neosr_wattn_desc* d, void* strea
   if (int rc = wattn_check(d)) return rc;
   NEOSR_CHECK(d->dout && d->dqkv && d->lse && d->d_rpb_table && d->workspace, "window_attention_bwd: null tensor");
   const int nbw = d->B * (d->H / WS) * (d->W / WS);
+  const bool prof = neosr_prof_on();
+  const double tok = (double)d->B * d->H * d->W;  // dP, dV, dQ, dK: four products (the recomputed P is not counted)
+  if (prof) neosr_prof_begin(NEOSR_PROF_ATTN_BWD, stream, 8.0 * WS * WS * tok * d->C, 4.0 * tok * 7 * d->C);
   hipLaunchKernelGGL(window_attention_bwd_kernel, dim3(nbw * d->heads), dim3(256), 0, (hipStream_t)stream, *d);
+  if (prof) neosr_prof_end(stream);
   NEOSR_LAUNCH_CHECK();
   // d_table[bin][head] (+)= column sums of the [nbw][bin*heads + head] per-window matrix (fixed order)
   const int cols = NB * d->heads;

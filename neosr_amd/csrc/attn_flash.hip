@@ -18,6 +18,7 @@
 // gather per table row.  No float atomics anywhere.
 #include "common.h"
 #include "../../include/neosr_amd.h"
+#include "prof.h"
 
 namespace {
 
@@ -555,9 +556,13 @@ int launch_bwd(const neosr_fattn_desc& d, hipStream_t st) {
   using G = Geo<WS, KS>;
   const BwdWs ws = bwd_ws(d);
   const int bw = d.B * (d.H / WS) * (d.W / WS);
+  const bool prof = neosr_prof_on();
+  const double tok = (double)d.B * d.H * d.W;  // dP, dV, dQ, dK over KS*KS keys per query (recompute not counted)
+  if (prof) neosr_prof_begin(NEOSR_PROF_ATTN_BWD, (void*)st, 8.0 * KS * KS * tok * d.C, 4.0 * tok * 8 * d.C);
   hipLaunchKernelGGL((flash_wattn_bwd_dq_kernel<WS, KS>), dim3(bw * d.heads * G::NQB), dim3(256), 0, st, d, ws);
   NEOSR_LAUNCH_CHECK();
   hipLaunchKernelGGL((flash_wattn_bwd_dkv_kernel<WS, KS>), dim3(bw * d.heads * G::NKB), dim3(256), 0, st, d, ws);
+  if (prof) neosr_prof_end((void*)st);
   NEOSR_LAUNCH_CHECK();
   if (!G::SELF) {
     const int64_t total = (int64_t)d.B * d.H * d.W * 2 * d.C;
@@ -596,10 +601,15 @@ extern "C" int neosr_flash_window_attention_fwd(const neosr_fattn_desc* d, void*
   if (int rc = check(d)) return rc;
   NEOSR_CHECK(d->out, "flash_window_attention_fwd: out missing");
   const int nblk = d->B * (d->H / 16) * (d->W / 16) * d->heads * 4;
+  const bool prof = neosr_prof_on();
+  if (prof)
+    neosr_prof_begin(NEOSR_PROF_ATTN_FWD, stream, 4.0 * d->ks * d->ks * (double)d->B * d->H * d->W * d->C,
+                     4.0 * (double)d->B * d->H * d->W * 4 * d->C);
   if (d->ks == 16)
     hipLaunchKernelGGL((flash_wattn_fwd_kernel<16, 16>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, *d);
   else
     hipLaunchKernelGGL((flash_wattn_fwd_kernel<16, 24>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, *d);
+  if (prof) neosr_prof_end(stream);
   NEOSR_LAUNCH_CHECK();
   return 0;
 }

@@ -7,10 +7,12 @@ mkdir -p "$OUT"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
 OBJS=""
+PIDS=""
 for f in api prof conv_mfma conv_glds conv_thin wgrad elementwise degrade layers gemm_mfma attn attn_flash cab augment ssim color losses optim nets; do
   "$HIPCC" $FLAGS -c "$HERE/$f.hip" -o "$OUT/$f.o" "$@" &
+  PIDS="$PIDS $!"
   OBJS="$OBJS $OUT/$f.o"
 done
-wait
+for p in $PIDS; do wait "$p" || { echo "compile failed" >&2; exit 1; }; done
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC $OBJS -o "$OUT/libneosr_amd.so"
 echo "built $OUT/libneosr_amd.so"

@@ -16,6 +16,7 @@
 // (qkv / proj Linears), and the same layers of neosr/archs/hat_arch.py.
 #include "common.h"
 #include "../../include/neosr_amd.h"
+#include "prof.h"
 
 namespace {
 
@@ -405,6 +406,10 @@ extern "C" int neosr_gemm(const neosr_gemm_desc* dp, void* stream) {
   a.tiles_m = ceil_div(d.M, BM);
   a.tiles_n = ceil_div(d.N, BN);
   dim3 grid(ceil_div(a.tiles_m * a.tiles_n, 8) * 8, 1, 1);
+  const bool prof = neosr_prof_on();
+  if (prof)  // algorithmic work of the product itself: 2MNK FLOP, 4(MK + NK + MN) bytes
+    neosr_prof_begin(NEOSR_PROF_GEMM_NT + d.mode, stream, 2.0 * d.M * d.N * d.K,
+                     4.0 * ((double)d.M * d.K + (double)d.N * d.K + (double)d.M * d.N));
   if (d.mode == NEOSR_GEMM_NT && a.b_vec && !g_no_glds) {
     hipLaunchKernelGGL(gemm_nt_glds_kernel, grid, dim3(256), 0, st, a);
   } else if (d.mode == NEOSR_GEMM_NT) {
@@ -429,6 +434,7 @@ extern "C" int neosr_gemm(const neosr_gemm_desc* dp, void* stream) {
     float* stage = d.workspace + (int64_t)nsplit * a.slab;
     grid.x = ceil_div(nsplit, 8) * 8 * a.tiles_m * a.tiles_n;
     hipLaunchKernelGGL(gemm_mfma_kernel<2>, grid, dim3(256), 0, st, a);
+    if (prof) neosr_prof_end(stream);
     NEOSR_LAUNCH_CHECK();
     if (d.colsum_a == out + mn)
       return neosr_colsum(d.workspace, out, stage, nsplit, (int)a.slab, (int)a.slab, d.accumulate, stream);
@@ -437,6 +443,7 @@ extern "C" int neosr_gemm(const neosr_gemm_desc* dp, void* stream) {
       return neosr_colsum(d.workspace + mn, d.colsum_a, stage, nsplit, d.M, (int)a.slab, d.accumulate, stream);
     return 0;
   }
+  if (prof) neosr_prof_end(stream);
   NEOSR_LAUNCH_CHECK();
   return 0;
 }

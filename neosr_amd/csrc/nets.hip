@@ -379,9 +379,33 @@ extern "C" int neosr_rrdbnet_forward(const neosr_rrdbnet_cfg* c, const float* co
   return 0;
 }
 
+namespace {
+int rrdb_backward_impl(const neosr_rrdbnet_cfg* c, const float* const* P, float* const* Gp, const float* gy,
+                       float* gx, void* ws, void* st, int n_marks, const int32_t* mark_block,
+                       void* const* mark_event);
+}
+
 extern "C" int neosr_rrdbnet_backward(const neosr_rrdbnet_cfg* c, const float* const* P,
                                       float* const* Gp, const float* gy, float* gx, void* ws,
                                       void* st) {
+  return rrdb_backward_impl(c, P, Gp, gy, gx, ws, st, 0, nullptr, nullptr);
+}
+
+extern "C" int neosr_rrdbnet_backward_marked(const neosr_rrdbnet_cfg* c, const float* const* P,
+                                             float* const* Gp, const float* gy, float* gx, void* ws,
+                                             void* st, int32_t n_marks, const int32_t* mark_block,
+                                             void* const* mark_event) {
+  NEOSR_CHECK(n_marks >= 0 && (n_marks == 0 || (mark_block && mark_event)), "rrdbnet_backward_marked: bad marks");
+  for (int i = 0; i < n_marks; ++i)
+    NEOSR_CHECK(c && mark_block[i] >= 0 && mark_block[i] < c->num_block && mark_event[i],
+                "rrdbnet_backward_marked: mark %d out of range", i);
+  return rrdb_backward_impl(c, P, Gp, gy, gx, ws, st, n_marks, mark_block, mark_event);
+}
+
+namespace {
+int rrdb_backward_impl(const neosr_rrdbnet_cfg* c, const float* const* P, float* const* Gp, const float* gy,
+                       float* gx, void* ws, void* st, int n_marks, const int32_t* mark_block,
+                       void* const* mark_event) {
   RUN(rrdb_check(c));
   NEOSR_CHECK(P && Gp && gy && ws, "rrdbnet_backward: null pointer");
   NEOSR_CHECK(c->training, "rrdbnet_backward: cfg.training must be set (activations are needed)");
@@ -525,6 +549,12 @@ extern "C" int neosr_rrdbnet_backward(const neosr_rrdbnet_cfg* c, const float* c
       // all five weight gradients of this RDB in one launch
       RUN(neosr_conv3x3_wgrad_multi(wd, 5, L.wg_ws, sw));
       if (ax) NEOSR_HIP(hipEventRecord(ax->ev[2 * NR + t], ax->s3));
+      // gradient marks: the weight gradients of RRDB n and of everything behind it in the parameter order
+      // (RRDBs n+1.., conv_body .. conv_last, which ran on `st` before the fork) are enqueued on `sw` -> the
+      // caller may start reducing that suffix of the gradient arena once this event has completed
+      if (r == 0)
+        for (int i = 0; i < n_marks; ++i)
+          if (mark_block[i] == n) NEOSR_HIP(hipEventRecord((hipEvent_t)mark_event[i], (hipStream_t)sw));
       prev = L.gb[(gbi + 1) & 3];
       gbi = (gbi + 1) & 3;
     }
@@ -554,6 +584,7 @@ extern "C" int neosr_rrdbnet_backward(const neosr_rrdbnet_cfg* c, const float* c
   }
   return 0;
 }
+}  // namespace
 
 // ------------------------------------------------------------------------------ SRVGGNetCompact
 namespace {

@@ -7,7 +7,12 @@ enum : int {
   NEOSR_PROF_WGRAD_REDUCE = 3,
   NEOSR_PROF_CONV_FWD_OTHER = 4,  // staged / thin kernels, forward
   NEOSR_PROF_CONV_DGRAD_OTHER = 5,
-  NEOSR_PROF_NCLASS = 6
+  NEOSR_PROF_GEMM_NT = 6,         // nn.Linear forward (gemm_nt_glds_kernel / gemm_mfma_kernel<0>)
+  NEOSR_PROF_GEMM_NN = 7,         // nn.Linear backward-data
+  NEOSR_PROF_GEMM_TN = 8,         // nn.Linear backward-weight (split-K kernel only, not its column-sum pass)
+  NEOSR_PROF_ATTN_FWD = 9,        // window_attention_fwd_kernel / flash_wattn_fwd_kernel
+  NEOSR_PROF_ATTN_BWD = 10,       // window_attention_bwd_kernel / flash_wattn_bwd_dq + bwd_dkv kernels
+  NEOSR_PROF_NCLASS = 11
 };
 bool neosr_prof_on();
 void neosr_prof_begin(int cls, void* stream, double flops, double bytes);

@@ -46,6 +46,8 @@ extern "C" int neosr_prof_enable(int on) {
   return 0;
 }
 
+extern "C" int neosr_prof_num_classes() { return NEOSR_PROF_NCLASS; }
+
 // ms[c], launches[c], flops[c], bytes[c] for c < NEOSR_PROF_NCLASS; synchronises the device.
 extern "C" int neosr_prof_collect(double* ms, long long* launches, double* flops, double* bytes) {
   NEOSR_HIP(hipDeviceSynchronize());

@@ -147,6 +147,7 @@ class RRDBNetFunction(torch.autograd.Function):
             ctx.ws = ws
             ctx.x = x
             ctx.params = params
+            ctx.sync = hp.get("sync")
         return y
 
     @staticmethod
@@ -154,14 +155,31 @@ class RRDBNetFunction(torch.autograd.Function):
         lib = _C.load()
         params = ctx.params
         gy = gy.contiguous()
-        _flat, gviews = _alloc_flat_grads(params)
+        flat, gviews = _alloc_flat_grads(params)
         gx = torch.empty_like(ctx.x) if ctx.needs_input_grad[0] else None
         ptab = _C.ptr_table(params)
         gtab = _C.ptr_table(gviews)
-        _C.check(lib.neosr_rrdbnet_backward(C.byref(ctx.cfg), ptab, gtab, gy.data_ptr(),
-                                            None if gx is None else gx.data_ptr(),
-                                            ctx.ws.data_ptr(), _C.stream_ptr()),
-                 "neosr_rrdbnet_backward")
+        sync = ctx.sync
+        if sync is not None and sync.armed and all(ctx.needs_input_grad[2:]):
+            # data-parallel: buckets of the gradient arena are all-reduced while the earlier RRDBs are still in
+            # backward (neosr_amd/utils/grad_sync.py); the head of the arena goes when the model calls start()
+            blocks = sync.mark_blocks(ctx.cfg.num_block)
+            handles = sync.event_handles(len(blocks))
+            barr = (C.c_int32 * max(1, len(blocks)))(*blocks)
+            earr = (C.c_void_p * max(1, len(blocks)))(*handles)
+            _C.check(lib.neosr_rrdbnet_backward_marked(C.byref(ctx.cfg), ptab, gtab, gy.data_ptr(),
+                                                       None if gx is None else gx.data_ptr(), ctx.ws.data_ptr(),
+                                                       _C.stream_ptr(), len(blocks), barr, earr),
+                     "neosr_rrdbnet_backward_marked")
+            offs = arena_layout(params)[0]
+            sync.begin(flat)
+            for i, b in enumerate(blocks):
+                sync.reduce_suffix(offs[2 + 30 * b], i)
+        else:
+            _C.check(lib.neosr_rrdbnet_backward(C.byref(ctx.cfg), ptab, gtab, gy.data_ptr(),
+                                                None if gx is None else gx.data_ptr(),
+                                                ctx.ws.data_ptr(), _C.stream_ptr()),
+                     "neosr_rrdbnet_backward")
         ctx.ws = None
         grads = tuple(g if need else None for g, need in zip(gviews, ctx.needs_input_grad[2:]))
         return (gx, None, *grads)

@@ -42,6 +42,23 @@ def allreduce_flat_(flat: torch.Tensor, bucket_bytes: int = 64 << 20) -> None:
         h.wait()
 
 
+def flatten_sn_buffers_(net: nn.Module) -> torch.Tensor | None:
+    """Re-home every spectral-norm `weight_u` / `weight_v` buffer of `net` into one flat fp32 arena (views), so
+    the per-forward buffer broadcast of the data-parallel path is ONE message.  None when the net has none."""
+    bufs = [b for n, b in net.named_buffers() if n.endswith(("weight_u", "weight_v")) and b.dtype == torch.float32]
+    if not bufs:
+        return None
+    arena = torch.empty(sum(b.numel() for b in bufs), device=bufs[0].device, dtype=torch.float32)
+    off = 0
+    with torch.no_grad():
+        for b in bufs:
+            view = arena[off: off + b.numel()].view(b.shape)
+            view.copy_(b)
+            b.data = view
+            off += b.numel()
+    return arena
+
+
 class base:
     """Default model."""
 
@@ -53,6 +70,7 @@ class base:
         self.schedulers: list[Any] = []
         self.log_dict: dict[str, Any] = OrderedDict()
         self._log_dev: tuple[list[str], torch.Tensor] | None = None
+        self._log_work = None
         self.n_accumulated = 0
         if self.is_train:
             self.sf_optim_g = opt["train"]["optim_g"].get("schedule_free", False)
@@ -81,6 +99,11 @@ class base:
         (reference: ValueError at image.py:611-619, checked every iteration)."""
         if self._log_dev is not None:
             keys, vals = self._log_dev
+            if self._log_work is not None:  # the rank reduce of these scalars was only enqueued (reduce_loss_dict)
+                self._log_work.wait()
+                self._log_work = None
+                if self.opt["rank"] == 0:
+                    vals = vals / self.opt["world_size"]
             host = vals.detach().float().cpu().tolist()
             self.log_dict = OrderedDict(zip(keys, host))
             self._log_dev = None
@@ -97,9 +120,9 @@ class base:
             keys = list(loss_dict.keys())
             vals = torch.stack([v.detach().reshape(-1)[0].float() for v in loss_dict.values()])
             if self.opt["dist"]:
-                dist.reduce(vals, dst=0)
-                if self.opt["rank"] == 0:
-                    vals /= self.opt["world_size"]
+                # asynchronous: nothing on the compute stream waits for it (it queues behind the gradient buckets
+                # on the communication stream); completed and divided when the caller reads the log
+                self._log_work = dist.reduce(vals, dst=0, async_op=True)
             self._log_dev = (keys, vals)
 
     # -- device / parallel ----------------------------------------------------------------
@@ -116,9 +139,25 @@ class base:
             raise RuntimeError(msg)
         net = net.to(self.device)
         flatten_parameters_(net)
-        if self.opt["dist"]:  # identical start on every rank (DDP broadcasts from rank 0 too)
+        if self.opt["dist"]:
+            # DDP's constructor broadcasts rank 0's parameters AND buffers (base.py:140-146): ranks seed with
+            # manual_seed + rank, so without this the spectral-norm weight_u / weight_v start different per rank
             dist.broadcast(net._neosr_arena, src=0)  # noqa: SLF001
+            for b in net.buffers():
+                if b.is_cuda:
+                    dist.broadcast(b, src=0)
+            net._neosr_sn_arena = flatten_sn_buffers_(net)  # noqa: SLF001
         return net
+
+    def broadcast_buffers(self, net: nn.Module) -> None:
+        """DDP `broadcast_buffers=True` (base.py:140-146): before every train-mode forward the buffers that a
+        forward mutates — the spectral-norm power-iteration vectors — are re-sent from rank 0 (one message: they
+        live in one flat arena).  The power iteration depends only on (W, u, v), never on the data, so with
+        identical weights and deterministic kernels this keeps the ranks bit-identical rather than making them so;
+        `opt["broadcast_buffers"] = false` drops the message."""
+        arena = getattr(net, "_neosr_sn_arena", None)
+        if self.opt["dist"] and arena is not None and net.training and self.opt.get("broadcast_buffers", True):
+            dist.broadcast(arena, src=0)
 
     def get_bare_model(self, net: nn.Module) -> nn.Module:
         return getattr(net, "module", net) if not hasattr(net, "_neosr_arena") else net
@@ -181,6 +220,7 @@ class base:
     # -- checkpoints (wire format of base.py:281-475) ----------------------------------------
     @master_only
     def save_network(self, net, net_label: str, current_iter: int, param_key: str = "params") -> None:
+        self.get_current_log()  # the deferred NaN check (image.py:611-619) fires BEFORE anything is written
         it = "latest" if current_iter == -1 else current_iter
         path = Path(self.opt["path"]["models"]) / f"{net_label}_{it}.pth"
         path.parent.mkdir(parents=True, exist_ok=True)
@@ -197,17 +237,27 @@ class base:
         # base.py:325-354: schedule-free optimizers are switched to eval (x weights) around the write
         sf = [o for o, on in ((getattr(self, "optimizer_g", None), self.sf_optim_g),
                               (getattr(self, "optimizer_d", None), self.sf_optim_d)) if o is not None and on and self.is_train]
-        for o in sf:
+        self._write_with_retry(save_dict, path, sf, "model")
+
+    def _write_with_retry(self, obj, path: Path, sf_optimizers, what: str) -> None:
+        """base.py:325-354,446-470: schedule-free optimizers sit in eval mode (x weights) around the write; three
+        attempts one second apart, then log and abort like the reference."""
+        logger = get_root_logger()
+        for o in sf_optimizers:
             o.eval()
-        for retry in range(3):
-            try:
-                torch.save(save_dict, path)
-                break
-            except OSError as e:
-                get_root_logger().warning(f"Save model error: {e}, remaining retry times: {2 - retry}")
-                time.sleep(1)
-        for o in sf:
-            o.train()
+        try:
+            for retry in range(3):
+                try:
+                    torch.save(obj, path)
+                    return
+                except OSError as e:
+                    logger.warning(f"{tc.red}Save {what} error ({e}). Remaining retry times: {2 - retry}{tc.end}")
+                    time.sleep(1)
+        finally:
+            for o in sf_optimizers:
+                o.train()
+        logger.error(f"{tc.red}Cannot save {path}.{tc.end}")
+        sys.exit(1)
 
     def load_network(self, net, load_path, param_key: str | None = None, strict: bool = True) -> None:
         load_net = torch.load(load_path, map_location="cpu", weights_only=True)
@@ -225,6 +275,7 @@ class base:
     def save_training_state(self, epoch: int, current_iter: int) -> None:
         if current_iter == -1:
             return
+        self.get_current_log()  # NaN check before the write, as in save_network
         state = {"epoch": epoch, "iter": current_iter,
                  "optimizers": [o.state_dict() for o in self.optimizers],
                  "schedulers": [s.state_dict() for s in self.schedulers]}
@@ -234,11 +285,7 @@ class base:
         # state dicts were taken before it, so the file holds train-mode groups)
         sf = [o for o, on in ((getattr(self, "optimizer_g", None), self.sf_optim_g),
                               (getattr(self, "optimizer_d", None), self.sf_optim_d)) if o is not None and on and self.is_train]
-        for o in sf:
-            o.eval()
-        torch.save(state, path)
-        for o in sf:
-            o.train()
+        self._write_with_retry(state, path, sf, "training state")
 
     def resume_training(self, resume_state) -> None:
         assert len(resume_state["optimizers"]) == len(self.optimizers), "Wrong lengths of optimizers"

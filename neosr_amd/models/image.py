@@ -30,8 +30,9 @@ from neosr_amd.data.draws import LiveDraws
 from neosr_amd.hip.nets import arena_layout, flat_grad_of, flatten_parameters_, pack_grads
 from neosr_amd.losses import build_loss
 from neosr_amd.losses.consistency_loss import _Clamp
-from neosr_amd.models.base import allreduce_flat_, base
+from neosr_amd.models.base import base
 from neosr_amd.models.tiling import tiled_inference
+from neosr_amd.utils.grad_sync import GradSync
 from neosr_amd.utils.misc import get_root_logger, tc
 from neosr_amd.utils.registry import MODEL_REGISTRY
 
@@ -147,12 +148,30 @@ class image(base):
         def crit(key):
             return build_loss(train_opt[key]).to(self.device) if train_opt.get(key) else None
 
+        # data-parallel exchange (base.py:140-146 wraps the nets in DDP): one GradSync per network; the RRDB plan
+        # reduces gradient buckets during its backward when the step follows directly (no accumulation, no SAM)
+        self._sync_g = self._sync_d = None
+        if self.opt["dist"]:
+            self._sync_g = GradSync()
+            self.net_g._neosr_grad_sync = self._sync_g  # noqa: SLF001
+            if self.net_d is not None:
+                self._sync_d = GradSync()
+
         self.cri_pix = crit("pixel_opt")
         self.cri_mssim = crit("mssim_opt")
         self.cri_consistency = crit("consistency_opt")
         self.cri_perceptual = crit("perceptual_opt")
         self.cri_gan = crit("gan_opt")
         self.gradclip = train_opt.get("grad_clip", True)
+        if self.opt["dist"]:
+            # frozen networks inside the losses (VGG19) sit outside DDP in the reference and hold the same pretrained
+            # weights on every rank; the offline fallback draws them from the per-rank seeded RNG -> rank 0's
+            import torch.distributed as dist
+            for cri in (self.cri_pix, self.cri_mssim, self.cri_consistency, self.cri_perceptual, self.cri_gan):
+                if cri is not None:
+                    for t in list(cri.parameters()) + list(cri.buffers()):
+                        if t.is_cuda:
+                            dist.broadcast(t.data, src=0)
 
         optim_d = train_opt.get("optim_d", None)
         if self.cri_pix is None and self.cri_mssim is None and self.cri_perceptual is None:
@@ -224,8 +243,11 @@ class image(base):
             self.gt, self.lq = apply_augment(self.gt, self.lq, self.draws, scale=self.scale, augs=self.aug,
                                              prob=self.aug_prob)
 
-    def _sync_grads(self, optimizer) -> None:
-        """data-parallel exchange + clip request for one network (after its backward)"""
+    def _sync_grads(self, optimizer, sync: GradSync | None) -> None:
+        """data-parallel exchange + clip request for one network (after its backward).  The all-reduce is only
+        ENQUEUED here (behind the buckets the RRDB plan already sent during backward); `optimize_parameters`
+        waits for it right before that network's optimizer step, so G's exchange overlaps the discriminator
+        phase and D's exchange overlaps G's optimizer step."""
         params = optimizer.param_groups[0]["params"]
         if self.opt["dist"]:
             flat = flat_grad_of(params)
@@ -233,7 +255,9 @@ class image(base):
                 flat = pack_grads(params)
                 for p, off in zip(params, arena_layout(params)[0]):
                     p.grad = flat[off : off + p.numel()].view_as(p)
-            allreduce_flat_(flat)
+            sync.start(flat)
+            if self._sam_now:  # the closure runs again inside fsam.step: finish this exchange first
+                sync.finish()
             optimizer.set_grad_scale(1.0 / self.opt["world_size"])
         if self.gradclip and not self._sam_now:  # image.py:533-544,597-609: no clipping under SAM
             optimizer.set_clip(1.0)
@@ -249,6 +273,8 @@ class image(base):
             self.n_accumulated = 0
         step_now = self.n_accumulated % self.accum_iters == 0
 
+        if self._sync_g is not None:  # buckets may go during backward only if this backward is the one stepped
+            self._sync_g.armed = step_now and self.accum_iters == 1 and not self._sam_now
         self.output = self.net_g(self.lq)
 
         l_g_total = torch.zeros(1, device=self.device)
@@ -276,6 +302,7 @@ class image(base):
             l_g_total = l_g_total + l_g_percep
             loss_dict["l_g_percep"] = l_g_percep
         if self.cri_gan:
+            self.broadcast_buffers(self.net_d)
             fake_g_pred = self.net_d(self.output)
             l_g_gan = self.cri_gan(fake_g_pred, target_is_real=True, is_disc=False)
             l_g_total = l_g_total + l_g_gan
@@ -284,17 +311,19 @@ class image(base):
         l_g_total = l_g_total / self.accum_iters
         l_g_total.backward()
         if step_now:
-            self._sync_grads(self.sam_optimizer_g if self._sam_now else self.optimizer_g)
+            self._sync_grads(self.sam_optimizer_g if self._sam_now else self.optimizer_g, self._sync_g)
 
         if self.net_d is not None:
             for p in self.net_d.parameters():
                 p.requires_grad = True
             if self.cri_gan:
                 # both forwards first, then both backwards (image.py:559,574,593-594)
+                self.broadcast_buffers(self.net_d)
                 real_d_pred = self.net_d(self.gt)
                 l_d_real = self.cri_gan(real_d_pred, target_is_real=True, is_disc=True) / self.accum_iters
                 loss_dict["l_d_real"] = l_d_real
                 loss_dict["out_d_real"] = self.cri_gan.last_mean
+                self.broadcast_buffers(self.net_d)
                 fake_d_pred = self.net_d(self.output.detach())
                 l_d_fake = self.cri_gan(fake_d_pred, target_is_real=False, is_disc=True) / self.accum_iters
                 loss_dict["l_d_fake"] = l_d_fake
@@ -303,7 +332,7 @@ class image(base):
                 l_d_real.backward()
                 l_d_fake.backward()
             if step_now:
-                self._sync_grads(self.optimizer_d)
+                self._sync_grads(self.optimizer_d, self._sync_d)
 
         self.reduce_loss_dict(loss_dict)
         return l_g_total
@@ -318,11 +347,15 @@ class image(base):
             opt_g = self.sam_optimizer_g if self._sam_now else self.optimizer_g
             if self.ema > 0:
                 opt_g.set_ema(self.net_g_ema.arena(), self.ema, self.net_g_ema.first)
+            if self._sync_g is not None:
+                self._sync_g.finish()
             if self._sam_now:  # image.py:639-640: first_step, closure at w + e(w), second_step
                 self.sam_optimizer_g.step(self.closure, current_iter)
             else:
                 self.optimizer_g.step()
             if self.net_d is not None:
+                if self._sync_d is not None:
+                    self._sync_d.finish()
                 self.optimizer_d.step()
             opt_g.zero_grad(set_to_none=True)
             if self.net_d is not None:

@@ -26,6 +26,9 @@ class _FlatOptimizer(AdamW):
 
     ARENAS: tuple[str, ...] = ()
     KIND = 0
+    # scalars torch.optim keeps per parameter (`state[p]["step"]`, NAdam's `mu_product`): mirrored as ONE host
+    # tensor shared by every state[p] (no device sync) and adopted from a loaded reference state
+    PER_PARAM_SCALARS: tuple[str, ...] = ()
 
     def _init_common(self, params, defaults) -> None:
         Optimizer.__init__(self, params, defaults)
@@ -41,9 +44,20 @@ class _FlatOptimizer(AdamW):
         dev = params[0].device
         if st is None or st[self.ARENAS[0]].numel() != total or st[self.ARENAS[0]].device != dev:
             st = {k: torch.zeros(total, device=dev, dtype=torch.float32) for k in self.ARENAS}
+            group = self.param_groups[gi]
+            shared = {k: torch.zeros((), dtype=torch.float32) for k in self.PER_PARAM_SCALARS}
+            for k in self.PER_PARAM_SCALARS:  # loaded torch.optim state: the bias-correction clock continues
+                olds = [self.state[p][k] for p in params if k in self.state.get(p, {})]
+                if olds and k not in group:  # a file written by torch.optim has it per parameter only
+                    group[k] = float(olds[0]) if k != "step" else int(olds[0])
+                if k in group:
+                    shared[k].fill_(group[k])
+            self._shared = getattr(self, "_shared", {})
+            self._shared[gi] = shared
             for p, off in zip(params, arena_layout(params)[0]):
                 old = self.state.get(p, {})
-                new = {k: v for k, v in old.items() if k not in self.ARENAS}
+                new = {k: v for k, v in old.items() if k not in self.ARENAS and k not in shared}
+                new.update(shared)
                 for k in self.ARENAS:
                     view = st[k][off: off + p.numel()].view(p.shape)
                     if k in old:
@@ -77,6 +91,8 @@ class _FlatOptimizer(AdamW):
             total = pflat.numel()
             st = self._ensure_state(gi, params, total)
             coef, flags = self._coefficients(group)
+            for k, t in getattr(self, "_shared", {}).get(gi, {}).items():
+                t.fill_(group[k])
             if self._norm_ws is None or self._norm_ws.device != pflat.device:
                 self._norm_ws = torch.zeros(4200, device=pflat.device, dtype=torch.float32)
             d = _C.OptimDesc(param=pflat.data_ptr(), grad=gflat.data_ptr(), norm_ws=self._norm_ws.data_ptr(), n=total,
@@ -115,6 +131,7 @@ class Adam(_FlatOptimizer):
     """torch.optim.Adam (L2 weight decay added to the gradient)."""
 
     ARENAS, KIND = ("exp_avg", "exp_avg_sq"), _C.OPT_ADAM
+    PER_PARAM_SCALARS = ("step",)
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False, **kwargs):  # noqa: ARG002
         _check_basic(lr, eps, betas)
@@ -132,6 +149,7 @@ class NAdam(_FlatOptimizer):
     """torch.optim.NAdam (momentum_decay schedule, L2 weight decay)."""
 
     ARENAS, KIND = ("exp_avg", "exp_avg_sq"), _C.OPT_NADAM
+    PER_PARAM_SCALARS = ("step", "mu_product")
 
     def __init__(self, params, lr=2e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, momentum_decay=4e-3,
                  decoupled_weight_decay=False, **kwargs):  # noqa: ARG002
@@ -139,14 +157,14 @@ class NAdam(_FlatOptimizer):
         if decoupled_weight_decay:
             raise NotImplementedError("NAdam: decoupled_weight_decay has no HIP path")
         self._init_common(params, {"lr": lr, "betas": betas, "eps": eps, "weight_decay": weight_decay,
-                                   "momentum_decay": momentum_decay, "mu_product": 1.0})
+                                   "momentum_decay": momentum_decay})
 
     def _coefficients(self, group):
         group["step"] = group.get("step", 0) + 1
         t, (b1, b2), md, lr = group["step"], group["betas"], group["momentum_decay"], group["lr"]
         mu = b1 * (1.0 - 0.5 * (0.96 ** (t * md)))
         mu_next = b1 * (1.0 - 0.5 * (0.96 ** ((t + 1) * md)))
-        group["mu_product"] *= mu
+        group["mu_product"] = group.get("mu_product", 1.0) * mu
         mp = group["mu_product"]
         return [b1, b2, group["eps"], group["weight_decay"], lr * (1.0 - mu) / (1.0 - mp), math.sqrt(1 - b2**t),
                 lr * mu_next / (1.0 - mp * mu_next)], 0

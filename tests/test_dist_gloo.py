@@ -40,11 +40,30 @@ def _worker(rank: int, world: int, port: int, q) -> None:
     m = base.__new__(base)
     m.opt = {"dist": True, "rank": rank, "world_size": world}
     m._log_dev = None
+    m._log_work = None
     m.log_dict = {}
     m.reduce_loss_dict({"l_g_pix": torch.tensor(float(rank + 1)), "l_g_total": torch.tensor([2.0 * (rank + 1)])})
     log = m.get_current_log()
     if rank == 0:
         ok = ok and abs(log["l_g_pix"] - 1.5) < 1e-6 and abs(log["l_g_total"] - 3.0) < 1e-6
+    # GradSync bookkeeping (the overlapped exchange of the model step): two suffix buckets as the RRDB plan would
+    # send them during backward, then the head of the arena from start(); finish() leaves the full SUM everywhere
+    from neosr_amd.utils.grad_sync import GradSync
+
+    gs = GradSync(n_marks=2, device="cpu")
+    assert gs.mark_blocks(23) == [15, 7] and gs.mark_blocks(2) == [1] and gs.mark_blocks(1) == []
+    flat2 = full[rank].clone()
+    gs.begin(flat2)
+    gs.reduce_suffix(70_000, None)
+    gs.reduce_suffix(30_001, None)
+    gs.start(flat2, bucket_elems=20_000)
+    gs.finish()
+    ok = ok and torch.allclose(flat2, full.sum(0), atol=1e-5)
+    ok = ok and gs.buckets == [(70_000, 100_003), (30_001, 70_000), (10_001, 30_001), (0, 10_001)]
+    flat3 = full[rank].clone()  # layer-composed network: nothing sent during backward
+    gs.start(flat3)
+    gs.finish()
+    ok = ok and torch.allclose(flat3, full.sum(0), atol=1e-5) and gs.buckets == [(0, 100_003)]
     q.put((rank, bool(ok), float(flat.sum())))
     dist.destroy_process_group()
 

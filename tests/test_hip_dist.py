@@ -1,7 +1,12 @@
-"""GPU: the data-parallel path over RCCL (backend "nccl") with a single-rank group — RCCL refuses two
-ranks on one device, so world_size 2 is covered by tests/test_dist_gloo.py on CPU; this one checks that
-RCCL initialises here and that an `image` model with `dist = True` (flat-arena all-reduce, 1/world scale in
-the optimizer kernel, loss-dict reduce) trains exactly like the non-distributed model."""
+"""GPU: the data-parallel path.
+
+* RCCL (backend "nccl") with a single-rank group — RCCL refuses two ranks on one device: RCCL initialises here and
+  an `image` model with `dist = True` trains bit-identically to the non-distributed model.
+* TWO ranks sharing this one MI355X over `gloo` (it stages HIP tensors through the host): the whole model step —
+  overlapped bucketed all-reduce issued from inside the RRDB backward plan, deferred all-reduce of the layer-composed
+  discriminator, 1/world scale in the optimizer kernel, spectral-norm buffer broadcast, loss-dict reduce — gives
+  averaged half-batch gradients == big-batch gradients, identical parameters AND buffers on both ranks.
+* the same two-rank test over RCCL when >= 2 devices are visible (skipped on the 1-GPU box)."""
 
 from __future__ import annotations
 
@@ -60,3 +65,109 @@ def test_rccl_single_rank_group_matches_non_distributed(tmp_path):
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600, cwd=str(ROOT))
     assert r.returncode == 0 and "RCCL_SINGLE_RANK_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+TWO_RANK = textwrap.dedent("""
+    import os, sys, numpy as np, torch
+    sys.path.insert(0, {root!r})
+    import torch.distributed as dist
+    from neosr_amd.models import build_model
+    from neosr_amd.utils.options import parse_options, set_global_opt
+    from tests.conftest import GOLDEN, rel_err
+
+    backend = os.environ["TEST_BACKEND"]
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(rank if backend == "nccl" else 0)
+    dist.init_process_group(backend)
+    g = torch.Generator().manual_seed(7)
+    LQ = torch.rand(2, 4, 3, 16, 16, generator=g)       # [iteration][global batch of 4]
+    GT = torch.rand(2, 4, 3, 64, 64, generator=g)
+
+    def run(cfg, use_dist):
+        opt, _ = parse_options({root!r}, True, argv=["-opt", str(GOLDEN / cfg)])
+        opt["dist"], opt["rank"], opt["world_size"] = use_dist, (rank if use_dist else 0), (world if use_dist else 1)
+        set_global_opt(opt)
+        torch.manual_seed(1024 + (rank if use_dist else 0))   # per-rank seeding as options.py:208 -> different inits
+        model = build_model(opt)
+        if not use_dist:
+            return model
+        return model
+
+    for cfg in ("golden_esrgan.toml", "golden_gan.toml"):
+        m = run(cfg, True)
+        init_g = {{k: v.detach().clone() for k, v in m.net_g.state_dict().items()}}
+        init_d = {{k: v.detach().clone() for k, v in m.net_d.state_dict().items()}} if m.net_d is not None else None
+        for it in (1, 2):
+            sl = slice(2 * rank, 2 * rank + 2)
+            m.feed_data({{"lq": LQ[it - 1, sl], "gt": GT[it - 1, sl]}})
+            m.optimize_parameters(it)
+            if cfg == "golden_esrgan.toml":   # the RRDB plan sent 2 buckets during backward + the head afterwards
+                assert len(m._sync_g.buckets) >= 2, m._sync_g.buckets
+        log = m.get_current_log()
+        torch.cuda.synchronize()
+        # every rank holds the same parameters, EMA and buffers, bit for bit
+        mine = torch.cat([t.detach().flatten().float() for t in list(m.net_g.state_dict().values())
+                          + (list(m.net_d.state_dict().values()) if m.net_d is not None else [])])
+        both = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(both, mine)
+        assert all(torch.equal(both[0], b) for b in both[1:]), "ranks diverged"
+        if rank == 0:
+            # single process, the whole batch of 4, same initial weights
+            ref = run(cfg, False)
+            ref.net_g.load_state_dict(init_g)
+            if init_d is not None:
+                ref.net_d.load_state_dict(init_d)
+            ref.net_g_ema.module.load_state_dict(init_g)
+            for it in (1, 2):
+                ref.feed_data({{"lq": LQ[it - 1], "gt": GT[it - 1]}})
+                ref.optimize_parameters(it)
+            rlog = ref.get_current_log()
+            for k in rlog:
+                assert abs(log[k] - rlog[k]) <= 2e-4 * max(1.0, abs(rlog[k])), (cfg, k, log[k], rlog[k])
+            for (k, a), b in zip(m.net_g.state_dict().items(), ref.net_g.state_dict().values()):
+                assert rel_err(a, b) < 2e-4, (cfg, "net_g", k, rel_err(a, b))
+            if init_d is not None:
+                for (k, a), b in zip(m.net_d.state_dict().items(), ref.net_d.state_dict().values()):
+                    assert rel_err(a, b) < 2e-4, (cfg, "net_d", k, rel_err(a, b))
+        dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        print("TWO_RANK_OK")
+""")
+
+
+def _run_two_ranks(tmp_path, backend: str) -> None:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    script = tmp_path / "two_rank.py"
+    script.write_text(TWO_RANK.format(root=str(ROOT)))
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r), WORLD_SIZE="2",
+                   LOCAL_RANK=str(r), HSA_ENABLE_IPC_MODE_LEGACY="0", TEST_BACKEND=backend)
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True, cwd=str(ROOT)))
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=900))
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, so[-2000:] + se[-4000:]
+    assert "TWO_RANK_OK" in outs[0][0], outs[0][0][-2000:] + outs[0][1][-2000:]
+
+
+def test_two_ranks_on_one_device_gloo_step_equals_big_batch(tmp_path):
+    _run_two_ranks(tmp_path, "gloo")
+
+
+def test_two_ranks_rccl_step_equals_big_batch(tmp_path):
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 MI355X (RCCL refuses two ranks on one device)")
+    _run_two_ranks(tmp_path, "nccl")

@@ -84,6 +84,40 @@ def test_torch_optimizers_vs_torch_cpu(name):
             assert rel_err(p, rp) < 1e-5
 
 
+@pytest.mark.parametrize("name", ["Adam", "NAdam"])
+def test_torch_optimizer_state_resumes_bias_correction(name):
+    """a `.state` written by torch.optim.Adam / NAdam (per-parameter `step`, NAdam's `mu_product`) is adopted:
+    the resumed run continues the bias correction / momentum schedule instead of restarting at step 0, and the
+    state written back carries `step` per parameter again (extra.py)."""
+    from neosr_amd import optimizers
+
+    g = torch.Generator().manual_seed(29)
+    init = [torch.randn(6, 5, generator=g), torch.randn(9, generator=g)]
+    grads = [[torch.randn(t.shape, generator=g) for t in init] for _ in range(6)]
+    kw = dict(lr=1e-3, betas=(0.9, 0.99), weight_decay=0.01)
+    ref_p = [t.clone().requires_grad_(True) for t in init]
+    ref = getattr(torch.optim, name)(ref_p, **kw)
+    for gs in grads[:3]:
+        for rp, gg in zip(ref_p, gs):
+            rp.grad = gg.clone()
+        ref.step()
+    ps = _arena_params([rp.detach() for rp in ref_p])
+    opt = getattr(optimizers, name)(ps, **kw)
+    opt.load_state_dict(ref.state_dict())
+    for gs in grads[3:]:
+        for p, rp, gg in zip(ps, ref_p, gs):
+            p.grad, rp.grad = gg.to(DEV), gg.clone()
+        opt.step()
+        ref.step()
+        for p, rp in zip(ps, ref_p):
+            assert rel_err(p, rp) < 1e-5
+    sd, rsd = opt.state_dict(), ref.state_dict()
+    for i in sd["state"]:
+        assert float(sd["state"][i]["step"]) == float(rsd["state"][i]["step"]) == 6.0
+        if name == "NAdam":
+            assert abs(float(sd["state"][i]["mu_product"]) - float(rsd["state"][i]["mu_product"])) < 1e-6
+
+
 def test_fused_clip_and_ema_in_generic_step():
     """the model-level clip + EMA hooks work for the generic kernel exactly as for adamw"""
     from neosr_amd import optimizers

@@ -45,12 +45,19 @@ def test_plugins_registered_under_reference_names():
     assert "L1Loss" in LOSS_REGISTRY and "image" in MODEL_REGISTRY
 
 
-@pytest.mark.parametrize("arch", ["compact", "esrgan"])
-def test_parse_options_matches_reference_dump(arch):
-    """Our parse of tests/golden/golden_<arch>.toml == the reference's parse (opt_<arch>.json)."""
+_OPT_CASES = [("compact", GOLDEN / "golden_compact.toml"), ("esrgan", GOLDEN / "golden_esrgan.toml")] + [
+    (f"bench_{n}", ROOT / "options" / f"bench_{n}.toml")
+    for n in ("compact", "esrgan", "esrgan_otf_gan", "swinir_medium", "hat_l_otf_gan")]
+
+
+@pytest.mark.parametrize(("arch", "toml"), _OPT_CASES, ids=[c[0] for c in _OPT_CASES])
+def test_parse_options_matches_reference_dump(arch, toml):
+    """Our parse of a TOML == the reference's parse of the same file (tests/golden/opt_<name>.json, written by
+    gen_golden.py / gen_golden_opts.py from neosr/utils/options.py:39-275): the two reduced golden configs and
+    the five shipped option files (options/bench_*.toml = BASELINE configs[0..4])."""
     from neosr_amd.utils.options import parse_options
 
-    opt, args = parse_options(str(ROOT), True, argv=["-opt", str(GOLDEN / f"golden_{arch}.toml")])
+    opt, args = parse_options(str(ROOT), True, argv=["-opt", str(toml)])
     ref = json.loads((GOLDEN / f"opt_{arch}.json").read_text())
 
     def norm(o):
