@@ -634,8 +634,14 @@ int neosr_rrdbnet_backward_marked(const neosr_rrdbnet_cfg* cfg, const float* con
                                   void* const* mark_event);
 /* The RRDB trunk runs the two halves of the batch as independent launch chains on the caller's stream
  * and one internal stream (fork / join by events; results do not depend on the setting).  n = 1
- * keeps everything on the caller's stream (used for per-kernel timing); returns the previous n. */
+ * keeps everything on the caller's stream (used for per-kernel timing), n = 2 (default) .. 4 cuts the batch into n
+ * groups of samples; returns the previous n. */
 int neosr_set_num_streams(int n);
+/* XCD-aware workgroup order of the 3x3 conv and weight-gradient kernels (each XCD = 32 CUs with a private L2 takes a
+ * contiguous band of pixel tiles / whole pixel splits, so halo rows and the tiles shared by several (cout, cin)
+ * pairs are fetched into ONE L2): 1 = on (default; env NEOSR_AMD_XCD=0 turns it off), returns the previous
+ * setting.  A pure scheduling choice: results are bit-identical either way. */
+int neosr_set_xcd_aware(int on);
 
 /*
  * SRVGGNetCompact ("compact", neosr/archs/compact_arch.py:11-85), act_type prelu|relu|leakyrelu.

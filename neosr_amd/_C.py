@@ -236,6 +236,7 @@ SIGNATURES: dict[str, tuple] = {
     "neosr_conv3x3_pack_weights": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp]),
     "neosr_debug_set_timeline": (C.c_int, [_vp]),
     "neosr_set_num_streams": (C.c_int, [C.c_int]),
+    "neosr_set_xcd_aware": (C.c_int, [C.c_int]),
     "neosr_conv3x3_wgrad_workspace_bytes": (_i64, [_i32, _i32, _i32, _i32, _i32]),
     "neosr_conv3x3_wgrad": (C.c_int, [C.POINTER(WgradDesc), _vp]),
     "neosr_conv3x3_wgrad_multi_workspace_bytes": (_i64, [C.POINTER(WgradDesc), _i32]),

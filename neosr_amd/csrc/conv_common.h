@@ -27,6 +27,7 @@ struct ConvArgs {
   neosr_conv_desc d;
   int tiles_x, tiles_y;
   int scalar_in;                 // thin-K kernel: the input's channel stride / base is not 16-byte friendly
+  int xcd;                       // 1: XCD-aware tile order (see xcd_tile)
   unsigned long long* timeline;  // debug only (NEOSR_TIMELINE builds)
 };
 
@@ -39,6 +40,21 @@ struct ConvArgs {
 #else
 #define TL_MARK(slot) do {} while (0)
 #endif
+
+
+// Workgroup b of a launch is observed to run on XCD b % 8, each XCD with a private 4 MB L2 (placement is not a
+// contract: this is a SPEED choice only, any permutation is correct).  With tiles dealt round-robin the vertical
+// neighbours of a tile (which share 2 of its 6 halo rows) and the n-blocks of a tile sit on different XCDs, so every
+// L2 fetches its own copy of the halo / of the whole input tile (measured 84 MB per RDB conv launch against 43 MB
+// algorithmic).  Here XCD x takes the x-th contiguous band of tiles instead; bijective for any tile count.
+__device__ __forceinline__ int xcd_tile(int bid, int ntiles, int on) {
+  if (!on) return bid;
+  const int q = ntiles >> 3, r = ntiles & 7;
+  const int x = bid & 7, k = bid >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
+}
+
+bool xcd_enabled();  // NEOSR_AMD_XCD=0 / neosr_set_xcd_aware(0) restores dispatch order (A/B measurements)
 
 
 // 4x4 / stride-2 kernels run as a 3x3 over the space-to-depth tensor (neosr_conv_desc.s2d_c): a channel

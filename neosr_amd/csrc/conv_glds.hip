@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_glds_kernel(const ConvArgs arg
   const int l31 = lane & 31, lh = lane >> 5;
   TL_MARK(0);
 
-  int bid = blockIdx.x;
+  int bid = xcd_tile(blockIdx.x, gridDim.x, args.xcd);
   const int tx = bid % args.tiles_x;
   bid /= args.tiles_x;
   const int ty = bid % args.tiles_y;

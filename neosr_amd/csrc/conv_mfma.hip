@@ -19,6 +19,7 @@
 #include <cstring>
 #include "conv_common.h"
 #include "prof.h"
+#include <stdlib.h>
 
 #ifndef NEOSR_INTERLEAVE
 #define NEOSR_INTERLEAVE 1  // spread the next chunk's global loads over the taps of the current one
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(256, GENERIC ? 2 : NEOSR_CONV_WPS) void conv3x3_mfm
   const int l31 = lane & 31, lh = lane >> 5;
   TL_MARK(0);
 
-  int bid = blockIdx.x;
+  int bid = xcd_tile(blockIdx.x, gridDim.x, args.xcd);
   const int tx = bid % args.tiles_x;
   bid /= args.tiles_x;
   const int ty = bid % args.tiles_y;
@@ -336,8 +337,25 @@ __global__ __launch_bounds__(256, GENERIC ? 2 : NEOSR_CONV_WPS) void conv3x3_mfm
 
 
 unsigned long long* g_timeline = nullptr;
+int g_xcd = -1;  // -1: read NEOSR_AMD_XCD on first use (default on)
 
 }  // namespace
+
+bool neosr_conv::xcd_enabled() {
+  if (g_xcd < 0) {
+    const char* e = getenv("NEOSR_AMD_XCD");
+    g_xcd = (e && atoi(e) == 0) ? 0 : 1;
+  }
+  return g_xcd != 0;
+}
+
+// XCD-aware workgroup order of the conv / weight-gradient kernels on (default) or off; returns the previous setting.
+// Results do not depend on it (a permutation of independent workgroups; the split-K reduce order is fixed).
+extern "C" int neosr_set_xcd_aware(int on) {
+  const int prev = neosr_conv::xcd_enabled() ? 1 : 0;
+  g_xcd = on ? 1 : 0;
+  return prev;
+}
 
 // debug hook (NEOSR_TIMELINE builds only record anything): device buffer of 4*64 uint64
 extern "C" int neosr_debug_set_timeline(void* dev_buf) {
@@ -367,6 +385,7 @@ extern "C" int neosr_conv3x3(const neosr_conv_desc* dp, void* stream) {
   a.tiles_y = ceil_div(d.H, TH);
   a.scalar_in = 0;
   a.timeline = g_timeline;
+  a.xcd = neosr_conv::xcd_enabled() ? 1 : 0;
   const bool al_in = (d.in_cs % 4 == 0) && ((uintptr_t)d.in % 16 == 0);
   const bool al_mk = !d.in_mask || ((d.mask_cs % 4 == 0) && ((uintptr_t)d.in_mask % 16 == 0));
   const bool al_w = ((uintptr_t)d.w % 16 == 0) && (d.w_cin % 4 == 0);

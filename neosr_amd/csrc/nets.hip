@@ -182,10 +182,12 @@ inline int p_tail(const RrdbLayout& L, int i) { return 2 + L.NB * 30 + 2 * i; } 
 // launch pays its fill / drain / first-load latency in full (~8 us of 30-60).  Running the two halves of
 // the batch as independent launch chains on two streams lets one chain's matrix work cover the other's
 // launch gap (measured on the forward chain: 110 -> 121 TFLOP/s).  Fork / join with events only.
+constexpr int MAX_CHAINS = 4;
 struct Aux {
   int dev = -1;
-  hipStream_t s2 = nullptr, s3 = nullptr;
-  hipEvent_t fork = nullptr, join = nullptr;
+  hipStream_t sc[MAX_CHAINS] = {nullptr, nullptr, nullptr, nullptr};  // sc[1..]: chains 1.. (chain 0 = the caller's stream)
+  hipStream_t s3 = nullptr;                                            // weight gradients
+  hipEvent_t fork = nullptr, join[MAX_CHAINS] = {nullptr, nullptr, nullptr, nullptr};
   std::vector<hipEvent_t> ev;
 };
 int g_num_streams = -1;  // -1: read NEOSR_AMD_STREAMS on first use (default 2)
@@ -196,20 +198,23 @@ Aux* aux_get(int nev) {
   std::lock_guard<std::mutex> lk(mu);
   if (g_num_streams < 0) {
     const char* e = getenv("NEOSR_AMD_STREAMS");
-    g_num_streams = (e && atoi(e) == 1) ? 1 : 2;
+    const int n = e ? atoi(e) : 2;
+    g_num_streams = n < 1 ? 2 : (n > MAX_CHAINS ? MAX_CHAINS : n);
   }
   if (g_num_streams < 2) return nullptr;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-  if (a.s2 && a.dev != dev) {  // streams / events belong to the device they were created on
+  if (a.s3 && a.dev != dev) {  // streams / events belong to the device they were created on
     a = Aux();
   }
   a.dev = dev;
-  if (!a.s2) {
-    if (hipStreamCreateWithFlags(&a.s2, hipStreamNonBlocking) != hipSuccess) return nullptr;
+  if (!a.s3) {
+    for (int i = 1; i < MAX_CHAINS; ++i)
+      if (hipStreamCreateWithFlags(&a.sc[i], hipStreamNonBlocking) != hipSuccess) return nullptr;
     if (hipStreamCreateWithFlags(&a.s3, hipStreamNonBlocking) != hipSuccess) return nullptr;
     if (hipEventCreateWithFlags(&a.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
-    if (hipEventCreateWithFlags(&a.join, hipEventDisableTiming) != hipSuccess) return nullptr;
+    for (int i = 0; i < MAX_CHAINS; ++i)
+      if (hipEventCreateWithFlags(&a.join[i], hipEventDisableTiming) != hipSuccess) return nullptr;
   }
   while ((int)a.ev.size() < nev) {
     hipEvent_t e;
@@ -297,18 +302,18 @@ extern "C" int neosr_rrdbnet_forward(const neosr_rrdbnet_cfg* c, const float* co
   RUN(rrdb_pack_fwd(L, P, st));
   // trunk: the two halves of the batch are independent launch chains (see Aux)
   Aux* ax = B >= 2 ? aux_get(0) : nullptr;
-  const int nhalf = ax ? 2 : 1;
+  const int nhalf = ax ? (g_num_streams < B ? g_num_streams : B) : 1;  // number of launch chains
   if (ax) {
     NEOSR_HIP(hipEventRecord(ax->fork, (hipStream_t)st));
-    NEOSR_HIP(hipStreamWaitEvent(ax->s2, ax->fork, 0));
+    for (int h = 1; h < nhalf; ++h) NEOSR_HIP(hipStreamWaitEvent(ax->sc[h], ax->fork, 0));
   }
   for (int n = 0; n < L.NB; ++n) {
     for (int r = 0; r < 3; ++r) {
       const float* pk = L.wpack_f + (int64_t)(3 * n + r) * L.pf_total;
       for (int h = 0; h < nhalf; ++h) {
-        const int b0 = h ? B / 2 : 0, nb = ax ? (h ? B - B / 2 : B / 2) : B;
-        void* sh = h ? (void*)ax->s2 : st;
-        const int64_t po = (int64_t)b0 * H * W;  // pixel offset of this half
+        const int b0 = (int)((int64_t)B * h / nhalf), nb = (int)((int64_t)B * (h + 1) / nhalf) - b0;
+        void* sh = h ? (void*)ax->sc[h] : st;
+        const int64_t po = (int64_t)b0 * H * W;  // pixel offset of this chain's samples
         float* A = L.act[act_idx(L, 3 * n + r)] + po * CC;
         for (int k = 0; k < 4; ++k) {
           neosr_conv_desc d = conv_base(nb, H, W);
@@ -335,10 +340,11 @@ extern "C" int neosr_rrdbnet_forward(const neosr_rrdbnet_cfg* c, const float* co
       }
     }
   }
-  if (ax) {
-    NEOSR_HIP(hipEventRecord(ax->join, ax->s2));
-    NEOSR_HIP(hipStreamWaitEvent((hipStream_t)st, ax->join, 0));
-  }
+  if (ax)
+    for (int h = 1; h < nhalf; ++h) {
+      NEOSR_HIP(hipEventRecord(ax->join[h], ax->sc[h]));
+      NEOSR_HIP(hipStreamWaitEvent((hipStream_t)st, ax->join[h], 0));
+    }
   {  // conv_body + skip
     neosr_conv_desc d = conv_base(B, H, W);
     d.in = L.trunk; d.in_cs = F; d.K = F;
@@ -489,12 +495,12 @@ int rrdb_backward_impl(const neosr_rrdbnet_cfg* c, const float* const* P, float*
   // of four gradient buffers bounds how far the chains may run ahead: RDB t+3 overwrites the g5 slot of
   // the buffer RDB t's weight gradient reads.
   const int NR = 3 * L.NB;
-  Aux* ax = B >= 2 ? aux_get(3 * NR) : nullptr;
-  const int nhalf = ax ? 2 : 1;
+  Aux* ax = B >= 2 ? aux_get((MAX_CHAINS + 1) * NR) : nullptr;
+  const int nhalf = ax ? (g_num_streams < B ? g_num_streams : B) : 1;  // number of launch chains
   void* sw = ax ? (void*)ax->s3 : st;  // weight-gradient stream
   if (ax) {
     NEOSR_HIP(hipEventRecord(ax->fork, (hipStream_t)st));
-    NEOSR_HIP(hipStreamWaitEvent(ax->s2, ax->fork, 0));
+    for (int h = 1; h < nhalf; ++h) NEOSR_HIP(hipStreamWaitEvent(ax->sc[h], ax->fork, 0));
     NEOSR_HIP(hipStreamWaitEvent(ax->s3, ax->fork, 0));
   }
   int gbi = 0, t = 0;
@@ -505,8 +511,8 @@ int rrdb_backward_impl(const neosr_rrdbnet_cfg* c, const float* const* P, float*
       if (r == 2) dOut = L.gb[gbi];
       const float* pk = L.wpack_d + (int64_t)(3 * n + r) * L.pd_total;
       for (int h = 0; h < nhalf; ++h) {
-        const int b0 = h ? B / 2 : 0, nb = ax ? (h ? B - B / 2 : B / 2) : B;
-        void* sh = h ? (void*)ax->s2 : st;
+        const int b0 = (int)((int64_t)B * h / nhalf), nb = (int)((int64_t)B * (h + 1) / nhalf) - b0;
+        void* sh = h ? (void*)ax->sc[h] : st;
         const int64_t po = (int64_t)b0 * H * W * CC;
         const float* A = L.act[3 * n + r] + po;
         float* GB = L.gb[gbi] + po;
@@ -521,7 +527,7 @@ int rrdb_backward_impl(const neosr_rrdbnet_cfg* c, const float* const* P, float*
           RUN(neosr_conv3x3(&d, sh));
         }
         {  // gradient wrt the RDB input -> g5 slot of the next RDB's buffer
-          if (ax && t >= 3) NEOSR_HIP(hipStreamWaitEvent((hipStream_t)sh, ax->ev[2 * NR + t - 3], 0));
+          if (ax && t >= 3) NEOSR_HIP(hipStreamWaitEvent((hipStream_t)sh, ax->ev[MAX_CHAINS * NR + t - 3], 0));
           neosr_conv_desc d = conv_base(nb, H, W);
           d.mode = NEOSR_CONV_DGRAD;
           d.in = GB; d.in_cs = CC; d.K = CC;
@@ -548,7 +554,7 @@ int rrdb_backward_impl(const neosr_rrdbnet_cfg* c, const float* const* P, float*
       }
       // all five weight gradients of this RDB in one launch
       RUN(neosr_conv3x3_wgrad_multi(wd, 5, L.wg_ws, sw));
-      if (ax) NEOSR_HIP(hipEventRecord(ax->ev[2 * NR + t], ax->s3));
+      if (ax) NEOSR_HIP(hipEventRecord(ax->ev[MAX_CHAINS * NR + t], ax->s3));
       // gradient marks: the weight gradients of RRDB n and of everything behind it in the parameter order
       // (RRDBs n+1.., conv_body .. conv_last, which ran on `st` before the fork) are enqueued on `sw` -> the
       // caller may start reducing that suffix of the gradient arena once this event has completed
@@ -560,10 +566,12 @@ int rrdb_backward_impl(const neosr_rrdbnet_cfg* c, const float* const* P, float*
     }
   }
   if (ax) {
-    NEOSR_HIP(hipEventRecord(ax->join, ax->s2));
-    NEOSR_HIP(hipStreamWaitEvent((hipStream_t)st, ax->join, 0));
-    NEOSR_HIP(hipEventRecord(ax->fork, ax->s3));
-    NEOSR_HIP(hipStreamWaitEvent((hipStream_t)st, ax->fork, 0));
+    for (int h = 1; h < nhalf; ++h) {
+      NEOSR_HIP(hipEventRecord(ax->join[h], ax->sc[h]));
+      NEOSR_HIP(hipStreamWaitEvent((hipStream_t)st, ax->join[h], 0));
+    }
+    NEOSR_HIP(hipEventRecord(ax->join[0], ax->s3));
+    NEOSR_HIP(hipStreamWaitEvent((hipStream_t)st, ax->join[0], 0));
   }
   // skip connection feat + body_feat, then conv_first
   RUN(neosr_axpy_slice(prev, L.g_fea, L.np1, F, CC, F, 1.0f, st));
@@ -746,11 +754,11 @@ extern "C" int neosr_compact_backward(const neosr_compact_cfg* c, const float* c
   return 0;
 }
 
-// 1 = the RRDB trunk runs on the caller's stream only, 2 (default) = batch halves on two streams.
-// Returns the previous setting.  Env NEOSR_AMD_STREAMS=1 selects 1 at start-up.
+// 1 = the RRDB trunk runs on the caller's stream only, n = 2 (default) .. 4 = the batch is cut into n groups of samples
+// that run as independent launch chains.  Returns the previous setting.  Env NEOSR_AMD_STREAMS=n selects it at start-up.
 extern "C" int neosr_set_num_streams(int n) {
   aux_get(0);  // resolve the default
   const int prev = g_num_streams;
-  g_num_streams = n >= 2 ? 2 : 1;
+  g_num_streams = n < 1 ? 1 : (n > MAX_CHAINS ? MAX_CHAINS : n);
   return prev;
 }

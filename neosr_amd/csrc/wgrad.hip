@@ -21,6 +21,8 @@
 #include <type_traits>
 #include "../../include/neosr_amd.h"
 
+namespace neosr_conv { bool xcd_enabled(); }
+
 namespace {
 
 #ifndef NEOSR_WG_UNROLL
@@ -48,6 +50,8 @@ struct WgradMultiArgs {
   float* part;    // [pair][split][WG_TILE]
   float* bpart;   // [desc-cout-tile][split][32]
   int btile_start[MAXD + 1];  // prefix sums of nnt per desc
+  // XCD-pinned order (1-D grid of 8 * xcd_q workgroups, see plan()): 0 = (pair, split) grid in dispatch order
+  int xcd, xcd_full, xcd_q;
 };
 
 __device__ __forceinline__ float4 ld4(const float* p, bool vec, int c, int C) {
@@ -78,8 +82,25 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_multi_kernel(const Wgrad
   const int lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
 
-  // which conv / tile pair does this workgroup own?
-  const int pair = blockIdx.x;
+  // which conv / tile pair and which pixel split does this workgroup own?
+  int pair = blockIdx.x, s = blockIdx.y;
+  if (args.xcd) {
+    // Workgroup b is observed to run on XCD b % 8 (a speed assumption only).  All pairs of one pixel split read the
+    // same G / X pixels (each tile is staged by up to 6 pairs): whole splits are pinned to one XCD so that its L2
+    // fetches them once; the splits left over after 8 * xcd_full are dealt in x-major order over the free slots.
+    const int P = args.pair_start[MAXD];
+    const int x = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int pinned = args.xcd_full * P;
+    if (q < pinned) {
+      s = x * args.xcd_full + q / P;
+      pair = q % P;
+    } else {
+      const int r = x * (args.xcd_q - pinned) + (q - pinned);
+      s = 8 * args.xcd_full + r / P;
+      pair = r % P;
+      if (s >= args.nsplit) return;
+    }
+  }
   int di = 0;
 #pragma unroll
   for (int i = 1; i < MAXD; ++i)
@@ -91,7 +112,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_multi_kernel(const Wgrad
   const int co0 = ntile * 32, ci0 = kt * 32;
   const bool vec_in = args.vec_in[di], vec_g = args.vec_g[di], vec_m = args.vec_m[di];
 
-  const int s = blockIdx.y;
   const int t_lo = s * args.tiles_per_split;
   const int t_hi = min(args.ntiles, t_lo + args.tiles_per_split);
 
@@ -530,6 +550,11 @@ int plan(const neosr_wgrad_desc* ds, int n, WgradMultiArgs& a) {
   if (nsplit > a.ntiles) nsplit = a.ntiles;
   a.tiles_per_split = ceil_div(a.ntiles, nsplit);
   a.nsplit = ceil_div(a.ntiles, a.tiles_per_split);
+  // XCD-pinned order: an XCD has 32 CUs x 2 resident workgroups = 64 slots
+  a.xcd = neosr_conv::xcd_enabled() ? 1 : 0;
+  a.xcd_full = pairs <= 64 ? 64 / pairs : 0;
+  if (a.xcd_full > a.nsplit / 8) a.xcd_full = a.nsplit / 8;
+  a.xcd_q = a.xcd_full * pairs + ceil_div((a.nsplit - 8 * a.xcd_full) * pairs, 8);
   return 0;
 }
 
@@ -621,18 +646,15 @@ extern "C" int neosr_conv3x3_wgrad_multi(const neosr_wgrad_desc* ds, int32_t n, 
     s2d = s2d || ds[i].s2d_c > 0;
     plain = plain && !ds[i].g_mask && !ds[i].in_prelu && !ds[i].mask_slopes;
   }
+  const dim3 grid = a.xcd ? dim3(8 * a.xcd_q) : dim3(a.pair_start[MAXD], a.nsplit);
   if (fast && s2d)
-    hipLaunchKernelGGL((conv3x3_wgrad_multi_kernel<true, true>), dim3(a.pair_start[MAXD], a.nsplit),
-                       dim3(256), 0, st, a);
+    hipLaunchKernelGGL((conv3x3_wgrad_multi_kernel<true, true>), grid, dim3(256), 0, st, a);
   else if (fast && plain)
-    hipLaunchKernelGGL((conv3x3_wgrad_multi_kernel<true, false, true>), dim3(a.pair_start[MAXD], a.nsplit),
-                       dim3(256), 0, st, a);
+    hipLaunchKernelGGL((conv3x3_wgrad_multi_kernel<true, false, true>), grid, dim3(256), 0, st, a);
   else if (fast)
-    hipLaunchKernelGGL(conv3x3_wgrad_multi_kernel<true>, dim3(a.pair_start[MAXD], a.nsplit),
-                       dim3(256), 0, st, a);
+    hipLaunchKernelGGL(conv3x3_wgrad_multi_kernel<true>, grid, dim3(256), 0, st, a);
   else
-    hipLaunchKernelGGL(conv3x3_wgrad_multi_kernel<false>, dim3(a.pair_start[MAXD], a.nsplit),
-                       dim3(256), 0, st, a);
+    hipLaunchKernelGGL(conv3x3_wgrad_multi_kernel<false>, grid, dim3(256), 0, st, a);
   if (prof) neosr_prof_end(stream);
   NEOSR_LAUNCH_CHECK();
   if (prof) neosr_prof_begin(NEOSR_PROF_WGRAD_REDUCE, stream, 0.0, 0.0);
