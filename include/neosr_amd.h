@@ -295,6 +295,17 @@ int neosr_chc_loss_fwd(const float* a, const float* b, int64_t n, float pre, int
 int neosr_chc_loss_bwd(const float* a, const float* b, const float* grad_out, int64_t n, float pre,
                        int32_t huber, float clip_min, float clip_max, float loss_weight, float* grad_a,
                        int32_t accumulate, void* stream);
+/* chc_loss with its cosine-similarity term (neosr/losses/basic_loss.py:192-219, loss_lambda != 0) on NCHW tensors
+ * (N, C, hw = H*W):  c = mean over pixels of (1 - cos_sim over the C channels, nn.CosineSimilarity(dim=1, eps)),
+ * loss = loss_weight * mean(clamp(t + loss_lambda * c, clip_min, clip_max)), t = |a-b| or sqrt((a-b)^2 + 1e-12).
+ * aux (2 floats, device): c and the number of elements inside the clamp range, kept for the backward; workspace
+ * 3072 floats.  bwd writes d loss / d a (the elementwise term where the clamp passes + the cosine term's share). */
+int neosr_chc_cos_loss_fwd(const float* a, const float* b, int32_t N, int32_t C, int64_t hw, int32_t huber,
+                           float clip_min, float clip_max, float loss_lambda, float loss_weight, float cos_eps,
+                           float* loss_out, float* aux, float* workspace, void* stream);
+int neosr_chc_cos_loss_bwd(const float* a, const float* b, const float* grad_out, int32_t N, int32_t C, int64_t hw,
+                           int32_t huber, float clip_min, float clip_max, float loss_lambda, float loss_weight,
+                           float cos_eps, const float* aux, float* grad_a, void* stream);
 /* nn.BCEWithLogitsLoss()(x, full_like(x, target)) * loss_weight (gan_loss.py:59-82);
  * mean_out (optional) receives mean(x) (`out_d_real/out_d_fake`, image.py:566,579).
  * workspace >= 2048 floats. */

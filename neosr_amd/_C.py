@@ -279,6 +279,8 @@ SIGNATURES: dict[str, tuple] = {
     "neosr_norm_nchw_nhwc": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _i32, _vp]),
     "neosr_chc_loss_fwd": (C.c_int, [_vp, _vp, _i64, _f32, _i32, _f32, _f32, _f32, _vp, _vp, _vp]),
     "neosr_chc_loss_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _f32, _i32, _f32, _f32, _f32, _vp, _i32, _vp]),
+    "neosr_chc_cos_loss_fwd": (C.c_int, [_vp, _vp, _i32, _i32, _i64, _i32, _f32, _f32, _f32, _f32, _f32, _vp, _vp, _vp, _vp]),
+    "neosr_chc_cos_loss_bwd": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i64, _i32, _f32, _f32, _f32, _f32, _f32, _vp, _vp, _vp]),
     "neosr_bce_logits_fwd": (C.c_int, [_vp, _i64, _f32, _f32, _vp, _vp, _vp, _vp]),
     "neosr_bce_logits_bwd": (C.c_int, [_vp, _vp, _i64, _f32, _f32, _vp, _vp]),
     "neosr_spectral_norm_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp]),

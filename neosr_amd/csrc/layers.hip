@@ -285,6 +285,95 @@ __global__ __launch_bounds__(256) void chc_bwd_kernel(const float* __restrict__ 
   }
 }
 
+
+// ------------------------------------------------------------------ chc loss with the cosine term (lambda != 0)
+// basic_loss.py:192-219 on NCHW tensors: c = mean over pixels of (1 - cos_sim over channels), then
+// loss = w * mean(clamp(t + lambda * c, lo, hi)).  aux[0] = c, aux[1] = number of elements inside the clamp range
+// (both stay on the device: the backward needs them, the host never does).
+__device__ __forceinline__ void pixel_cos(const float* __restrict__ a, const float* __restrict__ b, int C, int64_t hw,
+                                          int64_t base, float eps, float& na, float& nb, float& cs) {
+  float saa = 0.f, sbb = 0.f;
+  for (int c = 0; c < C; ++c) {
+    const float x = a[base + c * hw], y = b[base + c * hw];
+    saa += x * x;
+    sbb += y * y;
+  }
+  na = fmaxf(sqrtf(saa), eps);  // ATen cosine_similarity: sum((x / max(|x|, eps)) * (y / max(|y|, eps)))
+  nb = fmaxf(sqrtf(sbb), eps);
+  float s = 0.f;
+  for (int c = 0; c < C; ++c) s += (a[base + c * hw] / na) * (b[base + c * hw] / nb);
+  cs = s;
+}
+
+__global__ __launch_bounds__(256) void cos_nchw_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                               int64_t npix, int C, int64_t hw, float eps,
+                                                               float* __restrict__ part) {
+  __shared__ float sm[4];
+  float s = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (int64_t)gridDim.x * 256) {
+    const int64_t n = i / hw, r = i - n * hw;
+    float na, nb, cs;
+    pixel_cos(a, b, C, hw, n * C * hw + r, eps, na, nb, cs);
+    s += 1.f - cs;
+  }
+  const float rsum = block_sum_256(s, sm);
+  if (threadIdx.x == 0) part[blockIdx.x] = rsum;
+}
+
+__global__ __launch_bounds__(256) void chc_cos_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                              int64_t n, int huber, float lo, float hi, float lambda,
+                                                              const float* __restrict__ aux, float* __restrict__ part,
+                                                              float* __restrict__ cnt_part) {
+  __shared__ float sm[4];
+  const float off = lambda * aux[0];
+  float s = 0.f, k = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float d = a[i] - b[i];
+    const float t = (huber ? sqrtf(d * d + 1e-12f) : fabsf(d)) + off;
+    s += fminf(fmaxf(t, lo), hi);
+    k += (t >= lo && t <= hi) ? 1.f : 0.f;
+  }
+  const float rs = block_sum_256(s, sm);
+  const float rk = block_sum_256(k, sm);
+  if (threadIdx.x == 0) {
+    part[blockIdx.x] = rs;
+    cnt_part[blockIdx.x] = rk;
+  }
+}
+
+// d loss / d a: the elementwise part where the clamp passes, plus lambda * (#elements inside the clamp) * d c / d a
+__global__ __launch_bounds__(256) void chc_cos_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                          const float* __restrict__ gout, int64_t npix, int C,
+                                                          int64_t hw, int huber, float lo, float hi, float lambda,
+                                                          float scale, float eps, const float* __restrict__ aux,
+                                                          float* __restrict__ ga) {
+  const float gs = gout[0] * scale;
+  const float off = lambda * aux[0];
+  const float kc = -gs * lambda * aux[1] / (float)npix;  // d/d cos of this pixel
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (int64_t)gridDim.x * 256) {
+    const int64_t n = i / hw, r = i - n * hw, base = n * C * hw + r;
+    float na, nb, cs;
+    pixel_cos(a, b, C, hw, base, eps, na, nb, cs);
+    for (int c = 0; c < C; ++c) {
+      const float x = a[base + c * hw], y = b[base + c * hw];
+      const float d = x - y;
+      float t, dt;
+      if (huber) {
+        t = sqrtf(d * d + 1e-12f);
+        dt = d / t;
+      } else {
+        t = fabsf(d);
+        dt = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+      }
+      t += off;
+      float g = (t >= lo && t <= hi) ? gs * dt : 0.f;
+      // cos = sum_c (x_c / na)(y_c / nb); for na above eps: d cos / d x_c = y_c / (na nb) - cos * x_c / na^2
+      const float dcos = na > eps ? (y / (na * nb) - cs * x / (na * na)) : y / (na * nb);
+      ga[base + c * hw] = g + kc * dcos;
+    }
+  }
+}
+
 // ------------------------------------------------------------------ BCE-with-logits vs constant t
 // mean(max(x,0) - x*t + log1p(exp(-|x|)))
 __global__ __launch_bounds__(256) void bce_partial_kernel(const float* __restrict__ x, int64_t n,
@@ -488,6 +577,40 @@ extern "C" int neosr_chc_loss_bwd(const float* a, const float* b, const float* g
   NEOSR_CHECK(a && b && grad_out && grad_a && n > 0, "chc_loss_bwd: bad args");
   hipLaunchKernelGGL(chc_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, ST, a, b, grad_out, n, pre,
                      huber, clip_min, clip_max, loss_weight / (float)n, grad_a, accumulate);
+  NEOSR_LAUNCH_CHECK();
+  return 0;
+}
+
+
+extern "C" int neosr_chc_cos_loss_fwd(const float* a, const float* b, int32_t N, int32_t C, int64_t hw, int32_t huber,
+                                      float clip_min, float clip_max, float loss_lambda, float loss_weight,
+                                      float cos_eps, float* loss_out, float* aux, float* workspace, void* stream) {
+  NEOSR_CHECK(a && b && loss_out && aux && workspace && N > 0 && C > 0 && hw > 0, "chc_cos_loss_fwd: bad args");
+  const int64_t npix = (int64_t)N * hw, n = npix * C;
+  const int nbp = grid_for(npix, 1024), nb = grid_for(n, 1024);
+  hipLaunchKernelGGL(cos_nchw_partial_kernel, dim3(nbp), dim3(256), 0, ST, a, b, npix, C, hw, cos_eps, workspace);
+  NEOSR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, ST, workspace, nbp, 1.f / (float)npix, aux);
+  NEOSR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(chc_cos_partial_kernel, dim3(nb), dim3(256), 0, ST, a, b, n, huber, clip_min, clip_max,
+                     loss_lambda, aux, workspace + 1024, workspace + 2048);
+  NEOSR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, ST, workspace + 1024, nb, loss_weight / (float)n,
+                     loss_out);
+  NEOSR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, ST, workspace + 2048, nb, 1.f, aux + 1);
+  NEOSR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int neosr_chc_cos_loss_bwd(const float* a, const float* b, const float* grad_out, int32_t N, int32_t C,
+                                      int64_t hw, int32_t huber, float clip_min, float clip_max, float loss_lambda,
+                                      float loss_weight, float cos_eps, const float* aux, float* grad_a,
+                                      void* stream) {
+  NEOSR_CHECK(a && b && grad_out && aux && grad_a && N > 0 && C > 0 && hw > 0, "chc_cos_loss_bwd: bad args");
+  const int64_t npix = (int64_t)N * hw;
+  hipLaunchKernelGGL(chc_cos_bwd_kernel, dim3(grid_for(npix)), dim3(256), 0, ST, a, b, grad_out, npix, C, hw, huber,
+                     clip_min, clip_max, loss_lambda, loss_weight / (float)(npix * C), cos_eps, aux, grad_a);
   NEOSR_LAUNCH_CHECK();
   return 0;
 }

@@ -365,6 +365,46 @@ class ChcLoss(torch.autograd.Function):
         return ga, gb, None, None, None, None, None
 
 
+class ChcCosLoss(torch.autograd.Function):
+    """chc_loss with loss_lambda != 0 (basic_loss.py:192-219) on NCHW tensors: the mean cosine distance over the
+    channel vectors shifts every element before the clamp; `neosr_chc_cos_loss_fwd/bwd`."""
+
+    COS_EPS = 1e-20  # nn.CosineSimilarity(dim=1, eps=1e-20)
+
+    @staticmethod
+    def forward(ctx, a, b, huber, lo, hi, lam, weight):
+        lib = _C.load()
+        a = _C.require_device(a, "pred").contiguous()
+        b = _C.require_device(b, "target").contiguous()
+        if a.shape != b.shape or a.dim() < 2:
+            raise _C.NeosrAmdError(f"chc_loss: shape mismatch {tuple(a.shape)} vs {tuple(b.shape)}")
+        n, c = a.shape[0], a.shape[1]
+        hw = a[0, 0].numel()
+        out = torch.empty((), device=a.device, dtype=torch.float32)
+        aux = torch.empty(2, device=a.device, dtype=torch.float32)
+        ws = torch.empty(3072, device=a.device, dtype=torch.float32)
+        _C.check(lib.neosr_chc_cos_loss_fwd(a.data_ptr(), b.data_ptr(), n, c, hw, int(huber), lo, hi, lam, weight,
+                                            ChcCosLoss.COS_EPS, out.data_ptr(), aux.data_ptr(), ws.data_ptr(), _st()),
+                 "neosr_chc_cos_loss_fwd")
+        ctx.save_for_backward(a, b, aux)
+        ctx.cfg = (n, c, hw, int(huber), lo, hi, lam, weight)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.needs_input_grad[1]:
+            raise _C.NeosrAmdError("chc_loss (loss_lambda != 0): gradient w.r.t. the target is not implemented")
+        lib = _C.load()
+        a, b, aux = ctx.saved_tensors
+        n, c, hw, huber, lo, hi, lam, weight = ctx.cfg
+        g = g.contiguous().float()
+        ga = torch.empty_like(a)
+        _C.check(lib.neosr_chc_cos_loss_bwd(a.data_ptr(), b.data_ptr(), g.data_ptr(), n, c, hw, huber, lo, hi, lam,
+                                            weight, ChcCosLoss.COS_EPS, aux.data_ptr(), ga.data_ptr(), _st()),
+                 "neosr_chc_cos_loss_bwd")
+        return ga, None, None, None, None, None, None
+
+
 class BceLogits(torch.autograd.Function):
     """weight * BCEWithLogits(x, constant target); also returns mean(x)."""
 

@@ -1,8 +1,9 @@
 """Pixel losses (drop-in for neosr/losses/basic_loss.py).
 
-``L1Loss`` with reduction="mean" — the configuration on the benchmarked path — runs on the HIP
-reduction kernels (`neosr_l1_loss_fwd/bwd`: fixed-order two-stage sum, run-to-run deterministic).
-Other reductions are rejected loudly rather than silently computed elsewhere.
+``L1Loss`` / ``MSELoss`` / ``HuberLoss`` with reduction "mean" or "sum" and ``chc_loss`` (with or without its
+cosine-similarity term) run on the HIP reduction kernels (fixed-order two-stage sums, run-to-run deterministic).
+reduction="none" returns a per-element map that `image.closure` could not back-propagate in the reference either
+(`l_g_total.backward()` needs a scalar); it is rejected loudly rather than computed elsewhere.
 """
 
 from __future__ import annotations
@@ -12,7 +13,7 @@ from torch import Tensor, nn
 
 from neosr_amd import _C
 
-from neosr_amd.hip.layers import ChcLoss
+from neosr_amd.hip.layers import ChcCosLoss, ChcLoss
 from neosr_amd.hip.nets import L1LossFunction
 from neosr_amd.utils.registry import LOSS_REGISTRY
 
@@ -28,14 +29,16 @@ class L1Loss(nn.Module):
         if reduction not in _reduction_modes:
             msg = f"Unsupported reduction mode: {reduction}. Supported ones are: {_reduction_modes}"
             raise ValueError(msg)
-        if reduction != "mean":
-            msg = "neosr_amd L1Loss: only reduction='mean' has a HIP kernel (the hot-path setting)"
+        if reduction == "none":
+            msg = "neosr_amd L1Loss: reduction='none' has no HIP kernel (the training loop needs a scalar loss)"
             raise NotImplementedError(msg)
         self.loss_weight = loss_weight
         self.reduction = reduction
 
     def forward(self, pred: Tensor, target: Tensor, **kwargs) -> Tensor:  # noqa: ARG002
-        return L1LossFunction.apply(pred, target, self.loss_weight)
+        # "sum" = numel * mean: the same kernels with the weight scaled
+        w = self.loss_weight * (pred.numel() if self.reduction == "sum" else 1)
+        return L1LossFunction.apply(pred, target, w)
 
 
 @LOSS_REGISTRY.register()
@@ -43,8 +46,10 @@ class chc_loss(nn.Module):
     """Clipped pseudo-Huber (+ cosine term) loss (basic_loss.py:132-219).
 
     `loss_weight * mean(clamp(t + loss_lambda * (1 - cos_sim).mean(), clip_min, clip_max))` with
-    `t = |d|` ("l1") or `sqrt(d^2 + 1e-12)` ("huber").  The HIP kernels implement loss_lambda = 0 —
-    the value every call site on the path uses (the class default and vgg_perceptual_loss.py:144)."""
+    `t = |d|` ("l1") or `sqrt(d^2 + 1e-12)` ("huber"), cos_sim over dim 1 of the (N, C, H, W) tensors.
+    loss_lambda = 0 (the class default and vgg_perceptual_loss.py:144) skips the cosine pass: the term then
+    shifts nothing and receives no gradient.  `reduction` is accepted and, as in the reference's forward
+    (basic_loss.py:192-219 always takes `torch.mean`), has no effect."""
 
     def __init__(self, loss_weight: float = 1.0, reduction: str = "mean", criterion: str = "huber",
                  loss_lambda: float = 0, clip_min: float = 0.003921, clip_max: float = 0.996078) -> None:
@@ -54,12 +59,13 @@ class chc_loss(nn.Module):
             raise ValueError(msg)
         if criterion not in {"l1", "huber"}:
             raise NotImplementedError(f"{criterion} not implemented.")
-        if loss_lambda != 0:
-            raise NotImplementedError("chc_loss: the cosine-similarity term (loss_lambda != 0) has no HIP kernel yet")
         self.loss_weight, self.criterion = loss_weight, criterion
         self.loss_lambda, self.clip_min, self.clip_max = loss_lambda, clip_min, clip_max
 
     def forward(self, pred: Tensor, target: Tensor, **kwargs) -> Tensor:  # noqa: ARG002
+        if self.loss_lambda != 0:
+            return ChcCosLoss.apply(pred, target, self.criterion == "huber", float(self.clip_min),
+                                    float(self.clip_max), float(self.loss_lambda), float(self.loss_weight))
         return ChcLoss.apply(pred, target, 1.0, self.criterion == "huber", float(self.clip_min),
                              float(self.clip_max), float(self.loss_weight))
 
@@ -97,8 +103,8 @@ class _PointwiseLoss(torch.autograd.Function):
 def _check_reduction(reduction: str, who: str) -> None:
     if reduction not in _reduction_modes:
         raise ValueError(f"Unsupported reduction mode: {reduction}. Supported ones are: {_reduction_modes}")
-    if reduction != "mean":
-        raise NotImplementedError(f"neosr_amd {who}: only reduction='mean' has a HIP kernel")
+    if reduction == "none":
+        raise NotImplementedError(f"neosr_amd {who}: reduction='none' has no HIP kernel (the training loop needs a scalar)")
 
 
 @LOSS_REGISTRY.register()
@@ -111,7 +117,8 @@ class MSELoss(nn.Module):
         self.loss_weight, self.reduction = loss_weight, reduction
 
     def forward(self, pred: Tensor, target: Tensor, **kwargs) -> Tensor:  # noqa: ARG002
-        return _PointwiseLoss.apply(pred, target, 1, 1.0, float(self.loss_weight))
+        w = self.loss_weight * (pred.numel() if self.reduction == "sum" else 1)
+        return _PointwiseLoss.apply(pred, target, 1, 1.0, float(w))
 
 
 @LOSS_REGISTRY.register()
@@ -124,4 +131,5 @@ class HuberLoss(nn.Module):
         self.loss_weight, self.reduction, self.delta = loss_weight, reduction, delta
 
     def forward(self, pred: Tensor, target: Tensor, **kwargs) -> Tensor:  # noqa: ARG002
-        return _PointwiseLoss.apply(pred, target, 2, float(self.delta), float(self.loss_weight))
+        w = self.loss_weight * (pred.numel() if self.reduction == "sum" else 1)
+        return _PointwiseLoss.apply(pred, target, 2, float(self.delta), float(w))

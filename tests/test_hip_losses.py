@@ -117,3 +117,27 @@ def test_gan_loss_mse_huber_vs_torch(gan_type):
             assert abs(float(loss.detach()) - float(ref)) < 1e-5 * abs(float(ref))
             assert rel_err(x.grad, xr.grad) < 1e-5
             assert abs(float(crit.last_mean) - float(logits.mean())) < 1e-5
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_chc_loss_cosine_term_and_sum_reductions_vs_reference_fixture(tag):
+    """chc_loss with loss_lambda in {0, 5/255, 0.5} (neosr_chc_cos_loss_fwd/bwd; basic_loss.py:192-219), both
+    criteria, upstream gradient != 1; L1 / MSE / Huber with reduction="sum" — vs the reference run"""
+    from neosr_amd.losses import build_loss
+
+    fix = load_golden("chc_lambda.npz")
+    y = T(fix[f"{tag}/y"]).to(DEV)
+    for crit in ("l1", "huber"):
+        for lam in (0.0, 5 / 255, 0.5):
+            x = T(fix[f"{tag}/x"]).to(DEV).requires_grad_(True)
+            v = build_loss({"type": "chc_loss", "loss_weight": 0.8, "criterion": crit, "loss_lambda": lam})(x, y)
+            (v * 1.7).backward()
+            key = f"{tag}/chc/{crit}_{lam:.6f}"
+            assert abs(float(v) - float(fix[key])) < 1e-5 * abs(float(fix[key])), key
+            assert rel_err(x.grad, T(fix[key + "/g"])) < 1e-4, key
+    for name in ("L1Loss", "MSELoss", "HuberLoss"):
+        x = T(fix[f"{tag}/x"]).to(DEV).requires_grad_(True)
+        v = build_loss({"type": name, "loss_weight": 0.6, "reduction": "sum"})(x, y)
+        v.backward()
+        assert abs(float(v) - float(fix[f"{tag}/sum/{name}"])) < 1e-5 * abs(float(fix[f"{tag}/sum/{name}"])), name
+        assert rel_err(x.grad, T(fix[f"{tag}/sum/{name}/g"])) < 1e-5, name
