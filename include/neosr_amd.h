@@ -90,6 +90,9 @@ typedef struct neosr_conv_desc {
                                (tap, sub-pixel) blocks are structurally zero and are skipped (4 taps per
                                sub-pixel instead of 9) */
   int32_t reserved0;
+  const float* w_wino;      /* optional Winograd F(2x2,3x3) image of the same weights (neosr_conv3x3_pack_wino):
+                               launches that qualify for w_pack and have no ups / s2d_c / PReLU take the Winograd
+                               kernel (16/36 of the multiplications; same epilogue); see neosr_set_winograd */
 } neosr_conv_desc;
 
 int neosr_conv3x3(const neosr_conv_desc* d, void* stream);
@@ -100,6 +103,14 @@ int neosr_conv3x3(const neosr_conv_desc* d, void* stream);
 int64_t neosr_conv3x3_pack_bytes(int32_t N, int32_t K);
 int neosr_conv3x3_pack_weights(const float* w, int32_t w_cout, int32_t w_cin, int32_t mode,
                                float* dst, void* stream);
+/* Winograd F(2x2, 3x3) image: [ceil(N/32)][ceil(K/16)][pos 16][k quad 4][n 32][4] floats, element (G g G^T)[pos] with g
+ * the 3x3 kernel of (n, k) exactly as the direct image addresses it (mode FWD / DGRAD), zero padded.  The kernel
+ * (conv_wino.hip) transforms the input patches in registers, so only the weights are pre-transformed.  Exact fp32
+ * arithmetic in a different summation order: results differ from the direct kernel by ~1e-6 relative.
+ * neosr_set_winograd(0) (env NEOSR_AMD_WINOGRAD=0) makes every launch ignore w_wino; returns the previous setting. */
+int64_t neosr_conv3x3_pack_wino_bytes(int32_t N, int32_t K);
+int neosr_conv3x3_pack_wino(const float* w, int32_t w_cout, int32_t w_cin, int32_t mode, float* dst, void* stream);
+int neosr_set_winograd(int on);
 /* Debug aid: device buffer (4 x 64 uint64) that NEOSR_TIMELINE builds of the conv kernel fill with
  * per-wave clock stamps of workgroup 0; NULL (default) disables.  No effect in normal builds. */
 int neosr_debug_set_timeline(void* dev_buf);

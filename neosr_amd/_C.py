@@ -59,6 +59,7 @@ class ConvDesc(C.Structure):
         ("out_mask_slope", C.c_float),
         ("s2d_c", C.c_int32),
         ("reserved0", C.c_int32),
+        ("w_wino", C.c_void_p),
     ]
 
 
@@ -237,6 +238,9 @@ SIGNATURES: dict[str, tuple] = {
     "neosr_debug_set_timeline": (C.c_int, [_vp]),
     "neosr_set_num_streams": (C.c_int, [C.c_int]),
     "neosr_set_xcd_aware": (C.c_int, [C.c_int]),
+    "neosr_set_winograd": (C.c_int, [C.c_int]),
+    "neosr_conv3x3_pack_wino_bytes": (_i64, [_i32, _i32]),
+    "neosr_conv3x3_pack_wino": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp]),
     "neosr_conv3x3_wgrad_workspace_bytes": (_i64, [_i32, _i32, _i32, _i32, _i32]),
     "neosr_conv3x3_wgrad": (C.c_int, [C.POINTER(WgradDesc), _vp]),
     "neosr_conv3x3_wgrad_multi_workspace_bytes": (_i64, [C.POINTER(WgradDesc), _i32]),

@@ -155,6 +155,8 @@ __device__ __forceinline__ void epi_store(const neosr_conv_desc& d, const f32x16
 
 // launchers of the kernels that live in other translation units
 void launch_glds(const ConvArgs& a, dim3 grid, hipStream_t st);
+void launch_wino(const ConvArgs& a, hipStream_t st);  // sizes its own grid (8 x 16-pixel tiles x 32-cout blocks)
+bool wino_enabled();                                   // NEOSR_AMD_WINOGRAD=0 / neosr_set_winograd(0): direct kernel
 void launch_thin_k(const ConvArgs& a, dim3 grid, hipStream_t st);
 void launch_thin_n(const ConvArgs& a, hipStream_t st);  // sizes its own grid (4 x 64-pixel tiles)
 

@@ -404,6 +404,9 @@ extern "C" int neosr_conv3x3(const neosr_conv_desc* dp, void* stream) {
                         !d.in_prelu && ((uintptr_t)d.w_pack % 16 == 0);
   NEOSR_CHECK(use_pack || d.w, "conv3x3: w_pack launch needs 16-byte aligned tensors, K,N %% 4 == 0");
   if (use_pack) grid.y = ceil_div(d.N, 32);
+  // Winograd F(2x2,3x3) form of the same launch (conv_wino.hip)
+  const bool use_wino = use_pack && d.w_wino && ((uintptr_t)d.w_wino % 16 == 0) && !d.ups && d.s2d_c == 0 &&
+                        d.act != NEOSR_ACT_PRELU && neosr_conv::wino_enabled();
   const bool prof = neosr_prof_on();
   if (prof) {
     const double px = (double)d.B * d.H * d.W;
@@ -419,7 +422,9 @@ extern "C" int neosr_conv3x3(const neosr_conv_desc* dp, void* stream) {
   a.scalar_in = thin_k && !al_in;
   const bool thin_n = plain_in && d.N <= 4 && d.K >= 8 && (d.K % 4 == 0) && al_mk && !d.res1 && !d.res2 &&
                       !d.accumulate && !d.out_mask && d.act != NEOSR_ACT_PRELU;
-  if (use_pack) {
+  if (use_wino) {
+    launch_wino(a, st);
+  } else if (use_pack) {
     launch_glds(a, grid, st);
   } else if (thin_k) {
     launch_thin_k(a, grid, st);

@@ -27,6 +27,13 @@ inline int64_t image_floats(int N, int K) {
   return (int64_t)((N + 31) / 32) * ((K + 15) / 16) * IMG_FLOATS;
 }
 
+// Winograd F(2x2,3x3) image (conv_wino.hip): [nblk][chunk 16 k][pos 16][k quad 4][n 32][4] floats, element =
+// (G g G^T)[pos] of the same (n, k) the direct image holds taps of; 32 KB per (n-block, chunk)
+constexpr int WINO_IMG_FLOATS = 16 * 4 * 32 * 4;
+inline int64_t wino_image_floats(int N, int K) {
+  return (int64_t)((N + 31) / 32) * ((K + 15) / 16) * WINO_IMG_FLOATS;
+}
+
 constexpr int BATCH = 24;  // images per launch (passed by value as kernel arguments: 3.4 KB)
 struct Batch {
   Image im[BATCH];
@@ -34,5 +41,6 @@ struct Batch {
 
 // `images` is a HOST array; ceil(n / BATCH) launches, nothing is copied to the device.
 int launch(const Image* images, int n, void* stream);
+int launch_wino(const Image* images, int n, void* stream);  // same descriptors, Winograd images
 
 }  // namespace neosr_pack

@@ -76,6 +76,9 @@ struct RrdbLayout {
   // image per gradient slice of the concat buffer, rows concatenating every conv that consumes it
   float *wpack_f, *wpack_d;
   int64_t pf_off[5], pd_off[5], pf_total, pd_total;
+  // Winograd images of the same launches (conv_wino.hip), same indexing
+  float *wwino_f, *wwino_d;
+  int64_t wf_off[5], wd_off[5], wf_total, wd_total;
   int64_t total;
 };
 
@@ -152,6 +155,20 @@ RrdbLayout rrdb_layout(const neosr_rrdbnet_cfg& c, void* ws) {
     L.pd_total = o;
     L.wpack_f = b.take(3 * L.NB * L.pf_total);
     L.wpack_d = c.training ? b.take(3 * L.NB * L.pd_total) : nullptr;
+    o = 0;
+    for (int k = 0; k < 5; ++k) {
+      L.wf_off[k] = o;
+      o += neosr_pack::wino_image_floats(k < 4 ? G : F, F + k * G);
+    }
+    L.wf_total = o;
+    o = 0;
+    for (int j = 0; j < 5; ++j) {
+      L.wd_off[j] = o;
+      o += neosr_pack::wino_image_floats(j == 0 ? F : G, F + (j == 0 ? 4 : 4 - j) * G);
+    }
+    L.wd_total = o;
+    L.wwino_f = b.take(3 * L.NB * L.wf_total);
+    L.wwino_d = c.training ? b.take(3 * L.NB * L.wd_total) : nullptr;
   }
   L.total = ((b.off + 255) & ~(int64_t)255);
   return L;
@@ -245,7 +262,10 @@ int rrdb_pack_fwd(const RrdbLayout& L, const float* const* P, void* st) {
       im.seg[0].w_cin = im.K;
       im.seg[0].k_cnt = im.K;
     }
-  return neosr_pack::launch(imgs.data(), (int)imgs.size(), st);
+  RUN(neosr_pack::launch(imgs.data(), (int)imgs.size(), st));
+  for (int i = 0; i < 3 * L.NB; ++i)
+    for (int k = 0; k < 5; ++k) imgs[i * 5 + k].dst = L.wwino_f + i * L.wf_total + L.wf_off[k];
+  return neosr_pack::launch_wino(imgs.data(), (int)imgs.size(), st);
 }
 
 int rrdb_pack_dgrad(const RrdbLayout& L, const float* const* P, void* st) {
@@ -271,7 +291,10 @@ int rrdb_pack_dgrad(const RrdbLayout& L, const float* const* P, void* st) {
       }
       im.nseg = ns;
     }
-  return neosr_pack::launch(imgs.data(), (int)imgs.size(), st);
+  RUN(neosr_pack::launch(imgs.data(), (int)imgs.size(), st));
+  for (int i = 0; i < 3 * L.NB; ++i)
+    for (int j = 0; j < 5; ++j) imgs[i * 5 + j].dst = L.wwino_d + i * L.wd_total + L.wd_off[j];
+  return neosr_pack::launch_wino(imgs.data(), (int)imgs.size(), st);
 }
 
 }  // namespace
@@ -310,6 +333,7 @@ extern "C" int neosr_rrdbnet_forward(const neosr_rrdbnet_cfg* c, const float* co
   for (int n = 0; n < L.NB; ++n) {
     for (int r = 0; r < 3; ++r) {
       const float* pk = L.wpack_f + (int64_t)(3 * n + r) * L.pf_total;
+      const float* wk = L.wwino_f + (int64_t)(3 * n + r) * L.wf_total;
       for (int h = 0; h < nhalf; ++h) {
         const int b0 = (int)((int64_t)B * h / nhalf), nb = (int)((int64_t)B * (h + 1) / nhalf) - b0;
         void* sh = h ? (void*)ax->sc[h] : st;
@@ -320,6 +344,7 @@ extern "C" int neosr_rrdbnet_forward(const neosr_rrdbnet_cfg* c, const float* co
           d.in = A; d.in_cs = CC; d.K = F + k * G;
           d.w = P[p_rdb(n, r, k)]; d.bias = P[p_rdb(n, r, k) + 1]; d.w_cout = G; d.w_cin = F + k * G;
           d.w_pack = pk + L.pf_off[k];
+          d.w_wino = wk + L.wf_off[k];
           d.out = A + F + k * G; d.out_cs = CC; d.N = G;
           d.act = NEOSR_ACT_LRELU; d.slope = 0.2f;
           RUN(neosr_conv3x3(&d, sh));
@@ -328,6 +353,7 @@ extern "C" int neosr_rrdbnet_forward(const neosr_rrdbnet_cfg* c, const float* co
         d.in = A; d.in_cs = CC; d.K = CC;
         d.w = P[p_rdb(n, r, 4)]; d.bias = P[p_rdb(n, r, 4) + 1]; d.w_cout = F; d.w_cin = CC;
         d.w_pack = pk + L.pf_off[4];
+        d.w_wino = wk + L.wf_off[4];
         const bool last = (n == L.NB - 1 && r == 2);
         d.out = last ? L.trunk + po * F : L.act[act_idx(L, 3 * n + r + 1)] + po * CC;
         d.out_cs = last ? F : CC;
@@ -510,6 +536,7 @@ int rrdb_backward_impl(const neosr_rrdbnet_cfg* c, const float* const* P, float*
     for (int r = 2; r >= 0; --r, ++t) {
       if (r == 2) dOut = L.gb[gbi];
       const float* pk = L.wpack_d + (int64_t)(3 * n + r) * L.pd_total;
+      const float* wk = L.wwino_d + (int64_t)(3 * n + r) * L.wd_total;
       for (int h = 0; h < nhalf; ++h) {
         const int b0 = (int)((int64_t)B * h / nhalf), nb = (int)((int64_t)B * (h + 1) / nhalf) - b0;
         void* sh = h ? (void*)ax->sc[h] : st;
@@ -522,6 +549,7 @@ int rrdb_backward_impl(const neosr_rrdbnet_cfg* c, const float* const* P, float*
           d.mode = NEOSR_CONV_DGRAD;
           d.in = GB; d.in_cs = CC; d.K = F + (4 - j) * G;
           d.w_pack = pk + L.pd_off[j];
+          d.w_wino = wk + L.wd_off[j];
           d.out = GB + g_off(F, G, j); d.out_cs = CC; d.N = G;
           d.out_mask = A + F + (j - 1) * G; d.out_mask_cs = CC; d.out_mask_slope = 0.2f;
           RUN(neosr_conv3x3(&d, sh));
@@ -532,6 +560,7 @@ int rrdb_backward_impl(const neosr_rrdbnet_cfg* c, const float* const* P, float*
           d.mode = NEOSR_CONV_DGRAD;
           d.in = GB; d.in_cs = CC; d.K = CC;
           d.w_pack = pk + L.pd_off[0];
+          d.w_wino = wk + L.wd_off[0];
           d.out = NG; d.out_cs = CC; d.N = F;
           d.alpha = 0.2f; d.res1 = GB; d.res1_cs = CC; d.res1_nch = F;
           if (r == 2) d.alpha2 = 0.2f;

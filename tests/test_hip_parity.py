@@ -167,6 +167,73 @@ def test_conv3x3_packed_fwd_and_dgrad(B, H, W, K, N):
     assert rel_err(_nchw(gin), ref_g) < 1e-5
 
 
+@pytest.mark.parametrize("B,H,W,K,N", PACK_CASES + [(1, 13, 21, 96, 12), (3, 8, 16, 128, 32)])
+def test_conv3x3_winograd_fwd_and_dgrad(B, H, W, K, N):
+    """Winograd F(2x2,3x3) kernel (w_wino) against autograd (float64), both modes, the same epilogues as the
+    direct-to-LDS kernel; odd sizes, ragged K / N.  Not the direct form's summation order: 1e-4 (observed ~1e-6)."""
+    from neosr_amd.hip import ops
+
+    g = torch.Generator().manual_seed(B * 37 + K + N)
+    x = torch.randn(B, K, H, W, generator=g).requires_grad_(True)
+    w = (torch.randn(N, K, 3, 3, generator=g) * 0.1)
+    b = torch.randn(N, generator=g)
+    r = torch.randn(B, N, H, W, generator=g)
+    pre = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    ref = F.leaky_relu(pre, 0.2) * 0.2 + r.double()
+    wd = w.to(DEV)
+    lib = _C_lib()
+    assert lib.neosr_set_winograd(1) in (0, 1)
+    out = ops.conv3x3(_nhwc(x.detach()), wd, b.to(DEV), act=ops.ACT_LRELU, slope=0.2, alpha=0.2, res1=_nhwc(r),
+                      w_pack=ops.conv3x3_pack_weights(wd, ops.CONV_FWD), w_wino=ops.conv3x3_pack_wino(wd, ops.CONV_FWD))
+    direct = ops.conv3x3(_nhwc(x.detach()), wd, b.to(DEV), act=ops.ACT_LRELU, slope=0.2, alpha=0.2, res1=_nhwc(r),
+                         w_pack=ops.conv3x3_pack_weights(wd, ops.CONV_FWD))
+    torch.cuda.synchronize()
+    assert rel_err(_nchw(out), ref.detach()) < 1e-4
+    assert not torch.equal(out, direct) or K * N < 200   # it really was the other kernel
+    assert rel_err(out.cpu(), direct.cpu()) < 1e-4
+    gy = torch.randn(B, N, H, W, generator=g)
+    a = torch.randn(B, K, H, W, generator=g)
+    (dx,) = torch.autograd.grad(F.conv2d(x.double(), w.double(), None, padding=1), x, gy.double())
+    ref_g = torch.where(a > 0, dx, dx * 0.2)
+    gin = ops.conv3x3(_nhwc(gy), wd, None, mode=ops.CONV_DGRAD, out_mask=_nhwc(a), out_mask_slope=0.2,
+                      w_pack=ops.conv3x3_pack_weights(wd, ops.CONV_DGRAD), w_wino=ops.conv3x3_pack_wino(wd, ops.CONV_DGRAD))
+    torch.cuda.synchronize()
+    assert rel_err(_nchw(gin), ref_g) < 1e-4
+
+
+def test_conv3x3_winograd_slices_residuals_accumulate_and_toggle():
+    """prefix-K read of a wide buffer, slice write, two residuals, accumulate; neosr_set_winograd(0) routes the same
+    descriptor to the direct kernel"""
+    from neosr_amd.hip import ops
+
+    g = torch.Generator().manual_seed(23)
+    B, H, W, CC, K, N = 2, 20, 36, 96, 64, 32
+    buf = _nhwc(torch.randn(B, CC, H, W, generator=g))
+    w = (torch.randn(N, K, 3, 3, generator=g) * 0.1).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    r2 = _nhwc(torch.randn(B, N, H, W, generator=g))
+    pack, wino = ops.conv3x3_pack_weights(w, ops.CONV_FWD), ops.conv3x3_pack_wino(w, ops.CONV_FWD)
+    lib = _C_lib()
+    outs = []
+    for on in (0, 1, 0):
+        prev = lib.neosr_set_winograd(on)
+        o = buf.clone()
+        ops.conv3x3(o[..., :K], w, b, out=o[..., K:K + N], alpha=0.2, res1=o[..., :N], alpha2=0.5, res2=r2,
+                    accumulate=True, w_pack=pack, w_wino=wino)
+        outs.append(o)
+        lib.neosr_set_winograd(prev)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[2]) and not torch.equal(outs[0], outs[1])
+    assert rel_err(outs[1].cpu(), outs[0].cpu()) < 1e-5
+    assert torch.equal(outs[1][..., :K], buf[..., :K])
+
+
+def _C_lib():
+    from neosr_amd import _C
+
+    return _C.load()
+
+
 def test_conv3x3_packed_matches_staged_kernel_on_slices():
     """same launch through both kernels: prefix-K read of a wide buffer, slice write, two residuals"""
     from neosr_amd.hip import ops
