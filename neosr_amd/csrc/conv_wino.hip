@@ -36,10 +36,13 @@ namespace {
 constexpr int WT_H = 8, WT_W = 16;            // output pixels per workgroup
 constexpr int WR_H = WT_H + 2, WR_W = WT_W + 2;  // raw input tile 10 x 18
 constexpr int WR_PIX = WR_H * WR_W;           // 180
-constexpr int WR_GRAN = WR_PIX * 4;           // 720 16-byte granules per 16-channel chunk
-constexpr int WR_BUF = 3 * 256 * 4;           // floats per raw buffer (3 workgroup-wide DMA rounds = 12 KB)
-constexpr int WCK = 16;                       // channels per chunk
-constexpr int WU_CHUNK = neosr_pack::WINO_IMG_FLOATS;  // 16 pos x 4 quads x 32 n x 4 = 8192 floats (32 KB)
+constexpr int WR_GRAN = WR_PIX * 4;           // 720 16-byte granules per 16-channel half chunk
+constexpr int WR_HALF = 3 * 256 * 4;          // floats per half chunk (3 workgroup-wide DMA rounds = 12 KB)
+constexpr int WR_BUF = 2 * WR_HALF;           // one raw buffer = a 32-channel chunk (24 KB); two buffers
+constexpr int WCK = 32;                       // channels per DMA chunk / barrier (two 16-channel halves)
+constexpr int WU_HALF = neosr_pack::WINO_IMG_FLOATS;  // 16 pos x 4 quads x 32 n x 4 = 8192 floats (32 KB) per 16 channels
+constexpr int WM_S = 36;                      // tile stride of the accumulator exchange (conflict-free b128 writes)
+constexpr int W_LDS = 16 * 32 * WM_S;         // 18432 floats = 72 KB (>= 2 raw buffers)
 
 __device__ __forceinline__ void glds16w(const float* src, float* lds_dst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -48,9 +51,17 @@ __device__ __forceinline__ void glds16w(const float* src, float* lds_dst) {
 
 __device__ __forceinline__ f32x4 ld4f(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
+// Raw tile image in LDS (per 16-channel half): granule index = pix' * 4 + slot,
+//   pix' = py * 18 + (px & 1) * 9 + (px >> 1)   (even columns first: the tiles of a row read pixels 2 apart, which
+//                                                 become consecutive 64-byte pixels),
+//   slot = channel quad ^ ((py >> 1) & 3)
+// -> the 16 lanes of every ds_read_b128 phase (8 consecutive tiles of a row x 2 tile rows) hit 16 distinct 16-byte bank
+// groups for all patch positions (checked exhaustively, tools/wino_lds_layout.py).
+__device__ __forceinline__ int raw_pix(int py, int px) { return py * WR_W + (px & 1) * (WR_W / 2) + (px >> 1); }
+
 __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const ConvArgs args) {
   const neosr_conv_desc& d = args.d;
-  __shared__ __attribute__((aligned(1024))) float lds[16 * 32 * 32];  // 64 KB: raw buffers in the loop, M at the end
+  __shared__ __attribute__((aligned(1024))) float lds[W_LDS];  // raw buffers in the loop, M at the end
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int m = lane & 31, lh = lane >> 5;
@@ -65,79 +76,88 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const ConvArgs arg
   const int n0 = blockIdx.y * 32;
   const int H = d.H, W = d.W, K = d.K;
   const float* __restrict__ inb = d.in + (int64_t)b * H * W * d.in_cs;
-  const int nchunks = (K + WCK - 1) / WCK;
+  const int nhalf = (K + 15) >> 4;          // 16-channel halves (= chunks of the U image)
+  const int nchunks = (nhalf + 1) >> 1;     // 32-channel DMA chunks
 
-  // DMA granule of this thread in round i: G = i*256 + tid -> pixel G >> 2, slot G & 3; the slot holds channel quad
-  // slot ^ ((pixel >> 1) & 3) (permutation applied on the global address: 4 lanes still fetch 64 contiguous bytes)
-  int in_off[3];
+  // DMA granule of this thread in round i: G = i*256 + tid -> pix' = G >> 2, slot = G & 3 (see raw_pix)
+  int in_off[3], in_q4[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const int G = i * 256 + tid;
-    const int pix = G >> 2, slot = G & 3;
+    const int pp = G >> 2, slot = G & 3;
     in_off[i] = -1;
+    in_q4[i] = 0;
     if (G < WR_GRAN) {
-      const int py = pix / WR_W, px = pix - py * WR_W;
+      const int py = pp / WR_W, rem = pp - py * WR_W;
+      const int par = rem >= WR_W / 2 ? 1 : 0;
+      const int px = 2 * (rem - par * (WR_W / 2)) + par;
       const int gy = y0 + py - 1, gx = x0 + px - 1;
-      if (gy >= 0 && gy < H && gx >= 0 && gx < W) in_off[i] = (gy * W + gx) * d.in_cs + ((slot ^ ((pix >> 1) & 3)) << 2);
+      in_q4[i] = (slot ^ ((py >> 1) & 3)) << 2;
+      if (gy >= 0 && gy < H && gx >= 0 && gx < W) in_off[i] = (gy * W + gx) * d.in_cs + in_q4[i];
     }
   }
   // this wave's row i = wave of B^T: t = sa * d[ra] + sb * d[rb]
   const int ra = wave == 0 ? 0 : 1, rb = wave == 3 ? 3 : 2;
   const float sa = wave == 2 ? -1.f : 1.f, sb = (wave == 0 || wave == 3) ? -1.f : 1.f;
-  // LDS float offsets of the 8 patch pixels this lane reads (2 rows x 4 columns), before the per-group slot
-  int pixo[8];
+  // LDS float offsets (within a half) of the 8 patch pixels this lane reads (2 rows x 4 columns) for k group 0;
+  // k group 1 is the quad 2 higher: slot ^ 2 -> offset ^ 8
+  int po[8];
 #pragma unroll
   for (int r = 0; r < 2; ++r)
 #pragma unroll
-    for (int s = 0; s < 4; ++s) pixo[r * 4 + s] = (2 * tyi + (r ? rb : ra)) * WR_W + 2 * txi + s;
+    for (int s = 0; s < 4; ++s) {
+      const int py = 2 * tyi + (r ? rb : ra), px = 2 * txi + s;
+      po[r * 4 + s] = raw_pix(py, px) * 16 + ((lh ^ ((py >> 1) & 3)) << 2);
+    }
 
-  // U image of this n-block: [chunk][pos 16][quad 4][n 32][4]; this lane's float4 of position (wave, j), quad q
-  const float* __restrict__ wp = d.w_wino + (int64_t)blockIdx.y * nchunks * WU_CHUNK + (wave * 4) * 512 + m * 4;
+  // U image of this n-block: [half][pos 16][quad 4][n 32][4]; this lane's float4 of position (wave, j), quad q
+  const float* __restrict__ wp = d.w_wino + (int64_t)blockIdx.y * nhalf * WU_HALF + (wave * 4) * 512 + m * 4;
 
-  auto issue = [&](int c, int buf) {
-    float* rbuf = lds + buf * WR_BUF;
-    const int c0 = c * WCK;
+  auto issue = [&](int c, int buf) {  // 32 channels: two halves of 3 DMA rounds each
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int G = i * 256 + tid;
-      const int q4 = ((G & 3) ^ (((G >> 2) >> 1) & 3)) << 2;
-      const float* src = (in_off[i] >= 0 && c0 + q4 < K) ? inb + in_off[i] + c0 : g_zero_page;
-      glds16w(src, rbuf + (i * 4 + wave) * 256);
+    for (int h = 0; h < 2; ++h) {
+      float* rbuf = lds + buf * WR_BUF + h * WR_HALF;
+      const int c0 = c * WCK + h * 16;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const float* src = (in_off[i] >= 0 && c0 + in_q4[i] < K) ? inb + in_off[i] + c0 : g_zero_page;
+        glds16w(src, rbuf + (i * 4 + wave) * 256);
+      }
     }
   };
-  auto load_u = [&](int c, f32x4 (&u)[4][2]) {
-    const float* p = wp + (int64_t)c * WU_CHUNK;
+  auto load_u = [&](int h, f32x4 (&u)[4][2]) {
+    const float* p = wp + (int64_t)h * WU_HALF;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int g = 0; g < 2; ++g) u[j][g] = ld4f(p + j * 512 + (2 * g + lh) * 128);
   };
 
+  // D = U^T V^T: rows = output channels (A operand = U), columns = tiles (B operand = V) -> a lane's accumulator
+  // registers 4r..4r+3 are 4 consecutive channels of ITS tile (16-byte exchange writes)
   f32x16 acc[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-  auto compute = [&](int buf, const f32x4 (&u)[4][2]) {
-    const float* rbuf = lds + buf * WR_BUF;
+  auto compute = [&](const float* rbuf, const f32x4 (&u)[4][2]) {
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
       f32x4 t[4];
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        const int pa = pixo[s], pb = pixo[4 + s];
-        const f32x4 da = ld4f(rbuf + pa * 16 + (((2 * g + lh) ^ ((pa >> 1) & 3)) << 2));
-        const f32x4 db = ld4f(rbuf + pb * 16 + (((2 * g + lh) ^ ((pb >> 1) & 3)) << 2));
+        const f32x4 da = ld4f(rbuf + (po[s] ^ (g << 3)));
+        const f32x4 db = ld4f(rbuf + (po[4 + s] ^ (g << 3)));
         t[s] = sa * da + sb * db;
       }
       const f32x4 v0 = t[0] - t[2], v1 = t[1] + t[2], v2 = t[2] - t[1], v3 = t[1] - t[3];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v0[e], u[0][g][e], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v1[e], u[1][g][e], acc[1], 0, 0, 0);
-        acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(v2[e], u[2][g][e], acc[2], 0, 0, 0);
-        acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(v3[e], u[3][g][e], acc[3], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[0][g][e], v0[e], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[1][g][e], v1[e], acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[2][g][e], v2[e], acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[3][g][e], v3[e], acc[3], 0, 0, 0);
       }
     }
   };
@@ -147,38 +167,25 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const ConvArgs arg
   load_u(0, ua);
   __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
   __syncthreads();
-  int c = 0;
-  for (; c + 2 < nchunks; c += 2) {
-    issue(c + 1, 1);
-    load_u(c + 1, ub);
-    compute(0, ua);
-    __builtin_amdgcn_s_waitcnt(0x0f70);
-    __syncthreads();
-    issue(c + 2, 0);
-    load_u(c + 2, ua);
-    compute(1, ub);
-    __builtin_amdgcn_s_waitcnt(0x0f70);
-    __syncthreads();
-  }
-  if (c + 1 < nchunks) {  // two chunks left: c (buffer 0, ua) and c + 1
-    issue(c + 1, 1);
-    load_u(c + 1, ub);
-    compute(0, ua);
-    __builtin_amdgcn_s_waitcnt(0x0f70);
-    __syncthreads();
-    compute(1, ub);
-  } else {
-    compute(0, ua);
+  for (int c = 0; c < nchunks; ++c) {
+    const float* rb0 = lds + (c & 1) * WR_BUF;
+    if (c + 1 < nchunks) issue(c + 1, (c + 1) & 1);
+    const bool h1 = 2 * c + 1 < nhalf, h2 = 2 * c + 2 < nhalf;  // workgroup-uniform
+    if (h1) load_u(2 * c + 1, ub);
+    compute(rb0, ua);
+    if (h2) load_u(2 * c + 2, ua);
+    if (h1) compute(rb0 + WR_HALF, ub);
+    __builtin_amdgcn_s_waitcnt(0x0f70);  // chunk c + 1 has landed ...
+    __syncthreads();                      // ... for every wave, and buffer c & 1 is free again
   }
 
-  // ---- accumulator exchange: M[pos][tile][cout] (D rows = tiles: (r & 3) + 8 (r >> 2) + 4 lh, column = lane & 31)
-  __syncthreads();  // every wave is done with the raw buffers
+  // ---- accumulator exchange: M[pos][tile][cout] with tile stride WM_S; register 4rr + e <-> channel 8rr + 4lh + e
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int tile = (r & 3) + 8 * (r >> 2) + 4 * lh;
-      lds[((wave * 4 + j) * 32 + tile) * 32 + m] = acc[j][r];
+    for (int rr = 0; rr < 4; ++rr) {
+      f32x4 v = {acc[j][4 * rr], acc[j][4 * rr + 1], acc[j][4 * rr + 2], acc[j][4 * rr + 3]};
+      *reinterpret_cast<f32x4*>(lds + ((wave * 4 + j) * 32 + m) * WM_S + 8 * rr + 4 * lh) = v;
     }
   __syncthreads();
 
@@ -187,10 +194,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const ConvArgs arg
   f32x4 s0[4], s1[4];  // rows of A^T M: s0[j] = M0j + M1j + M2j, s1[j] = M1j - M2j - M3j
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const f32x4 m0 = ld4f(lds + ((0 * 4 + j) * 32 + et) * 32 + cq);
-    const f32x4 m1 = ld4f(lds + ((1 * 4 + j) * 32 + et) * 32 + cq);
-    const f32x4 m2 = ld4f(lds + ((2 * 4 + j) * 32 + et) * 32 + cq);
-    const f32x4 m3 = ld4f(lds + ((3 * 4 + j) * 32 + et) * 32 + cq);
+    const f32x4 m0 = ld4f(lds + ((0 * 4 + j) * 32 + et) * WM_S + cq);
+    const f32x4 m1 = ld4f(lds + ((1 * 4 + j) * 32 + et) * WM_S + cq);
+    const f32x4 m2 = ld4f(lds + ((2 * 4 + j) * 32 + et) * WM_S + cq);
+    const f32x4 m3 = ld4f(lds + ((3 * 4 + j) * 32 + et) * WM_S + cq);
     s0[j] = m0 + m1 + m2;
     s1[j] = m1 - m2 - m3;
   }
@@ -241,7 +248,7 @@ __global__ __launch_bounds__(256) void conv_pack_wino_kernel(const neosr_pack::B
   const neosr_pack::Image& im = batch.im[blockIdx.y];
   const int nch = (im.K + 15) >> 4, nblk = (im.N + 31) >> 5;
   const int g = blockIdx.x * 256 + threadIdx.x;
-  if (g >= nblk * nch * (WU_CHUNK / 4)) return;
+  if (g >= nblk * nch * (WU_HALF / 4)) return;
   const int n32 = g & 31, q = (g >> 5) & 3, pos = (g >> 7) & 15;
   const int rest = g >> 11;
   const int chunk = rest % nch, nb = rest / nch;

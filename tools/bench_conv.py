@@ -1,4 +1,4 @@
-"""Per-shape timing of the two 3x3 kernels (register-staged vs direct-to-LDS) on the RDB shapes.
+"""Per-shape timing of the 3x3 kernels (register-staged, direct-to-LDS, Winograd F(2x2,3x3)) on the RDB shapes.
 usage: python tools/bench_conv.py [B] [H]"""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -32,4 +32,7 @@ for K, N in ([(64, 32), (96, 32), (128, 32), (160, 32), (192, 64)] if H <= 64 el
     fl = 2.0 * B * H * W * K * N * 9
     t0 = timeit(lambda: ops.conv3x3(buf[..., :K], w, bias, out=out[..., :N], act=ops.ACT_LRELU, slope=0.2))
     t1 = timeit(lambda: ops.conv3x3(buf[..., :K], w, bias, out=out[..., :N], act=ops.ACT_LRELU, slope=0.2, w_pack=pack))
-    print(f"K={K:3d} N={N:2d}  staged {t0:7.1f} us {fl / t0 / 1e6:6.1f} TF   glds {t1:7.1f} us {fl / t1 / 1e6:6.1f} TF")
+    wino = ops.conv3x3_pack_wino(w)
+    t2 = timeit(lambda: ops.conv3x3(buf[..., :K], w, bias, out=out[..., :N], act=ops.ACT_LRELU, slope=0.2, w_pack=pack, w_wino=wino))
+    print(f"K={K:3d} N={N:2d}  staged {t0:7.1f} us {fl / t0 / 1e6:6.1f} TF   glds {t1:7.1f} us {fl / t1 / 1e6:6.1f} TF   "
+          f"winograd {t2:7.1f} us {fl / t2 / 1e6:6.1f} TF(direct-equivalent)")
