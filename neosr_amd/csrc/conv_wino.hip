@@ -17,10 +17,11 @@
 //   * the B operand of position (i, j), channel pair, cout = lane & 31 is one float of the packed U image: each wave
 //     reads ITS four positions of the next 16-channel chunk straight from global memory (coalesced 1 KB rows, L2
 //     resident: every workgroup of the launch reads the same image) one chunk ahead — U never touches LDS either;
-//   * LDS holds only the raw 10 x 18 x 16-channel input tile of a chunk (11.25 KB, global_load_lds_dwordx4, two
-//     buffers, ONE barrier per chunk), shared by the four waves, and at the end the 16 x 32 x 32 accumulator exchange
-//     for the output transform A^T M A, after which thread (tile, cout quad) runs the epilogue and stores 2 x 2 pixels
-//     x 4 channels with 16-byte stores.
+//   * LDS holds only the raw 10 x 18 input tile of a 32-channel chunk (2 x 11.25 KB, global_load_lds_dwordx4, two
+//     buffers, ONE barrier per chunk = per 64 MFMAs of a wave), shared by the four waves; at the end each wave applies
+//     the column pass of A^T M A to its own four accumulators, the 8 x 32 x 32 result crosses LDS once, and thread
+//     (tile, cout quad) finishes the row pass, runs the epilogue and stores 2 x 2 pixels x 4 channels with 16-byte
+//     stores.
 // Exact fp32 products and sums, but not the direct form's summation order: results differ from it by ~1e-6 relative
 // (tests: <= 1e-4 against the oracle at kernel level; north_star allows 1e-3).  neosr_set_winograd(0) /
 // NEOSR_AMD_WINOGRAD=0 selects the direct kernel for the same launches.
@@ -42,7 +43,8 @@ constexpr int WR_BUF = 2 * WR_HALF;           // one raw buffer = a 32-channel c
 constexpr int WCK = 32;                       // channels per DMA chunk / barrier (two 16-channel halves)
 constexpr int WU_HALF = neosr_pack::WINO_IMG_FLOATS;  // 16 pos x 4 quads x 32 n x 4 = 8192 floats (32 KB) per 16 channels
 constexpr int WM_S = 36;                      // tile stride of the accumulator exchange (conflict-free b128 writes)
-constexpr int W_LDS = 16 * 32 * WM_S;         // 18432 floats = 72 KB (>= 2 raw buffers)
+constexpr int W_LDS = 2 * WR_BUF;              // 12288 floats = 48 KB: two raw buffers (>= the 36 KB exchange image)
+static_assert(8 * 32 * WM_S <= W_LDS, "exchange image must fit the raw buffers");
 
 __device__ __forceinline__ void glds16w(const float* src, float* lds_dst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -179,33 +181,35 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const ConvArgs arg
     __syncthreads();                      // ... for every wave, and buffer c & 1 is free again
   }
 
-  // ---- accumulator exchange: M[pos][tile][cout] with tile stride WM_S; register 4rr + e <-> channel 8rr + 4lh + e
+  // ---- output transform, column pass IN THE WAVE: (M A)[i][b] = M[i][0] + M[i][1] + M[i][2] (b = 0), M[i][1] - M[i][2] - M[i][3]
+  // (b = 1) on the wave's own four accumulators -> only 2 x 16 registers per lane cross the LDS
+  // exchange image: X[i][b][tile][cout], tile stride WM_S; register 4rr + e <-> channel 8rr + 4lh + e
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+  for (int bq = 0; bq < 2; ++bq)
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
-      f32x4 v = {acc[j][4 * rr], acc[j][4 * rr + 1], acc[j][4 * rr + 2], acc[j][4 * rr + 3]};
-      *reinterpret_cast<f32x4*>(lds + ((wave * 4 + j) * 32 + m) * WM_S + 8 * rr + 4 * lh) = v;
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * rr + e;
+        v[e] = bq == 0 ? (acc[0][r] + acc[1][r]) + acc[2][r] : (acc[1][r] - acc[2][r]) - acc[3][r];
+      }
+      *reinterpret_cast<f32x4*>(lds + ((wave * 2 + bq) * 32 + m) * WM_S + 8 * rr + 4 * lh) = v;
     }
   __syncthreads();
 
-  // ---- output transform + epilogue: thread = (tile, cout quad)
+  // ---- row pass + epilogue: thread = (tile, cout quad); Y[a][b] = X[0][b] + X[1][b] + X[2][b] (a = 0), X[1][b] - X[2][b] - X[3][b]
   const int et = tid >> 3, cq = (tid & 7) << 2;
-  f32x4 s0[4], s1[4];  // rows of A^T M: s0[j] = M0j + M1j + M2j, s1[j] = M1j - M2j - M3j
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const f32x4 m0 = ld4f(lds + ((0 * 4 + j) * 32 + et) * WM_S + cq);
-    const f32x4 m1 = ld4f(lds + ((1 * 4 + j) * 32 + et) * WM_S + cq);
-    const f32x4 m2 = ld4f(lds + ((2 * 4 + j) * 32 + et) * WM_S + cq);
-    const f32x4 m3 = ld4f(lds + ((3 * 4 + j) * 32 + et) * WM_S + cq);
-    s0[j] = m0 + m1 + m2;
-    s1[j] = m1 - m2 - m3;
-  }
   f32x4 y[2][2];
-  y[0][0] = s0[0] + s0[1] + s0[2];
-  y[0][1] = s0[1] - s0[2] - s0[3];
-  y[1][0] = s1[0] + s1[1] + s1[2];
-  y[1][1] = s1[1] - s1[2] - s1[3];
+#pragma unroll
+  for (int bq = 0; bq < 2; ++bq) {
+    const f32x4 x0 = ld4f(lds + ((0 * 2 + bq) * 32 + et) * WM_S + cq);
+    const f32x4 x1 = ld4f(lds + ((1 * 2 + bq) * 32 + et) * WM_S + cq);
+    const f32x4 x2 = ld4f(lds + ((2 * 2 + bq) * 32 + et) * WM_S + cq);
+    const f32x4 x3 = ld4f(lds + ((3 * 2 + bq) * 32 + et) * WM_S + cq);
+    y[0][bq] = (x0 + x1) + x2;
+    y[1][bq] = (x1 - x2) - x3;
+  }
 
   const int chq = n0 + cq;
   const bool ch_ok = chq < d.N;

@@ -21,7 +21,7 @@
 #include <type_traits>
 #include "../../include/neosr_amd.h"
 
-namespace neosr_conv { bool xcd_enabled(); }
+namespace neosr_conv { bool xcd_enabled(); bool wino_enabled(); }
 
 namespace {
 
@@ -52,6 +52,8 @@ struct WgradMultiArgs {
   int btile_start[MAXD + 1];  // prefix sums of nnt per desc
   // XCD-pinned order (1-D grid of 8 * xcd_q workgroups, see plan()): 0 = (pair, split) grid in dispatch order
   int xcd, xcd_full, xcd_q;
+  // Winograd path (conv3x3_wgrad_wino_kernel): units of 2 rows x 32 columns, its own split of them
+  int w_units_x, w_units_y, w_nunits, w_units_per_split, w_nsplit;
 };
 
 __device__ __forceinline__ float4 ld4(const float* p, bool vec, int c, int C) {
@@ -279,6 +281,257 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_multi_kernel(const Wgrad
     if (tid < 32) {
       const float v = ((bred[tid] + bred[32 + tid]) + bred[64 + tid]) + bred[96 + tid];
       args.bpart[((int64_t)(args.btile_start[di] + ntile) * args.nsplit + s) * 32 + tid] = v;
+    }
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Winograd form of the same weight gradient, F(3x3 taps <- 2x2 gradient tile (*) 4x4 input patch):
+//   dW(3x3) = A'^T [ sum over tiles and batch of  (G' dy G'^T) (.) (B^T d B) ] A'
+//   B^T as in conv_wino.hip; G' = [[1,0],[1,1],[1,-1],[0,-1]] (adds only); A'^T = [[1,.5,.5,0],[0,.5,-.5,0],[0,.5,.5,1]]
+// (the F(2x2,3x3) algorithm with the roles of filter and output exchanged: the trilinear form is symmetric in them).
+// 16 multiplications per (tile, cout, cin) instead of 36.  A workgroup owns a (32 cout, 32 cin) pair and a split of
+// the pixel tiles exactly like conv3x3_wgrad_multi_kernel (same XCD-pinned order, same bias partials); each of the 16
+// transform positions is a 32 x 32 GEMM whose reduction index is the TILE.  WAVE i OWNS ROW i of both transforms:
+//   * MFMA K = 2 tiles per instruction: lanes lh = 0 / 1 walk the left / right 8 tiles of a 2-row x 32-column unit, so
+//     consecutive steps of a lane are ADJACENT tiles and the row-combined columns t2, t3 of one patch are t0, t1 of the
+//     next: 4 new input floats + 2 (or 4) gradient floats per step, lane = channel -> conflict-free ds_read_b32;
+//   * A operand = row i of G' dy G'^T for the lane's cout, B operand = row i of B^T d B for the lane's cin, both built in
+//     registers from the raw tiles; nothing transformed is ever stored;
+//   * raw tiles (4 x 34 input pixels x 32 cin, 2 x 32 gradient pixels x 32 cout) go global -> LDS with
+//     global_load_lds_dwordx4 into two 28 KB buffers, ONE barrier per unit.
+// The 16 x 32 x 32 partial of a workgroup is summed over the splits in a fixed order and inverse-transformed by
+// conv3x3_wgrad_wino_reduce_kernel (run-to-run deterministic, like the direct path).
+constexpr int WW_XR = 4, WW_XC = 34;                 // raw input rows / columns of a unit
+constexpr int WW_XGRAN = WW_XR * WW_XC * 8;          // 1088 16-byte granules (32 channels = 8 per pixel)
+constexpr int WW_XROUNDS = (WW_XGRAN + 255) / 256;   // 5: four workgroup-wide DMA rounds + one of wave 0 alone (64 granules)
+static_assert(WW_XGRAN == 4 * 256 + 64, "the last DMA round is exactly wave 0");
+constexpr int WW_XF = WW_XGRAN * 4;                  // 4352 floats (17 KB)
+constexpr int WW_GF = 2 * 32 * 32;                   // gradient tile floats (8 KB) = 2 DMA rounds
+constexpr int WW_BUF = WW_XF + WW_GF;                // 6400 floats = 25 KB; two buffers -> three workgroups per CU
+constexpr int WW_SLOTS = 768;                        // resident workgroups the split count aims at (3 per CU)
+constexpr int WW_PART = 16 * 1024;                   // floats per (pair, split) partial
+
+__device__ __forceinline__ void glds16g(const float* src, float* lds_dst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+__global__ __launch_bounds__(256, 3) void conv3x3_wgrad_wino_kernel(const WgradMultiArgs args) {
+  __shared__ __attribute__((aligned(1024))) float lds[2 * WW_BUF];
+  __shared__ float bred[2 * 32];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  int pair = blockIdx.x, s = blockIdx.y;
+  if (args.xcd) {  // XCD-pinned order, see conv3x3_wgrad_multi_kernel
+    const int P = args.pair_start[MAXD];
+    const int x = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int pinned = args.xcd_full * P;
+    if (q < pinned) {
+      s = x * args.xcd_full + q / P;
+      pair = q % P;
+    } else {
+      const int r = x * (args.xcd_q - pinned) + (q - pinned);
+      s = 8 * args.xcd_full + r / P;
+      pair = r % P;
+      if (s >= args.w_nsplit) return;
+    }
+  }
+  int di = 0;
+#pragma unroll
+  for (int i = 1; i < MAXD; ++i)
+    if (i < args.ndesc && pair >= args.pair_start[i]) di = i;
+  const neosr_wgrad_desc& d = args.d[di];
+  const int local = pair - args.pair_start[di];
+  const int nkt = args.nkt[di];
+  const int ntile = local / nkt, kt = local - ntile * nkt;
+  const int co0 = ntile * 32, ci0 = kt * 32;
+  const int H = args.H, W = args.W;
+  const int u_lo = s * args.w_units_per_split;
+  const int u_hi = min(args.w_nunits, u_lo + args.w_units_per_split);
+
+  // DMA granules of this thread: input rounds i = 0..4: G = i*256 + tid -> pixel G >> 3 (row, col of the 4 x 34 tile),
+  // channel quad G & 7; gradient rounds i = 0, 1: pixel (row 0..1, col 0..31)
+  int xr[WW_XROUNDS], xc[WW_XROUNDS];
+#pragma unroll
+  for (int i = 0; i < WW_XROUNDS; ++i) {
+    const int G = i * 256 + tid;
+    const int pix = G >> 3;
+    xr[i] = G < WW_XGRAN ? pix / WW_XC : -100000;
+    xc[i] = pix - (pix / WW_XC) * WW_XC;
+  }
+  const int q4 = (tid & 7) << 2;
+  const bool ci_ok = ci0 + q4 < d.K, co_ok = co0 + q4 < d.N;
+
+  auto issue = [&](int u, int buf) {
+    const int xx = u % args.w_units_x;
+    const int r = u / args.w_units_x;
+    const int yy = r % args.w_units_y;
+    const int b = r / args.w_units_y;
+    const int x0 = xx * 32, y0 = yy * 2;
+    float* xb = lds + buf * WW_BUF;
+    float* gb = xb + WW_XF;
+#pragma unroll
+    for (int i = 0; i < WW_XROUNDS; ++i) {
+      if (i == WW_XROUNDS - 1 && wave != 0) break;  // granules 1024..1087
+      const int gy = y0 - 1 + xr[i], gx = x0 - 1 + xc[i];
+      const bool ok = ci_ok && gy >= 0 && gy < H && gx >= 0 && gx < W;
+      const float* src = ok ? d.in + (((int64_t)b * H + gy) * W + gx) * d.in_cs + ci0 + q4 : wg_zero_page;
+      glds16g(src, xb + (i * 4 + wave) * 256);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int pix = (i * 256 + tid) >> 3;
+      const int gy = y0 + (pix >> 5), gx = x0 + (pix & 31);
+      const bool ok = co_ok && gy < H && gx < W;
+      const float* src = ok ? d.g + (((int64_t)b * H + gy) * W + gx) * d.g_cs + co0 + q4 : wg_zero_page;
+      glds16g(src, gb + (i * 4 + wave) * 256);
+    }
+  };
+
+  // this wave's row i = wave of the transforms
+  const int ra = wave == 0 ? 0 : 1, rb = wave == 3 ? 3 : 2;                      // input rows: t = sa x[ra] + sb x[rb]
+  const float sa = wave == 2 ? -1.f : 1.f, sb = (wave == 0 || wave == 3) ? -1.f : 1.f;
+  const bool two = wave == 1 || wave == 2;                                         // gradient rows: 0 | 0+1 | 0-1 | -1
+  const int gr = wave == 3 ? 1 : 0;
+  const float ga = wave == 3 ? -1.f : 1.f, gbq = wave == 2 ? -1.f : 1.f;
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  float bsum = 0.f;
+
+  auto compute = [&](int buf) {
+    const float* xb = lds + buf * WW_BUF + l31;
+    const float* gb = lds + buf * WW_BUF + WW_XF + l31;
+    const float* xa = xb + (ra * WW_XC + lh * 16) * 32;   // raw column of tile t, patch column s: 2 t + s, t = lh*8 + kt
+    const float* xq = xb + (rb * WW_XC + lh * 16) * 32;
+    const float* g0 = gb + (gr * 32 + lh * 16) * 32;
+    const float* g1 = gb + (32 + lh * 16) * 32;
+    float t0 = sa * xa[0] + sb * xq[0];
+    float t1 = sa * xa[32] + sb * xq[32];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float t2 = sa * xa[(2 * k + 2) * 32] + sb * xq[(2 * k + 2) * 32];
+      const float t3 = sa * xa[(2 * k + 3) * 32] + sb * xq[(2 * k + 3) * 32];
+      float r0 = ga * g0[(2 * k) * 32], r1 = ga * g0[(2 * k + 1) * 32];
+      if (two) {
+        r0 += gbq * g1[(2 * k) * 32];
+        r1 += gbq * g1[(2 * k + 1) * 32];
+      }
+      bsum += r0 + r1;
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(r0, t0 - t2, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(r0 + r1, t1 + t2, acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(r0 - r1, t2 - t1, acc[2], 0, 0, 0);
+      acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(-r1, t1 - t3, acc[3], 0, 0, 0);
+      t0 = t2;
+      t1 = t3;
+    }
+  };
+
+  if (u_lo < u_hi) {
+    issue(u_lo, 0);
+    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
+    __syncthreads();
+    for (int u = u_lo; u < u_hi; ++u) {
+      const int buf = (u - u_lo) & 1;
+      if (u + 1 < u_hi) issue(u + 1, buf ^ 1);
+      compute(buf);
+      __builtin_amdgcn_s_waitcnt(0x0f70);
+      __syncthreads();
+    }
+  }
+
+  // partial[pos = 4 wave + j][co row][ci column]: D rows = (r & 3) + 8 (r >> 2) + 4 lh, column = lane & 31
+  float* part = args.part + ((int64_t)pair * args.w_nsplit + s) * WW_PART + (wave * 4) * 1024 + l31;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part[j * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * lh) * 32] = acc[j][r];
+
+  if (d.db && kt == 0) {  // sum of the gradient tile = (row 0 sums of wave 0) - (negated row 1 sums of wave 3)
+    bsum += __shfl_xor(bsum, 32, 64);
+    if (lh == 0 && (wave == 0 || wave == 3)) bred[(wave ? 32 : 0) + l31] = bsum;
+    __syncthreads();
+    if (tid < 32)
+      args.bpart[((int64_t)(args.btile_start[di] + ntile) * args.w_nsplit + s) * 32 + tid] = bred[tid] - bred[32 + tid];
+  }
+}
+
+// stage 2 of the Winograd path: sum the 16-position partials over the splits (fixed order), inverse transform
+// A'^T M A', scale, scatter into the canonical (N, K, 3, 3) layout; bias gradient as in conv3x3_wgrad_reduce_kernel
+__global__ __launch_bounds__(256) void conv3x3_wgrad_wino_reduce_kernel(const WgradMultiArgs args) {
+  __shared__ float red[4][16][64];
+  const int pair = blockIdx.y;
+  int di = 0;
+#pragma unroll
+  for (int i = 1; i < MAXD; ++i)
+    if (i < args.ndesc && pair >= args.pair_start[i]) di = i;
+  const neosr_wgrad_desc& d = args.d[di];
+  const int local = pair - args.pair_start[di];
+  const int nkt = args.nkt[di];
+  const int ntile = local / nkt, kt = local - ntile * nkt;
+  const int o = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int r = blockIdx.x * 64 + o;  // < 1024: (co i, ci j) of the tile
+  const int i = r >> 5, j = r & 31;
+  const int co = ntile * 32 + i, ci = kt * 32 + j;
+  const bool live = co < d.N && ci < d.K;
+  float m[16];
+#pragma unroll
+  for (int p = 0; p < 16; ++p) m[p] = 0.f;
+  if (live) {
+    const float* p0 = args.part + (int64_t)pair * args.w_nsplit * WW_PART + r;
+    for (int s = sl; s < args.w_nsplit; s += 4) {
+      const float* ps = p0 + (int64_t)s * WW_PART;
+#pragma unroll
+      for (int p = 0; p < 16; ++p) m[p] += ps[p * 1024];
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < 16; ++p) red[sl][p][o] = m[p];
+  __syncthreads();
+  if (sl == 0 && live) {
+    float M[4][4];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) M[p >> 2][p & 3] = ((red[0][p][o] + red[1][p][o]) + red[2][p][o]) + red[3][p][o];
+    float u[3][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      u[0][q] = M[0][q] + 0.5f * (M[1][q] + M[2][q]);
+      u[1][q] = 0.5f * (M[1][q] - M[2][q]);
+      u[2][q] = 0.5f * (M[1][q] + M[2][q]) + M[3][q];
+    }
+    float* qd = d.dw + ((int64_t)co * d.K + ci) * 9;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float w0 = u[a][0] + 0.5f * (u[a][1] + u[a][2]);
+      const float w1 = 0.5f * (u[a][1] - u[a][2]);
+      const float w2 = 0.5f * (u[a][1] + u[a][2]) + u[a][3];
+      const float v[3] = {w0 * d.scale, w1 * d.scale, w2 * d.scale};
+#pragma unroll
+      for (int b = 0; b < 3; ++b) qd[a * 3 + b] = d.accumulate ? qd[a * 3 + b] + v[b] : v[b];
+    }
+  }
+  if (d.db && kt == 0 && blockIdx.x == 0) {
+    __shared__ float bred[8][33];
+    const int cbl = threadIdx.x & 31, bl = threadIdx.x >> 5;
+    const float* bp = args.bpart + (int64_t)(args.btile_start[di] + ntile) * args.w_nsplit * 32 + cbl;
+    float sum = 0.f;
+    for (int s = bl; s < args.w_nsplit; s += 8) sum += bp[(int64_t)s * 32];
+    bred[bl][cbl] = sum;
+    __syncthreads();
+    const int cb = ntile * 32 + cbl;
+    if (bl == 0 && cb < d.N) {
+      float tot = 0.f;
+#pragma unroll
+      for (int l = 0; l < 8; ++l) tot += bred[l][cbl];
+      tot *= d.scale;
+      d.db[cb] = d.accumulate ? (d.db[cb] + tot) : tot;
     }
   }
 }
@@ -555,6 +808,14 @@ int plan(const neosr_wgrad_desc* ds, int n, WgradMultiArgs& a) {
   a.xcd_full = pairs <= 64 ? 64 / pairs : 0;
   if (a.xcd_full > a.nsplit / 8) a.xcd_full = a.nsplit / 8;
   a.xcd_q = a.xcd_full * pairs + ceil_div((a.nsplit - 8 * a.xcd_full) * pairs, 8);
+  a.w_units_x = ceil_div(a.W, 32);
+  a.w_units_y = ceil_div(a.H, 2);
+  a.w_nunits = a.w_units_x * a.w_units_y * a.B;
+  int wsplit = WW_SLOTS / pairs;
+  if (wsplit < 1) wsplit = 1;
+  if (wsplit > a.w_nunits) wsplit = a.w_nunits;
+  a.w_units_per_split = ceil_div(a.w_nunits, wsplit);
+  a.w_nsplit = ceil_div(a.w_nunits, a.w_units_per_split);
   return 0;
 }
 
@@ -579,6 +840,8 @@ int64_t thin_ws_floats(const neosr_wgrad_desc& d) {
 
 int64_t ws_floats(const WgradMultiArgs& a) {
   int64_t w = (int64_t)a.pair_start[MAXD] * a.nsplit * WG_TILE + (int64_t)a.btile_start[MAXD] * a.nsplit * 32 + 64;
+  const int64_t ww = (int64_t)a.pair_start[MAXD] * a.w_nsplit * WW_PART + (int64_t)a.btile_start[MAXD] * a.w_nsplit * 32 + 64;
+  if (ww > w) w = ww;  // the Winograd path keeps 16 positions per partial
   if (thin_ok(a.d, a.ndesc)) {
     const int64_t t = thin_ws_floats(a.d[0]);
     if (t > w) w = t;
@@ -645,6 +908,23 @@ extern "C" int neosr_conv3x3_wgrad_multi(const neosr_wgrad_desc* ds, int32_t n, 
   for (int i = 0; i < n; ++i) {
     s2d = s2d || ds[i].s2d_c > 0;
     plain = plain && !ds[i].g_mask && !ds[i].in_prelu && !ds[i].mask_slopes;
+  }
+  if (fast && plain && !s2d && !a.ups && neosr_conv::wino_enabled()) {  // Winograd form (see conv3x3_wgrad_wino_kernel)
+    WgradMultiArgs w = a;
+    const int P = a.pair_start[MAXD];
+    w.bpart = workspace + (int64_t)P * a.w_nsplit * WW_PART;
+    w.xcd_full = P <= WW_SLOTS / 8 ? (WW_SLOTS / 8) / P : 0;  // 96 slots per XCD
+    if (w.xcd_full > a.w_nsplit / 8) w.xcd_full = a.w_nsplit / 8;
+    w.xcd_q = w.xcd_full * P + ceil_div((a.w_nsplit - 8 * w.xcd_full) * P, 8);
+    const dim3 wgrid = w.xcd ? dim3(8 * w.xcd_q) : dim3(P, a.w_nsplit);
+    hipLaunchKernelGGL(conv3x3_wgrad_wino_kernel, wgrid, dim3(256), 0, st, w);
+    if (prof) neosr_prof_end(stream);
+    NEOSR_LAUNCH_CHECK();
+    if (prof) neosr_prof_begin(NEOSR_PROF_WGRAD_REDUCE, stream, 0.0, 0.0);
+    hipLaunchKernelGGL(conv3x3_wgrad_wino_reduce_kernel, dim3(1024 / 64, P), dim3(256), 0, st, w);
+    if (prof) neosr_prof_end(stream);
+    NEOSR_LAUNCH_CHECK();
+    return 0;
   }
   const dim3 grid = a.xcd ? dim3(8 * a.xcd_q) : dim3(a.pair_start[MAXD], a.nsplit);
   if (fast && s2d)
