@@ -52,8 +52,9 @@ ALGO_MB_PER_PATCH = {"esrgan": 2852.8}
 ALIASES = {"paired_l1": "bench_esrgan", "otf_gan": "bench_esrgan_otf_gan", "swinir_percep": "bench_swinir_medium"}
 
 CLASS_NAMES = [
-    "conv3x3_glds_kernel (forward launches)", "conv3x3_glds_kernel (backward-data launches)",
-    "conv3x3_wgrad_multi_kernel", "conv3x3_wgrad_reduce_kernel",
+    "packed-weight 3x3 conv, forward launches (conv3x3_wino_kernel | conv3x3_glds_kernel)",
+    "packed-weight 3x3 conv, backward-data launches (conv3x3_wino_kernel | conv3x3_glds_kernel)",
+    "3x3 weight gradient (conv3x3_wgrad_wino_kernel | conv3x3_wgrad_multi_kernel)", "weight-gradient split reduce",
     "staged + thin conv kernels (forward)", "staged + thin conv kernels (backward-data)",
     "gemm NT (nn.Linear forward)", "gemm NN (nn.Linear backward-data)", "gemm TN (nn.Linear backward-weight)",
     "window attention forward", "window attention backward",
@@ -340,7 +341,11 @@ def main() -> None:
         ach = fl[dom] / (ms[dom] * 1e9) if ms[dom] > 0 else 0.0
         allms = sum(ms[i] for i in COMPUTE_CLASSES)
         allfl = sum(fl[i] for i in COMPUTE_CLASSES)
-        tr = pmc_traffic(cfg_name, CLASS_SYMBOL[dom]) if not (args.batch or args.arch) else None
+        wino = lib.neosr_set_winograd(1)
+        lib.neosr_set_winograd(wino)
+        wino_dom = bool(wino) and dom in (0, 1, 2) and opt["network_g"]["type"] == "esrgan"
+        sym = {0: "conv3x3_wino_kernel", 1: "conv3x3_wino_kernel", 2: "conv3x3_wgrad_wino_kernel"}[dom] if wino_dom else CLASS_SYMBOL[dom]
+        tr = pmc_traffic(cfg_name, sym) if not (args.batch or args.arch) else None
         step_s = elapsed / args.steps
         roofline = {"bound": "mfma", "kernel": CLASS_NAMES[dom], "achieved": round(ach, 2),
                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -356,12 +361,20 @@ def main() -> None:
                     "step_frac": round(allfl / nprof / (step_s * 1e12) / PEAK_F32_MFMA_TFLOPS, 4),
                     "hbm_algo_frac_of_8TBps": round((by[dom] / (ms[dom] * 1e6)) / PEAK_HBM_GBS, 4) if ms[dom] > 0 else None,
                     "kernels": kern,
+                    # Winograd F(2x2,3x3) launches execute 16/36 of the direct form's multiplications: `achieved` (and
+                    # every `tflops` above) counts the DIRECT form's FLOPs per launch (SURVEY §8d's algorithmic figure),
+                    # so it can exceed the fp32 MFMA peak; the matrix pipe itself runs at executed_mfma_tflops
+                    "algorithm": ("winograd F(2x2,3x3) for the RDB trunk's forward / backward-data / weight-gradient launches "
+                                  "(16 multiplications per 2x2 output tile, channel pair and filter instead of 36)")
+                                 if wino_dom else "direct",
+                    "executed_mfma_tflops": round(ach * 16.0 / 36.0, 2) if wino_dom else round(ach, 2),
+                    "executed_mfma_frac": round(ach * (16.0 / 36.0 if wino_dom else 1.0) / PEAK_F32_MFMA_TFLOPS, 4),
                     "method": "HIP events around every launch of the class on the launch stream, separate "
                               "profiled pass after the timed region with the trunk on ONE stream "
                               "(neosr_set_num_streams(1)); profiles/r02_<config>_kernel_stats.csv is rocprofv3 "
                               "--kernel-trace --stats of `NEOSR_AMD_STREAMS=1 python bench.py --config <config>`"}
-        if ms[0] + ms[1] > 0:  # all launches of the symbol, directly comparable with its rocprofv3 row
-            roofline["conv3x3_glds_kernel_avg_us"] = round(1e3 * (ms[0] + ms[1]) / max(1, ln[0] + ln[1]), 2)
+        if ms[0] + ms[1] > 0:  # forward + backward-data launches of ONE symbol: comparable with its rocprofv3 row
+            roofline["packed_conv_kernel_avg_us"] = round(1e3 * (ms[0] + ms[1]) / max(1, ln[0] + ln[1]), 2)
 
     if world > 1:
         dist.barrier()
