@@ -246,21 +246,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const ConvArgs arg
     }
 }
 
-// U = G g G^T of every (cin, cout) pair of an image, one thread per 16-byte granule (pos, quad, n, 4 channels):
+// U = G g G^T of every (cin, cout) pair of an image: one thread per (n-block, chunk, k quad, n) loads the 4 x 9 taps of
+// its four channels once and writes the 16 positions' 16-byte granules (each a coalesced 512-byte row across n):
 //   dst[nblk][chunk][pos = i*4 + j][quad][n 32][4]
 __global__ __launch_bounds__(256) void conv_pack_wino_kernel(const neosr_pack::Batch batch) {
   const neosr_pack::Image& im = batch.im[blockIdx.y];
   const int nch = (im.K + 15) >> 4, nblk = (im.N + 31) >> 5;
-  const int g = blockIdx.x * 256 + threadIdx.x;
-  if (g >= nblk * nch * (WU_HALF / 4)) return;
-  const int n32 = g & 31, q = (g >> 5) & 3, pos = (g >> 7) & 15;
-  const int rest = g >> 11;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= nblk * nch * 128) return;
+  const int n32 = t & 31, q = (t >> 5) & 3;
+  const int rest = t >> 7;
   const int chunk = rest % nch, nb = rest / nch;
   const int n = nb * 32 + n32, k0 = chunk * 16 + q * 4;
-  const int i = pos >> 2, j = pos & 3;
-  // rows of G: (1,0,0), (.5,.5,.5), (.5,-.5,.5), (0,0,1)
-  const float Gm[4][3] = {{1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.f, 0.f, 1.f}};
-  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  float g[4][9];
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) g[e][tap] = 0.f;
   if (n < im.N && k0 < im.K) {
     for (int s = 0; s < im.nseg; ++s) {
       const neosr_pack::Seg& sg = im.seg[s];
@@ -269,25 +271,38 @@ __global__ __launch_bounds__(256) void conv_pack_wino_kernel(const neosr_pack::B
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         if (kk + e >= sg.k_cnt) break;
-        float u = 0.f;
+        const float* src = im.mode == NEOSR_CONV_FWD ? sg.w + ((int64_t)(sg.n_lo + n) * sg.w_cin + kk + e) * 9
+                                                     : sg.w + ((int64_t)(kk + e) * sg.w_cin + sg.n_lo + n) * 9;
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-          float row = 0.f;  // (g G^T)[a][j]
-#pragma unroll
-          for (int bq = 0; bq < 3; ++bq) {
-            const int tap = a * 3 + bq;
-            const float w = im.mode == NEOSR_CONV_FWD
-                                ? sg.w[((int64_t)(sg.n_lo + n) * sg.w_cin + kk + e) * 9 + tap]
-                                : sg.w[((int64_t)(kk + e) * sg.w_cin + sg.n_lo + n) * 9 + (8 - tap)];
-            row += w * Gm[j][bq];
-          }
-          u += Gm[i][a] * row;
-        }
-        v[e] = u;
+        for (int tap = 0; tap < 9; ++tap) g[e][tap] = src[im.mode == NEOSR_CONV_FWD ? tap : 8 - tap];
       }
     }
   }
-  *reinterpret_cast<float4*>(im.dst + (int64_t)g * 4) = make_float4(v[0], v[1], v[2], v[3]);
+  // rows of G: (1,0,0), (.5,.5,.5), (.5,-.5,.5), (0,0,1):  U = G g G^T, column pass then row pass
+  float u[16][4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float c[3][4];  // (g G^T)[a][j]
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float g0 = g[e][a * 3], g1 = g[e][a * 3 + 1], g2 = g[e][a * 3 + 2];
+      c[a][0] = g0;
+      c[a][1] = 0.5f * g0 + 0.5f * g1 + 0.5f * g2;
+      c[a][2] = 0.5f * g0 - 0.5f * g1 + 0.5f * g2;
+      c[a][3] = g2;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      u[0 * 4 + j][e] = c[0][j];
+      u[1 * 4 + j][e] = 0.5f * c[0][j] + 0.5f * c[1][j] + 0.5f * c[2][j];
+      u[2 * 4 + j][e] = 0.5f * c[0][j] - 0.5f * c[1][j] + 0.5f * c[2][j];
+      u[3 * 4 + j][e] = c[2][j];
+    }
+  }
+  float* dst = im.dst + ((int64_t)(nb * nch + chunk) * WU_HALF) + (q * 32 + n32) * 4;
+#pragma unroll
+  for (int pos = 0; pos < 16; ++pos)
+    *reinterpret_cast<float4*>(dst + pos * 512) = make_float4(u[pos][0], u[pos][1], u[pos][2], u[pos][3]);
 }
 
 int g_wino = -1;  // -1: read NEOSR_AMD_WINOGRAD on first use (default on)
@@ -325,7 +340,7 @@ int neosr_pack::launch_wino(const Image* images, int n, void* stream) {
     int64_t gran = 0;
     for (int i = 0; i < cnt; ++i) {
       bt.im[i] = images[i0 + i];
-      const int64_t g = wino_image_floats(bt.im[i].N, bt.im[i].K) / 4;
+      const int64_t g = wino_image_floats(bt.im[i].N, bt.im[i].K) / 64;  // one thread per 16 granules
       gran = g > gran ? g : gran;
     }
     dim3 grid((unsigned)((gran + 255) / 256), cnt);

@@ -94,6 +94,20 @@ def packed_weights(w: torch.Tensor, mode: int):
     return pack
 
 
+def packed_wino(w: torch.Tensor, mode: int):
+    """Winograd F(2x2,3x3) image of `w` (`neosr_conv3x3_pack_wino`), cached like `packed_weights`."""
+    if min(w.shape[0], w.shape[1]) <= 4 or w.shape[0] % 4 or w.shape[1] % 4:
+        return None
+    key = (w._version, _C.WEIGHTS_EPOCH, w.data_ptr())
+    cache = w.__dict__.setdefault("_neosr_winos", {}) if hasattr(w, "__dict__") else {}
+    hit = cache.get(mode)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    pack = ops.conv3x3_pack_wino(w, mode)
+    cache[mode] = (key, pack)
+    return pack
+
+
 class Conv3x3(torch.autograd.Function):
     """y = act(conv3x3(x'[..., :K], w) + b) (+ res), fused bias/activation/residual; x' = x or its
     nearest x2 upsampling (`ups`, folded into the conv loader).  backward = MFMA dgrad (activation
@@ -103,8 +117,9 @@ class Conv3x3(torch.autograd.Function):
     def forward(ctx, x, w, b, act, slope, ups, res, s2d_c=0):
         _C.require_device(x, "x")
         w = _C.require_device(w, "weight").contiguous()
+        wino = packed_wino(w, ops.CONV_FWD) if not ups and s2d_c == 0 else None  # F(2x2,3x3) kernel when eligible
         y = ops.conv3x3(x, w, b, act=act, slope=slope, k_in=w.shape[1], ups=ups, res1=res,
-                        w_pack=packed_weights(w, ops.CONV_FWD), s2d_c=s2d_c)
+                        w_pack=packed_weights(w, ops.CONV_FWD), s2d_c=s2d_c, w_wino=wino)
         ctx.s2d_c = s2d_c
         ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
         ctx.act, ctx.slope, ctx.has_bias, ctx.ups, ctx.has_res = act, slope, b is not None, ups, res is not None
@@ -119,8 +134,10 @@ class Conv3x3(torch.autograd.Function):
         slope = ctx.slope if ctx.act == ACT_LRELU else 0.0
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
+            plain = y is None  # no activation derivative to apply on load -> packed / Winograd kernels
             gx = ops.conv3x3(g, w, None, mode=ops.CONV_DGRAD, in_mask=y, mask_slope=slope,
-                             w_pack=packed_weights(w, ops.CONV_DGRAD) if y is None else None, s2d_c=ctx.s2d_c)
+                             w_pack=packed_weights(w, ops.CONV_DGRAD) if plain else None, s2d_c=ctx.s2d_c,
+                             w_wino=packed_wino(w, ops.CONV_DGRAD) if plain and ctx.s2d_c == 0 else None)
             if ctx.ups:
                 gx = ops.pool2x2_sum(gx)
             if x.shape[3] > gx.shape[3]:  # conv read a channel prefix of a wider buffer
