@@ -168,7 +168,11 @@ def make_batch(opt: dict, dev, rank: int) -> dict:
 
         from neosr_amd.data.degradations import KernelSampler
         random.seed(1024 + rank)
-        ks = KernelSampler(np.random.default_rng(1024 + rank)).otf_kernel_batch(opt["datasets"]["train"], B)
+        ks = KernelSampler(np.random.default_rng(1024 + rank))
+        if torch.device(dev).type == "cuda":  # 3 x B kernels evaluated on the device (neosr_blur_kernels)
+            ks = ks.otf_kernel_batch_device(opt["datasets"]["train"], B, dev)
+        else:
+            ks = ks.otf_kernel_batch(opt["datasets"]["train"], B)
         return {"gt": torch.rand(B, 3, 512, 512, device=dev), **{k: v.to(dev) for k, v in ks.items()}}
     return {"lq": torch.rand(B, 3, 64, 64, device=dev), "gt": torch.rand(B, 3, 256, 256, device=dev)}
 

@@ -272,6 +272,16 @@ int neosr_crop(const float* in, float* out, int32_t planes, int32_t H, int32_t W
 /* training-pair pool shuffle `queue = queue[randperm]` (otf.py:70-72): dst[i] = src[idx[i]]. */
 int neosr_gather_rows(const float* src, const int64_t* idx, float* dst, int32_t nrows,
                       int64_t row_elems, void* stream);
+/* Standard normal field, a pure function of (seed, offset): Philox4x32-10 + Box-Muller.  Replaces `torch.randn` in the
+ * live draw stream of the degradation bank (neosr/data/degradations.py:593-598, 781-785); a replayed draw stream
+ * (tests) bypasses it. */
+int neosr_normal_sample(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream);
+/* Blur / sinc kernels of the OTF dataset (neosr/data/otf_dataset.py:189-246; generators neosr/data/degradations.py:24-512)
+ * evaluated on the device for a whole batch: params (n, 8) float64 on the device =
+ * {type, k, sig_x, sig_y, theta, beta | cutoff, isotropic, -}, type 0 Gaussian, 1 generalized Gaussian, 2 plateau,
+ * 3 circular low-pass (sinc), 4 pulse; out (n, 21, 21) float32, each k x k kernel normalised and zero-padded to 21.
+ * The random parameters themselves are drawn on the host in the reference's order (KernelSampler). */
+int neosr_blur_kernels(const double* params, int32_t n, float* out, void* stream);
 
 /* GAN / perceptual branch: non-conv layers and losses (channels-last activations) ---------------
  * U-Net-SN discriminator (neosr/archs/unet_arch.py:9-67), VGG19 feature extractor

@@ -591,7 +591,91 @@ __global__ __launch_bounds__(256) void poisson_sample_kernel(const float* __rest
   }
 }
 
+
+// Standard normal field (replaces torch.randn in the live draw stream of the degradation bank, degradations.py:593-598):
+// element pair (2i, 2i+1) = Box-Muller of two Philox uniforms of counter stream i -> a pure function of (seed, offset).
+__global__ __launch_bounds__(256) void normal_sample_kernel(float* __restrict__ out, int64_t n, uint64_t seed,
+                                                            uint64_t offset) {
+  const int64_t npair = (n + 1) >> 1;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < npair; e += (int64_t)gridDim.x * 256) {
+    Philox rng(seed, offset, (uint64_t)e);
+    const float u1 = rng.uniform(), u2 = rng.uniform();
+    const float r = sqrtf(-2.f * logf(u1));
+    float sn, cs;
+    sincosf(6.283185307179586f * u2, &sn, &cs);
+    out[2 * e] = r * cs;
+    if (2 * e + 1 < n) out[2 * e + 1] = r * sn;
+  }
+}
+
+// Blur / sinc kernel synthesis on the device (neosr/data/degradations.py:24-512 evaluated for a whole batch; the
+// random PARAMETERS are drawn on the host in the reference's order, neosr_amd/data/degradations.py).  One workgroup per
+// 21 x 21 kernel, float64 like the reference's numpy code, output float32 zero-padded around the k x k support.
+//   params[i] = {type, k, sig_x, sig_y, theta, beta (or cutoff), isotropic, unused}
+//   type 0 Gaussian exp(-q/2) | 1 generalized exp(-q^beta / 2) | 2 plateau 1 / (1 + q^beta) | 3 circular low-pass
+//   cutoff * J1(cutoff r) / (2 pi r) (centre cutoff^2 / 4 pi) | 4 pulse;  q = g^T Sigma^-1 g on the centred grid
+__global__ __launch_bounds__(512) void blur_kernels_kernel(const double* __restrict__ params, float* __restrict__ out) {
+  __shared__ double red[8];
+  const double* P = params + (int64_t)blockIdx.x * 8;
+  const int type = (int)P[0], k = (int)P[1];
+  const double sx = P[2], sy = P[3], th = P[4], beta = P[5];
+  const bool iso = P[6] != 0.0;
+  const int tid = threadIdx.x;
+  const int py = tid / 21, px = tid - py * 21;
+  const int pad = (21 - k) / 2;
+  const int iy = py - pad, ix = px - pad;
+  const bool in = tid < 441 && iy >= 0 && iy < k && ix >= 0 && ix < k;
+  double v = 0.0;
+  if (type == 4) {
+    v = (tid == 10 * 21 + 10) ? 1.0 : 0.0;
+  } else if (in) {
+    const double c = (k - 1) * 0.5;
+    const double gx = ix - c, gy = iy - c;
+    if (type == 3) {
+      const double r = sqrt(gx * gx + gy * gy);
+      v = r == 0.0 ? beta * beta / (4.0 * 3.141592653589793) : beta * j1(beta * r) / (2.0 * 3.141592653589793 * r);
+    } else {
+      double a11, a12, a22;  // Sigma^-1
+      if (iso) {
+        a11 = a22 = 1.0 / (sx * sx);
+        a12 = 0.0;
+      } else {
+        const double cs = cos(th), sn = sin(th), ix2 = 1.0 / (sx * sx), iy2 = 1.0 / (sy * sy);
+        a11 = cs * cs * ix2 + sn * sn * iy2;
+        a12 = cs * sn * (ix2 - iy2);
+        a22 = sn * sn * ix2 + cs * cs * iy2;
+      }
+      const double q = a11 * gx * gx + 2.0 * a12 * gx * gy + a22 * gy * gy;
+      v = type == 0 ? exp(-0.5 * q) : (type == 1 ? exp(-0.5 * pow(q, beta)) : 1.0 / (pow(q, beta) + 1.0));
+    }
+  }
+  double s = v;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if ((tid & 63) == 0) red[tid >> 6] = s;
+  __syncthreads();
+  double tot = 0.0;
+#pragma unroll
+  for (int w = 0; w < 8; ++w) tot += red[w];
+  if (tid < 441) out[(int64_t)blockIdx.x * 441 + tid] = (float)(type == 4 ? v : v / tot);
+}
+
 }  // namespace
+
+extern "C" int neosr_normal_sample(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream) {
+  NEOSR_CHECK(out && n > 0, "normal_sample: bad args");
+  hipLaunchKernelGGL(normal_sample_kernel, dim3(grid_for((n + 1) / 2)), dim3(256), 0, (hipStream_t)stream, out, n, seed,
+                     offset);
+  NEOSR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int neosr_blur_kernels(const double* params, int32_t n, float* out, void* stream) {
+  NEOSR_CHECK(params && out && n > 0, "blur_kernels: bad args");
+  hipLaunchKernelGGL(blur_kernels_kernel, dim3(n), dim3(512), 0, (hipStream_t)stream, params, out);
+  NEOSR_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int neosr_poisson_sample(const float* rate, float* out, int64_t n, uint64_t seed, uint64_t offset,
                                     void* stream) {

@@ -1,4 +1,6 @@
-"""Blur / sinc kernel synthesis for the on-the-fly degradation pipeline (host side, numpy fp64).
+"""Blur / sinc kernel synthesis for the on-the-fly degradation pipeline: the random draws (host, reference order) and
+two evaluators — numpy fp64 on the host (`otf_kernel_batch`) and `neosr_blur_kernels` on the device
+(`otf_kernel_batch_device`, float64 too).
 
 These are the *inputs* of `neosr_filter2d` (`kernel1`, `kernel2`, `sinc_kernel` of the otf batch
 dict).  Behaviour follows neosr/data/degradations.py:24-512 and the sampling order of
@@ -103,6 +105,23 @@ class KernelSampler:
             kernel = kernel * self.rng.uniform(noise_range[0], noise_range[1], size=kernel.shape)
         return _normalise(kernel)
 
+    def mixed_params(self, kernel_list, kernel_prob, k, sigma_x_range, sigma_y_range, rotation_range, betag_range,
+                     betap_range) -> list[float]:
+        """the DRAWS of random_mixed_kernels (degradations.py:410-475) without evaluating the kernel: one row of the
+        `neosr_blur_kernels` parameter table {type, k, sig_x, sig_y, theta, beta, isotropic, 0}"""
+        assert k % 2 == 1, "Kernel size must be an odd number."
+        kind = self.random.choices(kernel_list, kernel_prob)[0]
+        iso = not kind.endswith("aniso")
+        sx, sy, th = self._shape_params(sigma_x_range, sigma_y_range, rotation_range, iso)
+        if kind in ("iso", "aniso"):
+            return [0.0, k, sx, sy, th, 1.0, float(iso), 0.0]
+        if kind.startswith("generalized"):
+            return [1.0, k, sx, sy, th, self._beta(betag_range), float(iso), 0.0]
+        if kind.startswith("plateau"):
+            return [2.0, k, sx, sy, th, self._beta(betap_range), float(iso), 0.0]
+        msg = f"unknown kernel type {kind!r}"
+        raise ValueError(msg)
+
     def mixed(self, kernel_list, kernel_prob, k=21, sigma_x_range=(0.6, 5), sigma_y_range=(0.6, 5),
               rotation_range=(-math.pi, math.pi), betag_range=(0.5, 8), betap_range=(0.5, 8),
               noise_range=None) -> np.ndarray:
@@ -147,6 +166,41 @@ class KernelSampler:
             sinc[10, 10] = 1
         return {"kernel1": k1.astype(np.float32), "kernel2": k2.astype(np.float32),
                 "sinc_kernel": sinc.astype(np.float32)}
+
+    # ---- the same draws as parameter rows for the device generator (`neosr_blur_kernels`)
+    def _blur_or_sinc_params(self, opt, suffix: str) -> list[float]:
+        k = self.random.choice(KERNEL_SIZES)
+        if self.rng.uniform() < opt.get(f"sinc_prob{suffix}"):
+            lo = np.pi / 3 if k < 13 else np.pi / 5
+            return [3.0, k, 0.0, 0.0, 0.0, self.rng.uniform(lo, np.pi), 1.0, 0.0]
+        sig = opt.get(f"blur_sigma{suffix}")
+        return self.mixed_params(opt.get(f"kernel_list{suffix}"), opt.get(f"kernel_prob{suffix}"), k, sig, sig,
+                                 [-math.pi, math.pi], opt.get(f"betag_range{suffix}"), opt.get(f"betap_range{suffix}"))
+
+    def otf_kernel_params(self, opt: dict) -> list[list[float]]:
+        """kernel1, kernel2, sinc_kernel of one sample as three parameter rows, consuming the RNG streams exactly like
+        `otf_kernels` (otf_dataset.py:189-246)"""
+        k1 = self._blur_or_sinc_params(opt, "")
+        k2 = self._blur_or_sinc_params(opt, "2")
+        if self.rng.uniform() < opt.get("final_sinc_prob"):
+            k = self.random.choice(KERNEL_SIZES)
+            sinc = [3.0, k, 0.0, 0.0, 0.0, self.rng.uniform(np.pi / 3, np.pi), 1.0, 0.0]
+        else:
+            sinc = [4.0, 21, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0]
+        return [k1, k2, sinc]
+
+    def otf_kernel_batch_device(self, opt: dict, batch: int, device="cuda"):
+        """`otf_kernel_batch` with the 3 x batch kernels evaluated on the device in one launch: only the 24 floats of
+        parameters per sample cross PCIe instead of three 21 x 21 kernels, and the float64 grid arithmetic leaves the
+        host (the reference does it in its DataLoader workers)."""
+        import torch
+
+        from neosr_amd.hip import degrade as D
+
+        rows = [self.otf_kernel_params(opt) for _ in range(batch)]
+        table = torch.tensor(rows, dtype=torch.float64).reshape(batch * 3, 8).to(device, non_blocking=True)
+        ks = D.blur_kernels(table).view(batch, 3, 21, 21)
+        return {"kernel1": ks[:, 0].contiguous(), "kernel2": ks[:, 1].contiguous(), "sinc_kernel": ks[:, 2].contiguous()}
 
     def otf_kernel_batch(self, opt: dict, batch: int):
         import torch

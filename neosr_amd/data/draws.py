@@ -47,7 +47,25 @@ class LiveDraws:
         return torch.rand(n, dtype=torch.float32, device=self.device)
 
     def randn(self, *shape: int) -> torch.Tensor:
-        return torch.randn(*shape, dtype=torch.float32, device=self.device)
+        """`torch.randn(shape)` (degradations.py:593-598).  On a HIP device the field comes from our own counter-based
+        sampler (Philox4x32-10 + Box-Muller), keyed by the device generator's (seed, offset) — advanced like a generator
+        draw would — so `torch.manual_seed` still fixes the run and no ATen RNG kernel is on the product path."""
+        if self.device.type != "cuda":
+            return torch.randn(*shape, dtype=torch.float32, device=self.device)
+        from neosr_amd.hip import degrade as D
+
+        n = 1
+        for v in shape:
+            n *= int(v)
+        seed, offset = self._advance(n)
+        return D.normal_sample(shape, seed, offset, self.device)
+
+    def _advance(self, n: int) -> tuple[int, int]:
+        gen = torch.cuda.default_generators[self.device.index if self.device.index is not None
+                                            else torch.cuda.current_device()]
+        seed, offset = gen.initial_seed(), gen.get_offset()
+        gen.set_offset(offset + 4 * ((n + 3) // 4))
+        return seed, offset
 
     def poisson(self, rate: torch.Tensor) -> torch.Tensor:
         """`torch.poisson(rate)` (degradations.py:782-785).  On a HIP device the field comes from our own

@@ -98,6 +98,27 @@ def poisson_sample(rate: torch.Tensor, seed: int, offset: int) -> torch.Tensor:
     return out
 
 
+def normal_sample(shape, seed: int, offset: int, device="cuda") -> torch.Tensor:
+    """N(0, 1) field, a pure function of (seed, offset): `neosr_normal_sample` (Philox4x32-10 + Box-Muller)."""
+    lib = _C.load()
+    out = torch.empty(*shape, device=device, dtype=torch.float32)
+    _C.check(lib.neosr_normal_sample(out.data_ptr(), out.numel(), seed & (2**64 - 1), offset & (2**64 - 1),
+                                     _C.stream_ptr()), "neosr_normal_sample")
+    return out
+
+
+def blur_kernels(params: torch.Tensor) -> torch.Tensor:
+    """(n, 8) float64 parameter table on the device -> (n, 21, 21) float32 kernels (`neosr_blur_kernels`)."""
+    lib = _C.load()
+    if not params.is_cuda or params.dtype != torch.float64 or params.dim() != 2 or params.shape[1] != 8:
+        raise _C.NeosrAmdError("blur_kernels: params must be a (n, 8) float64 tensor on a HIP device")
+    params = params.contiguous()
+    out = torch.empty(params.shape[0], 21, 21, device=params.device, dtype=torch.float32)
+    _C.check(lib.neosr_blur_kernels(params.data_ptr(), params.shape[0], out.data_ptr(), _C.stream_ptr()),
+             "neosr_blur_kernels")
+    return out
+
+
 def poisson_noise(img, P, vals, P_gray, vals_gray, scale, gray) -> torch.Tensor:
     lib = _C.load()
     img = _img(img)

@@ -88,9 +88,30 @@ class base:
     def get_current_visuals(self): ...
     def save(self, epoch: int, current_iter: int) -> None: ...
 
-    def validation(self, dataloader, current_iter, tb_logger, save_img=True) -> None:
-        msg = "validation is outside the accelerated hot path (SURVEY §2.1 row 17)"
-        raise NotImplementedError(msg)
+    def validation(self, dataloader, current_iter: int, tb_logger, save_img: bool = True) -> None:
+        """base.py:54-71: rank 0 validates under a launcher, everyone otherwise."""
+        if self.opt["dist"]:
+            self.dist_validation(dataloader, current_iter, tb_logger, save_img)
+        else:
+            self.nondist_validation(dataloader, current_iter, tb_logger, save_img)
+
+    def _initialize_best_metric_results(self, dataset_name: str) -> None:
+        """base.py:87-104"""
+        if not hasattr(self, "best_metric_results"):
+            self.best_metric_results = {}
+        if dataset_name in self.best_metric_results:
+            return
+        record = {}
+        for metric, content in self.opt["val"]["metrics"].items():
+            better = content.get("better", "higher")
+            record[metric] = {"better": better, "val": float("-inf") if better == "higher" else float("inf"), "iter": -1}
+        self.best_metric_results[dataset_name] = record
+
+    def _update_best_metric_result(self, dataset_name, metric: str, val, current_iter: int) -> None:
+        """base.py:106-115"""
+        rec = self.best_metric_results[dataset_name][metric]
+        if (rec["better"] == "higher" and val >= rec["val"]) or (rec["better"] != "higher" and val <= rec["val"]):
+            rec["val"], rec["iter"] = val, current_iter
 
     # -- logging ------------------------------------------------------------------------
     def get_current_log(self) -> dict[str, Any]:

@@ -366,7 +366,7 @@ class image(base):
     # ------------------------------------------------------------------------------------
     def _eval_net(self):
         """which weights `test()` runs (image.py:672-680,741-760): the EMA copy while training with EMA"""
-        if self.is_train and getattr(self, "ema", -1) > 0:
+        if getattr(self, "ema", -1) > 0 and hasattr(self, "net_g_ema"):  # `is_train` is False inside validation
             return self.net_g_ema
         return self.net_g
 
@@ -390,6 +390,74 @@ class image(base):
         self.net_g.train()
         if sf:
             self.optimizer_g.train()
+
+    def dist_validation(self, dataloader, current_iter: int, tb_logger, save_img: bool = True) -> None:
+        if self.opt["rank"] == 0:
+            self.nondist_validation(dataloader, current_iter, tb_logger, save_img)
+
+    def nondist_validation(self, dataloader, current_iter: int, tb_logger, save_img: bool = True) -> None:  # noqa: ARG002
+        """image.py:792-922: per validation image `feed_data` -> `test()` (the HIP inference path, whole image or
+        partitioned) -> uint8 image -> metrics (`val.metrics`: calculate_psnr / calculate_ssim on the host, as in the
+        reference) -> optional PNG; running means, best-so-far record, log line, TensorBoard scalars.  The dataloader is
+        the caller's (any iterable of {"lq", "gt"?, "lq_path"} batches of one image with `.dataset.opt`)."""
+        from pathlib import Path
+
+        from neosr_amd.metrics import calculate_metric, imwrite_png, tensor2img
+
+        self.is_train = False  # no augmentation during validation
+        dataset_name = dataloader.dataset.opt["name"]
+        with_metrics = dataloader.dataset.opt.get("type") != "single" and self.opt["val"].get("metrics") is not None
+        if with_metrics:
+            self._initialize_best_metric_results(dataset_name)
+            self.metric_results = dict.fromkeys(self.opt["val"]["metrics"].keys(), 0)
+        n = 0
+        try:
+            for val_data in dataloader:
+                n += 1
+                img_name = Path(Path(val_data["lq_path"][0]).name).stem
+                self.feed_data(val_data)
+                self.test()
+                visuals = self.get_current_visuals()
+                metric_data = {"img": tensor2img(visuals["result"])}
+                if "gt" in visuals:
+                    metric_data["img2"] = tensor2img(visuals["gt"])
+                    del self.gt
+                del self.lq
+                del self.output
+                if self.opt["val"].get("save_img", True):
+                    vis = Path(self.opt["path"]["visualization"])
+                    suffix = self.opt["val"].get("suffix", None)
+                    if self.opt["is_train"]:
+                        out = vis / img_name / f"{img_name}_{current_iter}.png"
+                    elif suffix is not None:
+                        out = vis / dataset_name / f"{img_name}_{suffix}.png"
+                    else:
+                        out = vis / dataset_name / f'{img_name}_{self.opt["name"]}.png'
+                    imwrite_png(metric_data["img"], out)
+                if with_metrics:
+                    for name, opt_ in self.opt["val"]["metrics"].items():
+                        self.metric_results[name] += calculate_metric(metric_data, opt_)
+        finally:
+            self.is_train = True
+        if with_metrics and n:
+            for metric in self.metric_results:
+                self.metric_results[metric] /= n
+                self._update_best_metric_result(dataset_name, metric, self.metric_results[metric], current_iter)
+            self._log_validation_metric_values(current_iter, dataset_name, tb_logger)
+
+    def _log_validation_metric_values(self, current_iter: int, dataset_name: str, tb_logger) -> None:
+        """image.py:903-922"""
+        log_str = f"Validation {dataset_name}\n\n"
+        for metric, value in self.metric_results.items():
+            log_str += f"\t # {metric}: {value:.4f}"
+            if hasattr(self, "best_metric_results"):
+                best = self.best_metric_results[dataset_name][metric]
+                log_str += f'{tc.light_green}........ Best: {best["val"]:.4f} @ {best["iter"]} iter{tc.end}'
+            log_str += "\n"
+        get_root_logger().info(log_str)
+        if tb_logger:
+            for metric, value in self.metric_results.items():
+                tb_logger.add_scalar(f"metrics/{dataset_name}/{metric}", value, current_iter)
 
     def get_current_visuals(self) -> OrderedDict:
         """image.py:924-930"""

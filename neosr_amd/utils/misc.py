@@ -38,6 +38,7 @@ class tc:
 
     red = "\033[31m"
     light_blue = "\033[94m"
+    light_green = "\033[92m"
     end = "\033[0m"
 
 

@@ -192,3 +192,68 @@ def test_poisson_sample_mixed_rates_and_zero():
     p = D.poisson_sample(rate, 7, 0).view(4096, 6).cpu()
     assert (p[:, :2] == 0).all() and (p >= 0).all() and torch.equal(p, p.round())
     assert abs(p[:, 3].mean() - 5.0) < 0.2 and abs(p[:, 4].mean() - 20.0) < 0.4 and abs(p[:, 5].mean() - 3000.0) < 5
+
+
+def test_blur_kernels_on_device_vs_reference_fixture_and_host_path():
+    """`neosr_blur_kernels` (device, float64) against (i) the reference generators' outputs for fixed parameters
+    (tests/golden/kernels.npz) and (ii) the host numpy path for 64 seeded otf draws, which consume the RNG streams
+    identically (SURVEY §8c `kernels/`: 1e-6 abs; observed ~1e-9)."""
+    import random
+
+    from neosr_amd.data import degradations as K
+    from neosr_amd.hip import degrade as D
+    from tools.bench_degrade import DEG_TABLE
+
+    fix = load_golden("kernels.npz")
+    rows, refs = [], []
+    for k in (7, 13, 21):
+        for name, row in ((f"gauss_iso_{k}", [0, k, 1.7, 1.7, 0, 1, 1, 0]), (f"gauss_aniso_{k}", [0, k, 2.3, 0.8, 0.6, 1, 0, 0]),
+                          (f"gen_iso_{k}", [1, k, 1.4, 1.4, 0, 0.7, 1, 0]), (f"gen_aniso_{k}", [1, k, 2.0, 1.1, -1.1, 2.5, 0, 0]),
+                          (f"plat_iso_{k}", [2, k, 1.9, 1.9, 0, 1.6, 1, 0]), (f"plat_aniso_{k}", [2, k, 2.6, 0.9, 2.2, 1.2, 0, 0]),
+                          (f"sinc_{k}", [3, k, 0, 0, 0, np.pi / 2.5, 1, 0])):
+            ref = np.array(fix[name], dtype=np.float64)
+            p = (21 - ref.shape[0]) // 2
+            refs.append(np.pad(ref, ((p, p), (p, p))))
+            rows.append([float(v) for v in row])
+    out = D.blur_kernels(torch.tensor(rows, dtype=torch.float64, device=DEV)).cpu().numpy()
+    assert np.abs(out - np.stack(refs)).max() < 1e-7
+
+    class Py:
+        def __init__(self, seed):
+            self.r = random.Random(seed)
+
+        def choices(self, *a, **k):
+            return self.r.choices(*a, **k)
+
+        def choice(self, a):
+            return self.r.choice(a)
+
+    host = K.KernelSampler(np.random.default_rng(11), Py(5)).otf_kernel_batch(DEG_TABLE, 64)
+    dev = K.KernelSampler(np.random.default_rng(11), Py(5)).otf_kernel_batch_device(DEG_TABLE, 64, DEV)
+    for name in ("kernel1", "kernel2", "sinc_kernel"):
+        assert float((dev[name].cpu() - host[name]).abs().max()) < 1e-7, name
+        assert dev[name].shape == (64, 21, 21)
+
+
+def test_normal_sample_distribution_and_determinism():
+    """`neosr_normal_sample` (Philox + Box-Muller): a pure function of (seed, offset); mean / variance / kurtosis and a
+    Kolmogorov-Smirnov test against N(0, 1); LiveDraws.randn advances the device generator like a torch draw"""
+    from scipy import stats
+
+    from neosr_amd.data.draws import LiveDraws
+    from neosr_amd.hip import degrade as D
+
+    n = 1 << 20
+    a = D.normal_sample((n,), 99, 0, DEV)
+    assert torch.equal(a, D.normal_sample((n,), 99, 0, DEV)) and not torch.equal(a, D.normal_sample((n,), 99, n, DEV))
+    x = a.cpu().double().numpy()
+    assert abs(x.mean()) < 5 / np.sqrt(n) and abs(x.var() - 1) < 8 * np.sqrt(2 / n)
+    assert abs(stats.kurtosis(x)) < 0.03
+    assert stats.kstest(x[:200000], "norm").pvalue > 1e-3
+    odd = D.normal_sample((3, 5, 7), 1, 2, DEV)
+    assert odd.shape == (3, 5, 7) and torch.isfinite(odd).all()
+    torch.manual_seed(5)
+    d = LiveDraws(5, DEV)
+    u, v = d.randn(2, 3, 8, 8), d.randn(2, 3, 8, 8)
+    torch.manual_seed(5)
+    assert torch.equal(u, LiveDraws(5, DEV).randn(2, 3, 8, 8)) and not torch.equal(u, v)
