@@ -162,6 +162,12 @@ int neosr_nhwc_to_nchw(const float* in, float* out, int32_t B, int32_t C, int32_
  * (B,2H,2W,in_cs), out (B,H,W,out_cs); out = accumulate ? out + pooled : pooled. */
 int neosr_pool2x2_sum(const float* in, float* out, int32_t B, int32_t H, int32_t W, int32_t C,
                       int32_t in_cs, int32_t out_cs, int32_t accumulate, void* stream);
+/* the same pool followed by the derivative of the LeakyReLU that produced the upsampled map: out = pooled *
+ * (mask > 0 ? 1 : mask_slope), mask (B,H,W,mask_cs) = that activation's output (esrgan_arch.py:207-212 backward:
+ * lets the gradient leave as dL/d(pre-activation), so the conv below needs no mask on load). */
+int neosr_pool2x2_sum_masked(const float* in, float* out, const float* mask, int32_t B, int32_t H, int32_t W,
+                             int32_t C, int32_t in_cs, int32_t out_cs, int32_t mask_cs, float mask_slope,
+                             void* stream);
 /* nn.PixelShuffle(r) fused with compact's `out += F.interpolate(x, nearest, r)`
  * (compact_arch.py:81-85): out[b,c,h*r+i,w*r+j] = in[b,h,w,c*r*r+i*r+j] (+ base[b,c,h,w]).
  * in channels-last (B,H,W,in_cs), out/base planar NCHW.  Pure index math: bit-exact. */

@@ -248,6 +248,7 @@ SIGNATURES: dict[str, tuple] = {
     "neosr_nchw_to_nhwc": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "neosr_nhwc_to_nchw": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "neosr_pool2x2_sum": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "neosr_pool2x2_sum_masked": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
     "neosr_pixel_shuffle_nhwc_to_nchw": (
         C.c_int,
         [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp],

@@ -405,7 +405,7 @@ extern "C" int neosr_conv3x3(const neosr_conv_desc* dp, void* stream) {
   NEOSR_CHECK(use_pack || d.w, "conv3x3: w_pack launch needs 16-byte aligned tensors, K,N %% 4 == 0");
   if (use_pack) grid.y = ceil_div(d.N, 32);
   // Winograd F(2x2,3x3) form of the same launch (conv_wino.hip)
-  const bool use_wino = use_pack && d.w_wino && ((uintptr_t)d.w_wino % 16 == 0) && !d.ups && d.s2d_c == 0 &&
+  const bool use_wino = use_pack && d.w_wino && ((uintptr_t)d.w_wino % 16 == 0) && d.s2d_c == 0 &&
                         d.act != NEOSR_ACT_PRELU && neosr_conv::wino_enabled();
   const bool prof = neosr_prof_on();
   if (prof) {

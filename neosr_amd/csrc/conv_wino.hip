@@ -77,7 +77,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const ConvArgs arg
   const int x0 = tx * WT_W, y0 = ty * WT_H;
   const int n0 = blockIdx.y * 32;
   const int H = d.H, W = d.W, K = d.K;
-  const float* __restrict__ inb = d.in + (int64_t)b * H * W * d.in_cs;
+  // `ups`: the input is the nearest x2 upsampling of a (H/2, W/2) map, gathered by the DMA addresses (never materialised)
+  const int Hin = d.ups ? (H >> 1) : H, Win = d.ups ? (W >> 1) : W;
+  const float* __restrict__ inb = d.in + (int64_t)b * Hin * Win * d.in_cs;
   const int nhalf = (K + 15) >> 4;          // 16-channel halves (= chunks of the U image)
   const int nchunks = (nhalf + 1) >> 1;     // 32-channel DMA chunks
 
@@ -95,7 +97,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const ConvArgs arg
       const int px = 2 * (rem - par * (WR_W / 2)) + par;
       const int gy = y0 + py - 1, gx = x0 + px - 1;
       in_q4[i] = (slot ^ ((py >> 1) & 3)) << 2;
-      if (gy >= 0 && gy < H && gx >= 0 && gx < W) in_off[i] = (gy * W + gx) * d.in_cs + in_q4[i];
+      if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+        const int sy = d.ups ? (gy >> 1) : gy, sx = d.ups ? (gx >> 1) : gx;
+        in_off[i] = (sy * Win + sx) * d.in_cs + in_q4[i];
+      }
     }
   }
   // this wave's row i = wave of B^T: t = sa * d[ra] + sb * d[rb]

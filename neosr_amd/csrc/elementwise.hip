@@ -54,7 +54,8 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restri
 __global__ __launch_bounds__(256) void pool2x2_sum_kernel(const float* __restrict__ in,
                                                           float* __restrict__ out, int B, int H,
                                                           int W, int C4, int in_cs, int out_cs,
-                                                          int accumulate) {
+                                                          int accumulate, const float* __restrict__ mask = nullptr,
+                                                          int mask_cs = 0, float mask_slope = 1.f) {
   const int64_t total = (int64_t)B * H * W * C4;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total;
        e += (int64_t)gridDim.x * 256) {
@@ -75,6 +76,13 @@ __global__ __launch_bounds__(256) void pool2x2_sum_kernel(const float* __restric
     r.y = (a.y + bq.y) + (c.y + dq.y);
     r.z = (a.z + bq.z) + (c.z + dq.z);
     r.w = (a.w + bq.w) + (c.w + dq.w);
+    if (mask) {  // derivative of the LeakyReLU whose output is `mask` (the pooled gradient's own activation)
+      const float4 m = *reinterpret_cast<const float4*>(mask + (((int64_t)b * H + y) * W + x) * mask_cs + c4 * 4);
+      r.x = m.x > 0.f ? r.x : r.x * mask_slope;
+      r.y = m.y > 0.f ? r.y : r.y * mask_slope;
+      r.z = m.z > 0.f ? r.z : r.z * mask_slope;
+      r.w = m.w > 0.f ? r.w : r.w * mask_slope;
+    }
     float4* o = reinterpret_cast<float4*>(out + (((int64_t)b * H + y) * W + x) * out_cs + c4 * 4);
     if (accumulate) {
       const float4 old = *o;
@@ -383,6 +391,19 @@ extern "C" int neosr_pool2x2_sum(const float* in, float* out, int32_t B, int32_t
               "pool2x2: needs 4-channel aligned tensors");
   hipLaunchKernelGGL(pool2x2_sum_kernel, dim3(grid_for((int64_t)B * H * W * (C / 4))), dim3(256), 0,
                      (hipStream_t)stream, in, out, B, H, W, C / 4, in_cs, out_cs, accumulate);
+  NEOSR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int neosr_pool2x2_sum_masked(const float* in, float* out, const float* mask, int32_t B, int32_t H,
+                                        int32_t W, int32_t C, int32_t in_cs, int32_t out_cs, int32_t mask_cs,
+                                        float mask_slope, void* stream) {
+  NEOSR_CHECK(in && out && mask && B > 0 && H > 0 && W > 0 && C > 0, "pool2x2_masked: bad args");
+  NEOSR_CHECK(C % 4 == 0 && in_cs % 4 == 0 && out_cs % 4 == 0 && mask_cs % 4 == 0 && (uintptr_t)in % 16 == 0 &&
+                  (uintptr_t)out % 16 == 0 && (uintptr_t)mask % 16 == 0,
+              "pool2x2_masked: needs 4-channel aligned tensors");
+  hipLaunchKernelGGL(pool2x2_sum_kernel, dim3(grid_for((int64_t)B * H * W * (C / 4))), dim3(256), 0,
+                     (hipStream_t)stream, in, out, B, H, W, C / 4, in_cs, out_cs, 0, mask, mask_cs, mask_slope);
   NEOSR_LAUNCH_CHECK();
   return 0;
 }

@@ -15,6 +15,9 @@
 #include <vector>
 
 extern "C" int neosr_fill(float* p, int64_t n, float v, void* stream);
+extern "C" int neosr_pool2x2_sum_masked(const float* in, float* out, const float* mask, int32_t B, int32_t H,
+                                        int32_t W, int32_t C, int32_t in_cs, int32_t out_cs, int32_t mask_cs,
+                                        float mask_slope, void* stream);
 extern "C" int neosr_axpy_slice(float* out, const float* in, int64_t npix, int32_t C,
                                 int32_t out_cs, int32_t in_cs, float alpha, void* stream);
 
@@ -79,6 +82,9 @@ struct RrdbLayout {
   // Winograd images of the same launches (conv_wino.hip), same indexing
   float *wwino_f, *wwino_d;
   int64_t wf_off[5], wd_off[5], wf_total, wd_total;
+  // direct + Winograd images of conv_body / conv_up1 / conv_up2 / conv_hr (forward) and of their backward-data
+  float *tail_pf, *tail_wf, *tail_pd, *tail_wd;
+  int64_t tail_p, tail_w;  // floats per image
   int64_t total;
 };
 
@@ -169,6 +175,12 @@ RrdbLayout rrdb_layout(const neosr_rrdbnet_cfg& c, void* ws) {
     L.wd_total = o;
     L.wwino_f = b.take(3 * L.NB * L.wf_total);
     L.wwino_d = c.training ? b.take(3 * L.NB * L.wd_total) : nullptr;
+    L.tail_p = neosr_pack::image_floats(F, F);
+    L.tail_w = neosr_pack::wino_image_floats(F, F);
+    L.tail_pf = b.take(4 * L.tail_p);
+    L.tail_wf = b.take(4 * L.tail_w);
+    L.tail_pd = c.training ? b.take(4 * L.tail_p) : nullptr;
+    L.tail_wd = c.training ? b.take(4 * L.tail_w) : nullptr;
   }
   L.total = ((b.off + 255) & ~(int64_t)255);
   return L;
@@ -247,7 +259,25 @@ Aux* aux_get(int nev) {
 // [0, F + (4-j) G), x by all five.
 inline int g_off(int F, int G, int m) { return m == 5 ? 0 : F + (4 - m) * G; }
 
+// images of the four F -> F convs behind the trunk (conv_body, conv_up1, conv_up2, conv_hr), direct then Winograd
+int rrdb_pack_tail(const RrdbLayout& L, const float* const* P, int mode, void* st) {
+  neosr_pack::Image imgs[4];
+  memset(imgs, 0, sizeof(imgs));
+  for (int i = 0; i < 4; ++i) {
+    neosr_pack::Image& im = imgs[i];
+    im.dst = (mode == NEOSR_CONV_FWD ? L.tail_pf : L.tail_pd) + i * L.tail_p;
+    im.N = L.F; im.K = L.F; im.mode = mode; im.nseg = 1;
+    im.seg[0].w = P[2 + L.NB * 30 + 2 * i];
+    im.seg[0].w_cin = L.F;
+    im.seg[0].k_cnt = L.F;
+  }
+  RUN(neosr_pack::launch(imgs, 4, st));
+  for (int i = 0; i < 4; ++i) imgs[i].dst = (mode == NEOSR_CONV_FWD ? L.tail_wf : L.tail_wd) + i * L.tail_w;
+  return neosr_pack::launch_wino(imgs, 4, st);
+}
+
 int rrdb_pack_fwd(const RrdbLayout& L, const float* const* P, void* st) {
+  RUN(rrdb_pack_tail(L, P, NEOSR_CONV_FWD, st));
   std::vector<neosr_pack::Image> imgs(3 * L.NB * 5);
   memset(imgs.data(), 0, imgs.size() * sizeof(neosr_pack::Image));
   for (int i = 0; i < 3 * L.NB; ++i)
@@ -269,6 +299,7 @@ int rrdb_pack_fwd(const RrdbLayout& L, const float* const* P, void* st) {
 }
 
 int rrdb_pack_dgrad(const RrdbLayout& L, const float* const* P, void* st) {
+  RUN(rrdb_pack_tail(L, P, NEOSR_CONV_DGRAD, st));
   const int F = L.F, G = L.G;
   std::vector<neosr_pack::Image> imgs(3 * L.NB * 5);
   memset(imgs.data(), 0, imgs.size() * sizeof(neosr_pack::Image));
@@ -375,6 +406,7 @@ extern "C" int neosr_rrdbnet_forward(const neosr_rrdbnet_cfg* c, const float* co
     neosr_conv_desc d = conv_base(B, H, W);
     d.in = L.trunk; d.in_cs = F; d.K = F;
     d.w = P[p_tail(L, 0)]; d.bias = P[p_tail(L, 0) + 1]; d.w_cout = F; d.w_cin = F;
+    d.w_pack = L.tail_pf; d.w_wino = L.tail_wf;
     d.out = L.fea; d.out_cs = F; d.N = F;
     d.res1 = L.act[0]; d.res1_cs = CC; d.res1_nch = F;
     RUN(neosr_conv3x3(&d, st));
@@ -383,6 +415,7 @@ extern "C" int neosr_rrdbnet_forward(const neosr_rrdbnet_cfg* c, const float* co
     neosr_conv_desc d = conv_base(B, 2 * H, 2 * W);
     d.ups = 1; d.in = L.fea; d.in_cs = F; d.K = F;
     d.w = P[p_tail(L, 1)]; d.bias = P[p_tail(L, 1) + 1]; d.w_cout = F; d.w_cin = F;
+    d.w_pack = L.tail_pf + L.tail_p; d.w_wino = L.tail_wf + L.tail_w;
     d.out = L.u1; d.out_cs = F; d.N = F; d.act = NEOSR_ACT_LRELU; d.slope = 0.2f;
     RUN(neosr_conv3x3(&d, st));
   }
@@ -390,6 +423,7 @@ extern "C" int neosr_rrdbnet_forward(const neosr_rrdbnet_cfg* c, const float* co
     neosr_conv_desc d = conv_base(B, 4 * H, 4 * W);
     d.ups = 1; d.in = L.u1; d.in_cs = F; d.K = F;
     d.w = P[p_tail(L, 2)]; d.bias = P[p_tail(L, 2) + 1]; d.w_cout = F; d.w_cin = F;
+    d.w_pack = L.tail_pf + 2 * L.tail_p; d.w_wino = L.tail_wf + 2 * L.tail_w;
     d.out = L.u2; d.out_cs = F; d.N = F; d.act = NEOSR_ACT_LRELU; d.slope = 0.2f;
     RUN(neosr_conv3x3(&d, st));
   }
@@ -397,6 +431,7 @@ extern "C" int neosr_rrdbnet_forward(const neosr_rrdbnet_cfg* c, const float* co
     neosr_conv_desc d = conv_base(B, 4 * H, 4 * W);
     d.in = L.u2; d.in_cs = F; d.K = F;
     d.w = P[p_tail(L, 3)]; d.bias = P[p_tail(L, 3) + 1]; d.w_cout = F; d.w_cin = F;
+    d.w_pack = L.tail_pf + 3 * L.tail_p; d.w_wino = L.tail_wf + 3 * L.tail_w;
     d.out = L.hr; d.out_cs = F; d.N = F; d.act = NEOSR_ACT_LRELU; d.slope = 0.2f;
     RUN(neosr_conv3x3(&d, st));
   }
@@ -446,7 +481,11 @@ int rrdb_backward_impl(const neosr_rrdbnet_cfg* c, const float* const* P, float*
   const int H2 = 2 * H, W2 = 2 * W, H4 = 4 * H, W4 = 4 * W;
 
   RUN(neosr_nchw_to_nhwc(gy, L.gy_nhwc, B, L.Cout, H4, W4, L.cout_cs, st));
-  {  // conv_last
+  RUN(rrdb_pack_dgrad(L, P, st));
+  // Behind the trunk every gradient leaves its producer as dL/d(pre-activation): the LeakyReLU derivative of the layer
+  // below is applied in the producer's epilogue (out_mask) or in the 2x2 pool, so no consumer masks on load and the
+  // backward-data / weight-gradient launches are plain -> packed / Winograd kernels (as in the RDB trunk).
+  {  // conv_last: g_hr = dgrad * lrelu'(hr)
     neosr_wgrad_desc w = wgrad_base(B, H4, W4);
     w.in = L.hr; w.in_cs = F; w.K = F; w.g = L.gy_nhwc; w.g_cs = L.cout_cs; w.N = L.Cout;
     w.dw = Gp[p_tail(L, 4)]; w.db = Gp[p_tail(L, 4) + 1]; w.workspace = L.wg_ws;
@@ -456,45 +495,47 @@ int rrdb_backward_impl(const neosr_rrdbnet_cfg* c, const float* const* P, float*
     d.in = L.gy_nhwc; d.in_cs = L.cout_cs; d.K = L.Cout;
     d.w = P[p_tail(L, 4)]; d.w_cout = L.Cout; d.w_cin = F;
     d.out = L.g_hr; d.out_cs = F; d.N = F;
+    d.out_mask = L.hr; d.out_mask_cs = F; d.out_mask_slope = 0.2f;
     RUN(neosr_conv3x3(&d, st));
   }
-  {  // conv_hr (LeakyReLU output hr)
+  {  // conv_hr: g_u2 = dgrad * lrelu'(u2)
     neosr_wgrad_desc w = wgrad_base(B, H4, W4);
     w.in = L.u2; w.in_cs = F; w.K = F; w.g = L.g_hr; w.g_cs = F; w.N = F;
-    w.g_mask = L.hr; w.mask_cs = F; w.mask_slope = 0.2f;
     w.dw = Gp[p_tail(L, 3)]; w.db = Gp[p_tail(L, 3) + 1]; w.workspace = L.wg_ws;
     RUN(neosr_conv3x3_wgrad(&w, st));
     neosr_conv_desc d = conv_base(B, H4, W4);
     d.mode = NEOSR_CONV_DGRAD;
-    d.in = L.g_hr; d.in_cs = F; d.K = F; d.in_mask = L.hr; d.mask_cs = F; d.mask_slope = 0.2f;
+    d.in = L.g_hr; d.in_cs = F; d.K = F;
     d.w = P[p_tail(L, 3)]; d.w_cout = F; d.w_cin = F;
+    d.w_pack = L.tail_pd + 3 * L.tail_p; d.w_wino = L.tail_wd + 3 * L.tail_w;
     d.out = L.g_u2; d.out_cs = F; d.N = F;
+    d.out_mask = L.u2; d.out_mask_cs = F; d.out_mask_slope = 0.2f;
     RUN(neosr_conv3x3(&d, st));
   }
-  {  // conv_up2 (input = nearest x2 of u1, LeakyReLU output u2)
+  {  // conv_up2 (input = nearest x2 of u1): g_u1 = pool(dgrad) * lrelu'(u1)
     neosr_wgrad_desc w = wgrad_base(B, H4, W4);
     w.ups = 1; w.in = L.u1; w.in_cs = F; w.K = F; w.g = L.g_u2; w.g_cs = F; w.N = F;
-    w.g_mask = L.u2; w.mask_cs = F; w.mask_slope = 0.2f;
     w.dw = Gp[p_tail(L, 2)]; w.db = Gp[p_tail(L, 2) + 1]; w.workspace = L.wg_ws;
     RUN(neosr_conv3x3_wgrad(&w, st));
     neosr_conv_desc d = conv_base(B, H4, W4);
     d.mode = NEOSR_CONV_DGRAD;
-    d.in = L.g_u2; d.in_cs = F; d.K = F; d.in_mask = L.u2; d.mask_cs = F; d.mask_slope = 0.2f;
+    d.in = L.g_u2; d.in_cs = F; d.K = F;
     d.w = P[p_tail(L, 2)]; d.w_cout = F; d.w_cin = F;
+    d.w_pack = L.tail_pd + 2 * L.tail_p; d.w_wino = L.tail_wd + 2 * L.tail_w;
     d.out = L.g_up2in; d.out_cs = F; d.N = F;
     RUN(neosr_conv3x3(&d, st));
-    RUN(neosr_pool2x2_sum(L.g_up2in, L.g_u1, B, H2, W2, F, F, F, 0, st));
+    RUN(neosr_pool2x2_sum_masked(L.g_up2in, L.g_u1, L.u1, B, H2, W2, F, F, F, F, 0.2f, st));
   }
-  {  // conv_up1
+  {  // conv_up1 (input = nearest x2 of fea; fea has no activation)
     neosr_wgrad_desc w = wgrad_base(B, H2, W2);
     w.ups = 1; w.in = L.fea; w.in_cs = F; w.K = F; w.g = L.g_u1; w.g_cs = F; w.N = F;
-    w.g_mask = L.u1; w.mask_cs = F; w.mask_slope = 0.2f;
     w.dw = Gp[p_tail(L, 1)]; w.db = Gp[p_tail(L, 1) + 1]; w.workspace = L.wg_ws;
     RUN(neosr_conv3x3_wgrad(&w, st));
     neosr_conv_desc d = conv_base(B, H2, W2);
     d.mode = NEOSR_CONV_DGRAD;
-    d.in = L.g_u1; d.in_cs = F; d.K = F; d.in_mask = L.u1; d.mask_cs = F; d.mask_slope = 0.2f;
+    d.in = L.g_u1; d.in_cs = F; d.K = F;
     d.w = P[p_tail(L, 1)]; d.w_cout = F; d.w_cin = F;
+    d.w_pack = L.tail_pd + L.tail_p; d.w_wino = L.tail_wd + L.tail_w;
     d.out = L.g_up1in; d.out_cs = F; d.N = F;
     RUN(neosr_conv3x3(&d, st));
     RUN(neosr_pool2x2_sum(L.g_up1in, L.g_fea, B, H, W, F, F, F, 0, st));
@@ -508,6 +549,7 @@ int rrdb_backward_impl(const neosr_rrdbnet_cfg* c, const float* const* P, float*
     d.mode = NEOSR_CONV_DGRAD;
     d.in = L.g_fea; d.in_cs = F; d.K = F;
     d.w = P[p_tail(L, 0)]; d.w_cout = F; d.w_cin = F;
+    d.w_pack = L.tail_pd; d.w_wino = L.tail_wd;
     d.out = L.gb[0]; d.out_cs = CC; d.N = F;  // = g5 of the last RDB
     RUN(neosr_conv3x3(&d, st));
   }
@@ -515,7 +557,6 @@ int rrdb_backward_impl(const neosr_rrdbnet_cfg* c, const float* const* P, float*
   // Gather form: each gradient slice of the concat buffer is produced ONCE, by a forward-shaped
   // convolution over a prefix of the RDB's gradient buffer (see g_off), with the LeakyReLU derivative
   // of that slice applied in the epilogue -> no read-modify-write, no masks on load, K = 64..192.
-  RUN(rrdb_pack_dgrad(L, P, st));
   // Two launch chains again (see Aux) for the data gradients; the weight gradients (one full-batch
   // launch per RDB, independent of the chain that follows) run on a third stream behind them.  The ring
   // of four gradient buffers bounds how far the chains may run ahead: RDB t+3 overwrites the g5 slot of

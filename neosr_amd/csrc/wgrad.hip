@@ -350,6 +350,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_wgrad_wino_kernel(const WgradM
   const int ntile = local / nkt, kt = local - ntile * nkt;
   const int co0 = ntile * 32, ci0 = kt * 32;
   const int H = args.H, W = args.W;
+  const int Hin = args.ups ? (H >> 1) : H, Win = args.ups ? (W >> 1) : W;  // input = nearest x2 of a (H/2, W/2) map
   const int u_lo = s * args.w_units_per_split;
   const int u_hi = min(args.w_nunits, u_lo + args.w_units_per_split);
 
@@ -379,7 +380,8 @@ __global__ __launch_bounds__(256, 3) void conv3x3_wgrad_wino_kernel(const WgradM
       if (i == WW_XROUNDS - 1 && wave != 0) break;  // granules 1024..1087
       const int gy = y0 - 1 + xr[i], gx = x0 - 1 + xc[i];
       const bool ok = ci_ok && gy >= 0 && gy < H && gx >= 0 && gx < W;
-      const float* src = ok ? d.in + (((int64_t)b * H + gy) * W + gx) * d.in_cs + ci0 + q4 : wg_zero_page;
+      const int sy = args.ups ? (gy >> 1) : gy, sx = args.ups ? (gx >> 1) : gx;
+      const float* src = ok ? d.in + (((int64_t)b * Hin + sy) * Win + sx) * d.in_cs + ci0 + q4 : wg_zero_page;
       glds16g(src, xb + (i * 4 + wave) * 256);
     }
 #pragma unroll
@@ -909,7 +911,7 @@ extern "C" int neosr_conv3x3_wgrad_multi(const neosr_wgrad_desc* ds, int32_t n, 
     s2d = s2d || ds[i].s2d_c > 0;
     plain = plain && !ds[i].g_mask && !ds[i].in_prelu && !ds[i].mask_slopes;
   }
-  if (fast && plain && !s2d && !a.ups && neosr_conv::wino_enabled()) {  // Winograd form (see conv3x3_wgrad_wino_kernel)
+  if (fast && plain && !s2d && neosr_conv::wino_enabled()) {  // Winograd form (see conv3x3_wgrad_wino_kernel)
     WgradMultiArgs w = a;
     const int P = a.pair_start[MAXD];
     w.bpart = workspace + (int64_t)P * a.w_nsplit * WW_PART;

@@ -117,7 +117,7 @@ class Conv3x3(torch.autograd.Function):
     def forward(ctx, x, w, b, act, slope, ups, res, s2d_c=0):
         _C.require_device(x, "x")
         w = _C.require_device(w, "weight").contiguous()
-        wino = packed_wino(w, ops.CONV_FWD) if not ups and s2d_c == 0 else None  # F(2x2,3x3) kernel when eligible
+        wino = packed_wino(w, ops.CONV_FWD) if s2d_c == 0 else None  # F(2x2,3x3) kernel when eligible
         y = ops.conv3x3(x, w, b, act=act, slope=slope, k_in=w.shape[1], ups=ups, res1=res,
                         w_pack=packed_weights(w, ops.CONV_FWD), s2d_c=s2d_c, w_wino=wino)
         ctx.s2d_c = s2d_c
