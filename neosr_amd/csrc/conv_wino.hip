@@ -148,42 +148,75 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const ConvArgs arg
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-  auto compute = [&](const float* rbuf, const f32x4 (&u)[4][2]) {
+  // row i of B^T as ONE fused multiply-add per component: t = d[ra] + sg * d[rb], sg = sa * sb; the overall sign sa
+  // (-1 for wave 2 only) is applied to the wave's accumulators once, after the loop
+  const float sg = sa * sb;
+  // patch loads (8 x ds_read_b128 per k group) are issued one k group AHEAD of the MFMAs that consume them, so their
+  // LDS latency hides under the previous group's 16 MFMAs
+  auto loadp = [&](const float* rbuf, int g, f32x4 (&dd)[8]) {
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
-      f32x4 t[4];
+    for (int s = 0; s < 8; ++s) dd[s] = ld4f(rbuf + (po[s] ^ (g << 3)));
+  };
+  auto mac = [&](const f32x4 (&dd)[8], const f32x4 (&u)[4][2], int g) {
+    f32x4 t[4];
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const f32x4 da = ld4f(rbuf + (po[s] ^ (g << 3)));
-        const f32x4 db = ld4f(rbuf + (po[4 + s] ^ (g << 3)));
-        t[s] = sa * da + sb * db;
-      }
-      const f32x4 v0 = t[0] - t[2], v1 = t[1] + t[2], v2 = t[2] - t[1], v3 = t[1] - t[3];
+    for (int s = 0; s < 4; ++s)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[0][g][e], v0[e], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[1][g][e], v1[e], acc[1], 0, 0, 0);
-        acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[2][g][e], v2[e], acc[2], 0, 0, 0);
-        acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[3][g][e], v3[e], acc[3], 0, 0, 0);
-      }
+      for (int e = 0; e < 4; ++e) t[s][e] = __builtin_fmaf(sg, dd[4 + s][e], dd[s][e]);
+    const f32x4 v0 = t[0] - t[2], v1 = t[1] + t[2], v2 = t[2] - t[1], v3 = t[1] - t[3];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[0][g][e], v0[e], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[1][g][e], v1[e], acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[2][g][e], v2[e], acc[2], 0, 0, 0);
+      acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[3][g][e], v3[e], acc[3], 0, 0, 0);
     }
   };
 
-  f32x4 ua[4][2], ub[4][2];
+  f32x4 ua[4][2], ub[4][2], pa[8], pb[8];
   issue(0, 0);
   load_u(0, ua);
   __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
   __syncthreads();
   for (int c = 0; c < nchunks; ++c) {
     const float* rb0 = lds + (c & 1) * WR_BUF;
-    if (c + 1 < nchunks) issue(c + 1, (c + 1) & 1);
+    const float* rb1 = rb0 + WR_HALF;
     const bool h1 = 2 * c + 1 < nhalf, h2 = 2 * c + 2 < nhalf;  // workgroup-uniform
+    // vmcnt retires in order: U of the second half is requested BEFORE the DMA of the next chunk, so that waiting for
+    // it later leaves the DMA (and the U of the half after) in flight
     if (h1) load_u(2 * c + 1, ub);
-    compute(rb0, ua);
-    if (h2) load_u(2 * c + 2, ua);
-    if (h1) compute(rb0 + WR_HALF, ub);
+    if (c + 1 < nchunks) issue(c + 1, (c + 1) & 1);
+    // (sched_barrier: keep the issue order load(next) -> mac(current); the waitcnt pass then emits partial lgkmcnt counts)
+    loadp(rb0, 0, pa);
+    loadp(rb0, 1, pb);
+    __builtin_amdgcn_sched_barrier(0);
+    mac(pa, ua, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (h1) loadp(rb1, 0, pa);
+    __builtin_amdgcn_sched_barrier(0);
+    mac(pb, ua, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    // (hipcc waits vmcnt(0) wherever a register filled by a global load is first used once LDS-DMA loads are in
+    // flight: the next half's U is therefore requested only AFTER the wait for this half's U, 16 MFMAs before its use)
+    if (h1) {
+      loadp(rb1, 1, pb);
+      __builtin_amdgcn_sched_barrier(0);
+      mac(pa, ub, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (h2) load_u(2 * c + 2, ua);
+      __builtin_amdgcn_sched_barrier(0);
+      mac(pb, ub, 1);
+    } else if (h2) {
+      load_u(2 * c + 2, ua);
+    }
     __builtin_amdgcn_s_waitcnt(0x0f70);  // chunk c + 1 has landed ...
     __syncthreads();                      // ... for every wave, and buffer c & 1 is free again
+  }
+  if (sa < 0.f) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = -acc[j][r];
   }
 
   // ---- output transform, column pass IN THE WAVE: (M A)[i][b] = M[i][0] + M[i][1] + M[i][2] (b = 0), M[i][1] - M[i][2] - M[i][3]

@@ -319,7 +319,10 @@ __device__ __forceinline__ void glds16g(const float* src, float* lds_dst) {
 }
 
 __global__ __launch_bounds__(256, 3) void conv3x3_wgrad_wino_kernel(const WgradMultiArgs args) {
-  __shared__ __attribute__((aligned(1024))) float lds[2 * WW_BUF];
+  // two DISTINCT LDS objects: hipcc waits vmcnt(0) before any ds_read that may alias a pending LDS-DMA write, which
+  // would serialise the next unit's DMA with this unit's compute if both buffers lived in one array
+  __shared__ __attribute__((aligned(1024))) float ldsA[WW_BUF];
+  __shared__ __attribute__((aligned(1024))) float ldsB[WW_BUF];
   __shared__ float bred[2 * 32];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -349,57 +352,74 @@ __global__ __launch_bounds__(256, 3) void conv3x3_wgrad_wino_kernel(const WgradM
   const int nkt = args.nkt[di];
   const int ntile = local / nkt, kt = local - ntile * nkt;
   const int co0 = ntile * 32, ci0 = kt * 32;
+  // descriptor fields this loop needs, once, in registers (d is indexed dynamically: every use would be a scalar load)
+  const float* __restrict__ d_in = d.in;
+  const float* __restrict__ d_g = d.g;
+  const int d_in_cs = d.in_cs, d_g_cs = d.g_cs, d_K = d.K, d_N = d.N;
+  const int ups = args.ups, units_x = args.w_units_x, units_y = args.w_units_y;
   const int H = args.H, W = args.W;
   const int Hin = args.ups ? (H >> 1) : H, Win = args.ups ? (W >> 1) : W;  // input = nearest x2 of a (H/2, W/2) map
   const int u_lo = s * args.w_units_per_split;
   const int u_hi = min(args.w_nunits, u_lo + args.w_units_per_split);
 
   // DMA granules of this thread: input rounds i = 0..4: G = i*256 + tid -> pixel G >> 3 (row, col of the 4 x 34 tile),
-  // channel quad G & 7; gradient rounds i = 0, 1: pixel (row 0..1, col 0..31)
-  int xr[WW_XROUNDS], xc[WW_XROUNDS];
+  // channel quad G & 7; gradient rounds i = 0, 1: pixel (row 0..1, col 0..31).  Per unit only a scalar base offset
+  // changes: the per-lane offsets relative to the unit's origin are fixed (with `ups`, (y0 - 1 + r) >> 1 = y0/2 +
+  // ((r - 1) >> 1) because y0 is even), so a round costs two range checks, one select and one 64-bit add.
+  const int q4 = (tid & 7) << 2;
+  const bool ci_ok = ci0 + q4 < d_K, co_ok = co0 + q4 < d_N;
+  int xr[WW_XROUNDS], xc[WW_XROUNDS], xrel[WW_XROUNDS], grel[2];
 #pragma unroll
   for (int i = 0; i < WW_XROUNDS; ++i) {
     const int G = i * 256 + tid;
     const int pix = G >> 3;
-    xr[i] = G < WW_XGRAN ? pix / WW_XC : -100000;
-    xc[i] = pix - (pix / WW_XC) * WW_XC;
+    const int r = pix / WW_XC, c = pix - r * WW_XC;
+    xr[i] = (G < WW_XGRAN && ci_ok) ? r - 1 : -100000;  // image row / column relative to the unit's first output pixel
+    xc[i] = c - 1;
+    const int ry = ups ? ((r - 1) >> 1) : r - 1, rx = ups ? ((c - 1) >> 1) : c - 1;
+    xrel[i] = (ry * Win + rx) * d_in_cs + ci0 + q4;
   }
-  const int q4 = (tid & 7) << 2;
-  const bool ci_ok = ci0 + q4 < d.K, co_ok = co0 + q4 < d.N;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int pix = (i * 256 + tid) >> 3;
+    grel[i] = ((pix >> 5) * W + (pix & 31)) * d_g_cs + co0 + q4;
+  }
 
-  auto issue = [&](int u, int buf) {
-    const int xx = u % args.w_units_x;
-    const int r = u / args.w_units_x;
-    const int yy = r % args.w_units_y;
-    const int b = r / args.w_units_y;
+  const float* zp = wg_zero_page;
+  asm volatile("" : "+s"(zp));  // keep the zero page's address in SGPRs (else it is re-read through the GOT per use)
+  auto issue = [&](int u, float* xb) {
+    const int xx = u % units_x;
+    const int r = u / units_x;
+    const int yy = r % units_y;
+    const int b = r / units_y;
     const int x0 = xx * 32, y0 = yy * 2;
-    float* xb = lds + buf * WW_BUF;
     float* gb = xb + WW_XF;
+    const float* xbase = d_in + (((int64_t)b * Hin + (ups ? (y0 >> 1) : y0)) * Win + (ups ? (x0 >> 1) : x0)) * d_in_cs;
+    const float* gbase = d_g + (((int64_t)b * H + y0) * W + x0) * d_g_cs;
 #pragma unroll
     for (int i = 0; i < WW_XROUNDS; ++i) {
       if (i == WW_XROUNDS - 1 && wave != 0) break;  // granules 1024..1087
-      const int gy = y0 - 1 + xr[i], gx = x0 - 1 + xc[i];
-      const bool ok = ci_ok && gy >= 0 && gy < H && gx >= 0 && gx < W;
-      const int sy = args.ups ? (gy >> 1) : gy, sx = args.ups ? (gx >> 1) : gx;
-      const float* src = ok ? d.in + (((int64_t)b * Hin + sy) * Win + sx) * d.in_cs + ci0 + q4 : wg_zero_page;
-      glds16g(src, xb + (i * 4 + wave) * 256);
+      const int gy = y0 + xr[i], gx = x0 + xc[i];
+      const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;  // xr = -100000 for unused slots / channels >= K
+      const float* cand = xbase + xrel[i];  // unconditional: the select below is two v_cndmask, not a branch
+      glds16g(ok ? cand : zp, xb + (i * 4 + wave) * 256);
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int pix = (i * 256 + tid) >> 3;
-      const int gy = y0 + (pix >> 5), gx = x0 + (pix & 31);
-      const bool ok = co_ok && gy < H && gx < W;
-      const float* src = ok ? d.g + (((int64_t)b * H + gy) * W + gx) * d.g_cs + co0 + q4 : wg_zero_page;
-      glds16g(src, gb + (i * 4 + wave) * 256);
+      const bool ok = co_ok && y0 + (pix >> 5) < H && x0 + (pix & 31) < W;
+      const float* cand = gbase + grel[i];
+      glds16g(ok ? cand : zp, gb + (i * 4 + wave) * 256);
     }
   };
 
   // this wave's row i = wave of the transforms
   const int ra = wave == 0 ? 0 : 1, rb = wave == 3 ? 3 : 2;                      // input rows: t = sa x[ra] + sb x[rb]
   const float sa = wave == 2 ? -1.f : 1.f, sb = (wave == 0 || wave == 3) ? -1.f : 1.f;
-  const bool two = wave == 1 || wave == 2;                                         // gradient rows: 0 | 0+1 | 0-1 | -1
+  // gradient rows: g0 | g0 + g1 | g0 - g1 | -g1  as  r = ga * g[gr] + gbq * g[1]  (branch-free: waves 0 and 3 read row 1
+  // with a zero coefficient rather than diverge)
   const int gr = wave == 3 ? 1 : 0;
-  const float ga = wave == 3 ? -1.f : 1.f, gbq = wave == 2 ? -1.f : 1.f;
+  const float ga = wave == 3 ? -1.f : 1.f, gbq = wave == 1 ? 1.f : (wave == 2 ? -1.f : 0.f);
 
   f32x16 acc[4];
 #pragma unroll
@@ -408,9 +428,9 @@ __global__ __launch_bounds__(256, 3) void conv3x3_wgrad_wino_kernel(const WgradM
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
   float bsum = 0.f;
 
-  auto compute = [&](int buf) {
-    const float* xb = lds + buf * WW_BUF + l31;
-    const float* gb = lds + buf * WW_BUF + WW_XF + l31;
+  auto compute = [&](const float* buf) {
+    const float* xb = buf + l31;
+    const float* gb = buf + WW_XF + l31;
     const float* xa = xb + (ra * WW_XC + lh * 16) * 32;   // raw column of tile t, patch column s: 2 t + s, t = lh*8 + kt
     const float* xq = xb + (rb * WW_XC + lh * 16) * 32;
     const float* g0 = gb + (gr * 32 + lh * 16) * 32;
@@ -421,11 +441,8 @@ __global__ __launch_bounds__(256, 3) void conv3x3_wgrad_wino_kernel(const WgradM
     for (int k = 0; k < 8; ++k) {
       const float t2 = sa * xa[(2 * k + 2) * 32] + sb * xq[(2 * k + 2) * 32];
       const float t3 = sa * xa[(2 * k + 3) * 32] + sb * xq[(2 * k + 3) * 32];
-      float r0 = ga * g0[(2 * k) * 32], r1 = ga * g0[(2 * k + 1) * 32];
-      if (two) {
-        r0 += gbq * g1[(2 * k) * 32];
-        r1 += gbq * g1[(2 * k + 1) * 32];
-      }
+      const float r0 = __builtin_fmaf(gbq, g1[(2 * k) * 32], ga * g0[(2 * k) * 32]);
+      const float r1 = __builtin_fmaf(gbq, g1[(2 * k + 1) * 32], ga * g0[(2 * k + 1) * 32]);
       bsum += r0 + r1;
       acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(r0, t0 - t2, acc[0], 0, 0, 0);
       acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(r0 + r1, t1 + t2, acc[1], 0, 0, 0);
@@ -437,13 +454,17 @@ __global__ __launch_bounds__(256, 3) void conv3x3_wgrad_wino_kernel(const WgradM
   };
 
   if (u_lo < u_hi) {
-    issue(u_lo, 0);
+    issue(u_lo, ldsA);
     __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
     __syncthreads();
-    for (int u = u_lo; u < u_hi; ++u) {
-      const int buf = (u - u_lo) & 1;
-      if (u + 1 < u_hi) issue(u + 1, buf ^ 1);
-      compute(buf);
+    for (int u = u_lo; u < u_hi; u += 2) {
+      if (u + 1 < u_hi) issue(u + 1, ldsB);
+      compute(ldsA);
+      __builtin_amdgcn_s_waitcnt(0x0f70);
+      __syncthreads();
+      if (u + 1 >= u_hi) break;
+      if (u + 2 < u_hi) issue(u + 2, ldsA);
+      compute(ldsB);
       __builtin_amdgcn_s_waitcnt(0x0f70);
       __syncthreads();
     }
