@@ -43,8 +43,7 @@ constexpr int WR_BUF = 2 * WR_HALF;           // one raw buffer = a 32-channel c
 constexpr int WCK = 32;                       // channels per DMA chunk / barrier (two 16-channel halves)
 constexpr int WU_HALF = neosr_pack::WINO_IMG_FLOATS;  // 16 pos x 4 quads x 32 n x 4 = 8192 floats (32 KB) per 16 channels
 constexpr int WM_S = 36;                      // tile stride of the accumulator exchange (conflict-free b128 writes)
-constexpr int W_LDS = 2 * WR_BUF;              // 12288 floats = 48 KB: two raw buffers (>= the 36 KB exchange image)
-static_assert(8 * 32 * WM_S <= W_LDS, "exchange image must fit the raw buffers");
+static_assert(4 * 32 * WM_S <= WR_BUF, "each half of the exchange image must fit one raw buffer");
 
 __device__ __forceinline__ void glds16w(const float* src, float* lds_dst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -63,7 +62,10 @@ __device__ __forceinline__ int raw_pix(int py, int px) { return py * WR_W + (px 
 
 __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const ConvArgs args) {
   const neosr_conv_desc& d = args.d;
-  __shared__ __attribute__((aligned(1024))) float lds[W_LDS];  // raw buffers in the loop, M at the end
+  // the two raw buffers are DISTINCT LDS objects (hipcc waits vmcnt(0) before a ds_read that may alias a pending LDS-DMA
+  // write); the exchange image at the end reuses buffer 0
+  __shared__ __attribute__((aligned(1024))) float lds[WR_BUF];
+  __shared__ __attribute__((aligned(1024))) float ldsB[WR_BUF];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int m = lane & 31, lh = lane >> 5;
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const ConvArgs arg
   auto issue = [&](int c, int buf) {  // 32 channels: two halves of 3 DMA rounds each
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      float* rbuf = lds + buf * WR_BUF + h * WR_HALF;
+      float* rbuf = (buf ? ldsB : lds) + h * WR_HALF;
       const int c0 = c * WCK + h * 16;
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
@@ -179,7 +181,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const ConvArgs arg
   __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
   __syncthreads();
   for (int c = 0; c < nchunks; ++c) {
-    const float* rb0 = lds + (c & 1) * WR_BUF;
+    const float* rb0 = (c & 1) ? ldsB : lds;
     const float* rb1 = rb0 + WR_HALF;
     const bool h1 = 2 * c + 1 < nhalf, h2 = 2 * c + 2 < nhalf;  // workgroup-uniform
     // vmcnt retires in order: U of the second half is requested BEFORE the DMA of the next chunk, so that waiting for
@@ -232,7 +234,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const ConvArgs arg
         const int r = 4 * rr + e;
         v[e] = bq == 0 ? (acc[0][r] + acc[1][r]) + acc[2][r] : (acc[1][r] - acc[2][r]) - acc[3][r];
       }
-      *reinterpret_cast<f32x4*>(lds + ((wave * 2 + bq) * 32 + m) * WM_S + 8 * rr + 4 * lh) = v;
+      // rows 0, 1 of the exchange image live in raw buffer 0, rows 2, 3 in raw buffer 1
+      *reinterpret_cast<f32x4*>((wave < 2 ? lds : ldsB) + (((wave & 1) * 2 + bq) * 32 + m) * WM_S + 8 * rr + 4 * lh) = v;
     }
   __syncthreads();
 
@@ -243,8 +246,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const ConvArgs arg
   for (int bq = 0; bq < 2; ++bq) {
     const f32x4 x0 = ld4f(lds + ((0 * 2 + bq) * 32 + et) * WM_S + cq);
     const f32x4 x1 = ld4f(lds + ((1 * 2 + bq) * 32 + et) * WM_S + cq);
-    const f32x4 x2 = ld4f(lds + ((2 * 2 + bq) * 32 + et) * WM_S + cq);
-    const f32x4 x3 = ld4f(lds + ((3 * 2 + bq) * 32 + et) * WM_S + cq);
+    const f32x4 x2 = ld4f(ldsB + ((0 * 2 + bq) * 32 + et) * WM_S + cq);
+    const f32x4 x3 = ld4f(ldsB + ((1 * 2 + bq) * 32 + et) * WM_S + cq);
     y[0][bq] = (x0 + x1) + x2;
     y[1][bq] = (x1 - x2) - x3;
   }
