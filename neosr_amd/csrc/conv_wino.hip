@@ -70,6 +70,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const ConvArgs arg
   const int lane = tid & 63, wave = tid >> 6;
   const int m = lane & 31, lh = lane >> 5;
   const int tyi = m >> 3, txi = m & 7;
+  TL_MARK(0);
 
   int bid = xcd_tile(blockIdx.x, gridDim.x, args.xcd);
   const int tx = bid % args.tiles_x;
@@ -180,6 +181,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const ConvArgs arg
   load_u(0, ua);
   __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
   __syncthreads();
+  TL_MARK(1);
   for (int c = 0; c < nchunks; ++c) {
     const float* rb0 = (c & 1) ? ldsB : lds;
     const float* rb1 = rb0 + WR_HALF;
@@ -198,6 +200,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const ConvArgs arg
     __builtin_amdgcn_sched_barrier(0);
     mac(pb, ua, 1);
     __builtin_amdgcn_sched_barrier(0);
+    TL_MARK(2 + c * 3);
     // (hipcc waits vmcnt(0) wherever a register filled by a global load is first used once LDS-DMA loads are in
     // flight: the next half's U is therefore requested only AFTER the wait for this half's U, 16 MFMAs before its use)
     if (h1) {
@@ -211,8 +214,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const ConvArgs arg
     } else if (h2) {
       load_u(2 * c + 2, ua);
     }
+    TL_MARK(3 + c * 3);
     __builtin_amdgcn_s_waitcnt(0x0f70);  // chunk c + 1 has landed ...
     __syncthreads();                      // ... for every wave, and buffer c & 1 is free again
+    TL_MARK(4 + c * 3);
   }
   if (sa < 0.f) {
 #pragma unroll
@@ -238,6 +243,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const ConvArgs arg
       *reinterpret_cast<f32x4*>((wave < 2 ? lds : ldsB) + (((wave & 1) * 2 + bq) * 32 + m) * WM_S + 8 * rr + 4 * lh) = v;
     }
   __syncthreads();
+  TL_MARK(61);
 
   // ---- row pass + epilogue: thread = (tile, cout quad); Y[a][b] = X[0][b] + X[1][b] + X[2][b] (a = 0), X[1][b] - X[2][b] - X[3][b]
   const int et = tid >> 3, cq = (tid & 7) << 2;
@@ -252,6 +258,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const ConvArgs arg
     y[1][bq] = (x1 - x2) - x3;
   }
 
+  TL_MARK(62);
   const int chq = n0 + cq;
   const bool ch_ok = chq < d.N;
   const int cs0 = ch_ok ? chq : 0;
@@ -285,6 +292,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const ConvArgs arg
       }
       *reinterpret_cast<f32x4*>(ok ? d.out + pix * d.out_cs + chq : g_trash + tid * 4) = o;
     }
+  TL_MARK(63);
 }
 
 // U = G g G^T of every (cin, cout) pair of an image: one thread per (n-block, chunk, k quad, n) loads the 4 x 9 taps of

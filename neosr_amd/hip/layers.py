@@ -132,6 +132,14 @@ class Conv3x3(torch.autograd.Function):
         x, w, y = ctx.saved_tensors
         g = g.contiguous()
         slope = ctx.slope if ctx.act == ACT_LRELU else 0.0
+        if y is not None and ctx.s2d_c == 0:
+            # producer-side activation derivative: g <- g * act'(y) in ONE elementwise pass, so that neither the
+            # backward-data nor the weight-gradient launch masks on load -> both are plain (packed / Winograd kernels)
+            lib = _C.load()
+            gm = torch.empty_like(g)
+            _C.check(lib.neosr_leaky_relu(y.data_ptr(), g.data_ptr(), slope, gm.data_ptr(), g.numel(), _st()),
+                     "neosr_leaky_relu")
+            g, y = gm, None
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             plain = y is None  # no activation derivative to apply on load -> packed / Winograd kernels

@@ -69,7 +69,44 @@ def run_glds(name, H, W, K, N, CC, B=16):
         print(f" wave{wv}: " + " ".join(row))
 
 
+def run_wino(name, H, W, K, N, CC, B=16):
+    """Winograd kernel: marks = start, first barrier, per 32-channel chunk (half 0 done, half 1 done, barrier), exchange
+    barrier, row pass done, end"""
+    lib = _C.load()
+    x = torch.randn(B, H, W, CC, device="cuda")
+    w = torch.randn(N, K, 3, 3, device="cuda") * 0.05
+    pack, wino = ops.conv3x3_pack_weights(w), ops.conv3x3_pack_wino(w)
+    out = torch.empty(B, H, W, N, device="cuda")
+    tl = torch.zeros(4 * 64, dtype=torch.int64, device="cuda")
+    for _ in range(3):
+        ops.conv3x3(x, w, None, out=out, k_in=K, w_pack=pack, w_wino=wino)
+    torch.cuda.synchronize()
+    lib.neosr_debug_set_timeline(tl.data_ptr())
+    ops.conv3x3(x, w, None, out=out, k_in=K, w_pack=pack, w_wino=wino)
+    torch.cuda.synchronize()
+    lib.neosr_debug_set_timeline(None)
+    t = tl.cpu().view(4, 64)
+    nchunks = (K + 31) // 32
+    print(f"== winograd {name}: K={K} N={N} chunks={nchunks}")
+    for wv in range(4):
+        r = t[wv]
+        base = int(r[0])
+        row = [f"first_bar@{int(r[1]) - base}"]
+        prev = int(r[1]) - base
+        for c in range(nchunks):
+            a, b_, bar = (int(r[2 + 3 * c + j]) - base for j in range(3))
+            row.append(f"[c{c} h0 {a - prev} h1 {b_ - a} wait+bar {bar - b_}]")
+            prev = bar
+        row.append(f"exch_bar@{int(r[61]) - base} rowpass@{int(r[62]) - base} end@{int(r[63]) - base}")
+        print(f" wave{wv}: " + " ".join(row))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "wino":
+        run_wino("rdb.conv1", 64, 64, 64, 32, 192)
+        run_wino("rdb.conv4", 64, 64, 160, 32, 192)
+        run_wino("rdb.conv5", 64, 64, 192, 64, 192)
+        raise SystemExit
     run_glds("rdb.conv1", 64, 64, 64, 32, 192)
     run_glds("rdb.conv4", 64, 64, 160, 32, 192)
     run_glds("rdb.conv5", 64, 64, 192, 64, 192)
