@@ -262,10 +262,17 @@ class image(base):
         if self.gradclip and not self._sam_now:  # image.py:533-544,597-609: no clipping under SAM
             optimizer.set_clip(1.0)
 
+    def _d_params(self) -> list:
+        """the discriminator's parameters as a cached list (walking the module tree twice per step is host time)"""
+        ps = getattr(self, "_d_param_list", None)
+        if ps is None:
+            ps = self._d_param_list = list(self.net_d.parameters())
+        return ps
+
     def closure(self, current_iter: int):  # noqa: ARG002
         """image.py:427-625: G forward, weighted losses, G backward; then D real/fake forward+backward."""
         if self.net_d is not None:
-            for p in self.net_d.parameters():
+            for p in self._d_params():
                 p.requires_grad = False
 
         self.n_accumulated += 1
@@ -314,7 +321,7 @@ class image(base):
             self._sync_grads(self.sam_optimizer_g if self._sam_now else self.optimizer_g, self._sync_g)
 
         if self.net_d is not None:
-            for p in self.net_d.parameters():
+            for p in self._d_params():
                 p.requires_grad = True
             if self.cri_gan:
                 # both forwards first, then both backwards (image.py:559,574,593-594)

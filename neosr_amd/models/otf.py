@@ -83,6 +83,10 @@ class otf(image):
             return self.draws.uniform(lo, 1)
         return 1
 
+    @property
+    def _no_sync(self) -> bool:
+        return isinstance(self.draws, LiveDraws) and self.draws.device.type == "cuda"
+
     def _add_noise(self, out: torch.Tensor, suffix: str) -> torch.Tensor:
         """gaussian (p = gaussian_noise_prob) else poisson; clip, no round (otf.py:128-148,188-210)."""
         d = self.draws
@@ -92,14 +96,17 @@ class otf(image):
             lo, hi = self.dopt.get(f"noise_range{suffix}")
             sigma = d.rand(b) * (hi - lo) + lo
             gray = (d.rand(b) < gray_prob).float()
-            noise_gray = d.randn(h, w) if bool(gray.sum() > 0) else None
+            # the reference draws the shared gray field only if some sample is gray (a device->host sync,
+            # degradations.py:593-598).  A replayed stream must follow that; the live stream (our own counter-based
+            # sampler, not torch's sequence anyway) draws it unconditionally and never stalls the host
+            noise_gray = d.randn(h, w) if (self._no_sync or bool(gray.sum() > 0)) else None
             noise = d.randn(b, 3, h, w)
             return D.gaussian_noise(out, noise, noise_gray, sigma, gray)
         lo, hi = self.dopt.get(f"poisson_scale_range{suffix}")
         scale = d.rand(b) * (hi - lo) + lo
         gray = (d.rand(b) < gray_prob).float()
         p_gray = vals_gray = None
-        if bool(gray.sum() > 0):
+        if self._no_sync or bool(gray.sum() > 0):
             rate_g, vals_gray = D.poisson_rate(out, gray=True)
             p_gray = d.poisson(rate_g)
         rate, vals = D.poisson_rate(out, gray=False)

@@ -1,0 +1,26 @@
+"""How long the HOST needs to enqueue one training step vs how long the GPU needs to run it (headline config)."""
+import os, sys, time, types
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch
+import bench
+
+args = types.SimpleNamespace(config=(sys.argv[1] if len(sys.argv) > 1 else "bench_esrgan"), batch=0, arch=None, template_losses=False, augment=False)
+opt = bench.load_opt(args, 1, 0)
+from neosr_amd.models import build_model
+import logging
+logging.getLogger("neosr").setLevel(logging.WARNING)
+torch.manual_seed(1024)
+model = build_model(opt)
+batch = bench.make_batch(opt, torch.device("cuda"), 0)
+for it in range(1, 6):
+    model.feed_data(batch); model.optimize_parameters(it)
+torch.cuda.synchronize()
+host, total = [], []
+for it in range(6, 16):
+    t0 = time.perf_counter()
+    model.feed_data(batch); model.optimize_parameters(it)
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    host.append(t1 - t0); total.append(t2 - t0)
+print("host enqueue ms/step: %.2f   enqueue + drain ms/step: %.2f" % (1e3 * sum(host) / len(host), 1e3 * sum(total) / len(total)))
