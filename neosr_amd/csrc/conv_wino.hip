@@ -226,6 +226,34 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const ConvArgs arg
       for (int r = 0; r < 16; ++r) acc[j][r] = -acc[j][r];
   }
 
+  // ---- epilogue operands of thread (tile, cout quad), requested NOW: their global-load latency hides under the column
+  // pass, the accumulator exchange and its barrier (the accumulators' inputs are dead, registers are plentiful here)
+  const int et = tid >> 3, cq = (tid & 7) << 2;
+  const int chq = n0 + cq;
+  const bool ch_ok = chq < d.N;
+  const int cs0 = ch_ok ? chq : 0;
+  f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+  if (d.bias) bias = ld4f(d.bias + cs0);
+  float s_uni = 1.f;
+  if (d.act == ACT_LRELU) s_uni = d.slope;
+  else if (d.act == ACT_RELU) s_uni = 0.f;
+  const int ey = y0 + 2 * (et >> 3), ex = x0 + 2 * (et & 7);
+  bool okp[4];
+  int64_t pixp[4];
+  f32x4 r1[4], r2[4], r0[4], mk[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int py = ey + (q >> 1), px = ex + (q & 1);
+    okp[q] = ch_ok && py < H && px < W;
+    pixp[q] = okp[q] ? ((int64_t)b * H + py) * W + px : 0;
+    r1[q] = r2[q] = r0[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    mk[q] = (f32x4){1.f, 1.f, 1.f, 1.f};
+    if (d.res1) r1[q] = ld4f((okp[q] && chq < d.res1_nch) ? d.res1 + pixp[q] * d.res1_cs + chq : g_zero_page);
+    if (d.res2) r2[q] = ld4f((okp[q] && chq < d.res2_nch) ? d.res2 + pixp[q] * d.res2_cs + chq : g_zero_page);
+    if (d.accumulate) r0[q] = ld4f(okp[q] ? d.out + pixp[q] * d.out_cs + chq : g_zero_page);
+    if (d.out_mask) mk[q] = ld4f(okp[q] ? d.out_mask + pixp[q] * d.out_mask_cs + chq : g_zero_page);
+  }
+
   // ---- output transform, column pass IN THE WAVE: (M A)[i][b] = M[i][0] + M[i][1] + M[i][2] (b = 0), M[i][1] - M[i][2] - M[i][3]
   // (b = 1) on the wave's own four accumulators -> only 2 x 16 registers per lane cross the LDS
   // exchange image: X[i][b][tile][cout], tile stride WM_S; register 4rr + e <-> channel 8rr + 4lh + e
@@ -245,8 +273,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const ConvArgs arg
   __syncthreads();
   TL_MARK(61);
 
-  // ---- row pass + epilogue: thread = (tile, cout quad); Y[a][b] = X[0][b] + X[1][b] + X[2][b] (a = 0), X[1][b] - X[2][b] - X[3][b]
-  const int et = tid >> 3, cq = (tid & 7) << 2;
+  // ---- row pass + epilogue: Y[a][b] = X[0][b] + X[1][b] + X[2][b] (a = 0), X[1][b] - X[2][b] - X[3][b]
   f32x4 y[2][2];
 #pragma unroll
   for (int bq = 0; bq < 2; ++bq) {
@@ -257,41 +284,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const ConvArgs arg
     y[0][bq] = (x0 + x1) + x2;
     y[1][bq] = (x1 - x2) - x3;
   }
-
   TL_MARK(62);
-  const int chq = n0 + cq;
-  const bool ch_ok = chq < d.N;
-  const int cs0 = ch_ok ? chq : 0;
-  f32x4 bias = {0.f, 0.f, 0.f, 0.f};
-  if (d.bias) bias = ld4f(d.bias + cs0);
-  float s_uni = 1.f;
-  if (d.act == ACT_LRELU) s_uni = d.slope;
-  else if (d.act == ACT_RELU) s_uni = 0.f;
-  const int ey = y0 + 2 * (et >> 3), ex = x0 + 2 * (et & 7);
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int q = 0; q < 4; ++q) {
+    f32x4 o;
 #pragma unroll
-    for (int bb = 0; bb < 2; ++bb) {
-      const int py = ey + a, px = ex + bb;
-      const bool ok = ch_ok && py < H && px < W;
-      const int64_t pix = ok ? ((int64_t)b * H + py) * W + px : 0;
-      f32x4 r1 = {0.f, 0.f, 0.f, 0.f}, r2 = r1, r0 = r1, mk = {1.f, 1.f, 1.f, 1.f};
-      if (d.res1) r1 = ld4f((ok && chq < d.res1_nch) ? d.res1 + pix * d.res1_cs + chq : g_zero_page);
-      if (d.res2) r2 = ld4f((ok && chq < d.res2_nch) ? d.res2 + pix * d.res2_cs + chq : g_zero_page);
-      if (d.accumulate) r0 = ld4f(ok ? d.out + pix * d.out_cs + chq : g_zero_page);
-      if (d.out_mask) mk = ld4f(ok ? d.out_mask + pix * d.out_mask_cs + chq : g_zero_page);
-      f32x4 o;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float t = y[a][bb][e] + bias[e];
-        t = t > 0.f ? t : t * s_uni;
-        t = t * d.alpha + r1[e];
-        t = t * d.alpha2 + r2[e];
-        t += r0[e];
-        o[e] = mk[e] > 0.f ? t : t * d.out_mask_slope;
-      }
-      *reinterpret_cast<f32x4*>(ok ? d.out + pix * d.out_cs + chq : g_trash + tid * 4) = o;
+    for (int e = 0; e < 4; ++e) {
+      float t = y[q >> 1][q & 1][e] + bias[e];
+      t = t > 0.f ? t : t * s_uni;
+      t = t * d.alpha + r1[q][e];
+      t = t * d.alpha2 + r2[q][e];
+      t += r0[q][e];
+      o[e] = mk[q][e] > 0.f ? t : t * d.out_mask_slope;
     }
+    *reinterpret_cast<f32x4*>(okp[q] ? d.out + pixp[q] * d.out_cs + chq : g_trash + tid * 4) = o;
+  }
   TL_MARK(63);
 }
 
