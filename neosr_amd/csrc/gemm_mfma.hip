@@ -320,6 +320,158 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(const GemmArgs arg
   epilogue<0>(args, acc, m0, n0, 0);
 }
 
+// TN GEMM fed from registers (weight gradients dW[m][n] = sum_t dY[t][m] X[t][n]): both operands are
+// contiguous along their OUTPUT index, so an MFMA fragment is a plain coalesced row load — lane (l31, lh) reads
+// 3 consecutive dY columns and 2 consecutive X columns of token 2s + lh (buffer_load_dwordx3 / dwordx2; a
+// half-wave covers 384 / 256 contiguous bytes of one token row) and feeds them to 3 x 2 MFMAs whose row /
+// column index is interleaved (m = m0 + 3 j + e1, n = n0 + 2 i + e2).  No LDS, no barrier: every WAVE is an
+// independent task — one 96 x 64 output tile (6 accumulators) over its own run of tokens — with the next batch of
+// RT_P token pairs in flight while the current one multiplies (one wave per SIMD, so the lookahead is in
+// registers, not in a second wave).  The 96 / 64 granularity pads the transformer shapes (180, 360, 540) by
+// 6.7 % per dimension where the 128 x 64 LDS tile pads 180 -> 256.  All tiles of a token split run on one XCD
+// (its rows are fetched from HBM once and re-read from that L2); the number of splits is chosen so that the
+// tasks just fill the 128 SIMDs of an XCD.  Partial tiles go to per-split slabs that `colsum_kernel` sums in
+// split order, as before.
+#ifndef RT_P
+#define RT_P 16
+#endif
+constexpr int RT_M = 96, RT_N = 64;
+
+#ifndef RT_OCC
+#define RT_OCC 1
+#endif
+__global__ __launch_bounds__(256, RT_OCC) void gemm_tn_reg_kernel(const GemmArgs args) {
+  const neosr_gemm_desc& d = args.d;
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles = args.tiles_m * args.tiles_n;
+  const int xcd = blockIdx.x & 7, task = (blockIdx.x >> 3) * 4 + wave;  // task index inside this XCD
+  const int split = (task / tiles) * 8 + xcd, tile = task % tiles;
+  if (split >= args.nsplit) return;
+  const int m0 = (tile / args.tiles_n) * RT_M, n0 = (tile % args.tiles_n) * RT_N;
+  const int M = d.M, N = d.N;
+  const int t_lo = split * args.ksplit_len;
+  const int t_hi = min(d.K, t_lo + args.ksplit_len);
+  // Operands come through buffer loads: a per-wave resource descriptor (base = the matrix, extent = the end of
+  // THIS wave's token run) + 32-bit lane offset + scalar row offset, so the address math is scalar.  Lanes whose
+  // columns fall outside the matrix read column 0 instead: their products only reach accumulator rows / columns
+  // that are never stored.  Tokens past the run (last batch) get an out-of-range lane offset and read 0.
+  const bool a_ok = m0 + 3 * l31 + 2 < M, b_ok = n0 + 2 * l31 + 1 < N;
+  const int oa = ((a_ok ? m0 + 3 * l31 : 0) + lh * d.lda) * 4, ob = ((b_ok ? n0 + 2 * l31 : 0) + lh * d.ldb) * 4;
+  const __amdgpu_buffer_rsrc_t ra =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.A), 0, d.K * d.lda * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.B), 0, d.K * d.ldb * 4, 0x00020000);
+  const int sa = 8 * d.lda, sb = 8 * d.ldb;  // bytes per token pair
+  int ta = t_lo * d.lda * 4, tb = t_lo * d.ldb * 4;  // scalar offsets of the next batch
+
+  f32x16 acc[3][2];
+#pragma unroll
+  for (int e1 = 0; e1 < 3; ++e1)
+#pragma unroll
+    for (int e2 = 0; e2 < 2; ++e2)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[e1][e2][r] = 0.f;
+  float cs[3] = {0.f, 0.f, 0.f};
+
+  // fragments stay in the loads' own 3- / 2-dword register tuples (re-packing them into one array makes the
+  // compiler build a wide tuple out of moves that wait for the batch just issued)
+  typedef decltype(__builtin_amdgcn_raw_buffer_load_b96(ra, 0, 0, 0)) frag3;
+  typedef decltype(__builtin_amdgcn_raw_buffer_load_b64(rb, 0, 0, 0)) frag2;
+  frag3 a0[RT_P], a1[RT_P];
+  frag2 b0[RT_P], b1[RT_P];
+  const int ntok = t_hi - t_lo;
+  const int nfull = ntok / (2 * RT_P);
+  const int nb = nfull + (ntok % (2 * RT_P) ? 1 : 0);  // batches of RT_P token pairs, the last one ragged
+  // one pair of the batch: its two loads / its 6 MFMAs
+  auto ld = [&](frag3& av, frag2& bv, int p, bool full, int t0) {
+    const bool ok = full || t0 + 2 * p < t_hi;  // tokens past the run: out-of-range lane offset -> 0
+    av = __builtin_amdgcn_raw_buffer_load_b96(ra, ok ? oa : 0x7ffffff0, ta + p * sa, 0);
+    bv = __builtin_amdgcn_raw_buffer_load_b64(rb, ok ? ob : 0x7ffffff0, tb + p * sb, 0);
+  };
+  auto mm = [&](const frag3& av, const frag2& bv) {
+#pragma unroll
+    for (int e1 = 0; e1 < 3; ++e1) {
+      const float a = __uint_as_float(av[e1]);
+#pragma unroll
+      for (int e2 = 0; e2 < 2; ++e2)
+        acc[e1][e2] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(bv[e2]), a, acc[e1][e2], 0, 0, 0);
+      cs[e1] += a;  // column sums of dY (kept only by the n-tile-0 tasks)
+    }
+  };
+  int ib = 0;  // index of the next batch to load
+  auto load = [&](frag3 (&ab)[RT_P], frag2 (&bb)[RT_P]) {
+    const bool full = ib < nfull;
+    const int t0 = t_lo + ib * 2 * RT_P + lh;
+#pragma unroll
+    for (int p = 0; p < RT_P; ++p) ld(ab[p], bb[p], p, full, t0);
+    ta += RT_P * sa;
+    tb += RT_P * sb;
+    ++ib;
+  };
+  auto mac = [&](const frag3 (&ab)[RT_P], const frag2 (&bb)[RT_P]) {
+#pragma unroll
+    for (int p = 0; p < RT_P; ++p) mm(ab[p], bb[p]);
+  };
+  // steady state: multiply batch `cur` while refilling `nxt` (all full batches), the two loads of a pair issued
+  // right behind the 6 MFMAs of the same slot so the matrix pipe never waits for an address burst
+  auto step = [&](const frag3 (&ca)[RT_P], const frag2 (&cb)[RT_P], frag3 (&na)[RT_P], frag2 (&nb_)[RT_P]) {
+#pragma unroll
+    for (int p = 0; p < RT_P; ++p) {
+      mm(ca[p], cb[p]);
+      ld(na[p], nb_[p], p, true, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    ta += RT_P * sa;
+    tb += RT_P * sb;
+    ++ib;
+  };
+  if (nb > 0) {
+    load(a0, b0);
+    while (ib + 2 <= nfull) {  // the next two batches to load are full ones
+      step(a0, b0, a1, b1);
+      step(a1, b1, a0, b0);
+    }
+    // a0 holds the last loaded batch; 0, 1 or 2 batches (one full and / or the ragged one) are left to load
+    const int rem = nb - ib;
+    if (rem == 0) {
+      mac(a0, b0);
+    } else {
+      load(a1, b1);
+      mac(a0, b0);
+      if (rem == 2) {
+        load(a0, b0);
+        mac(a1, b1);
+        mac(a0, b0);
+      } else {
+        mac(a1, b1);
+      }
+    }
+  }
+
+  float* slab = d.C + (int64_t)split * args.slab;
+  const bool do_colsum = args.colsum_part && n0 == 0;
+#pragma unroll
+  for (int e1 = 0; e1 < 3; ++e1) {
+    const int m = m0 + 3 * l31 + e1;
+    const float csum = cs[e1] + __shfl_xor(cs[e1], 32);  // even + odd tokens
+    if (m >= M) continue;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      // D rows i = 8 g + 4 lh + r  ->  n = n0 + 2 i + e2: (r, e2) walk 8 consecutive columns
+      const int n = n0 + 16 * g + 8 * lh;
+      float* o = slab + (int64_t)m * N + n;
+      if (n < N)
+        *reinterpret_cast<float4*>(o) = make_float4(acc[e1][0][4 * g], acc[e1][1][4 * g], acc[e1][0][4 * g + 1],
+                                                    acc[e1][1][4 * g + 1]);
+      if (n + 4 < N)
+        *reinterpret_cast<float4*>(o + 4) = make_float4(acc[e1][0][4 * g + 2], acc[e1][1][4 * g + 2],
+                                                        acc[e1][0][4 * g + 3], acc[e1][1][4 * g + 3]);
+    }
+    if (do_colsum && lh == 0) args.colsum_part[(int64_t)split * args.slab + m] = csum;
+  }
+}
+
 // column sums of a row-major [rows, cols] matrix (bias gradients, LayerNorm / relative-position-bias
 // partials): 64 columns x 4 row lanes per workgroup, each row lane walks its rows with 256-byte
 // coalesced wave loads, the 4 lanes are combined through LDS in a fixed order.  Two launches when
@@ -363,6 +515,31 @@ constexpr bool g_no_glds = true;
 #else
 constexpr bool g_no_glds = false;
 #endif
+#ifdef GEMM_NO_TNREG
+constexpr bool g_no_tnreg = true;
+#else
+constexpr bool g_no_tnreg = false;
+#endif
+#ifndef TN_REG_ROUNDS
+#define TN_REG_ROUNDS RT_OCC
+#endif
+int g_tn_rounds = TN_REG_ROUNDS;
+
+// register-fed TN kernel: usable when the ragged last m tile still splits into whole 3-column lane groups
+bool tn_reg_ok(int M, int N, int K) {
+  return !g_no_tnreg && (M % RT_M) % 3 == 0 && N % 4 == 0 && (int64_t)K * (M > N ? M : N) * 4 < (1ll << 31);
+}
+// tokens per split: the (tile, split) tasks — one wave each — just fill the 128 SIMDs of every XCD (g_tn_rounds
+// times over), in whole batches of 2 RT_P tokens and never less than 4 batches
+int tn_reg_ksplit(int M, int N, int K) {
+  const int tiles = ceil_div(M, RT_M) * ceil_div(N, RT_N);
+  int per_xcd = (128 * g_tn_rounds) / tiles;
+  if (per_xcd < 1) per_xcd = 1;
+  int len = ceil_div(ceil_div(K, 8 * per_xcd), 2 * RT_P) * 2 * RT_P;
+  const int min_len = 4 * 2 * RT_P;
+  if (len < min_len) len = min_len;
+  return len;
+}
 
 int tn_splits(int M, int N, int K) {
   const int tiles = ceil_div(M, BM) * ceil_div(N, BN);
@@ -380,7 +557,12 @@ extern "C" int64_t neosr_gemm_workspace_bytes(const neosr_gemm_desc* d) {
   // split-K slabs + the staging area of the column-sum reduction (<= 16384 + M*N floats)
   // (slabs carry M extra floats for the column sums of A; the stage is sized for <= 256 row slabs of 64 columns)
   const int64_t slab = (int64_t)d->M * d->N + d->M;
-  return ((int64_t)(tn_splits(d->M, d->N, d->K) + 1) * slab + 16384 + 256 * 64 + 64) * 4;
+  int ns = tn_splits(d->M, d->N, d->K);
+  if (tn_reg_ok(d->M, d->N, d->K)) {
+    const int nr = ceil_div(d->K, tn_reg_ksplit(d->M, d->N, d->K));
+    if (nr > ns) ns = nr;
+  }
+  return ((int64_t)(ns + 1) * slab + 16384 + 256 * 64 + 64) * 4;
 }
 
 extern "C" int neosr_gemm(const neosr_gemm_desc* dp, void* stream) {
@@ -418,8 +600,15 @@ extern "C" int neosr_gemm(const neosr_gemm_desc* dp, void* stream) {
     hipLaunchKernelGGL(gemm_mfma_kernel<1>, grid, dim3(256), 0, st, a);
   } else {
     NEOSR_CHECK(d.workspace, "gemm TN: workspace missing");
-    const int ns = tn_splits(d.M, d.N, d.K);
-    a.ksplit_len = ceil_div(ceil_div(d.K, ns), BK) * BK;
+    const bool reg = tn_reg_ok(d.M, d.N, d.K);
+    if (reg) {
+      a.ksplit_len = tn_reg_ksplit(d.M, d.N, d.K);
+      a.tiles_m = ceil_div(d.M, RT_M);
+      a.tiles_n = ceil_div(d.N, RT_N);
+    } else {
+      const int ns = tn_splits(d.M, d.N, d.K);
+      a.ksplit_len = ceil_div(ceil_div(d.K, ns), BK) * BK;
+    }
     const int nsplit = ceil_div(d.K, a.ksplit_len);
     float* out = d.C;
     const int ldc = d.ldc;
@@ -432,8 +621,12 @@ extern "C" int neosr_gemm(const neosr_gemm_desc* dp, void* stream) {
     a.nsplit = nsplit;
     a.colsum_part = d.colsum_a ? d.workspace + mn : nullptr;
     float* stage = d.workspace + (int64_t)nsplit * a.slab;
-    grid.x = ceil_div(nsplit, 8) * 8 * a.tiles_m * a.tiles_n;
-    hipLaunchKernelGGL(gemm_mfma_kernel<2>, grid, dim3(256), 0, st, a);
+    grid.x = reg ? 8 * ceil_div(ceil_div(nsplit, 8) * a.tiles_m * a.tiles_n, 4)
+                 : ceil_div(nsplit, 8) * 8 * a.tiles_m * a.tiles_n;
+    if (reg)
+      hipLaunchKernelGGL(gemm_tn_reg_kernel, grid, dim3(256), 0, st, a);
+    else
+      hipLaunchKernelGGL(gemm_mfma_kernel<2>, grid, dim3(256), 0, st, a);
     if (prof) neosr_prof_end(stream);
     NEOSR_LAUNCH_CHECK();
     if (d.colsum_a == out + mn)

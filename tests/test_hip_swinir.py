@@ -46,6 +46,31 @@ def test_gemm_modes_vs_float64(M, N, K):
     assert rel_err(cs, Y.double().sum(0)) < 1e-5
 
 
+@pytest.mark.parametrize("Mo,No,T_", [(96, 64, 16), (180, 180, 1), (540, 180, 32768), (192, 8, 37), (12, 4, 5001),
+                                     (360, 180, 8191), (180, 360, 4100), (128, 64, 777)])
+def test_gemm_tn_weight_gradient_with_bias_sum(Mo, No, T_):
+    """dW = dY^T X and db = sum_t dY through the TN GEMM (register-fed 96 x 64 wave tiles when the ragged last m tile
+    splits into whole 3-column lane groups, else the staged 128 x 64 kernel): ragged / odd token counts, token runs
+    shorter than one batch, every transformer shape, accumulate on top of an existing gradient, run-to-run bits."""
+    from neosr_amd import _C
+    from neosr_amd.hip import transformer as tr
+
+    g = torch.Generator().manual_seed(Mo + No + T_)
+    dY, X = torch.randn(T_, Mo, generator=g), torch.randn(T_, No, generator=g)
+    ref, refb = dY.double().t() @ X.double(), dY.double().sum(0)
+    gw, gb = tr._wgrad_pair(dY.to(DEV), Mo, No, True)
+    tr.gemm(_C.GEMM_TN, dY.to(DEV), X.to(DEV), Mo, No, T_, out=gw, colsum_a=gb)
+    assert rel_err(gw, ref) < 1e-5 and rel_err(gb, refb) < 1e-5
+    first = (gw.clone(), gb.clone())
+    tr.gemm(_C.GEMM_TN, dY.to(DEV), X.to(DEV), Mo, No, T_, out=gw, colsum_a=gb)
+    assert torch.equal(gw, first[0]) and torch.equal(gb, first[1])
+    tr.gemm(_C.GEMM_TN, dY.to(DEV), X.to(DEV), Mo, No, T_, out=gw, colsum_a=gb, accumulate=True)
+    assert rel_err(gw, 2 * ref) < 1e-5 and rel_err(gb, 2 * refb) < 1e-5
+    sep = torch.empty(Mo, device=DEV)  # bias sum kept away from dW: second reduction pass
+    gw2 = tr.gemm(_C.GEMM_TN, dY.to(DEV), X.to(DEV), Mo, No, T_, colsum_a=sep)
+    assert torch.equal(gw2, first[0]) and rel_err(sep, refb) < 1e-5  # (two-stage column sum: other rounding order)
+
+
 def test_gemm_weight_at_unaligned_arena_offset():
     """weights living at a 4-byte-aligned (not 16-byte) offset of the packed parameter arena"""
     from neosr_amd import _C
