@@ -397,7 +397,8 @@ int neosr_layernorm_bwd(const float* dy, const float* x, const float* stats, con
  * rebuilds it 18x per forward).  One workgroup per (window, head); QK^T and PV on fp32 MFMA.
  * fwd: out [B*H*W, C] image order, lse [B*nW*heads*N] kept for backward.
  * bwd: dqkv [B*H*W, 3*C] (every element written once), d_rpb_table (+)= (fixed-order reduction
- * over windows; workspace >= (B*nW + 256)*heads*(2ws-1)^2 floats). */
+ * over windows; workspace >= (2*B*nW + 256)*heads*(2ws-1)^2 floats).  With `out` = the forward output also set
+ * (and head_dim <= 30) both passes run the wave-per-(window, head) kernels of attn_wave.hip. */
 typedef struct neosr_wattn_desc {
   const float* qkv;
   const float* rpb_table;

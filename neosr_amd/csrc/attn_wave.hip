@@ -1,0 +1,459 @@
+// attn_wave.hip — (shifted-)window attention of the SwinIR blocks, 8x8 windows, one WAVE per (window, head).
+//
+// A (window, head) problem is 64 tokens x head_dim <= 30: small enough that one wave holds every matrix of it in
+// registers, so the kernels have no workgroup barrier and (forward) no LDS traffic besides the 225-entry
+// relative-position table.  The layout trick that makes this work: the 32x32x2 fp32 MFMA returns D[i][j] with the
+// column j in the lane and the rows i = 8g + 4lh + r in the registers — which is exactly what the NEXT product
+// needs as its first operand when it contracts over i (lane = row of the operand, k-slot lh <-> register (g, r)),
+// provided the other operand is fetched with the same k order.  So
+//   forward   S^T[j][i] = K Q^T (lane = query i, registers = keys j): the softmax over j is an in-register
+//             reduction + one cross-half shuffle, and O = P V contracts over the registers with V read column-wise
+//             (lane = feature d) straight from global memory;
+//   backward  S[i][j], dP[i][j] (lane = key j): dV = P^T dO and dK = dS^T Q contract over the registers; dQ = dS K
+//             contracts over j, so dS goes through a per-wave LDS tile once (the relative-position-bias gradient
+//             bins are summed from the same tile).  -lse[i] and -delta[i] (delta = rowsum(dO . O)) are folded into
+//             the products as a 16th k-slot, so P = exp(S + bias - lse) and dS = P (dP - delta) need no broadcast.
+// Row operands (lane = token, 15 consecutive features per half-wave) are loaded directly from the fused qkv matrix
+// in image order: torch.roll, window_partition / window_reverse and the head split are address arithmetic.
+// A wave loops over its (window, head) units and requests the next unit's rows as soon as the current scores
+// are formed.  Reference: neosr/archs/swinir_arch.py:150-212 (WindowAttention), :313-341 (mask), :343-392.
+#include "common.h"
+#include "attn_wave.h"
+#include "prof.h"
+
+namespace {
+
+constexpr int WS = 8, NTOK = 64, NBIN = (2 * WS - 1) * (2 * WS - 1), NS = 16;
+
+struct __attribute__((packed, aligned(4))) F3 { float v[3]; };
+
+struct Unit {
+  int b, Wy, Wx, head;
+  int nWy, nWx;
+};
+
+__device__ __forceinline__ Unit decode(const neosr_wattn_desc& d, int u) {
+  Unit w;
+  w.nWx = d.W / WS;
+  w.nWy = d.H / WS;
+  const int nW = w.nWy * w.nWx;
+  w.head = u % d.heads;
+  const int t = u / d.heads;
+  const int wi = t % nW;
+  w.b = t / nW;
+  w.Wy = wi / w.nWx;
+  w.Wx = wi - w.Wy * w.nWx;
+  return w;
+}
+
+// image row / column of window coordinate (y, x) after the cyclic shift (shift < WS <= H, W)
+__device__ __forceinline__ int wrap(int v, int n) { return v >= n ? v - n : v; }
+
+// pixel index of window token n
+__device__ __forceinline__ int pixel(const neosr_wattn_desc& d, const Unit& w, int n) {
+  const int Y = wrap(w.Wy * WS + (n >> 3) + d.shift, d.H), X = wrap(w.Wx * WS + (n & 7) + d.shift, d.W);
+  return (w.b * d.H + Y) * d.W + X;
+}
+
+// shifted-window mask region (swinir_arch.py:313-341) of window coordinate c along one axis
+__device__ __forceinline__ int region1(int c, int Wc, int nWc, int shift) {
+  return Wc == nWc - 1 ? (c < WS - shift ? 1 : 2) : 0;
+}
+
+// Row fragment of one 32-token tile: lane (l31, lh) <- X[pixel(32 t + l31)][col0 + half * lh + s], s < NS, zero past
+// the lane's half of the head row.  HALF = 15 (head_dim 30): five 12-byte loads; HALF = 0: any head_dim <= 30.
+template <int HALF>
+__device__ __forceinline__ void load_rows(const float* X, int ld, int pix, int col0, int hd, int lh, float mul,
+                                          float (&f)[NS]) {
+  if (HALF == 15) {
+    const float* p = X + (int64_t)pix * ld + col0 + 15 * lh;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+      const F3 v = *reinterpret_cast<const F3*>(p + 3 * q);
+      f[3 * q] = v.v[0] * mul;
+      f[3 * q + 1] = v.v[1] * mul;
+      f[3 * q + 2] = v.v[2] * mul;
+    }
+    f[15] = 0.f;
+  } else {
+    const int half = (hd + 1) >> 1;
+    const int cnt = lh ? hd - half : half;
+    const float* p = X + (int64_t)pix * ld + col0 + half * lh;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) f[s] = s < cnt ? p[s] * mul : 0.f;
+  }
+}
+
+// per-lane column offsets (pixels) of the window columns 4 lh + r, r = 0..3 — the x part of the register order
+__device__ __forceinline__ void col_offsets(const neosr_wattn_desc& d, const Unit& w, int lh, int64_t (&xoff)[4]) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) xoff[r] = (int64_t)wrap(w.Wx * WS + 4 * lh + r + d.shift, d.W);
+}
+
+// first pixel of the image row of window row y (wave-uniform)
+__device__ __forceinline__ int64_t row_base(const neosr_wattn_desc& d, const Unit& w, int y) {
+  return ((int64_t)w.b * d.H + wrap(w.Wy * WS + y + d.shift, d.H)) * d.W;
+}
+
+// Column operand of one 32-token tile t: lane (d, lh), k-slot (g, r) <-> token 32 t + 8 g + 4 lh + r (the register
+// order of an MFMA result): 16 dword loads, each wave-load two 4*head_dim-byte row pieces
+__device__ __forceinline__ void load_cols(const neosr_wattn_desc& d, const Unit& w, const float* base, int ld, int t,
+                                          const int64_t (&xoff)[4], float (&c)[4][4]) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int64_t row = row_base(d, w, 4 * t + g);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) c[g][r] = base[(row + xoff[r]) * ld];
+  }
+}
+
+__device__ __forceinline__ void zero(f32x16& a) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) a[r] = 0.f;
+}
+
+__device__ __forceinline__ void load_table(const neosr_wattn_desc& d, int head, int lane, float* tab) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int n = lane + 64 * k;
+    tab[n] = n < NBIN ? d.rpb_table[n * d.heads + head] : 0.f;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------- forward
+// unit = (window, head, query tile ti): S^T tiles [tj] with rows (registers) = keys j, column (lane) = query i
+template <int HALF>
+__global__ __launch_bounds__(256, 2) void wattn_wave_fwd_kernel(const neosr_wattn_desc d, int units) {
+  __shared__ float tabs[4][256];
+  const int lane = threadIdx.x & 63, l31 = lane & 31, lh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float* tab = tabs[wave];
+  const int hd = d.C / d.heads, ld = 3 * d.C;
+  constexpr int KS = HALF ? HALF : NS;
+  const int stride = gridDim.x * 4;
+  const int dl = l31 < hd ? l31 : hd - 1;  // feature of this lane in the column operands / outputs
+  for (int u2 = blockIdx.x * 4 + wave; u2 < 2 * units; u2 += stride) {
+    const int u = u2 >> 1, ti = u2 & 1;
+    const Unit w = decode(d, u);
+    float qf[NS], kf[2][NS];
+    load_rows<HALF>(d.qkv, ld, pixel(d, w, 32 * ti + l31), w.head * hd, hd, lh, d.scale, qf);
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+      load_rows<HALF>(d.qkv, ld, pixel(d, w, 32 * tj + l31), d.C + w.head * hd, hd, lh, 1.f, kf[tj]);
+    load_table(d, w.head, lane, tab);
+    int64_t xoff[4];
+    col_offsets(d, w, lh, xoff);
+    float vc[2][4][4];  // V as a column operand, keys in the register order of P
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj) load_cols(d, w, d.qkv + 2 * d.C + w.head * hd + dl, ld, tj, xoff, vc[tj]);
+
+    f32x16 st[2];
+    zero(st[0]);
+    zero(st[1]);
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj)
+        st[tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[tj][s], qf[s], st[tj], 0, 0, 0);
+
+    // bias + mask, softmax over the keys (registers + the other half-wave)
+    const bool masked = d.shift > 0 && (w.Wy == w.nWy - 1 || w.Wx == w.nWx - 1);
+    const int yi = 4 * ti + (l31 >> 3), xi = l31 & 7;
+    const float* tb = tab + (yi + WS - 1) * (2 * WS - 1) + xi + WS - 1 - 4 * lh;
+    const int ri = region1(yi, w.Wy, w.nWy, d.shift) * 3 + region1(xi, w.Wx, w.nWx, d.shift);
+    float m = -3.0e38f;
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int ryj = region1(4 * tj + g, w.Wy, w.nWy, d.shift) * 3;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float sc = st[tj][4 * g + r] + tb[-((4 * tj + g) * (2 * WS - 1) + r)];
+          if (masked && ryj + region1(4 * lh + r, w.Wx, w.nWx, d.shift) != ri) sc -= 100.f;
+          st[tj][4 * g + r] = sc;
+          m = fmaxf(m, sc);
+        }
+      }
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = __expf(st[tj][r] - m);
+        st[tj][r] = e;
+        sum += e;
+      }
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.f / sum;
+    if (d.lse && lh == 0) d.lse[(int64_t)u * NTOK + 32 * ti + l31] = m + __logf(sum);
+
+    // O[i][d] = sum_j P[i][j] V[j][d]: P is its own first operand (lane = row i, k-slot = register)
+    f32x16 o;
+    zero(o);
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          o = __builtin_amdgcn_mfma_f32_32x32x2f32(st[tj][4 * g + r] * inv, vc[tj][g][r], o, 0, 0, 0);
+    if (l31 < hd) {
+      float* ob = d.out + w.head * hd + l31;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int64_t row = row_base(d, w, 4 * ti + g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ob[(row + xoff[r]) * d.C] = o[4 * g + r];
+      }
+    }
+  }
+}
+
+// --------------------------------------------------------------------------------------------------- backward
+// delta[i] = sum_d dO[i][d] O[i][d] of the lane's token (both half-waves end up with the full sum)
+__device__ __forceinline__ float row_delta(const float (&g)[NS], const float (&o)[NS]) {
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < NS - 1; ++k) s = fmaf(g[k], o[k], s);
+  return s + __shfl_xor(s, 32);
+}
+
+// query-side unit (window, head, ti): S^T / dP^T tiles (lane = query i, registers = keys j) -> dQ rows of tile ti
+template <int HALF>
+__device__ __forceinline__ void bwd_q_unit(const neosr_wattn_desc& d, int u, int ti, int lane, float* tab) {
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int hd = d.C / d.heads, ld = 3 * d.C;
+  const int dl = l31 < hd ? l31 : hd - 1;
+  const Unit w = decode(d, u);
+  float qf[NS], gf[NS], kf[2][NS], vf[2][NS];
+  {
+    const int pix = pixel(d, w, 32 * ti + l31);
+    load_rows<HALF>(d.qkv, ld, pix, w.head * hd, hd, lh, d.scale, qf);
+    load_rows<HALF>(d.dout, d.C, pix, w.head * hd, hd, lh, 1.f, gf);
+    float of[NS];
+    load_rows<HALF>(d.out, d.C, pix, w.head * hd, hd, lh, 1.f, of);
+    const float delta = row_delta(gf, of);
+    // 16th k-slot: S^T[j][i] - lse[i] and dP^T[j][i] - delta[i] come out of the products themselves
+    qf[NS - 1] = lh ? 0.f : d.lse[(int64_t)u * NTOK + 32 * ti + l31];
+    gf[NS - 1] = lh ? 0.f : delta;
+  }
+#pragma unroll
+  for (int tj = 0; tj < 2; ++tj) {
+    const int pix = pixel(d, w, 32 * tj + l31);
+    load_rows<HALF>(d.qkv, ld, pix, d.C + w.head * hd, hd, lh, 1.f, kf[tj]);
+    load_rows<HALF>(d.qkv, ld, pix, 2 * d.C + w.head * hd, hd, lh, 1.f, vf[tj]);
+    kf[tj][NS - 1] = vf[tj][NS - 1] = lh ? 0.f : -1.f;
+  }
+  load_table(d, w.head, lane, tab);
+  int64_t xoff[4];
+  col_offsets(d, w, lh, xoff);
+  float kc[2][4][4];  // K as a column operand, keys in the register order of dS^T
+#pragma unroll
+  for (int tj = 0; tj < 2; ++tj) load_cols(d, w, d.qkv + d.C + w.head * hd + dl, ld, tj, xoff, kc[tj]);
+
+  f32x16 st[2], dp[2];
+#pragma unroll
+  for (int tj = 0; tj < 2; ++tj) {
+    zero(st[tj]);
+    zero(dp[tj]);
+  }
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj) {
+      st[tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[tj][s], qf[s], st[tj], 0, 0, 0);
+      dp[tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[tj][s], gf[s], dp[tj], 0, 0, 0);
+    }
+  const bool masked = d.shift > 0 && (w.Wy == w.nWy - 1 || w.Wx == w.nWx - 1);
+  const int yi = 4 * ti + (l31 >> 3), xi = l31 & 7;
+  const float* tb = tab + (yi + WS - 1) * (2 * WS - 1) + xi + WS - 1 - 4 * lh;
+  const int ri = region1(yi, w.Wy, w.nWy, d.shift) * 3 + region1(xi, w.Wx, w.nWx, d.shift);
+  f32x16 dq;
+  zero(dq);
+#pragma unroll
+  for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int ryj = region1(4 * tj + g, w.Wy, w.nWy, d.shift) * 3;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float sc = st[tj][4 * g + r] + tb[-((4 * tj + g) * (2 * WS - 1) + r)];
+        if (masked && ryj + region1(4 * lh + r, w.Wx, w.nWx, d.shift) != ri) sc -= 100.f;
+        const float ds = __expf(sc) * dp[tj][4 * g + r];  // dS^T = P^T (dP^T - delta)
+        dq = __builtin_amdgcn_mfma_f32_32x32x2f32(ds, kc[tj][g][r], dq, 0, 0, 0);
+      }
+    }
+  if (l31 < hd) {
+    float* ob = d.dqkv + w.head * hd + l31;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int64_t row = row_base(d, w, 4 * ti + g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ob[(row + xoff[r]) * ld] = dq[4 * g + r] * d.scale;
+    }
+  }
+}
+
+// key-side unit (window, head, tj): S / dP tiles (lane = key j, registers = queries i) -> dV, dK rows of tile tj and
+// this tile's share of the relative-position-bias gradient bins (through the per-wave LDS tile `dsl`, [jl][i])
+constexpr int DS_LD = NTOK + 4;
+template <int HALF>
+__device__ __forceinline__ void bwd_kv_unit(const neosr_wattn_desc& d, int u, int tj, int lane, float* tab,
+                                            float* dsl) {
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int hd = d.C / d.heads, ld = 3 * d.C;
+  const int dl = l31 < hd ? l31 : hd - 1;
+  const Unit w = decode(d, u);
+  float kf[NS], vf[NS], qf[2][NS], gf[2][NS];
+  {
+    const int pix = pixel(d, w, 32 * tj + l31);
+    load_rows<HALF>(d.qkv, ld, pix, d.C + w.head * hd, hd, lh, 1.f, kf);
+    load_rows<HALF>(d.qkv, ld, pix, 2 * d.C + w.head * hd, hd, lh, 1.f, vf);
+    kf[NS - 1] = vf[NS - 1] = lh ? 0.f : -1.f;
+  }
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti) {
+    const int pix = pixel(d, w, 32 * ti + l31);
+    load_rows<HALF>(d.qkv, ld, pix, w.head * hd, hd, lh, d.scale, qf[ti]);
+    load_rows<HALF>(d.dout, d.C, pix, w.head * hd, hd, lh, 1.f, gf[ti]);
+    float of[NS];
+    load_rows<HALF>(d.out, d.C, pix, w.head * hd, hd, lh, 1.f, of);
+    const float delta = row_delta(gf[ti], of);
+    qf[ti][NS - 1] = lh ? 0.f : d.lse[(int64_t)u * NTOK + 32 * ti + l31];
+    gf[ti][NS - 1] = lh ? 0.f : delta;
+  }
+  load_table(d, w.head, lane, tab);
+  int64_t xoff[4];
+  col_offsets(d, w, lh, xoff);
+  float gc[2][4][4];  // dO as a column operand, queries in the register order of P
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti) load_cols(d, w, d.dout + w.head * hd + dl, d.C, ti, xoff, gc[ti]);
+
+  f32x16 st[2], dp[2];
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti) {
+    zero(st[ti]);
+    zero(dp[ti]);
+  }
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) {
+      st[ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[ti][s], kf[s], st[ti], 0, 0, 0);
+      dp[ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(gf[ti][s], vf[s], dp[ti], 0, 0, 0);
+    }
+  float qc[2][4][4];  // (unscaled) Q as a column operand — requested now, used by the dK product
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti) load_cols(d, w, d.qkv + w.head * hd + dl, ld, ti, xoff, qc[ti]);
+
+  const bool masked = d.shift > 0 && (w.Wy == w.nWy - 1 || w.Wx == w.nWx - 1);
+  const int yj = 4 * tj + (l31 >> 3), xj = l31 & 7;
+  const float* tb = tab + (WS - 1 - yj) * (2 * WS - 1) + WS - 1 - xj + 4 * lh;
+  const int rj = region1(yj, w.Wy, w.nWy, d.shift) * 3 + region1(xj, w.Wx, w.nWx, d.shift);
+  f32x16 dv, dk;
+  zero(dv);
+  zero(dk);
+  float* myrow = dsl + l31 * DS_LD + 4 * lh;
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int ryi = region1(4 * ti + g, w.Wy, w.nWy, d.shift) * 3;
+      float4 dsv;
+      float* dsp = &dsv.x;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float sc = st[ti][4 * g + r] + tb[(4 * ti + g) * (2 * WS - 1) + r];
+        if (masked && ryi + region1(4 * lh + r, w.Wx, w.nWx, d.shift) != rj) sc -= 100.f;
+        const float p = __expf(sc);
+        const float ds = p * dp[ti][4 * g + r];
+        dsp[r] = ds;
+        dv = __builtin_amdgcn_mfma_f32_32x32x2f32(p, gc[ti][g][r], dv, 0, 0, 0);
+        dk = __builtin_amdgcn_mfma_f32_32x32x2f32(ds, qc[ti][g][r], dk, 0, 0, 0);
+      }
+      *reinterpret_cast<float4*>(myrow + 32 * ti + 8 * g) = dsv;  // dS[i = 32 ti + 8 g + 4 lh + r][j]
+    }
+  if (l31 < hd) {
+    float* ob = d.dqkv + w.head * hd + l31;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int64_t row = row_base(d, w, 4 * tj + g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        ob[(row + xoff[r]) * ld + 2 * d.C] = dv[4 * g + r];
+        ob[(row + xoff[r]) * ld + d.C] = dk[4 * g + r] * d.scale;
+      }
+    }
+  }
+  // relative-position-bias gradient of (window, head) restricted to the keys of tile tj: bin (dy, dx) sums dS over
+  // the query / key pairs with (yi - yj, xi - xj) = (dy, dx), in a fixed order
+  float* wrow = d.workspace + ((int64_t)(2 * (u / d.heads) + tj) * NBIN) * d.heads + w.head;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int bin = lane + 64 * k;
+#ifdef WATTN_NOBINS
+    if (bin < NBIN && d.shift == 77) {
+#else
+    if (bin < NBIN) {
+#endif
+      const int dy = bin / (2 * WS - 1) - (WS - 1), dx = bin % (2 * WS - 1) - (WS - 1);
+      float s = 0.f;
+      for (int yk = 4 * tj; yk < 4 * tj + 4; ++yk) {  // key row yk, query row yk + dy
+        const int yq = yk + dy;
+        if (yq < 0 || yq >= WS) continue;
+        for (int xk = max(0, -dx); xk <= min(WS - 1, WS - 1 - dx); ++xk)
+          s += dsl[((yk - 4 * tj) * WS + xk) * DS_LD + yq * WS + xk + dx];
+      }
+      wrow[(int64_t)bin * d.heads] = s;
+    }
+  }
+}
+
+#ifndef WATTN_OCC
+#define WATTN_OCC 2
+#endif
+template <int HALF>
+__global__ __launch_bounds__(256, WATTN_OCC) void wattn_wave_bwd_kernel(const neosr_wattn_desc d, int units) {
+  __shared__ float tabs[4][256];
+  __shared__ __attribute__((aligned(16))) float dsl[4][32 * DS_LD];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int stride = gridDim.x * 4;
+  // 4 units per (window, head): the key-side ones (more products) first
+  for (int x = blockIdx.x * 4 + wave; x < 4 * units; x += stride) {
+    if (x < 2 * units)
+      bwd_kv_unit<HALF>(d, x >> 1, x & 1, lane, tabs[wave], dsl[wave]);
+    else
+      bwd_q_unit<HALF>(d, (x - 2 * units) >> 1, x & 1, lane, tabs[wave]);
+  }
+}
+
+}  // namespace
+
+namespace neosr_wattn {
+
+bool wave_ok(const neosr_wattn_desc& d) { return d.ws == WS && d.C % d.heads == 0 && d.C / d.heads <= 30; }
+
+void launch_fwd(const neosr_wattn_desc& d, void* stream) {
+  const int units = d.B * (d.H / WS) * (d.W / WS) * d.heads;
+  int nwg = (2 * units + 3) / 4;
+  if (nwg > 512) nwg = 512;  // two workgroups per CU; the waves walk the (window, head, query tile) list
+  if (d.C / d.heads == 30)
+    hipLaunchKernelGGL(wattn_wave_fwd_kernel<15>, dim3(nwg), dim3(256), 0, (hipStream_t)stream, d, units);
+  else
+    hipLaunchKernelGGL(wattn_wave_fwd_kernel<0>, dim3(nwg), dim3(256), 0, (hipStream_t)stream, d, units);
+}
+
+void launch_bwd(const neosr_wattn_desc& d, void* stream) {
+  const int units = d.B * (d.H / WS) * (d.W / WS) * d.heads;
+  int nwg = units;  // 4 units per (window, head), 4 waves per workgroup
+  if (nwg > 512) nwg = 512;
+  if (d.C / d.heads == 30)
+    hipLaunchKernelGGL(wattn_wave_bwd_kernel<15>, dim3(nwg), dim3(256), 0, (hipStream_t)stream, d, units);
+  else
+    hipLaunchKernelGGL(wattn_wave_bwd_kernel<0>, dim3(nwg), dim3(256), 0, (hipStream_t)stream, d, units);
+}
+
+}  // namespace neosr_wattn
