@@ -14,6 +14,8 @@
 //
 // Reference call sites: neosr/archs/swinir_arch.py:15-38 (Mlp), :139-143,150-156,209-210
 // (qkv / proj Linears), and the same layers of neosr/archs/hat_arch.py.
+#include <type_traits>
+
 #include "common.h"
 #include "../../include/neosr_amd.h"
 #include "prof.h"
@@ -268,6 +270,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(const GemmArgs arg
   const int K = d.K;
   // per-lane source rows: instruction i of this wave covers tile rows (4 i + wave) * 8 + lane / 8
   const int rsub = lane >> 3, slot = lane & 7;
+  const float* zp = gm_zero_page;  // pinned in SGPRs (else its address is re-read through the GOT in every chunk)
+  asm volatile("" : "+s"(zp));
   auto issue = [&](int k0, int buf) {
     float* abuf = lds + buf * (BM + BN) * BK;
     float* bbuf = abuf + BM * BK;
@@ -275,7 +279,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(const GemmArgs arg
     for (int i = 0; i < 4; ++i) {
       const int r = (4 * i + wave) * 8 + rsub;
       const int k = k0 + 4 * (slot ^ (r & 7));
-      const float* src = (m0 + r < d.M && k < K) ? d.A + (int64_t)(m0 + r) * d.lda + k : gm_zero_page;
+      const float* src = (m0 + r < d.M && k < K) ? d.A + (int64_t)(m0 + r) * d.lda + k : zp;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(abuf + (4 * i + wave) * 256), 16, 0, 0);
     }
@@ -283,7 +287,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(const GemmArgs arg
     for (int i = 0; i < 2; ++i) {
       const int r = (4 * i + wave) * 8 + rsub;
       const int k = k0 + 4 * (slot ^ (r & 7));
-      const float* src = (n0 + r < d.N && k < K) ? d.B + (int64_t)(n0 + r) * d.ldb + k : gm_zero_page;
+      const float* src = (n0 + r < d.N && k < K) ? d.B + (int64_t)(n0 + r) * d.ldb + k : zp;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(bbuf + (4 * i + wave) * 256), 16, 0, 0);
     }
@@ -298,25 +302,44 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(const GemmArgs arg
   __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
   __syncthreads();
   const int arow = wave * 32 + l31;
-  for (int c = 0; c < nchunks; ++c) {
-    if (c + 1 < nchunks) issue((c + 1) * BK, (c + 1) & 1);
-    const float* abuf = lds + (c & 1) * (BM + BN) * BK;
-    const float* bbuf = abuf + BM * BK;
+  // K = 180 / 360 end in a chunk with 20 / 8 valid columns: the last chunk runs only the 8-column steps it needs
+  // (the DMA zero-fills the rest of a started step); a column tile that lies wholly past N (N = 540: the last
+  // 64-wide tile holds 28 columns) skips its MFMAs
+  const int last_steps = (K - (nchunks - 1) * BK + 7) >> 3;
+  const bool two = n0 + 32 < d.N;
+  auto run = [&](auto two_tag) {
+    constexpr bool TWO = decltype(two_tag)::value;
+    auto mac = [&](int c, int nsteps) {
+      const float* abuf = lds + (c & 1) * (BM + BN) * BK;
+      const float* bbuf = abuf + BM * BK;
 #pragma unroll
-    for (int s = 0; s < BK / 8; ++s) {
-      const int q = 2 * s + lh;
-      const f32x4 a = *reinterpret_cast<const f32x4*>(abuf + arow * BK + 4 * (q ^ (arow & 7)));
-      const f32x4 b0 = *reinterpret_cast<const f32x4*>(bbuf + l31 * BK + 4 * (q ^ (l31 & 7)));
-      const f32x4 b1 = *reinterpret_cast<const f32x4*>(bbuf + (32 + l31) * BK + 4 * (q ^ (l31 & 7)));
+      for (int s = 0; s < BK / 8; ++s) {
+        if (s < nsteps) {
+          const int q = 2 * s + lh;
+          const f32x4 a = *reinterpret_cast<const f32x4*>(abuf + arow * BK + 4 * (q ^ (arow & 7)));
+          const f32x4 b0 = *reinterpret_cast<const f32x4*>(bbuf + l31 * BK + 4 * (q ^ (l31 & 7)));
+          f32x4 b1 = {0.f, 0.f, 0.f, 0.f};
+          if (TWO) b1 = *reinterpret_cast<const f32x4*>(bbuf + (32 + l31) * BK + 4 * (q ^ (l31 & 7)));
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[e], a[e], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b1[e], a[e], acc[1], 0, 0, 0);
+          for (int e = 0; e < 4; ++e) {
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[e], a[e], acc[0], 0, 0, 0);
+            if (TWO) acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b1[e], a[e], acc[1], 0, 0, 0);
+          }
+        }
       }
+    };
+    for (int c = 0; c + 1 < nchunks; ++c) {
+      issue((c + 1) * BK, (c + 1) & 1);
+      mac(c, BK / 8);
+      __builtin_amdgcn_s_waitcnt(0x0f70);  // the next chunk has landed ...
+      __syncthreads();                      // ... for every wave, and this buffer is free to overwrite
     }
-    __builtin_amdgcn_s_waitcnt(0x0f70);  // the next chunk has landed ...
-    __syncthreads();                      // ... for every wave, and this buffer is free to overwrite
-  }
+    mac(nchunks - 1, last_steps);
+  };
+  if (two)
+    run(std::true_type{});
+  else
+    run(std::false_type{});
   epilogue<0>(args, acc, m0, n0, 0);
 }
 
