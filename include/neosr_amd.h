@@ -111,6 +111,15 @@ int neosr_conv3x3_pack_weights(const float* w, int32_t w_cout, int32_t w_cin, in
 int64_t neosr_conv3x3_pack_wino_bytes(int32_t N, int32_t K);
 int neosr_conv3x3_pack_wino(const float* w, int32_t w_cout, int32_t w_cin, int32_t mode, float* dst, void* stream);
 int neosr_set_winograd(int on);
+/* Both images of MANY weight tensors in ceil(n / 24) launches per image kind (the per-layer calls above cost one launch
+ * each: a transformer generator with ~160 convolutions re-packs 4 images per layer after every optimizer step).
+ * `items` is a HOST array; kind 0 = direct image (neosr_conv3x3_pack_weights), 1 = Winograd image. */
+typedef struct neosr_pack_item {
+  const float* w;
+  float* dst;
+  int32_t w_cout, w_cin, mode, kind;
+} neosr_pack_item;
+int neosr_conv3x3_pack_many(const neosr_pack_item* items, int32_t n, void* stream);
 /* Debug aid: device buffer (4 x 64 uint64) that NEOSR_TIMELINE builds of the conv kernel fill with
  * per-wave clock stamps of workgroup 0; NULL (default) disables.  No effect in normal builds. */
 int neosr_debug_set_timeline(void* dev_buf);

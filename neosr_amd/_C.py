@@ -186,6 +186,13 @@ class CompactCfg(C.Structure):
     ]
 
 
+class PackItem(C.Structure):
+    """neosr_pack_item"""
+
+    _fields_ = [("w", C.c_void_p), ("dst", C.c_void_p), ("w_cout", C.c_int32), ("w_cin", C.c_int32),
+                ("mode", C.c_int32), ("kind", C.c_int32)]
+
+
 class GemmDesc(C.Structure):
     """neosr_gemm_desc"""
 
@@ -241,6 +248,7 @@ SIGNATURES: dict[str, tuple] = {
     "neosr_set_winograd": (C.c_int, [C.c_int]),
     "neosr_conv3x3_pack_wino_bytes": (_i64, [_i32, _i32]),
     "neosr_conv3x3_pack_wino": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp]),
+    "neosr_conv3x3_pack_many": (C.c_int, [C.POINTER(PackItem), _i32, _vp]),
     "neosr_conv3x3_wgrad_workspace_bytes": (_i64, [_i32, _i32, _i32, _i32, _i32]),
     "neosr_conv3x3_wgrad": (C.c_int, [C.POINTER(WgradDesc), _vp]),
     "neosr_conv3x3_wgrad_multi_workspace_bytes": (_i64, [C.POINTER(WgradDesc), _i32]),

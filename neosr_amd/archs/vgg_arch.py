@@ -78,6 +78,7 @@ class VGGFeatureExtractor(nn.Module):
         self.vgg_net.eval()
         for p in self.parameters():
             p.requires_grad = False
+            p._neosr_frozen = True  # packed conv images survive the optimizer steps of the other networks
         if self.use_input_norm:
             self.register_buffer("mean", torch.tensor([0.5, 0.5, 0.5]).view(1, 3, 1, 1))
             self.register_buffer("std", torch.tensor([0.25, 0.25, 0.25]).view(1, 3, 1, 1))

@@ -26,6 +26,7 @@
 // (tests: <= 1e-4 against the oracle at kernel level; north_star allows 1e-3).  neosr_set_winograd(0) /
 // NEOSR_AMD_WINOGRAD=0 selects the direct kernel for the same launches.
 #include <cstring>
+#include <vector>
 #include <stdlib.h>
 #include "conv_common.h"
 #include "conv_pack.h"
@@ -429,4 +430,33 @@ extern "C" int neosr_conv3x3_pack_wino(const float* w, int32_t w_cout, int32_t w
   im.seg[0].k_cnt = im.K;
   im.seg[0].n_lo = 0;
   return neosr_pack::launch_wino(&im, 1, stream);
+}
+
+extern "C" int neosr_conv3x3_pack_many(const neosr_pack_item* items, int32_t n, void* stream) {
+  NEOSR_CHECK(items && n > 0, "conv3x3_pack_many: bad arguments");
+  std::vector<neosr_pack::Image> direct, wino;
+  for (int i = 0; i < n; ++i) {
+    const neosr_pack_item& it = items[i];
+    NEOSR_CHECK(it.w && it.dst && it.w_cout > 0 && it.w_cin > 0, "conv3x3_pack_many: bad item");
+    NEOSR_CHECK(it.mode == NEOSR_CONV_FWD || it.mode == NEOSR_CONV_DGRAD, "conv3x3_pack_many: bad mode");
+    NEOSR_CHECK((uintptr_t)it.dst % 16 == 0, "conv3x3_pack_many: dst must be 16-byte aligned");
+    neosr_pack::Image im;
+    memset(&im, 0, sizeof(im));
+    im.dst = it.dst;
+    im.mode = it.mode;
+    im.N = it.mode == NEOSR_CONV_FWD ? it.w_cout : it.w_cin;
+    im.K = it.mode == NEOSR_CONV_FWD ? it.w_cin : it.w_cout;
+    im.nseg = 1;
+    im.seg[0].w = it.w;
+    im.seg[0].w_cin = it.w_cin;
+    im.seg[0].k_lo = 0;
+    im.seg[0].k_cnt = im.K;
+    im.seg[0].n_lo = 0;
+    (it.kind ? wino : direct).push_back(im);
+  }
+  if (!direct.empty())
+    if (int rc = neosr_pack::launch(direct.data(), (int)direct.size(), stream)) return rc;
+  if (!wino.empty())
+    if (int rc = neosr_pack::launch_wino(wino.data(), (int)wino.size(), stream)) return rc;
+  return 0;
 }

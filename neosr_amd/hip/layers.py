@@ -9,6 +9,8 @@ used for allocation, the autograd graph, and index plumbing on small weight tens
 
 from __future__ import annotations
 
+import weakref
+
 import torch
 
 from neosr_amd import _C
@@ -76,36 +78,90 @@ class VGGInput(torch.autograd.Function):
 # --------------------------------------------------------------------------------------------
 # convolution
 # --------------------------------------------------------------------------------------------
-def packed_weights(w: torch.Tensor, mode: int):
-    """Packed image of `w` for the direct-to-LDS kernel (`neosr_conv3x3_pack_weights`), cached ON the weight
-    tensor object and rebuilt when the weights changed: torch in-place ops move `w._version`, the fused
-    optimizer kernels (raw pointers) move `_C.WEIGHTS_EPOCH`, re-homing (flatten_parameters_) moves
-    `data_ptr()`.  Frozen networks (VGG) are packed once; temporaries (spectral-normalised weights) carry
-    no cache.  Thin layers have their own kernels and are not packed."""
+# Packed images (direct-to-LDS image = kind 0, Winograd image = kind 1) are cached ON the weight tensor object and
+# rebuilt when the weights changed: torch in-place ops move `w._version`, the fused optimizer kernels (raw pointers)
+# move `_C.WEIGHTS_EPOCH`, re-homing (flatten_parameters_) moves `data_ptr()`.  Weights marked frozen
+# (`w._neosr_frozen = True`: the VGG feature extractor, never touched by an optimizer or an EMA) ignore the epoch and
+# are packed once.  Temporaries (spectral-normalised weights) carry no cache.  Thin layers have their own kernels
+# and are not packed.
+#
+# A cache miss re-packs EVERY registered image that is stale on that device in one `neosr_conv3x3_pack_many` call
+# (ceil(n / 24) launches per kind) instead of one launch per (layer, mode, kind): after an optimizer step the first
+# convolution of the next forward pass refreshes the whole network.
+_PACKS: dict[tuple[int, int, int], "weakref.ref"] = {}  # (id(w), kind, mode) -> weakref(w)
+
+
+# Set by neosr_amd.utils.graph before a hipGraph capture: the first packed-image request made while the stream is
+# capturing re-packs every registered trainable weight (whatever its cache key says), so the launch becomes a node
+# of the graph and every replay starts from the weights of that moment.
+FORCE_REPACK_IN_CAPTURE = False
+
+
+def _pack_key(w):
+    return (w._version, 0 if getattr(w, "_neosr_frozen", False) else _C.WEIGHTS_EPOCH, w.data_ptr())
+
+
+def _image_floats(w, kind, mode):
+    lib = _C.load()
+    cout, cin = w.shape[0], w.shape[1]
+    N, K = (cout, cin) if mode == ops.CONV_FWD else (cin, cout)
+    return (lib.neosr_conv3x3_pack_wino_bytes(N, K) if kind else lib.neosr_conv3x3_pack_bytes(N, K)) // 4
+
+
+def _packed(w: torch.Tensor, mode: int, kind: int):
     if min(w.shape[0], w.shape[1]) <= 4 or w.shape[0] % 4 or w.shape[1] % 4:
         return None
-    key = (w._version, _C.WEIGHTS_EPOCH, w.data_ptr())
-    cache = w.__dict__.setdefault("_neosr_packs", {}) if hasattr(w, "__dict__") else {}
-    hit = cache.get(mode)
-    if hit is not None and hit[0] == key:
+    if not hasattr(w, "__dict__"):
+        return ops.conv3x3_pack_wino(w, mode) if kind else ops.conv3x3_pack_weights(w, mode)
+    global FORCE_REPACK_IN_CAPTURE
+    if FORCE_REPACK_IN_CAPTURE and torch.cuda.is_current_stream_capturing():
+        FORCE_REPACK_IN_CAPTURE = False
+        _repack_stale(w.device, force=True)
+    cache = w.__dict__.setdefault("_neosr_packs", {})
+    hit = cache.get((kind, mode))
+    if hit is not None and hit[0] == _pack_key(w):
         return hit[1]
-    pack = ops.conv3x3_pack_weights(w, mode)
-    cache[mode] = (key, pack)
-    return pack
+    if not w.is_leaf:  # temporaries (spectral norm): a fresh tensor every forward, nothing to batch with
+        return ops.conv3x3_pack_wino(w, mode) if kind else ops.conv3x3_pack_weights(w, mode)
+    _PACKS[(id(w), kind, mode)] = weakref.ref(w)
+    _repack_stale(w.device)
+    return cache[(kind, mode)][1]
+
+
+def _repack_stale(device, force: bool = False) -> None:
+    lib = _C.load()
+    todo = []
+    for (wid, kind, mode), ref in list(_PACKS.items()):
+        w = ref()
+        if w is None or id(w) != wid:
+            del _PACKS[(wid, kind, mode)]
+            continue
+        if w.device != device:
+            continue
+        cache = w.__dict__.setdefault("_neosr_packs", {})
+        key = _pack_key(w)
+        hit = cache.get((kind, mode))
+        if hit is not None and hit[0] == key and not (force and w.requires_grad):
+            continue
+        assert w.is_contiguous() and w.shape[2:] == (3, 3)
+        n = _image_floats(w, kind, mode)
+        dst = hit[1] if hit is not None and hit[1].numel() == n else torch.empty(n, device=device, dtype=torch.float32)
+        cache[(kind, mode)] = (key, dst)
+        todo.append(_C.PackItem(w=w.data_ptr(), dst=dst.data_ptr(), w_cout=w.shape[0], w_cin=w.shape[1], mode=mode,
+                                kind=kind))
+    if todo:
+        arr = (_C.PackItem * len(todo))(*todo)
+        _C.check(lib.neosr_conv3x3_pack_many(arr, len(todo), _st()), "neosr_conv3x3_pack_many")
+
+
+def packed_weights(w: torch.Tensor, mode: int):
+    """Packed image of `w` for the direct-to-LDS kernel (`neosr_conv3x3_pack_weights`); see the note above."""
+    return _packed(w, mode, 0)
 
 
 def packed_wino(w: torch.Tensor, mode: int):
     """Winograd F(2x2,3x3) image of `w` (`neosr_conv3x3_pack_wino`), cached like `packed_weights`."""
-    if min(w.shape[0], w.shape[1]) <= 4 or w.shape[0] % 4 or w.shape[1] % 4:
-        return None
-    key = (w._version, _C.WEIGHTS_EPOCH, w.data_ptr())
-    cache = w.__dict__.setdefault("_neosr_winos", {}) if hasattr(w, "__dict__") else {}
-    hit = cache.get(mode)
-    if hit is not None and hit[0] == key:
-        return hit[1]
-    pack = ops.conv3x3_pack_wino(w, mode)
-    cache[mode] = (key, pack)
-    return pack
+    return _packed(w, mode, 1)
 
 
 class Conv3x3(torch.autograd.Function):

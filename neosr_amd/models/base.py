@@ -12,6 +12,8 @@ MI355X-first differences (behaviour-preserving):
 
 from __future__ import annotations
 
+import os
+
 import sys
 import time
 from collections import OrderedDict
@@ -153,8 +155,6 @@ class base:
         if self.opt.get("use_amp", False) is True:
             msg = "use_amp: the HIP kernels on this path are fp32 (north_star: 1e-3 rel fp32)"
             raise NotImplementedError(msg)
-        if self.opt.get("compile", False) is True:
-            get_root_logger().warning("`compile = true` ignored: kernels are hand-written HIP")
         if not torch.cuda.is_available():
             msg = "neosr_amd models need a HIP device (no CPU fallback on the product path)"
             raise RuntimeError(msg)
@@ -169,6 +169,29 @@ class base:
                     dist.broadcast(b, src=0)
             net._neosr_sn_arena = flatten_sn_buffers_(net)  # noqa: SLF001
         return net
+
+    def graph_generator(self) -> None:
+        """`compile = true` (base.py:136-137 gives the network to torch.compile): capture the train-mode forward /
+        backward of an op-by-op dispatched generator into hipGraphs (neosr_amd/utils/graph.py).  The esrgan /
+        compact generators already run as one C++ plan per pass and are left alone."""
+        want = self.opt.get("compile", False) is True
+        if os.environ.get("NEOSR_AMD_COMPILE") is not None:  # A/B switch for measurements
+            want = os.environ["NEOSR_AMD_COMPILE"] == "1"
+        if not want or not self.is_train:
+            return
+        logger = get_root_logger()
+        from neosr_amd.archs.arch_util import HipNet
+        from neosr_amd.utils.graph import graph_train_forward
+
+        ds = self.opt["datasets"]["train"]
+        if isinstance(self.net_g, HipNet) or not ds.get("patch_size") or not ds.get("batch_size"):
+            logger.info("`compile = true`: nothing to capture for this generator")
+            return
+        p = int(ds["patch_size"])
+        sample = torch.rand(int(ds["batch_size"]), int(self.opt["network_g"].get("in_chans", 3)), p, p,
+                            device=self.device)
+        graph_train_forward(self.net_g, sample)
+        logger.info("`compile = true`: generator forward / backward captured as hipGraphs (%s)", tuple(sample.shape))
 
     def broadcast_buffers(self, net: nn.Module) -> None:
         """DDP `broadcast_buffers=True` (base.py:140-146): before every train-mode forward the buffers that a

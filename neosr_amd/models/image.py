@@ -123,6 +123,7 @@ class image(base):
         self.setup_optimizers()
         self.setup_schedulers()
         self.net_g.train()
+        self.graph_generator()  # `compile = true`
         if self.sf_optim_g:
             self.optimizer_g.train()  # image.py:99-105
         if self.net_d is not None:

@@ -197,3 +197,41 @@ def test_full_size_config2_step_b32_deterministic_and_finite():
     assert runs[0][0] == runs[1][0]
     assert all(torch.equal(a, b) for a, b in zip(runs[0][1], runs[1][1]))
     assert all(torch.equal(a, b) for a, b in zip(runs[0][2], runs[1][2]))
+
+
+# ---------------------------------------------------------------------------------------------- compile = true
+def test_compile_option_captures_generator_as_hip_graphs_bit_identical():
+    """`compile = true` (reference: torch.compile, base.py:136-137; here: the generator's train-mode forward / backward
+    replayed as hipGraphs): same trajectory, bit for bit, as the eagerly dispatched model — including the packed
+    convolution images, which a node of the forward graph rebuilds after every optimizer step."""
+    from neosr_amd.models import build_model
+    from neosr_amd.utils.options import parse_options
+
+    fix = load_golden("step_cfg3.npz")
+    runs = []
+    for compiled in (False, True):
+        opt, _ = parse_options(str(ROOT), True, argv=["-opt", str(GOLDEN / "golden_cfg3.toml")])
+        opt["compile"] = compiled
+        torch.manual_seed(1024)
+        random.seed(1024)
+        model = build_model(opt)
+        assert bool(getattr(model.net_g, "_neosr_graphed", False)) == compiled
+        _load_vgg(model.cri_perceptual.vgg)
+        logs = []
+        for it in range(1, 4):
+            k = min(it, fix["log"].shape[0])
+            model.feed_data({"lq": T(fix[f"it{k}/lq"]), "gt": T(fix[f"it{k}/gt"])})
+            model.optimize_parameters(it)
+            logs.append(model.get_current_log())
+        torch.cuda.synchronize()
+        runs.append((logs, model.output.clone(), [p.detach().clone() for p in model.net_g.parameters()]))
+        # eval-mode / no_grad calls fall back to the eager forward
+        model.net_g.eval()
+        with torch.no_grad():
+            ev = model.net_g(model.lq)
+        model.net_g.train()
+        runs[-1] += (ev.clone(),)
+        del model
+    assert runs[0][0] == runs[1][0]
+    assert torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[0][3], runs[1][3])
+    assert all(torch.equal(a, b) for a, b in zip(runs[0][2], runs[1][2]))
