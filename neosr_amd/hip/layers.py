@@ -121,7 +121,8 @@ def _packed(w: torch.Tensor, mode: int, kind: int):
     hit = cache.get((kind, mode))
     if hit is not None and hit[0] == _pack_key(w):
         return hit[1]
-    if not w.is_leaf:  # temporaries (spectral norm): a fresh tensor every forward, nothing to batch with
+    if not isinstance(w, torch.nn.Parameter):
+        # temporaries (spectral-normalised weights): a fresh tensor every forward, nothing to cache or to batch with
         return ops.conv3x3_pack_wino(w, mode) if kind else ops.conv3x3_pack_weights(w, mode)
     _PACKS[(id(w), kind, mode)] = weakref.ref(w)
     _repack_stale(w.device)

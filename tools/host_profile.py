@@ -24,3 +24,5 @@ pr.disable()
 torch.cuda.synchronize()
 st = pstats.Stats(pr)
 st.sort_stats("tottime").print_stats(28)
+st.print_callers("_named_members")
+st.print_callers("_repack_stale")
