@@ -362,11 +362,23 @@ __global__ __launch_bounds__(256) void window_attention_bwd_kernel(const neosr_w
   __syncthreads();
   // relative-position-bias gradient of this (window, head): bin sums in a fixed order
   if (tid < NB) {
+    // all 64 query positions, straight-line: the pairs that leave the window read element 0 and add 0, so the LDS
+    // reads are independent (a loop over the valid range is a chain of dependent read + add latencies); same
+    // summation order (yi, then xi)
     const int dy = tid / (2 * WS - 1) - (WS - 1), dx = tid % (2 * WS - 1) - (WS - 1);
     float s = 0.f;
-    for (int yi = max(0, dy); yi <= min(WS - 1, WS - 1 + dy); ++yi)
-      for (int xi = max(0, dx); xi <= min(WS - 1, WS - 1 + dx); ++xi)
-        s += dS[(yi * WS + xi) * PS + (yi - dy) * WS + (xi - dx)];
+#pragma unroll
+    for (int yi = 0; yi < WS; ++yi) {
+      const int yj = yi - dy;
+      const bool oky = yj >= 0 && yj < WS;
+#pragma unroll
+      for (int xi = 0; xi < WS; ++xi) {
+        const int xj = xi - dx;
+        const bool ok = oky && xj >= 0 && xj < WS;
+        const float v = dS[ok ? (yi * WS + xi) * PS + yj * WS + xj : 0];
+        s += ok ? v : 0.f;
+      }
+    }
     d.workspace[((int64_t)(blockIdx.x / d.heads) * NB + tid) * d.heads + w.head] = s;
   }
   float* g = d.dqkv + w.head * hd + l31;
