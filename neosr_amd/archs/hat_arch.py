@@ -21,7 +21,7 @@ from torch import nn
 from torch.nn.init import trunc_normal_
 
 from neosr_amd import _C
-from neosr_amd.archs.arch_util import droppath_ctor_reseed, net_opt
+from neosr_amd.archs.arch_util import DropPathBank, drop_path_bank, drop_scale, droppath_ctor_reseed, net_opt
 from neosr_amd.hip import layers as L
 from neosr_amd.hip import transformer as T
 from neosr_amd.utils.registry import ARCH_REGISTRY
@@ -84,17 +84,6 @@ class WindowAttention(nn.Module):
         trunc_normal_(self.relative_position_bias_table, std=0.02)
 
 
-def _drop_scale(drop_prob: float, training: bool, b: int, device):
-    """DropPath (arch_util.py:118-133): per-sample Bernoulli(keep) / keep, drawn on the device."""
-    if drop_prob == 0.0 or not training:
-        return None
-    keep = 1.0 - drop_prob
-    rs = torch.empty(b, device=device, dtype=torch.float32).bernoulli_(keep)
-    if keep > 0.0:
-        rs.div_(keep)
-    return rs
-
-
 class HAB(nn.Module):
     def __init__(self, dim, input_resolution, num_heads, window_size=7, shift_size=0, compress_ratio=3,
                  squeeze_factor=30, conv_scale=0.01, mlp_ratio=4.0, qkv_bias=True, qk_scale=None, drop_path=0.0) -> None:
@@ -118,11 +107,11 @@ class HAB(nn.Module):
         y = T.layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
         qkv = T.linear(y, a.qkv.weight, a.qkv.bias)
         at = T.flash_window_attention(qkv, a.relative_position_bias_table, self.num_heads, 16, self.shift_size, a.scale)
-        x = T.linear(at, a.proj.weight, a.proj.bias, x, _drop_scale(self.drop_prob, self.training, b, x.device), h * w)
+        x = T.linear(at, a.proj.weight, a.proj.bias, x, drop_scale(self.drop_prob, self.training, b, x.device), h * w)
         x = self.conv_block(y, x, self.conv_scale)
         y = T.layer_norm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
         return T.mlp(y, self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight, self.mlp.fc2.bias, x,
-                     _drop_scale(self.drop_prob, self.training, b, x.device), h * w)
+                     drop_scale(self.drop_prob, self.training, b, x.device), h * w)
 
 
 class OCAB(nn.Module):
@@ -264,8 +253,11 @@ class hat(nn.Module):
         if hasattr(self.patch_embed, "norm"):
             n = self.patch_embed.norm
             tok = T.layer_norm(tok, n.weight, n.bias, n.eps)
-        for layer in self.layers:
-            tok = layer(tok)
+        if not hasattr(self, "_dp_bank"):
+            self._dp_bank = DropPathBank()
+        with drop_path_bank(self._dp_bank, self.training, x.shape[0], x.device):
+            for layer in self.layers:
+                tok = layer(tok)
         tok = T.layer_norm(tok, self.norm.weight, self.norm.bias, self.norm.eps)
         if isinstance(self.conv_after_body, nn.Conv2d):
             y = L.conv3x3(tok, self.conv_after_body.weight, self.conv_after_body.bias, res=x0)

@@ -24,7 +24,7 @@ from torch import nn
 from torch.nn.init import trunc_normal_
 
 from neosr_amd import _C
-from neosr_amd.archs.arch_util import droppath_ctor_reseed, net_opt
+from neosr_amd.archs.arch_util import DropPathBank, drop_path_bank, drop_scale, droppath_ctor_reseed, net_opt
 from neosr_amd.hip import layers as L
 from neosr_amd.hip import transformer as T
 from neosr_amd.utils.registry import ARCH_REGISTRY
@@ -86,16 +86,6 @@ class SwinTransformerBlock(nn.Module):
         mask = _shift_mask(*input_resolution, self.window_size, self.shift_size) if self.shift_size > 0 else None
         self.register_buffer("attn_mask", mask)
 
-    def _drop_scale(self, b: int, device):
-        """DropPath (arch_util.py:118-133): per-sample Bernoulli(keep) / keep, drawn on the device."""
-        if self.drop_prob == 0.0 or not self.training:
-            return None
-        keep = 1.0 - self.drop_prob
-        rs = torch.empty(b, device=device, dtype=torch.float32).bernoulli_(keep)
-        if keep > 0.0:
-            rs.div_(keep)
-        return rs
-
     def forward(self, x: torch.Tensor) -> torch.Tensor:  # x: (B, H, W, C) channels-last tokens
         b, h, w, _ = x.shape
         a = self.attn
@@ -103,10 +93,10 @@ class SwinTransformerBlock(nn.Module):
         qkv = T.linear(y, a.qkv.weight, a.qkv.bias)
         y = T.window_attention(qkv, a.relative_position_bias_table, self.num_heads, self.window_size,
                                self.shift_size, a.scale)
-        x = T.linear(y, a.proj.weight, a.proj.bias, x, self._drop_scale(b, x.device), h * w)
+        x = T.linear(y, a.proj.weight, a.proj.bias, x, drop_scale(self.drop_prob, self.training, b, x.device), h * w)
         y = T.layer_norm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
         return T.mlp(y, self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight, self.mlp.fc2.bias, x,
-                     self._drop_scale(b, x.device), h * w)
+                     drop_scale(self.drop_prob, self.training, b, x.device), h * w)
 
 
 class BasicLayer(nn.Module):
@@ -249,8 +239,11 @@ class swinir(nn.Module):
         if hasattr(self.patch_embed, "norm"):
             n = self.patch_embed.norm
             tok = T.layer_norm(tok, n.weight, n.bias, n.eps)
-        for layer in self.layers:
-            tok = layer(tok)
+        if not hasattr(self, "_dp_bank"):
+            self._dp_bank = DropPathBank()
+        with drop_path_bank(self._dp_bank, self.training, x.shape[0], x.device):
+            for layer in self.layers:
+                tok = layer(tok)
         tok = T.layer_norm(tok, self.norm.weight, self.norm.bias, self.norm.eps)
         y = _resi_conv(self.conv_after_body, tok, x0)
         if self.upsampler == "pixelshuffle":

@@ -288,6 +288,7 @@ struct SharedBwd {
   float tab[TAB_MAX];
   int qpk[QB], kpk[QB], qtok[QB], ktok[QB];
   float lse[QB], dsum[QB];
+  float bins[31 * 31];  // self-attention dQ pass: this workgroup's share of the relative-position-bias gradient
 };
 
 struct BwdWs {  // carve-up of the backward workspace (floats)
@@ -360,6 +361,8 @@ __global__ __launch_bounds__(256) void flash_wattn_bwd_dq_kernel(const neosr_fat
     S.lse[tid] = d.lse[(int64_t)blockIdx.x * QB + tid];
   }
   for (int k = tid; k < G::NBINS; k += 256) S.tab[k] = d.rpb_table[k * d.heads + w.head];
+  if (G::SELF)
+    for (int k = tid; k < 31 * 31; k += 256) S.bins[k] = 0.f;
   __syncthreads();
   {
     float q[8], g[8], o[8];
@@ -400,7 +403,30 @@ __global__ __launch_bounds__(256) void flash_wattn_bwd_dq_kernel(const neosr_fat
       load_row8(d.qkv, ktok, ld, 2 * d.C + w.head * hd, hd, part, vr);
     }
     recompute_p_ds<G::NBINS, G::SELF>(S, kq, wave, l31, lh);
-    {  // dump this dS tile (rows n, 16 columns per thread) for the bias gradient
+    if (G::SELF) {
+      // bias gradient of this 64-query x 64-key tile, owner-computes: the tile is 4 x 4 window rows of 16, so it
+      // touches 7 x 31 bins (dy = yi - yj, dx = xi - xj) and thread t < 217 sums the pairs of ITS bin in a fixed
+      // order (64 predicated LDS reads, out-of-window pairs read element 0 and add 0) into the workgroup's 31 x 31
+      // accumulator — no dS dump to HBM (it was 256 x 256 floats per (window, head): 100 MB per call at B = 4)
+      if (tid < 7 * 31) {
+        const int dyi = tid / 31, dx = tid % 31 - 15;
+        float s = 0.f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const int b = a - (dyi - 3);  // key row of the tile paired with query row a
+          const bool oky = b >= 0 && b < 4;
+#pragma unroll
+          for (int xi = 0; xi < 16; ++xi) {
+            const int xj = xi - dx;
+            const bool ok = oky && xj >= 0 && xj < 16;
+            const float v = S.dS[ok ? (a * 16 + xi) * PS + b * 16 + xj : 0];
+            s += ok ? v : 0.f;
+          }
+        }
+        const int dy = 4 * (w.qb - kb) - 3 + dyi;
+        if (dy > -16 && dy < 16) S.bins[(dy + 15) * 31 + dx + 15] += s;
+      }
+    } else {  // dump this dS tile (rows n, 16 columns per thread) for the bias gradient
       const float* gr = S.dS + n * PS + part * 16;
       float* o = dump + (int64_t)n * G::NK + kb * QB + part * 16;
 #pragma unroll
@@ -408,6 +434,12 @@ __global__ __launch_bounds__(256) void flash_wattn_bwd_dq_kernel(const neosr_fat
         if (kb * QB + part * 16 + c < G::NK) o[c] = gr[c];
     }
     if (wave < 2) dq = mm_ab(dq, S.dS, PS, S.Ks, QS, wave, 0, l31, lh);
+  }
+  if (G::SELF) {  // partial bins of (window, query block): row (bw index, qb) of a [rows][bin][head] matrix
+    __syncthreads();
+    float* row = d.workspace + ws.ds_full +
+                 ((int64_t)(blockIdx.x / (d.heads * G::NQB)) * G::NQB + w.qb) * (31 * 31) * d.heads + w.head;
+    for (int k = tid; k < 31 * 31; k += 256) row[(int64_t)k * d.heads] = S.bins[k];
   }
   if (wave < 2 && l31 < hd) {
     float* g = d.dqkv + w.head * hd + l31;
@@ -570,6 +602,11 @@ int launch_bwd(const neosr_fattn_desc& d, hipStream_t st) {
     if (g > 4096) g = 4096;
     hipLaunchKernelGGL((fold_dkv_kernel<WS, KS>), dim3(g), dim3(256), 0, st, d, ws);
     NEOSR_LAUNCH_CHECK();
+  }
+  if (G::SELF) {  // bias gradient: fixed-order column sums of the per-(window, query block) bin partials
+    const int cols = G::NBINS * d.heads;
+    return neosr_colsum(d.workspace + ws.ds_full, d.d_rpb_table, d.workspace + ws.stage, bw * G::NQB, cols, cols,
+                        d.accumulate_rpb, (void*)st);
   }
   // bias gradient: sum the dS dump over (batch, window), then gather per table row
   const int cols = d.heads * G::NQ * G::NK;

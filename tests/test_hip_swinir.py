@@ -285,17 +285,52 @@ def test_drop_path_train_mode_scales_rows():
     P = group(fix, "blk_s4/p")
     blk.load_state_dict(P, strict=False)
     blk = blk.to(DEV).train()
+    import neosr_amd.archs.swinir_arch as SA
+
     draws = []
-    orig = blk._drop_scale
-    blk._drop_scale = lambda b, dev: draws.append(orig(b, dev)) or draws[-1]
+    orig = SA.drop_scale
+    SA.drop_scale = lambda p, tr, b, dev: draws.append(orig(p, tr, b, dev)) or draws[-1]
     x = T(fix["blk_s4/x"])
     x = torch.cat([x, x, x, x])  # 8 samples so both outcomes occur
-    y = blk(x.view(8, 16, 24, 24).to(DEV))
+    try:
+        y = blk(x.view(8, 16, 24, 24).to(DEV))
+    finally:
+        SA.drop_scale = orig
     keep = [(d.cpu() * 0.5) for d in draws]
     assert all(set(k.tolist()) <= {0.0, 1.0} for k in keep)
     Pb = {f"b.{k}": v for k, v in P.items()}
     ref = sorc.swin_block(Pb, "b", x, (16, 24), 2, 8, 4, (keep[0], keep[1], 0.5))
     assert rel_err(y.view(8, -1, 24), ref) < 1e-4
+
+
+def test_drop_path_bank_draws_all_sites_at_once():
+    """From the second train-mode forward on, the DropPath scales of every site come from ONE (sites, batch) draw:
+    rows are 0 or 1/keep with the site's own keep probability, the forward is reproducible from the torch seed, eval
+    mode draws nothing."""
+    from neosr_amd.archs.swinir_arch import swinir_small
+
+    torch.manual_seed(3)
+    net = swinir_small(upscale=4, drop_path_rate=0.3).to(DEV).train()
+    x = torch.rand(4, 3, 16, 16, device=DEV)
+    net(x)  # records the site sequence
+    bank = net._dp_bank
+    assert bank.recorded and len(bank.probs) == 2 * 23  # 24 blocks, the first one has drop_prob 0
+    outs = []
+    for _ in range(2):
+        torch.manual_seed(11)
+        outs.append(net(x).detach().clone())
+    assert torch.equal(outs[0], outs[1])
+    torch.manual_seed(11)
+    bank.begin(True, 4, x.device)
+    rows = bank._rows.cpu()
+    bank.end(True)
+    for p, r in zip(bank.probs, rows):
+        assert all(abs(v) < 1e-6 or abs(v - 1.0 / (1.0 - p)) < 1e-5 for v in r.tolist())
+    assert 0.02 < float((rows == 0).float().mean()) < 0.5
+    net.eval()
+    with torch.no_grad():
+        a, b = net(x), net(x)
+    assert torch.equal(a, b)
 
 
 def test_image_model_trajectory_swinir_small_vs_reference_fixture():
