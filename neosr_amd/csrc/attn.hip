@@ -153,6 +153,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 constexpr int WS = 8, NTOK = 64, HD_MAX = 32, QS = 33 /* q/k/v row stride */, PS = 65 /* P row stride */;
 constexpr int NB = (2 * WS - 1) * (2 * WS - 1);  // 225 relative positions
 
+// see attn_flash.hip: contiguous band of logical workgroup ids per XCD, so the heads of one window share an L2
+__device__ __forceinline__ int xcd_bid() {
+  const int n = gridDim.x, q = n >> 3, r = n & 7;
+  const int x = blockIdx.x & 7, k = blockIdx.x >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
+}
+
 struct Win {
   int b, Wy, Wx, head;
 };
@@ -274,7 +281,8 @@ __global__ __launch_bounds__(256) void window_attention_fwd_kernel(const neosr_w
   __shared__ float Qs[NTOK * QS], Ks[NTOK * QS], Vs[NTOK * QS], P[NTOK * PS];
   __shared__ Tables T;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
-  const Win w = decode(d, blockIdx.x);
+  const int bid = xcd_bid();
+  const Win w = decode(d, bid);
   const int hd = d.C / d.heads, ld = 3 * d.C;
   build_tables(d, w, T);
   __syncthreads();
@@ -307,7 +315,7 @@ __global__ __launch_bounds__(256) void window_attention_fwd_kernel(const neosr_w
     const float inv = 1.f / s;
 #pragma unroll
     for (int c = 0; c < 16; ++c) row[c] = e[c] * inv;
-    if (q == 0 && d.lse) d.lse[(int64_t)blockIdx.x * NTOK + i] = m + __logf(s);
+    if (q == 0 && d.lse) d.lse[(int64_t)bid * NTOK + i] = m + __logf(s);
   }
   __syncthreads();
   if (wave < 2) {  // O = P V : rows 32*wave.., cols d
@@ -327,10 +335,11 @@ __global__ __launch_bounds__(256) void window_attention_bwd_kernel(const neosr_w
   __shared__ float lse_s[NTOK];
   __shared__ Tables T;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
-  const Win w = decode(d, blockIdx.x);
+  const int bid = xcd_bid();
+  const Win w = decode(d, bid);
   const int hd = d.C / d.heads, ld = 3 * d.C, kq = (hd + 1) & ~1;
   build_tables(d, w, T);
-  if (tid < NTOK) lse_s[tid] = d.lse[(int64_t)blockIdx.x * NTOK + tid];
+  if (tid < NTOK) lse_s[tid] = d.lse[(int64_t)bid * NTOK + tid];
   __syncthreads();
   load_tile(T, d.qkv, ld, w.head * hd, hd, d.scale, Qs);
   load_tile(T, d.qkv, ld, d.C + w.head * hd, hd, 1.f, Ks);
@@ -379,7 +388,7 @@ __global__ __launch_bounds__(256) void window_attention_bwd_kernel(const neosr_w
         s += ok ? v : 0.f;
       }
     }
-    d.workspace[((int64_t)(blockIdx.x / d.heads) * NB + tid) * d.heads + w.head] = s;
+    d.workspace[((int64_t)(bid / d.heads) * NB + tid) * d.heads + w.head] = s;
   }
   float* g = d.dqkv + w.head * hd + l31;
   if (wave < 2) {

@@ -34,6 +34,15 @@ struct Geo {
   static constexpr bool SELF = KS == WS;
 };
 
+// Workgroup ids go round-robin over the 8 XCDs (private L2 each): hand every XCD a contiguous band of the logical ids,
+// so the (head, block) workgroups of one window — which read the same token rows — share one L2 instead of each XCD
+// fetching the rows again (rocprofv3 FETCH_SIZE showed 6x the algorithmic bytes with the dispatch order).
+__device__ __forceinline__ int xcd_bid() {
+  const int n = gridDim.x, q = n >> 3, r = n & 7;
+  const int x = blockIdx.x & 7, k = blockIdx.x >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
+}
+
 struct Win {
   int b, Wy, Wx, head, qb;
 };
@@ -201,7 +210,8 @@ __global__ __launch_bounds__(256) void flash_wattn_fwd_kernel(const neosr_fattn_
   using G = Geo<WS, KS>;
   __shared__ Shared S;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
-  const Win w = decode(d, blockIdx.x, G::NQB);
+  const int bid = xcd_bid();
+  const Win w = decode(d, bid, G::NQB);
   const int hd = d.C / d.heads, ld = 3 * d.C, kq = (hd + 1) & ~1;
   const int n = tid >> 2, part = tid & 3;
   setup_block<WS, KS>(d, w, S);
@@ -269,7 +279,7 @@ __global__ __launch_bounds__(256) void flash_wattn_fwd_kernel(const neosr_fattn_
   __syncthreads();
   if (part == 0) {
     S.alpha[n] = 1.f / l_run;
-    if (d.lse) d.lse[(int64_t)blockIdx.x * QB + n] = m_run + __logf(l_run);
+    if (d.lse) d.lse[(int64_t)bid * QB + n] = m_run + __logf(l_run);
   }
   __syncthreads();
   if (wave < 2 && l31 < hd) {
@@ -350,7 +360,8 @@ __global__ __launch_bounds__(256) void flash_wattn_bwd_dq_kernel(const neosr_fat
   using G = Geo<WS, KS>;
   __shared__ SharedBwd S;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
-  const Win w = decode(d, blockIdx.x, G::NQB);
+  const int bid = xcd_bid();
+  const Win w = decode(d, bid, G::NQB);
   const int hd = d.C / d.heads, ld = 3 * d.C, kq = (hd + 1) & ~1;
   const int n = tid >> 2, part = tid & 3;
   if (tid < QB) {
@@ -358,7 +369,7 @@ __global__ __launch_bounds__(256) void flash_wattn_bwd_dq_kernel(const neosr_fat
     query_geom<WS>(d, w, w.qb * QB + tid, tok, reg);
     S.qtok[tid] = tok;
     S.qpk[tid] = query_term<WS, KS>(w.qb * QB + tid) * 16 + reg;
-    S.lse[tid] = d.lse[(int64_t)blockIdx.x * QB + tid];
+    S.lse[tid] = d.lse[(int64_t)bid * QB + tid];
   }
   for (int k = tid; k < G::NBINS; k += 256) S.tab[k] = d.rpb_table[k * d.heads + w.head];
   if (G::SELF)
@@ -379,7 +390,7 @@ __global__ __launch_bounds__(256) void flash_wattn_bwd_dq_kernel(const neosr_fat
     ds += __shfl_xor(ds, 2, 64);
     if (part == 0) {
       S.dsum[n] = ds;
-      d.workspace[ws.dsum + (int64_t)blockIdx.x * QB + n] = ds;
+      d.workspace[ws.dsum + (int64_t)bid * QB + n] = ds;
     }
   }
   float kr[8], vr[8];
@@ -390,7 +401,7 @@ __global__ __launch_bounds__(256) void flash_wattn_bwd_dq_kernel(const neosr_fat
   load_row8(d.qkv, ktok, ld, 2 * d.C + w.head * hd, hd, part, vr);
   f32x16 dq = zero16();
   // dS dump: [(b, window, head)][query 256][key NK]
-  float* dump = d.workspace + ws.ds_full + ((int64_t)(blockIdx.x / G::NQB) * G::NQ + w.qb * QB) * G::NK;
+  float* dump = d.workspace + ws.ds_full + ((int64_t)(bid / G::NQB) * G::NQ + w.qb * QB) * G::NK;
   for (int kb = 0; kb < G::NKB; ++kb) {
     __syncthreads();
     store_row8(S.Ks, n, part, kr, 1.f);
@@ -438,7 +449,7 @@ __global__ __launch_bounds__(256) void flash_wattn_bwd_dq_kernel(const neosr_fat
   if (G::SELF) {  // partial bins of (window, query block): row (bw index, qb) of a [rows][bin][head] matrix
     __syncthreads();
     float* row = d.workspace + ws.ds_full +
-                 ((int64_t)(blockIdx.x / (d.heads * G::NQB)) * G::NQB + w.qb) * (31 * 31) * d.heads + w.head;
+                 ((int64_t)(bid / (d.heads * G::NQB)) * G::NQB + w.qb) * (31 * 31) * d.heads + w.head;
     for (int k = tid; k < 31 * 31; k += 256) row[(int64_t)k * d.heads] = S.bins[k];
   }
   if (wave < 2 && l31 < hd) {
@@ -455,11 +466,12 @@ __global__ __launch_bounds__(256) void flash_wattn_bwd_dkv_kernel(const neosr_fa
   using G = Geo<WS, KS>;
   __shared__ SharedBwd S;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
-  Win w = decode(d, blockIdx.x, G::NKB);
+  const int bid = xcd_bid();
+  Win w = decode(d, bid, G::NKB);
   const int kb = w.qb;  // decode()'s innermost index is the key block here
   const int hd = d.C / d.heads, ld = 3 * d.C, kq = (hd + 1) & ~1;
   const int n = tid >> 2, part = tid & 3;
-  const int64_t wh = blockIdx.x / G::NKB;  // (b, window, head)
+  const int64_t wh = bid / G::NKB;  // (b, window, head)
   if (tid < QB) {
     int tok, reg, kterm;
     bool ex;

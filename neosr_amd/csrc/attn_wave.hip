@@ -27,6 +27,13 @@ constexpr int WS = 8, NTOK = 64, NBIN = (2 * WS - 1) * (2 * WS - 1), NS = 16;
 
 struct __attribute__((packed, aligned(4))) F3 { float v[3]; };
 
+// see attn_flash.hip: contiguous band of logical workgroup ids per XCD, so the heads of one window share an L2
+__device__ __forceinline__ int xcd_bid() {
+  const int n = gridDim.x, q = n >> 3, r = n & 7;
+  const int x = blockIdx.x & 7, k = blockIdx.x >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
+}
+
 struct Unit {
   int b, Wy, Wx, head;
   int nWy, nWx;
@@ -132,7 +139,7 @@ __global__ __launch_bounds__(256, 2) void wattn_wave_fwd_kernel(const neosr_watt
   constexpr int KS = HALF ? HALF : NS;
   const int stride = gridDim.x * 4;
   const int dl = l31 < hd ? l31 : hd - 1;  // feature of this lane in the column operands / outputs
-  for (int u2 = blockIdx.x * 4 + wave; u2 < 2 * units; u2 += stride) {
+  for (int u2 = xcd_bid() * 4 + wave; u2 < 2 * units; u2 += stride) {
     const int u = u2 >> 1, ti = u2 & 1;
     const Unit w = decode(d, u);
     float qf[NS], kf[2][NS];
@@ -422,7 +429,7 @@ __global__ __launch_bounds__(256, WATTN_OCC) void wattn_wave_bwd_kernel(const ne
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int stride = gridDim.x * 4;
   // 4 units per (window, head): the key-side ones (more products) first
-  for (int x = blockIdx.x * 4 + wave; x < 4 * units; x += stride) {
+  for (int x = xcd_bid() * 4 + wave; x < 4 * units; x += stride) {
     if (x < 2 * units)
       bwd_kv_unit<HALF>(d, x >> 1, x & 1, lane, tabs[wave], dsl[wave]);
     else
