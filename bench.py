@@ -60,9 +60,12 @@ CLASS_NAMES = [
     "window attention forward", "window attention backward",
 ]
 # rocprofv3 symbol a class is launched as (for the PMC traffic lookup / the profiles cross-check)
+# (alternatives in order of preference; "a+b": one launch of the class = one dispatch of each)
 CLASS_SYMBOL = ["conv3x3_glds_kernel", "conv3x3_glds_kernel", "conv3x3_wgrad_multi_kernel", "conv3x3_wgrad_reduce_kernel",
                 "conv3x3_mfma_kernel", "conv3x3_mfma_kernel", "gemm_nt_glds_kernel", "gemm_mfma_kernel<1>",
-                "gemm_mfma_kernel<2>", "attention_fwd", "attention_bwd"]
+                "gemm_tn_reg_kernel|gemm_mfma_kernel<2>",
+                "wattn_wave_fwd_kernel|flash_wattn_fwd_kernel|window_attention_fwd_kernel",
+                "flash_wattn_bwd_dq_kernel+flash_wattn_bwd_dkv_kernel|window_attention_bwd_kernel"]
 COMPUTE_CLASSES = (0, 1, 2, 4, 5, 6, 7, 8, 9, 10)
 
 
@@ -146,15 +149,22 @@ def pmc_traffic(cfg_name: str, symbol: str) -> dict | None:
     if not files:
         return None
     summ = json.loads(files[-1].read_text())
-    hits = [(d.get("dispatches_fetch", 0), name, d) for name, d in summ.items()
-            if symbol in name and "FETCH_SIZE_per_dispatch" in d]
-    if not hits:
-        return None
-    _, name, d = max(hits, key=lambda h: h[0])  # the instantiation launched most
-    rd = 2.0 * d["FETCH_SIZE_per_dispatch"] * 1024
-    wr = d.get("WRITE_SIZE_per_dispatch", 0.0) * 1024
-    return {"bytes_per_launch": round(rd + wr), "read": round(rd), "write": round(wr),
-            "source": files[-1].name, "kernel": name[:96]}
+
+    def one(sym):
+        hits = [(d.get("dispatches_fetch", 0), name, d) for name, d in summ.items()
+                if sym in name and "FETCH_SIZE_per_dispatch" in d]
+        if not hits:
+            return None
+        _, name, d = max(hits, key=lambda h: h[0])  # the instantiation launched most
+        return 2.0 * d["FETCH_SIZE_per_dispatch"] * 1024, d.get("WRITE_SIZE_per_dispatch", 0.0) * 1024, name
+
+    for alt in symbol.split("|"):
+        parts = [one(p) for p in alt.split("+")]
+        if all(parts):
+            rd, wr = sum(p[0] for p in parts), sum(p[1] for p in parts)
+            return {"bytes_per_launch": round(rd + wr), "read": round(rd), "write": round(wr),
+                    "source": files[-1].name, "kernel": " + ".join(p[2][:96] for p in parts)}
+    return None
 
 
 def make_batch(opt: dict, dev, rank: int) -> dict:
