@@ -57,8 +57,12 @@ __device__ __forceinline__ f32x4 ld4(const float* p, int vec) {
 
 // epilogue shared by all GEMM kernels: lane owns C row m = m0 + 32*wave + l31 and the column quads
 // 32t + 8g + 4lh + {0..3} (D was formed as Bfrag x Afrag)
-template <int MODE>
-__device__ __forceinline__ void epilogue(const GemmArgs& args, const f32x16 (&acc)[2], int m0, int n0, int split) {
+struct NoPref {};
+// PREF = float4[8]: residual quads already in registers (index 4 t + g), bias tile in LDS (`bias_lds`)
+template <int MODE, typename PREF = NoPref>
+__device__ __forceinline__ void epilogue(const GemmArgs& args, const f32x16 (&acc)[2], int m0, int n0, int split,
+                                         const float* bias_lds = nullptr, const PREF& res_pref = PREF{}) {
+  constexpr bool HAS_PREF = !std::is_same<PREF, NoPref>::value;
   const neosr_gemm_desc& d = args.d;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
   const int M = d.M, N = d.N;
@@ -78,7 +82,8 @@ __device__ __forceinline__ void epilogue(const GemmArgs& args, const f32x16 (&ac
       if (MODE != 2) {
         const int ns = n < N ? n : 0;
         if (d.bias) {
-          const f32x4 b = ld4(d.bias + ns, args.b_vec);
+          const f32x4 b = bias_lds ? *reinterpret_cast<const f32x4*>(bias_lds + 32 * t + 8 * g + 4 * lh)
+                                   : ld4(d.bias + ns, args.b_vec);
           v[0] += b[0]; v[1] += b[1]; v[2] += b[2]; v[3] += b[3];
         }
         if (d.aux_out)  // keep the pre-activation for the backward pass
@@ -95,7 +100,11 @@ __device__ __forceinline__ void epilogue(const GemmArgs& args, const f32x16 (&ac
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] *= rs;
         if (d.res) {
-          const float4 r = *reinterpret_cast<const float4*>(ok ? d.res + mrow * d.ldres + n : gm_zero_page);
+          float4 r;
+          if constexpr (HAS_PREF)
+            r = res_pref[4 * t + g];
+          else
+            r = *reinterpret_cast<const float4*>(ok ? d.res + mrow * d.ldres + n : gm_zero_page);
           v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
         }
       }
@@ -272,6 +281,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(const GemmArgs arg
   const int rsub = lane >> 3, slot = lane & 7;
   const float* zp = gm_zero_page;  // pinned in SGPRs (else its address is re-read through the GOT in every chunk)
   asm volatile("" : "+s"(zp));
+  // epilogue operands off the critical path: the 64 bias values of this column tile wait in LDS (one load per lane at
+  // the start instead of 8 exposed L2 round trips per lane at the end), the residual quads are requested under the
+  // last chunk's MFMAs
+  __shared__ __attribute__((aligned(16))) float bias_s[BN];
+  if (d.bias && tid < BN) bias_s[tid] = n0 + tid < d.N ? d.bias[n0 + tid] : 0.f;
   auto issue = [&](int k0, int buf) {
     float* abuf = lds + buf * (BM + BN) * BK;
     float* bbuf = abuf + BM * BK;
@@ -307,6 +321,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(const GemmArgs arg
   // 64-wide tile holds 28 columns) skips its MFMAs
   const int last_steps = (K - (nchunks - 1) * BK + 7) >> 3;
   const bool two = n0 + 32 < d.N;
+  float4 resq[8];
   auto run = [&](auto two_tag) {
     constexpr bool TWO = decltype(two_tag)::value;
     auto mac = [&](int c, int nsteps) {
@@ -334,13 +349,23 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(const GemmArgs arg
       __builtin_amdgcn_s_waitcnt(0x0f70);  // the next chunk has landed ...
       __syncthreads();                      // ... for every wave, and this buffer is free to overwrite
     }
+    if (d.res) {
+      const int m = m0 + wave * 32 + l31;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = n0 + 32 * t + 8 * g + 4 * lh;
+          resq[4 * t + g] = *reinterpret_cast<const float4*>(m < d.M && n < d.N ? d.res + (int64_t)m * d.ldres + n : zp);
+        }
+    }
     mac(nchunks - 1, last_steps);
   };
   if (two)
     run(std::true_type{});
   else
     run(std::false_type{});
-  epilogue<0>(args, acc, m0, n0, 0);
+  epilogue<0, float4[8]>(args, acc, m0, n0, 0, bias_s, resq);
 }
 
 // TN GEMM fed from registers (weight gradients dW[m][n] = sum_t dY[t][m] X[t][n]): both operands are
