@@ -399,6 +399,12 @@ int neosr_layernorm_fwd(const float* x, const float* gamma, const float* beta, f
 int neosr_layernorm_bwd(const float* dy, const float* x, const float* stats, const float* gamma,
                         float* dx, float* dgamma, float* dbeta, float* workspace, int64_t rows,
                         int32_t C, int32_t accumulate, void* stream);
+/* Same with dx += dres: the gradient that reaches x over the shortcut of a pre-norm residual block
+ * (x -> x + f(norm(x)), swinir_arch.py:343-392) is added in the same pass (autograd would otherwise sum the two with an
+ * elementwise kernel per norm).  dres may be NULL. */
+int neosr_layernorm_bwd_res(const float* dy, const float* x, const float* stats, const float* gamma,
+                            const float* dres, float* dx, float* dgamma, float* dbeta, float* workspace,
+                            int64_t rows, int32_t C, int32_t accumulate, void* stream);
 /* (Shifted-)window multi-head self-attention (swinir_arch.py:150-212,343-392) on the fused
  * qkv matrix [B*H*W, 3*C] in IMAGE order: torch.roll, window_partition/reverse and the head split are
  * folded into addressing; relative-position bias is gathered from `rpb_table` ((2ws-1)^2, heads) by

@@ -305,6 +305,7 @@ SIGNATURES: dict[str, tuple] = {
     "neosr_colsum": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "neosr_layernorm_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp]),
     "neosr_layernorm_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
+    "neosr_layernorm_bwd_res": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     "neosr_window_attention_fwd": (C.c_int, [C.POINTER(WattnDesc), _vp]),
     "neosr_window_attention_bwd": (C.c_int, [C.POINTER(WattnDesc), _vp]),
     "neosr_pointwise_loss_fwd": (C.c_int, [_vp, _vp, _i64, _i32, _f32, _f32, _vp, _vp, _vp]),

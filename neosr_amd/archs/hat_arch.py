@@ -104,12 +104,12 @@ class HAB(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:  # (B, H, W, C)
         b, h, w, _ = x.shape
         a = self.attn
-        y = T.layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        x, y = T.residual_layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)  # (shortcut, norm)
         qkv = T.linear(y, a.qkv.weight, a.qkv.bias)
         at = T.flash_window_attention(qkv, a.relative_position_bias_table, self.num_heads, 16, self.shift_size, a.scale)
         x = T.linear(at, a.proj.weight, a.proj.bias, x, drop_scale(self.drop_prob, self.training, b, x.device), h * w)
         x = self.conv_block(y, x, self.conv_scale)
-        y = T.layer_norm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        x, y = T.residual_layer_norm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
         return T.mlp(y, self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight, self.mlp.fc2.bias, x,
                      drop_scale(self.drop_prob, self.training, b, x.device), h * w)
 
@@ -131,12 +131,12 @@ class OCAB(nn.Module):
         self.mlp = Mlp(dim, int(dim * mlp_ratio))
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        y = T.layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        x, y = T.residual_layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)  # (shortcut, norm)
         qkv = T.linear(y, self.qkv.weight, self.qkv.bias)
         at = T.flash_window_attention(qkv, self.relative_position_bias_table, self.num_heads, self.overlap_win_size, 0,
                                       self.scale)
         x = T.linear(at, self.proj.weight, self.proj.bias, x)
-        y = T.layer_norm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        x, y = T.residual_layer_norm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
         return T.mlp(y, self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight, self.mlp.fc2.bias, x)
 
 

@@ -89,12 +89,12 @@ class SwinTransformerBlock(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:  # x: (B, H, W, C) channels-last tokens
         b, h, w, _ = x.shape
         a = self.attn
-        y = T.layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        x, y = T.residual_layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)  # (shortcut, norm)
         qkv = T.linear(y, a.qkv.weight, a.qkv.bias)
         y = T.window_attention(qkv, a.relative_position_bias_table, self.num_heads, self.window_size,
                                self.shift_size, a.scale)
         x = T.linear(y, a.proj.weight, a.proj.bias, x, drop_scale(self.drop_prob, self.training, b, x.device), h * w)
-        y = T.layer_norm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        x, y = T.residual_layer_norm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
         return T.mlp(y, self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight, self.mlp.fc2.bias, x,
                      drop_scale(self.drop_prob, self.training, b, x.device), h * w)
 

@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             const float* __restrict__ gamma,
                                                             float* __restrict__ dx,
                                                             float* __restrict__ part, int64_t rows,
-                                                            int C) {
+                                                            int C, const float* __restrict__ dres) {
   __shared__ float red[2][4][NI * 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t stride = (int64_t)gridDim.x * 4;
@@ -132,7 +132,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int c = lane + 64 * i;
-      if (c < C) dx[row * C + c] = rstd * (gy[i] - s1 - xh[i] * s2);
+      // dres: gradient arriving over the shortcut that by-passed this norm (x -> x + f(norm(x))): summed here instead
+      // of by a separate elementwise pass
+      if (c < C) dx[row * C + c] = rstd * (gy[i] - s1 - xh[i] * s2) + (dres ? dres[row * C + c] : 0.f);
       g[i] = ng[i];
       xv[i] = nxv[i];
     }
@@ -486,13 +488,19 @@ extern "C" int neosr_layernorm_fwd(const float* x, const float* gamma, const flo
 extern "C" int neosr_layernorm_bwd(const float* dy, const float* x, const float* stats, const float* gamma,
                                    float* dx, float* dgamma, float* dbeta, float* workspace, int64_t rows,
                                    int32_t C, int32_t accumulate, void* stream) {
+  return neosr_layernorm_bwd_res(dy, x, stats, gamma, nullptr, dx, dgamma, dbeta, workspace, rows, C, accumulate, stream);
+}
+
+extern "C" int neosr_layernorm_bwd_res(const float* dy, const float* x, const float* stats, const float* gamma,
+                                       const float* dres, float* dx, float* dgamma, float* dbeta, float* workspace,
+                                       int64_t rows, int32_t C, int32_t accumulate, void* stream) {
   NEOSR_CHECK(dy && x && stats && gamma && dx && dgamma && dbeta && workspace && rows > 0 && C > 0 &&
                   C <= LN_MAXI * 64, "layernorm_bwd: bad args");
   int nblk = (int)((rows + 15) / 16);  // >= 4 rows per wave
   if (nblk > 1024) nblk = 1024;
 #define LN_BWD(NI)                                                                                              \
   hipLaunchKernelGGL(layernorm_bwd_kernel<NI>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, dy, x, stats, \
-                     gamma, dx, workspace, rows, C)
+                     gamma, dx, workspace, rows, C, dres)
   switch ((C + 63) / 64) {
     case 1: LN_BWD(1); break;
     case 2: LN_BWD(2); break;

@@ -192,6 +192,48 @@ def layer_norm(x, gamma, beta, eps=1e-5):
     return LayerNorm.apply(x, gamma, beta, eps)
 
 
+class ResidualLayerNorm(torch.autograd.Function):
+    """(x, LayerNorm(x)) for a pre-norm residual block x -> x + f(norm(x)) (swinir_arch.py:343-392): the first output is
+    the shortcut.  Autograd then hands BOTH gradients — the one that came over the shortcut and the one through the
+    norm — to this backward, which sums them inside the LayerNorm backward kernel (`neosr_layernorm_bwd_res`) instead
+    of with an elementwise add per norm."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        lib = _C.load()
+        x2 = _as2d(x)
+        rows, C_ = x2.shape
+        y = torch.empty_like(x2)
+        stats = _new((rows, 2), x2)
+        _C.check(lib.neosr_layernorm_fwd(x2.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
+                                         stats.data_ptr(), rows, C_, eps, _st()), "neosr_layernorm_fwd")
+        ctx.save_for_backward(x2, gamma, stats)
+        return x.view_as(x), y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, gs, g):
+        lib = _C.load()
+        x2, gamma, stats = ctx.saved_tensors
+        rows, C_ = x2.shape
+        if g is None:  # the normed branch was not used
+            return gs, None, None, None
+        g2 = _as2d(g)
+        gs2 = None if gs is None else _as2d(gs)
+        dx = torch.empty_like(x2)
+        dgb = _new((2 * C_,), x2)  # dgamma | dbeta adjacent: one reduction launch
+        dg, db = dgb[:C_], dgb[C_:]
+        ws = _new(((2 * 1024 + 512) * C_,), x2)
+        _C.check(lib.neosr_layernorm_bwd_res(g2.data_ptr(), x2.data_ptr(), stats.data_ptr(), gamma.data_ptr(),
+                                             _p(gs2), dx.data_ptr(), dg.data_ptr(), db.data_ptr(), ws.data_ptr(),
+                                             rows, C_, 0, _st()), "neosr_layernorm_bwd_res")
+        return dx.view(g.shape), dg, db, None
+
+
+def residual_layer_norm(x, gamma, beta, eps=1e-5):
+    """-> (shortcut, norm(x)); use the shortcut (not x) as the residual operand of the block."""
+    return ResidualLayerNorm.apply(x, gamma, beta, eps)
+
+
 class WindowAttention(torch.autograd.Function):
     """softmax(q k^T * scale + rpb + shift-mask) v per (window, head) on the fused qkv matrix
     (B, H, W, 3C) in image order (swinir_arch.py:150-212 inside :343-385)."""
