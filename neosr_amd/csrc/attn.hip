@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256) void window_attention_fwd_kernel(const neosr_w
 __global__ __launch_bounds__(256) void window_attention_bwd_kernel(const neosr_wattn_desc d) {
   __shared__ float Qs[NTOK * QS], Ks[NTOK * QS], Vs[NTOK * QS], Gs[NTOK * QS];
   __shared__ float P[NTOK * PS], dS[NTOK * PS];
-  __shared__ float lse_s[NTOK];
+  __shared__ float lse_s[NTOK], delta_s[NTOK];
   __shared__ Tables T;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
   const int bid = xcd_bid();
@@ -346,19 +346,47 @@ __global__ __launch_bounds__(256) void window_attention_bwd_kernel(const neosr_w
   load_tile(T, d.qkv, ld, w.head * hd, hd, d.scale, Qs);
   load_tile(T, d.qkv, ld, d.C + w.head * hd, hd, 1.f, Ks);
   load_tile(T, d.qkv, ld, 2 * d.C + w.head * hd, hd, 1.f, Vs);
-  load_tile(T, d.dout, d.C, w.head * hd, hd, 1.f, Gs);
+  const bool have_o = d.out != nullptr;
+  if (have_o) {
+    // delta[i] = sum_j P dP = sum_d dO[i][d] O[i][d]: with the forward output at hand the row sums come from two
+    // 30-float rows instead of two 64 x 64 LDS tiles, and dS is finished in the score tile's registers.  The O row is
+    // requested in the same batch as the dO row it multiplies (one round trip, no second pass over dO).
+    const int n = tid >> 2, part = tid & 3;
+    const int64_t row = (int64_t)T.tok[n] * d.C + w.head * hd;
+    float gv[8], ov[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = part * 8 + e;
+      gv[e] = c < hd ? d.dout[row + c] : 0.f;
+      ov[e] = c < hd ? d.out[row + c] : 0.f;
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      Gs[n * QS + part * 8 + e] = gv[e];
+      s += gv[e] * ov[e];
+    }
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    if (part == 0) delta_s[n] = s;
+  } else {
+    load_tile(T, d.dout, d.C, w.head * hd, hd, 1.f, Gs);
+  }
   __syncthreads();
   {
     const int ti = wave >> 1, tj = wave & 1;
     const f32x16 s = tile_abt(Qs, QS, Ks, QS, ti, tj, kq, l31, lh);
     scores_to_lds(T, s, ti, tj, l31, lh, lse_s, P);                   // P = softmax (recomputed)
     const f32x16 dp = tile_abt(Gs, QS, Vs, QS, ti, tj, kq, l31, lh);  // dP = dO V^T
-    float* o = dS + (32 * ti + 4 * lh) * PS + 32 * tj + l31;
+    const int i0 = 32 * ti + 4 * lh, j = 32 * tj + l31;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) o[((r & 3) + 8 * (r >> 2)) * PS] = dp[r];
+    for (int r = 0; r < 16; ++r) {
+      const int i = i0 + (r & 3) + 8 * (r >> 2);
+      dS[i * PS + j] = have_o ? P[i * PS + j] * (dp[r] - delta_s[i]) : dp[r];
+    }
   }
   __syncthreads();
-  {  // dS = P * (dP - sum_j P dP), 4 threads per row
+  if (!have_o) {  // dS = P * (dP - sum_j P dP), 4 threads per row
     const int i = tid >> 2, q = tid & 3;
     const float* pr = P + i * PS + q * 16;
     float* gr = dS + i * PS + q * 16;
@@ -369,8 +397,8 @@ __global__ __launch_bounds__(256) void window_attention_bwd_kernel(const neosr_w
     s += __shfl_xor(s, 2, 64);
 #pragma unroll
     for (int c = 0; c < 16; ++c) gr[c] = pr[c] * (gr[c] - s);
+    __syncthreads();
   }
-  __syncthreads();
   // relative-position-bias gradient of this (window, head): bin sums in a fixed order
   if (tid < NB) {
     // all 64 query positions, straight-line: the pairs that leave the window read element 0 and add 0, so the LDS
@@ -548,10 +576,14 @@ extern "C" int neosr_window_attention_bwd(const neosr_wattn_desc* d, void* strea
   // (the wave-per-unit backward is opt-in: its row-gather loads make it L1-request-bound, slower than the staged kernel)
   static const bool wave_bwd = getenv("NEOSR_WATTN_WAVE_BWD") != nullptr;
   const bool wave = wave_bwd && neosr_wattn::wave_ok(*d) && d->out && !staged;  // needs the forward output
-  if (wave)
+  if (wave) {
     neosr_wattn::launch_bwd(*d, stream);
-  else
-    hipLaunchKernelGGL(window_attention_bwd_kernel, dim3(nbw * d->heads), dim3(256), 0, (hipStream_t)stream, *d);
+  } else {
+    static const bool rowpass = getenv("NEOSR_WATTN_ROWPASS") != nullptr;  // A/B: delta from the score tiles, not from O
+    neosr_wattn_desc dd = *d;
+    if (rowpass) dd.out = nullptr;
+    hipLaunchKernelGGL(window_attention_bwd_kernel, dim3(nbw * d->heads), dim3(256), 0, (hipStream_t)stream, dd);
+  }
   if (prof) neosr_prof_end(stream);
   NEOSR_LAUNCH_CHECK();
   // d_table[bin][head] (+)= column sums of the [rows][bin*heads + head] partial matrix (fixed order); the wave kernels

@@ -320,7 +320,6 @@ __host__ __device__ inline BwdWs bwd_ws(const neosr_fattn_desc& d) {
 // (query block in Qs/Gs, key block in Ks/Vs); leaves P and dS tiles in LDS
 template <int NBINS, bool SELF>
 __device__ __forceinline__ void recompute_p_ds(SharedBwd& S, int kq, int wave, int l31, int lh) {
-  const int tid = threadIdx.x;
   {
     const int ti = wave >> 1, tj = wave & 1;
     const f32x16 s = mm_abt(zero16(), S.Qs, QS, S.Ks, QS, ti, tj, kq, l31, lh);
@@ -338,18 +337,12 @@ __device__ __forceinline__ void recompute_p_ds(SharedBwd& S, int kq, int wave, i
       if (!SELF && idx < 0) idx += NBINS;
       float v = s[r] + S.tab[none ? 0 : idx];
       if (SELF && (qp & 15) != kreg) v -= 100.f;
-      S.P[i * PS + j] = none ? 0.f : __expf(v - S.lse[i]);
-      S.dS[i * PS + j] = dp[r];
+      // dS = P (dP - D) with D = rowsum(dO . O) already in LDS: finished in the tile's own registers (a separate row
+      // pass over the two LDS tiles cost 32 reads + 16 writes per thread and one more barrier per key block)
+      const float p = none ? 0.f : __expf(v - S.lse[i]);
+      S.P[i * PS + j] = p;
+      S.dS[i * PS + j] = p * (dp[r] - S.dsum[i]);
     }
-  }
-  __syncthreads();
-  {
-    const int i = tid >> 2, q = tid & 3;
-    const float* pr = S.P + i * PS + q * 16;
-    float* gr = S.dS + i * PS + q * 16;
-    const float dsum = S.dsum[i];
-#pragma unroll
-    for (int c = 0; c < 16; ++c) gr[c] = pr[c] * (gr[c] - dsum);
   }
   __syncthreads();
 }
