@@ -142,16 +142,29 @@ __device__ __forceinline__ f32x16 mm_abt(f32x16 acc, const float* A, int sa, con
                                          int tj, int kdim, int l31, int lh) {
   const float* ap = A + (32 * ti + l31) * sa + lh;
   const float* bp = B + (32 * tj + l31) * sb + lh;
+#pragma unroll 5
   for (int ks = 0; ks < kdim / 2; ++ks)
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * ks], bp[2 * ks], acc, 0, 0, 0);
   return acc;
+}
+// two products over the same k range at once (S = Q K^T and dP = dO V^T of one tile): two independent accumulator
+// chains, the LDS reads of a step batched ahead of its MFMAs
+__device__ __forceinline__ void mm_abt_pair(f32x16& acc1, const float* A1, const float* B1, f32x16& acc2, const float* A2,
+                                            const float* B2, int sa, int sb, int ti, int tj, int kdim, int l31, int lh) {
+  const int ao = (32 * ti + l31) * sa + lh, bo = (32 * tj + l31) * sb + lh;
+#pragma unroll 5
+  for (int ks = 0; ks < kdim / 2; ++ks) {
+    const float a1 = A1[ao + 2 * ks], b1 = B1[bo + 2 * ks], a2 = A2[ao + 2 * ks], b2 = B2[bo + 2 * ks];
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc1, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2, acc2, 0, 0, 0);
+  }
 }
 // D[i][j] += sum_k A[i][k] B[k][j], k < 64
 __device__ __forceinline__ f32x16 mm_ab(f32x16 acc, const float* A, int sa, const float* B, int sb, int ti, int tj,
                                         int l31, int lh) {
   const float* ap = A + (32 * ti + l31) * sa + lh;
   const float* bp = B + lh * sb + 32 * tj + l31;
-#pragma unroll 8
+#pragma unroll 16
   for (int ks = 0; ks < QB / 2; ++ks)
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * ks], bp[2 * ks * sb], acc, 0, 0, 0);
   return acc;
@@ -161,7 +174,7 @@ __device__ __forceinline__ f32x16 mm_atb(f32x16 acc, const float* A, int sa, con
                                          int tj, int l31, int lh) {
   const float* ap = A + lh * sa + 32 * ti + l31;
   const float* bp = B + lh * sb + 32 * tj + l31;
-#pragma unroll 8
+#pragma unroll 16
   for (int ks = 0; ks < QB / 2; ++ks)
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * ks * sa], bp[2 * ks * sb], acc, 0, 0, 0);
   return acc;
@@ -322,13 +335,13 @@ template <int NBINS, bool SELF>
 __device__ __forceinline__ void recompute_p_ds(SharedBwd& S, int kq, int wave, int l31, int lh) {
   {
     const int ti = wave >> 1, tj = wave & 1;
-    const f32x16 s = mm_abt(zero16(), S.Qs, QS, S.Ks, QS, ti, tj, kq, l31, lh);
+    f32x16 s = zero16(), dp = zero16();
+    mm_abt_pair(s, S.Qs, S.Ks, dp, S.Gs, S.Vs, QS, QS, ti, tj, kq, l31, lh);
     // scores_to_lds wants the forward Shared layout: replicate its body on SharedBwd fields
     const int j = 32 * tj + l31;
     const int kp = S.kpk[j];
     const bool none = kp == KEY_NONE;
     const int kterm = kp >> 4, kreg = kp & 15;
-    const f32x16 dp = mm_abt(zero16(), S.Gs, QS, S.Vs, QS, ti, tj, kq, l31, lh);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int i = 32 * ti + (r & 3) + 8 * (r >> 2) + 4 * lh;
