@@ -412,8 +412,9 @@ int neosr_layernorm_bwd_res(const float* dy, const float* x, const float* stats,
  * rebuilds it 18x per forward).  One workgroup per (window, head); QK^T and PV on fp32 MFMA.
  * fwd: out [B*H*W, C] image order, lse [B*nW*heads*N] kept for backward.
  * bwd: dqkv [B*H*W, 3*C] (every element written once), d_rpb_table (+)= (fixed-order reduction
- * over windows; workspace >= (2*B*nW + 256)*heads*(2ws-1)^2 floats).  With `out` = the forward output also set
- * (and head_dim <= 30) both passes run the wave-per-(window, head) kernels of attn_wave.hip. */
+ * over windows; workspace >= (B*nW + 256)*heads*(2ws-1)^2 floats).  With `out` = the forward output also set, delta =
+ * rowsum(dO . O) comes from it and dS is finished in the score tiles' registers (else from the P / dP tiles in a row pass).
+ * The forward with head_dim <= 30 runs the wave-per-(window, head, query tile) kernel of attn_wave.hip. */
 typedef struct neosr_wattn_desc {
   const float* qkv;
   const float* rpb_table;

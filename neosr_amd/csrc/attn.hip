@@ -572,13 +572,7 @@ extern "C" int neosr_window_attention_bwd(const neosr_wattn_desc* d, void* strea
   const bool prof = neosr_prof_on();
   const double tok = (double)d->B * d->H * d->W;  // dP, dV, dQ, dK: four products (the recomputed P is not counted)
   if (prof) neosr_prof_begin(NEOSR_PROF_ATTN_BWD, stream, 8.0 * WS * WS * tok * d->C, 4.0 * tok * 7 * d->C);
-  static const bool staged = getenv("NEOSR_WATTN_STAGED") != nullptr;  // A/B switch: the workgroup-per-unit kernels
-  // (the wave-per-unit backward is opt-in: its row-gather loads make it L1-request-bound, slower than the staged kernel)
-  static const bool wave_bwd = getenv("NEOSR_WATTN_WAVE_BWD") != nullptr;
-  const bool wave = wave_bwd && neosr_wattn::wave_ok(*d) && d->out && !staged;  // needs the forward output
-  if (wave) {
-    neosr_wattn::launch_bwd(*d, stream);
-  } else {
+  {
     static const bool rowpass = getenv("NEOSR_WATTN_ROWPASS") != nullptr;  // A/B: delta from the score tiles, not from O
     neosr_wattn_desc dd = *d;
     if (rowpass) dd.out = nullptr;
@@ -586,10 +580,9 @@ extern "C" int neosr_window_attention_bwd(const neosr_wattn_desc* d, void* strea
   }
   if (prof) neosr_prof_end(stream);
   NEOSR_LAUNCH_CHECK();
-  // d_table[bin][head] (+)= column sums of the [rows][bin*heads + head] partial matrix (fixed order); the wave kernels
-  // write one row per (window, key tile), the staged kernel one per window
-  const int cols = NB * d->heads, rows = wave ? 2 * nbw : nbw;
-  return neosr_colsum(d->workspace, d->d_rpb_table, d->workspace + (int64_t)rows * cols, rows, cols, cols,
+  // d_table[bin][head] (+)= column sums of the [nbw][bin*heads + head] per-window matrix (fixed order)
+  const int cols = NB * d->heads;
+  return neosr_colsum(d->workspace, d->d_rpb_table, d->workspace + (int64_t)nbw * cols, nbw, cols, cols,
                       d->accumulate_rpb, stream);
 }
 

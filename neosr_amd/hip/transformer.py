@@ -251,7 +251,7 @@ class WindowAttention(torch.autograd.Function):
         d = _C.WattnDesc(qkv=qkv.data_ptr(), rpb_table=table.data_ptr(), out=out.data_ptr(), lse=lse.data_ptr(),
                          B=B, H=H, W=W, C=C_, heads=heads, ws=ws, shift=shift, accumulate_rpb=0, scale=scale)
         _C.check(lib.neosr_window_attention_fwd(d, _st()), "neosr_window_attention_fwd")
-        ctx.save_for_backward(qkv, table, lse, out)  # out: delta = rowsum(dO . O) in the backward kernels
+        ctx.save_for_backward(qkv, table, lse, out)  # out: delta = rowsum(dO . O) in the backward kernel
         ctx.meta = (B, H, W, C_, heads, ws, shift, scale, nW)
         return out
 
@@ -263,7 +263,7 @@ class WindowAttention(torch.autograd.Function):
         g = g.contiguous()
         dqkv = torch.empty_like(qkv)
         dtab = torch.empty_like(table)
-        wsp = _new(((2 * B * nW + 256) * heads * (2 * ws - 1) ** 2,), qkv)
+        wsp = _new(((B * nW + 256) * heads * (2 * ws - 1) ** 2,), qkv)
         d = _C.WattnDesc(qkv=qkv.data_ptr(), rpb_table=table.data_ptr(), out=out.data_ptr(), lse=lse.data_ptr(),
                          dout=g.data_ptr(), dqkv=dqkv.data_ptr(), d_rpb_table=dtab.data_ptr(),
                          workspace=wsp.data_ptr(), B=B, H=H, W=W, C=C_, heads=heads, ws=ws, shift=shift,
