@@ -572,3 +572,40 @@ def test_image_model_trajectory_vs_reference_fixture(arch):
     assert max(rel_err(sd[k], v) for k, v in final.items()) < 1e-3
     assert max(rel_err(esd[k], v) for k, v in ema.items() if k != "n_averaged") < 1e-3
     assert int(esd["n_averaged"]) == 3
+
+
+def test_pack_many_equals_per_layer_packing():
+    """neosr_conv3x3_pack_many (both image kinds, both modes, many layers per launch) writes exactly what the per-layer
+    entry points write; the cached images of a layer stack are refreshed by one batched call after a parameter change"""
+    import ctypes as C_
+
+    from neosr_amd import _C
+    from neosr_amd.hip import layers, ops
+
+    lib = _C.load()
+    g = torch.Generator().manual_seed(9)
+    shapes = [(64, 64), (32, 96), (180, 60), (60, 180), (8, 12), (64, 192)] * 6  # 36 layers: two launches per kind
+    ws = [torch.randn(co, ci, 3, 3, generator=g).to(DEV) for co, ci in shapes]
+    items, want = [], []
+    for w in ws:
+        for mode in (ops.CONV_FWD, ops.CONV_DGRAD):
+            for kind, single in ((0, ops.conv3x3_pack_weights), (1, ops.conv3x3_pack_wino)):
+                ref = single(w, mode)
+                dst = torch.full_like(ref, float("nan"))
+                items.append(_C.PackItem(w=w.data_ptr(), dst=dst.data_ptr(), w_cout=w.shape[0], w_cin=w.shape[1],
+                                         mode=mode, kind=kind))
+                want.append((ref, dst))
+    arr = (_C.PackItem * len(items))(*items)
+    _C.check(lib.neosr_conv3x3_pack_many(arr, len(items), _C.stream_ptr()), "pack_many")
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in want)
+    # the cache: every registered image of the device is rebuilt by the first miss after a parameter change
+    ps = [torch.nn.Parameter(w.clone()) for w in ws[:6]]
+    first = [layers.packed_weights(p, ops.CONV_FWD).clone() for p in ps]
+    with torch.no_grad():
+        for p in ps:
+            p.mul_(2.0)  # moves every parameter's _version
+    again = layers.packed_weights(ps[0], ops.CONV_FWD)  # one miss ...
+    assert all(p.__dict__["_neosr_packs"][(0, ops.CONV_FWD)][0] == layers._pack_key(p) for p in ps)  # ... refreshed all
+    assert torch.equal(again, 2.0 * first[0])
+    assert all(torch.equal(layers.packed_weights(p, ops.CONV_FWD), 2.0 * f) for p, f in zip(ps, first))

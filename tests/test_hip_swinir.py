@@ -161,6 +161,33 @@ def test_layernorm_fwd_bwd(rows, C):
         assert rel_err(a, b) < 1e-5
 
 
+def test_residual_layer_norm_sums_the_shortcut_gradient_in_the_kernel():
+    """(shortcut, norm(x)) with both gradients summed inside the LayerNorm backward kernel == torch's LayerNorm with the
+    shortcut gradient added by autograd"""
+    from neosr_amd.hip import transformer as tr
+
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(3, 8, 16, 180, generator=g)
+    gm, bt = torch.randn(180, generator=g), torch.randn(180, generator=g)
+    gs, gy = torch.randn(3, 8, 16, 180, generator=g), torch.randn(3, 8, 16, 180, generator=g)
+    xr = x.clone().requires_grad_(True)
+    gmr, btr = gm.clone().requires_grad_(True), bt.clone().requires_grad_(True)
+    yr = torch.nn.functional.layer_norm(xr.double(), (180,), gmr.double(), btr.double(), 1e-5)
+    (xr.double() * gs.double()).sum().backward(retain_graph=True)
+    (yr * gy.double()).sum().backward()
+    xd = x.to(DEV).requires_grad_(True)
+    gmd, btd = gm.to(DEV).requires_grad_(True), bt.to(DEV).requires_grad_(True)
+    sc, y = tr.residual_layer_norm(xd, gmd, btd, 1e-5)
+    assert torch.equal(sc, xd) and rel_err(y, yr) < 1e-5
+    ((sc * gs.to(DEV)).sum() + (y * gy.to(DEV)).sum()).backward()
+    assert rel_err(xd.grad, xr.grad) < 1e-5 and rel_err(gmd.grad, gmr.grad) < 1e-5 and rel_err(btd.grad, btr.grad) < 1e-5
+    # only one of the two outputs used
+    xd.grad = None
+    sc, y = tr.residual_layer_norm(xd, gmd, btd, 1e-5)
+    (sc * gs.to(DEV)).sum().backward()
+    assert rel_err(xd.grad, gs) < 1e-6
+
+
 @pytest.mark.parametrize("shift", [0, 4])
 @pytest.mark.parametrize("B,H,W,C,heads", [(2, 16, 24, 60, 6), (1, 8, 8, 24, 2), (2, 32, 16, 180, 6), (1, 16, 16, 64, 2)])
 def test_window_attention_fwd_bwd_vs_oracle(B, H, W, C, heads, shift):
