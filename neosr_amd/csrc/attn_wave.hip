@@ -225,7 +225,7 @@ bool wave_ok(const neosr_wattn_desc& d) { return d.ws == WS && d.C % d.heads == 
 void launch_fwd(const neosr_wattn_desc& d, void* stream) {
   const int units = d.B * (d.H / WS) * (d.W / WS) * d.heads;
   int nwg = (2 * units + 3) / 4;
-  if (nwg > 512) nwg = 512;  // two workgroups per CU; the waves walk the (window, head, query tile) list
+  if (nwg > 768) nwg = 768;  // three workgroups per CU (150 VGPRs); the waves walk the (window, head, query tile) list
   if (d.C / d.heads == 30)
     hipLaunchKernelGGL(wattn_wave_fwd_kernel<15>, dim3(nwg), dim3(256), 0, (hipStream_t)stream, d, units);
   else
