@@ -74,30 +74,33 @@ __device__ __forceinline__ f32x4 ld4(const float* p, int vec) {
 // 32t + 8g + 4lh + {0..3} (D was formed as Bfrag x Afrag)
 struct NoPref {};
 // PREF = float4[8]: residual quads already in registers (index 4 t + g), bias tile in LDS (`bias_lds`)
-template <int MODE, typename PREF = NoPref>
-__device__ __forceinline__ void epilogue(const GemmArgs& args, const f32x16 (&acc)[2], int m0, int n0, int split,
-                                         const float* bias_lds = nullptr, const PREF& res_pref = PREF{}) {
+// NTILE 32-column accumulator tiles per wave; row_off / col_off: position of the wave's tile inside the workgroup tile
+// (default: wave w owns rows 32 w.., columns 0..)
+template <int MODE, typename PREF = NoPref, int NTILE = 2>
+__device__ __forceinline__ void epilogue(const GemmArgs& args, const f32x16 (&acc)[NTILE], int m0, int n0, int split,
+                                         const float* bias_lds = nullptr, const PREF& res_pref = PREF{},
+                                         int row_off = -1, int col_off = 0) {
   constexpr bool HAS_PREF = !std::is_same<PREF, NoPref>::value;
   const neosr_gemm_desc& d = args.d;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
   const int M = d.M, N = d.N;
-  const int m = m0 + wave * 32 + l31;
+  const int m = m0 + (row_off < 0 ? wave * 32 : row_off) + l31;
   const bool m_ok = m < M;
   const int64_t mrow = m_ok ? m : 0;
   float* Cbase = d.C;
   if (MODE == 2) Cbase = d.C + (int64_t)split * args.slab;  // split-K partial slab
   const float rs = (MODE != 2 && d.row_scale && m_ok) ? d.row_scale[m / d.rows_per_scale] : 1.f;
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+  for (int t = 0; t < NTILE; ++t)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const int n = n0 + 32 * t + 8 * g + 4 * lh;
+      const int n = n0 + col_off + 32 * t + 8 * g + 4 * lh;
       const bool ok = m_ok && n < N;
       float v[4] = {acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
       if (MODE != 2) {
         const int ns = n < N ? n : 0;
         if (d.bias) {
-          const f32x4 b = bias_lds ? *reinterpret_cast<const f32x4*>(bias_lds + 32 * t + 8 * g + 4 * lh)
+          const f32x4 b = bias_lds ? *reinterpret_cast<const f32x4*>(bias_lds + col_off + 32 * t + 8 * g + 4 * lh)
                                    : ld4(d.bias + ns, args.b_vec);
           v[0] += b[0]; v[1] += b[1]; v[2] += b[2]; v[3] += b[3];
         }
@@ -383,6 +386,84 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(const GemmArgs arg
   epilogue<0, float4[8]>(args, acc, m0, n0, 0, bias_s, resq);
 }
 
+// 64-row variant of gemm_nt_glds_kernel for launches that would not fill the chip with 128-row tiles (M = 16 384 tokens:
+// 384 tiles of 128 x 64 for N = 180 on 768 resident slots).  The 4 waves form a 2 x 2 grid of 32 x 32 tiles (one
+// accumulator each: one A and one B ds_read_b128 per 4 MFMAs), everything else — DMA staging, XOR-swizzled images, one
+// barrier per chunk, trimmed last chunk, bias tile in LDS, residual quads requested under the last chunk — as above.
+constexpr int BM2 = 64;
+__global__ __launch_bounds__(256, 2) void gemm_nt_glds64_kernel(const GemmArgs args) {
+  const neosr_gemm_desc& d = args.d;
+  __shared__ __attribute__((aligned(1024))) float lds[2 * (BM2 + BN) * BK];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int tiles = args.tiles_m * args.tiles_n;
+  const int chunk = gridDim.x >> 3;
+  const int logical = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+  if (logical >= tiles) return;
+  const int m0 = (logical / args.tiles_n) * BM2, n0 = (logical % args.tiles_n) * BN;
+  const int K = d.K;
+  const int rsub = lane >> 3, slot = lane & 7;
+  const float* zp = gm_zero_page;
+  asm volatile("" : "+s"(zp));
+  __shared__ __attribute__((aligned(16))) float bias_s[BN];
+  if (d.bias && tid < BN) bias_s[tid] = n0 + tid < d.N ? d.bias[n0 + tid] : 0.f;
+  auto issue = [&](int k0, int buf) {
+    float* abuf = lds + buf * (BM2 + BN) * BK;
+    float* bbuf = abuf + BM2 * BK;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = (4 * i + wave) * 8 + rsub;
+      const int k = k0 + 4 * (slot ^ (r & 7));
+      const float* sa = (m0 + r < d.M && k < K) ? d.A + (int64_t)(m0 + r) * d.lda + k : zp;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sa,
+                                       (__attribute__((address_space(3))) void*)(abuf + (4 * i + wave) * 256), 16, 0, 0);
+      const float* sb = (n0 + r < d.N && k < K) ? d.B + (int64_t)(n0 + r) * d.ldb + k : zp;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sb,
+                                       (__attribute__((address_space(3))) void*)(bbuf + (4 * i + wave) * 256), 16, 0, 0);
+    }
+  };
+  f32x16 acc[1];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
+  const int nchunks = (K + BK - 1) / BK;
+  issue(0, 0);
+  __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
+  __syncthreads();
+  const int arow = wm * 32 + l31, brow = wn * 32 + l31;
+  const int last_steps = (K - (nchunks - 1) * BK + 7) >> 3;
+  auto mac = [&](int c, int nsteps) {
+    const float* abuf = lds + (c & 1) * (BM2 + BN) * BK;
+    const float* bbuf = abuf + BM2 * BK;
+#pragma unroll
+    for (int s = 0; s < BK / 8; ++s) {
+      if (s < nsteps) {
+        const int q = 2 * s + lh;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(abuf + arow * BK + 4 * (q ^ (arow & 7)));
+        const f32x4 b = *reinterpret_cast<const f32x4*>(bbuf + brow * BK + 4 * (q ^ (brow & 7)));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[e], a[e], acc[0], 0, 0, 0);
+      }
+    }
+  };
+  for (int c = 0; c + 1 < nchunks; ++c) {
+    issue((c + 1) * BK, (c + 1) & 1);
+    mac(c, BK / 8);
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    __syncthreads();
+  }
+  float4 resq[4];
+  if (d.res) {
+    const int m = m0 + arow;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int n = n0 + wn * 32 + 8 * g + 4 * lh;
+      resq[g] = *reinterpret_cast<const float4*>(m < d.M && n < d.N ? d.res + (int64_t)m * d.ldres + n : zp);
+    }
+  }
+  mac(nchunks - 1, last_steps);
+  epilogue<0, float4[4], 1>(args, acc, m0, n0, 0, bias_s, resq, wm * 32, wn * 32);
+}
+
 // TN GEMM fed from registers (weight gradients dW[m][n] = sum_t dY[t][m] X[t][n]): both operands are
 // contiguous along their OUTPUT index, so an MFMA fragment is a plain coalesced row load — lane (l31, lh) reads
 // 3 consecutive dY columns and 2 consecutive X columns of token 2s + lh (buffer_load_dwordx3 / dwordx2; a
@@ -587,6 +668,7 @@ constexpr bool g_no_tnreg = false;
 #define TN_REG_ROUNDS RT_OCC
 #endif
 int g_tn_rounds = TN_REG_ROUNDS;
+int g_bm64_below = 600;   // 128 x 64 tiles of a launch below which the NT GEMM switches to 64-row tiles
 
 // register-fed TN kernel: usable when the ragged last m tile still splits into whole 3-column lane groups
 bool tn_reg_ok(int M, int N, int K) {
@@ -656,7 +738,16 @@ extern "C" int neosr_gemm(const neosr_gemm_desc* dp, void* stream) {
     neosr_prof_begin(NEOSR_PROF_GEMM_NT + d.mode, stream, 2.0 * d.M * d.N * d.K,
                      4.0 * ((double)d.M * d.K + (double)d.N * d.K + (double)d.M * d.N));
   if (d.mode == NEOSR_GEMM_NT && a.b_vec && !g_no_glds) {
-    hipLaunchKernelGGL(gemm_nt_glds_kernel, grid, dim3(256), 0, st, a);
+    // 128-row tiles when they fill the chip's resident workgroup slots at least ~twice, else 64-row tiles
+    static const int env64 = [] { const char* e = getenv("NEOSR_GEMM_BM64"); return e ? atoi(e) : -1; }();
+    const bool bm64 = env64 >= 0 ? env64 != 0 : a.tiles_m * a.tiles_n < g_bm64_below;
+    if (bm64) {
+      a.tiles_m = ceil_div(d.M, BM2);
+      grid.x = ceil_div(a.tiles_m * a.tiles_n, 8) * 8;
+      hipLaunchKernelGGL(gemm_nt_glds64_kernel, grid, dim3(256), 0, st, a);
+    } else {
+      hipLaunchKernelGGL(gemm_nt_glds_kernel, grid, dim3(256), 0, st, a);
+    }
   } else if (d.mode == NEOSR_GEMM_NT) {
     hipLaunchKernelGGL(gemm_mfma_kernel<0>, grid, dim3(256), 0, st, a);
   } else if (d.mode == NEOSR_GEMM_NN) {

@@ -25,7 +25,8 @@ def T(a):
     return torch.from_numpy(np.array(a))
 
 
-GEMM_CASES = [(200, 180, 60), (128, 64, 32), (4096, 540, 180), (333, 360, 180), (70, 8, 8), (1000, 180, 360)]
+GEMM_CASES = [(200, 180, 60), (128, 64, 32), (4096, 540, 180), (333, 360, 180), (70, 8, 8), (1000, 180, 360),
+              (32768, 540, 180), (32768, 180, 360)]  # (the last two: 128-row NT tiles; the small ones take the 64-row kernel)
 
 
 @pytest.mark.parametrize("M,N,K", GEMM_CASES)
