@@ -95,6 +95,7 @@ _PACKS: dict[tuple[int, int, int], "weakref.ref"] = {}  # (id(w), kind, mode) ->
 # capturing re-packs every registered trainable weight (whatever its cache key says), so the launch becomes a node
 # of the graph and every replay starts from the weights of that moment.
 FORCE_REPACK_IN_CAPTURE = False
+_S2D_PREMASK = __import__('os').environ.get('NEOSR_AMD_S2D_PREMASK', '1') != '0'  # A/B switch
 
 
 def _pack_key(w):
@@ -189,7 +190,7 @@ class Conv3x3(torch.autograd.Function):
         x, w, y = ctx.saved_tensors
         g = g.contiguous()
         slope = ctx.slope if ctx.act == ACT_LRELU else 0.0
-        if y is not None and ctx.s2d_c == 0:
+        if y is not None and (ctx.s2d_c == 0 or _S2D_PREMASK):
             # producer-side activation derivative: g <- g * act'(y) in ONE elementwise pass, so that neither the
             # backward-data nor the weight-gradient launch masks on load -> both are plain (packed / Winograd kernels)
             lib = _C.load()
