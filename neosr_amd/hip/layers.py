@@ -183,6 +183,12 @@ class Conv3x3(torch.autograd.Function):
         ctx.act, ctx.slope, ctx.has_bias, ctx.ups, ctx.has_res = act, slope, b is not None, ups, res is not None
         if act != ACT_NONE and res is not None:
             raise _C.NeosrAmdError("Conv3x3: activation + residual cannot be differentiated from the output")
+        # conv -> ReLU -> conv chains (VGG19): the consumer's backward-data epilogue can apply THIS layer's ReLU derivative
+        # (mask = own input > 0), which saves the producer-side elementwise pass over the gradient; see backward
+        ctx.x_is_relu_out = bool(getattr(x, "_neosr_relu_out", False)) and not ups and s2d_c == 0 \
+            and x.shape[3] == w.shape[1]
+        if act == ACT_RELU:
+            y._neosr_relu_out = True
         return y
 
     @staticmethod
@@ -190,6 +196,8 @@ class Conv3x3(torch.autograd.Function):
         x, w, y = ctx.saved_tensors
         g = g.contiguous()
         slope = ctx.slope if ctx.act == ACT_LRELU else 0.0
+        if y is not None and ctx.act == ACT_RELU and getattr(g, "_neosr_relu_masked", None) == y.data_ptr():
+            y = None  # the consumer's backward-data epilogue already multiplied g by relu'(y) (below)
         if y is not None and (ctx.s2d_c == 0 or _S2D_PREMASK):
             # producer-side activation derivative: g <- g * act'(y) in ONE elementwise pass, so that neither the
             # backward-data nor the weight-gradient launch masks on load -> both are plain (packed / Winograd kernels)
@@ -201,9 +209,17 @@ class Conv3x3(torch.autograd.Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             plain = y is None  # no activation derivative to apply on load -> packed / Winograd kernels
+            # x is the ReLU output of the layer below: fold ITS derivative into this epilogue and tell it so.  The tag
+            # only survives when this gradient is the sole contribution to x (autograd hands the same tensor on); if
+            # x has other consumers the sum arrives untagged and the layer below masks it itself — ReLU's 0 / 1 mask is
+            # idempotent, so masking twice is the same as once.
+            fold = plain and ctx.x_is_relu_out
             gx = ops.conv3x3(g, w, None, mode=ops.CONV_DGRAD, in_mask=y, mask_slope=slope,
                              w_pack=packed_weights(w, ops.CONV_DGRAD) if plain else None, s2d_c=ctx.s2d_c,
-                             w_wino=packed_wino(w, ops.CONV_DGRAD) if plain and ctx.s2d_c == 0 else None)
+                             w_wino=packed_wino(w, ops.CONV_DGRAD) if plain and ctx.s2d_c == 0 else None,
+                             out_mask=x if fold else None, out_mask_slope=0.0)
+            if fold:
+                gx._neosr_relu_masked = x.data_ptr()
             if ctx.ups:
                 gx = ops.pool2x2_sum(gx)
             if x.shape[3] > gx.shape[3]:  # conv read a channel prefix of a wider buffer
