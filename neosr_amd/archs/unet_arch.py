@@ -59,7 +59,9 @@ class unet(nn.Module):
         x6 = L.conv3x3(x5, self._w(self.conv6), None, lr, 0.2)
         if self.skip_connection:
             x6 = L.Add.apply(x6, x0)
-        out = L.conv3x3(x6, self._w(self.conv7), None, lr, 0.2)
-        out = L.conv3x3(out, self._w(self.conv8), None, lr, 0.2)
+        # conv7 -> conv8 -> conv9: each output feeds exactly one conv, so the LeakyReLU derivatives are applied in the
+        # consumers' backward-data epilogues instead of by an elementwise pass over two 256^2 x 64-channel gradients
+        out = L.conv3x3(x6, self._w(self.conv7), None, lr, 0.2, sole_consumer_is_conv=True)
+        out = L.conv3x3(out, self._w(self.conv8), None, lr, 0.2, sole_consumer_is_conv=True)
         out = L.conv3x3(out, self.conv9.weight, self.conv9.bias)
         return L.ToNCHW.apply(out, 1)

@@ -172,7 +172,7 @@ class Conv3x3(torch.autograd.Function):
     derivative applied on load; 2x2 sum-pool after it for `ups`) + multi-conv wgrad kernel."""
 
     @staticmethod
-    def forward(ctx, x, w, b, act, slope, ups, res, s2d_c=0):
+    def forward(ctx, x, w, b, act, slope, ups, res, s2d_c=0, sole_consumer_is_conv=False):
         _C.require_device(x, "x")
         w = _C.require_device(w, "weight").contiguous()
         wino = packed_wino(w, ops.CONV_FWD) if s2d_c == 0 else None  # F(2x2,3x3) kernel when eligible
@@ -183,12 +183,17 @@ class Conv3x3(torch.autograd.Function):
         ctx.act, ctx.slope, ctx.has_bias, ctx.ups, ctx.has_res = act, slope, b is not None, ups, res is not None
         if act != ACT_NONE and res is not None:
             raise _C.NeosrAmdError("Conv3x3: activation + residual cannot be differentiated from the output")
-        # conv -> ReLU -> conv chains (VGG19): the consumer's backward-data epilogue can apply THIS layer's ReLU derivative
-        # (mask = own input > 0), which saves the producer-side elementwise pass over the gradient; see backward
-        ctx.x_is_relu_out = bool(getattr(x, "_neosr_relu_out", False)) and not ups and s2d_c == 0 \
-            and x.shape[3] == w.shape[1]
+        # conv -> act -> conv chains: the consumer's backward-data epilogue can apply THIS layer's activation derivative
+        # (mask = own input > 0), which saves the producer-side elementwise pass over the gradient; see backward.
+        # ReLU (VGG19) is always offered: its 0 / 1 mask is idempotent, so a gradient that was accumulated with other
+        # contributions is simply masked again.  LeakyReLU is only offered when the caller promises that the next
+        # conv3x3 is the ONLY consumer of this output (`sole_consumer_is_conv`, the U-Net's conv7 -> conv8 -> conv9).
+        fold = getattr(x, "_neosr_act_fold", None)
+        ctx.x_fold_slope = fold if fold is not None and not ups and s2d_c == 0 and x.shape[3] == w.shape[1] else None
         if act == ACT_RELU:
-            y._neosr_relu_out = True
+            y._neosr_act_fold = 0.0
+        elif act == ACT_LRELU and sole_consumer_is_conv:
+            y._neosr_act_fold = float(slope)
         return y
 
     @staticmethod
@@ -196,8 +201,8 @@ class Conv3x3(torch.autograd.Function):
         x, w, y = ctx.saved_tensors
         g = g.contiguous()
         slope = ctx.slope if ctx.act == ACT_LRELU else 0.0
-        if y is not None and ctx.act == ACT_RELU and getattr(g, "_neosr_relu_masked", None) == y.data_ptr():
-            y = None  # the consumer's backward-data epilogue already multiplied g by relu'(y) (below)
+        if y is not None and getattr(g, "_neosr_act_masked", None) == y.data_ptr():
+            y = None  # the consumer's backward-data epilogue already multiplied g by act'(y) (below)
         if y is not None and (ctx.s2d_c == 0 or _S2D_PREMASK):
             # producer-side activation derivative: g <- g * act'(y) in ONE elementwise pass, so that neither the
             # backward-data nor the weight-gradient launch masks on load -> both are plain (packed / Winograd kernels)
@@ -209,17 +214,16 @@ class Conv3x3(torch.autograd.Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             plain = y is None  # no activation derivative to apply on load -> packed / Winograd kernels
-            # x is the ReLU output of the layer below: fold ITS derivative into this epilogue and tell it so.  The tag
-            # only survives when this gradient is the sole contribution to x (autograd hands the same tensor on); if
-            # x has other consumers the sum arrives untagged and the layer below masks it itself — ReLU's 0 / 1 mask is
-            # idempotent, so masking twice is the same as once.
-            fold = plain and ctx.x_is_relu_out
+            # x is the activation output of the layer below: fold ITS derivative into this epilogue and tell it so.  The
+            # tag only survives when this gradient is the sole contribution to x (autograd hands the same tensor on); if
+            # x has other consumers the sum arrives untagged and the layer below masks it itself (ReLU: idempotent).
+            fold = plain and ctx.x_fold_slope is not None
             gx = ops.conv3x3(g, w, None, mode=ops.CONV_DGRAD, in_mask=y, mask_slope=slope,
                              w_pack=packed_weights(w, ops.CONV_DGRAD) if plain else None, s2d_c=ctx.s2d_c,
                              w_wino=packed_wino(w, ops.CONV_DGRAD) if plain and ctx.s2d_c == 0 else None,
-                             out_mask=x if fold else None, out_mask_slope=0.0)
+                             out_mask=x if fold else None, out_mask_slope=ctx.x_fold_slope if fold else 1.0)
             if fold:
-                gx._neosr_relu_masked = x.data_ptr()
+                gx._neosr_act_masked = x.data_ptr()
             if ctx.ups:
                 gx = ops.pool2x2_sum(gx)
             if x.shape[3] > gx.shape[3]:  # conv read a channel prefix of a wider buffer
@@ -228,11 +232,11 @@ class Conv3x3(torch.autograd.Function):
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             gw, gb = ops.conv3x3_wgrad(x, g, w.shape[0], w.shape[1], g_mask=y, mask_slope=slope,
                                        want_bias=ctx.has_bias, ups=ctx.ups, s2d_c=ctx.s2d_c)
-        return gx, gw, gb, None, None, None, (g if ctx.has_res else None), None
+        return gx, gw, gb, None, None, None, (g if ctx.has_res else None), None, None
 
 
-def conv3x3(x, w, b=None, act=ACT_NONE, slope=0.0, ups=False, res=None, s2d_c=0):
-    return Conv3x3.apply(x, w, b, act, slope, ups, res, s2d_c)
+def conv3x3(x, w, b=None, act=ACT_NONE, slope=0.0, ups=False, res=None, s2d_c=0, sole_consumer_is_conv=False):
+    return Conv3x3.apply(x, w, b, act, slope, ups, res, s2d_c, sole_consumer_is_conv)
 
 
 class SpaceToDepth2(torch.autograd.Function):
