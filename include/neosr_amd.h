@@ -429,20 +429,20 @@ typedef struct neosr_wattn_desc {
 } neosr_wattn_desc;
 int neosr_window_attention_fwd(const neosr_wattn_desc* d, void* stream);
 int neosr_window_attention_bwd(const neosr_wattn_desc* d, void* stream);
-/* 16x16-window attention of HAT on the fused qkv matrix [B*H*W, 3*C] in image order:
- *   ks == 16: (shifted-)window self-attention of HAB (hat_arch.py:168-216 inside :299-351), rel-pos
- *             index (yi-yj+15)*31 + (xi-xj+15), shift mask as in neosr_window_attention;
- *   ks == 24: overlapping cross-attention of OCAB (hat_arch.py:445-516): queries = the 16x16 window,
- *             keys/values = the zero-padded 24x24 window around it (nn.Unfold(24, stride 16, pad 4)),
- *             rel-pos index per calculate_rpi_oca (hat_arch.py:1035-1068) including its negative-index
- *             wrap-around into the 1521-row table; shift must be 0.
+/* Window attention of HAT on the fused qkv matrix [B*H*W, 3*C] in image order, windows of ws = 16 (hat_s / m / l) or 8:
+ *   ks == ws:     (shifted-)window self-attention of HAB (hat_arch.py:168-216 inside :299-351), rel-pos
+ *                 index (yi-yj+ws-1)*(2ws-1) + (xi-xj+ws-1), shift mask as in neosr_window_attention;
+ *   ks == 1.5 ws: overlapping cross-attention of OCAB (hat_arch.py:445-516): queries = the ws x ws window,
+ *                 keys/values = the zero-padded ks x ks window around it (nn.Unfold(ks, stride ws, pad ws/4)),
+ *                 rel-pos index per calculate_rpi_oca (hat_arch.py:1035-1068) including its negative-index
+ *                 wrap-around into the (ws+ks-1)^2-row table; shift must be 0.
  * Streams 64-key blocks past 64-query blocks with an online softmax (one workgroup per window, head and
- * query block).  fwd: out [B*H*W, C], lse [B*nW*heads*256].  bwd: dqkv [B*H*W, 3*C] fully written,
+ * query block).  fwd: out [B*H*W, C], lse [B*nW*heads*ws*ws].  bwd: dqkv [B*H*W, 3*C] fully written,
  * d_rpb_table (+)= ; needs `out` (forward result) and workspace of
  * neosr_flash_window_attention_workspace_bytes().  Deterministic (no float atomics). */
 typedef struct neosr_fattn_desc {
   const float* qkv;
-  const float* rpb_table; /* ((16+ks-1)^2, heads) */
+  const float* rpb_table; /* ((ws+ks-1)^2, heads) */
   float* out;
   float* lse;
   const float* dout;   /* bwd */

@@ -106,7 +106,8 @@ class HAB(nn.Module):
         a = self.attn
         x, y = T.residual_layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)  # (shortcut, norm)
         qkv = T.linear(y, a.qkv.weight, a.qkv.bias)
-        at = T.flash_window_attention(qkv, a.relative_position_bias_table, self.num_heads, 16, self.shift_size, a.scale)
+        at = T.flash_window_attention(qkv, a.relative_position_bias_table, self.num_heads, self.window_size,
+                                      self.shift_size, a.scale, self.window_size)
         x = T.linear(at, a.proj.weight, a.proj.bias, x, drop_scale(self.drop_prob, self.training, b, x.device), h * w)
         x = self.conv_block(y, x, self.conv_scale)
         x, y = T.residual_layer_norm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
@@ -134,7 +135,7 @@ class OCAB(nn.Module):
         x, y = T.residual_layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)  # (shortcut, norm)
         qkv = T.linear(y, self.qkv.weight, self.qkv.bias)
         at = T.flash_window_attention(qkv, self.relative_position_bias_table, self.num_heads, self.overlap_win_size, 0,
-                                      self.scale)
+                                      self.scale, self.window_size)
         x = T.linear(at, self.proj.weight, self.proj.bias, x)
         x, y = T.residual_layer_norm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
         return T.mlp(y, self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight, self.mlp.fc2.bias, x)
@@ -187,9 +188,9 @@ class hat(nn.Module):
         super().__init__()
         if ape or drop_rate or attn_drop_rate or patch_size != 1 or norm_layer is not nn.LayerNorm:
             raise _C.NeosrAmdError("hat: ape / dropout / patch_size != 1 are not implemented")
-        if window_size != 16 or int(window_size * overlap_ratio) != 8:
-            raise _C.NeosrAmdError("hat: the attention kernels implement window_size 16 with overlap_ratio 0.5 "
-                                   "(hat_s / hat_m / hat_l)")
+        if window_size not in (16, 8) or 2 * int(window_size * overlap_ratio) != window_size:
+            raise _C.NeosrAmdError("hat: the attention kernels implement window_size 16 (hat_s / hat_m / hat_l) or 8, "
+                                   "with overlap_ratio 0.5")
         if upsampler != "pixelshuffle":
             raise _C.NeosrAmdError("hat: only upsampler='pixelshuffle' does anything in the reference forward "
                                    "(hat_arch.py:1134-1147)")
@@ -245,8 +246,9 @@ class hat(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         _C.require_device(x, "x")
-        if x.shape[2] % 16 or x.shape[3] % 16:
-            raise _C.NeosrAmdError(f"hat: input {tuple(x.shape[2:])} must be a multiple of window_size 16")
+        if x.shape[2] % self.window_size or x.shape[3] % self.window_size:
+            raise _C.NeosrAmdError(f"hat: input {tuple(x.shape[2:])} must be a multiple of window_size "
+                                   f"{self.window_size}")
         t = L.VGGInput.apply(x, self.mean, 1.0 / self.img_range, (self.in_chans + 3) // 4 * 4)
         x0 = L.conv3x3(t, self.conv_first.weight, self.conv_first.bias)
         tok = x0

@@ -1,6 +1,7 @@
-// attn_flash.hip — 16x16-window attention of HAT for gfx950: 256 query tokens against 256 keys of the
-// same (shifted) window (HAB, neosr/archs/hat_arch.py:168-216 inside :299-351) or against the 576
-// keys of the overlapping 24x24 window (OCAB, hat_arch.py:445-516).
+// attn_flash.hip — window attention of HAT for gfx950 (template <WS, KS>: 16/16, 16/24 = hat_s / m / l; 8/8, 8/12 =
+// window_size 8): WS*WS query tokens against the WS*WS keys of the same (shifted) window (HAB,
+// neosr/archs/hat_arch.py:168-216 inside :299-351) or against the KS*KS keys of the overlapping window (OCAB,
+// hat_arch.py:445-516).  The comments below speak of the 16 / 24 case.
 //
 // A 256 x 576 score matrix does not fit in LDS, so the kernels stream 64-key blocks past a 64-query
 // block with an online softmax (running max / sum per row, accumulator rescaled per block); one
@@ -142,7 +143,6 @@ __device__ __forceinline__ f32x16 mm_abt(f32x16 acc, const float* A, int sa, con
                                          int tj, int kdim, int l31, int lh) {
   const float* ap = A + (32 * ti + l31) * sa + lh;
   const float* bp = B + (32 * tj + l31) * sb + lh;
-#pragma unroll 5
   for (int ks = 0; ks < kdim / 2; ++ks)
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * ks], bp[2 * ks], acc, 0, 0, 0);
   return acc;
@@ -152,7 +152,6 @@ __device__ __forceinline__ f32x16 mm_abt(f32x16 acc, const float* A, int sa, con
 __device__ __forceinline__ void mm_abt_pair(f32x16& acc1, const float* A1, const float* B1, f32x16& acc2, const float* A2,
                                             const float* B2, int sa, int sb, int ti, int tj, int kdim, int l31, int lh) {
   const int ao = (32 * ti + l31) * sa + lh, bo = (32 * tj + l31) * sb + lh;
-#pragma unroll 5
   for (int ks = 0; ks < kdim / 2; ++ks) {
     const float a1 = A1[ao + 2 * ks], b1 = B1[bo + 2 * ks], a2 = A2[ao + 2 * ks], b2 = B2[bo + 2 * ks];
     acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc1, 0, 0, 0);
@@ -312,6 +311,7 @@ struct SharedBwd {
   int qpk[QB], kpk[QB], qtok[QB], ktok[QB];
   float lse[QB], dsum[QB];
   float bins[31 * 31];  // self-attention dQ pass: this workgroup's share of the relative-position-bias gradient
+                        // ((2 WS - 1)^2 bins, WS <= 16)
 };
 
 struct BwdWs {  // carve-up of the backward workspace (floats)
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256) void flash_wattn_bwd_dq_kernel(const neosr_fat
   }
   for (int k = tid; k < G::NBINS; k += 256) S.tab[k] = d.rpb_table[k * d.heads + w.head];
   if (G::SELF)
-    for (int k = tid; k < 31 * 31; k += 256) S.bins[k] = 0.f;
+    for (int k = tid; k < G::NBINS; k += 256) S.bins[k] = 0.f;
   __syncthreads();
   {
     float q[8], g[8], o[8];
@@ -421,27 +421,30 @@ __global__ __launch_bounds__(256) void flash_wattn_bwd_dq_kernel(const neosr_fat
     }
     recompute_p_ds<G::NBINS, G::SELF>(S, kq, wave, l31, lh);
     if (G::SELF) {
-      // bias gradient of this 64-query x 64-key tile, owner-computes: the tile is 4 x 4 window rows of 16, so it
-      // touches 7 x 31 bins (dy = yi - yj, dx = xi - xj) and thread t < 217 sums the pairs of ITS bin in a fixed
-      // order (64 predicated LDS reads, out-of-window pairs read element 0 and add 0) into the workgroup's 31 x 31
-      // accumulator — no dS dump to HBM (it was 256 x 256 floats per (window, head): 100 MB per call at B = 4)
-      if (tid < 7 * 31) {
-        const int dyi = tid / 31, dx = tid % 31 - 15;
+      // bias gradient of this 64-query x 64-key tile, owner-computes: the tile is RQ x RQ window rows of WS (4 x 4 rows of
+      // 16, or the whole 8 x 8 window), so it touches (2 RQ - 1) x (2 WS - 1) bins (dy = yi - yj, dx = xi - xj) and thread
+      // t sums the pairs of ITS bin in a fixed order (64 predicated LDS reads, out-of-window pairs read element 0 and
+      // add 0) into the workgroup's accumulator — no dS dump to HBM (it was 256 x 256 floats per (window, head): 100 MB
+      // per call at B = 4)
+      constexpr int RQ = QB / WS, NB1 = 2 * WS - 1;
+      static_assert((2 * RQ - 1) * NB1 <= 256, "one bin of the tile per thread");
+      if (tid < (2 * RQ - 1) * NB1) {
+        const int dyi = tid / NB1, dx = tid % NB1 - (WS - 1);
         float s = 0.f;
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-          const int b = a - (dyi - 3);  // key row of the tile paired with query row a
-          const bool oky = b >= 0 && b < 4;
+        for (int a = 0; a < RQ; ++a) {
+          const int b = a - (dyi - (RQ - 1));  // key row of the tile paired with query row a
+          const bool oky = b >= 0 && b < RQ;
 #pragma unroll
-          for (int xi = 0; xi < 16; ++xi) {
+          for (int xi = 0; xi < WS; ++xi) {
             const int xj = xi - dx;
-            const bool ok = oky && xj >= 0 && xj < 16;
-            const float v = S.dS[ok ? (a * 16 + xi) * PS + b * 16 + xj : 0];
+            const bool ok = oky && xj >= 0 && xj < WS;
+            const float v = S.dS[ok ? (a * WS + xi) * PS + b * WS + xj : 0];
             s += ok ? v : 0.f;
           }
         }
-        const int dy = 4 * (w.qb - kb) - 3 + dyi;
-        if (dy > -16 && dy < 16) S.bins[(dy + 15) * 31 + dx + 15] += s;
+        const int dy = RQ * (w.qb - kb) - (RQ - 1) + dyi;
+        if (dy > -WS && dy < WS) S.bins[(dy + WS - 1) * NB1 + dx + WS - 1] += s;
       }
     } else {  // dump this dS tile (rows n, 16 columns per thread) for the bias gradient
       const float* gr = S.dS + n * PS + part * 16;
@@ -455,8 +458,8 @@ __global__ __launch_bounds__(256) void flash_wattn_bwd_dq_kernel(const neosr_fat
   if (G::SELF) {  // partial bins of (window, query block): row (bw index, qb) of a [rows][bin][head] matrix
     __syncthreads();
     float* row = d.workspace + ws.ds_full +
-                 ((int64_t)(bid / (d.heads * G::NQB)) * G::NQB + w.qb) * (31 * 31) * d.heads + w.head;
-    for (int k = tid; k < 31 * 31; k += 256) row[(int64_t)k * d.heads] = S.bins[k];
+                 ((int64_t)(bid / (d.heads * G::NQB)) * G::NQB + w.qb) * G::NBINS * d.heads + w.head;
+    for (int k = tid; k < G::NBINS; k += 256) row[(int64_t)k * d.heads] = S.bins[k];
   }
   if (wave < 2 && l31 < hd) {
     float* g = d.dqkv + w.head * hd + l31;
@@ -640,12 +643,12 @@ int launch_bwd(const neosr_fattn_desc& d, hipStream_t st) {
 int check(const neosr_fattn_desc* d) {
   NEOSR_CHECK(d && d->qkv && d->rpb_table, "flash_window_attention: null tensor");
   NEOSR_CHECK(d->B > 0 && d->H > 0 && d->W > 0 && d->C > 0 && d->heads > 0, "flash_window_attention: bad geometry");
-  NEOSR_CHECK(d->ws == 16 && (d->ks == 16 || d->ks == 24),
-              "flash_window_attention: window 16 with key window 16 (self) or 24 (overlapping) only (got %d / %d)",
-              d->ws, d->ks);
-  NEOSR_CHECK(d->H % 16 == 0 && d->W % 16 == 0, "flash_window_attention: H, W must be multiples of 16");
+  NEOSR_CHECK((d->ws == 16 && (d->ks == 16 || d->ks == 24)) || (d->ws == 8 && (d->ks == 8 || d->ks == 12)),
+              "flash_window_attention: window 16 or 8 with the same key window (self) or 1.5x (overlapping) only "
+              "(got %d / %d)", d->ws, d->ks);
+  NEOSR_CHECK(d->H % d->ws == 0 && d->W % d->ws == 0, "flash_window_attention: H, W must be multiples of the window");
   NEOSR_CHECK(d->C % d->heads == 0 && d->C / d->heads <= 32, "flash_window_attention: head_dim must be <= 32");
-  NEOSR_CHECK(d->shift >= 0 && d->shift < 16 && (d->ks == 16 || d->shift == 0),
+  NEOSR_CHECK(d->shift >= 0 && d->shift < d->ws && (d->ks == d->ws || d->shift == 0),
               "flash_window_attention: bad shift");
   return 0;
 }
@@ -655,22 +658,24 @@ int check(const neosr_fattn_desc* d) {
 extern "C" int neosr_flash_window_attention_fwd(const neosr_fattn_desc* d, void* stream) {
   if (int rc = check(d)) return rc;
   NEOSR_CHECK(d->out, "flash_window_attention_fwd: out missing");
-  const int nblk = d->B * (d->H / 16) * (d->W / 16) * d->heads * 4;
+  const int nblk = d->B * (d->H / d->ws) * (d->W / d->ws) * d->heads * (d->ws * d->ws / QB);
   const bool prof = neosr_prof_on();
   if (prof)
     neosr_prof_begin(NEOSR_PROF_ATTN_FWD, stream, 4.0 * d->ks * d->ks * (double)d->B * d->H * d->W * d->C,
                      4.0 * (double)d->B * d->H * d->W * 4 * d->C);
-  if (d->ks == 16)
-    hipLaunchKernelGGL((flash_wattn_fwd_kernel<16, 16>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, *d);
-  else
-    hipLaunchKernelGGL((flash_wattn_fwd_kernel<16, 24>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, *d);
+  const dim3 grid(nblk), blk(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (d->ws == 16 && d->ks == 16) hipLaunchKernelGGL((flash_wattn_fwd_kernel<16, 16>), grid, blk, 0, st, *d);
+  else if (d->ws == 16) hipLaunchKernelGGL((flash_wattn_fwd_kernel<16, 24>), grid, blk, 0, st, *d);
+  else if (d->ks == 8) hipLaunchKernelGGL((flash_wattn_fwd_kernel<8, 8>), grid, blk, 0, st, *d);
+  else hipLaunchKernelGGL((flash_wattn_fwd_kernel<8, 12>), grid, blk, 0, st, *d);
   if (prof) neosr_prof_end(stream);
   NEOSR_LAUNCH_CHECK();
   return 0;
 }
 
 extern "C" int64_t neosr_flash_window_attention_workspace_bytes(const neosr_fattn_desc* d) {
-  if (!d || d->ws != 16 || (d->ks != 16 && d->ks != 24) || d->B <= 0) return 0;
+  if (!d || check(d) || d->B <= 0) return 0;
   return bwd_ws(*d).total * 4;
 }
 
@@ -678,5 +683,7 @@ extern "C" int neosr_flash_window_attention_bwd(const neosr_fattn_desc* d, void*
   if (int rc = check(d)) return rc;
   NEOSR_CHECK(d->out && d->dout && d->dqkv && d->lse && d->d_rpb_table && d->workspace,
               "flash_window_attention_bwd: null tensor");
-  return d->ks == 16 ? launch_bwd<16, 16>(*d, (hipStream_t)stream) : launch_bwd<16, 24>(*d, (hipStream_t)stream);
+  hipStream_t st = (hipStream_t)stream;
+  if (d->ws == 16) return d->ks == 16 ? launch_bwd<16, 16>(*d, st) : launch_bwd<16, 24>(*d, st);
+  return d->ks == 8 ? launch_bwd<8, 8>(*d, st) : launch_bwd<8, 12>(*d, st);
 }

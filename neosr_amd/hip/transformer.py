@@ -324,45 +324,46 @@ class Affine(torch.autograd.Function):
 
 
 class FlashWindowAttention(torch.autograd.Function):
-    """16x16-window attention of HAT on the fused qkv matrix (B, H, W, 3C): `ks=16` = (shifted-)window
-    self-attention of HAB, `ks=24` = overlapping cross-attention of OCAB (hat_arch.py:168-216, 445-516)."""
+    """Window attention of HAT on the fused qkv matrix (B, H, W, 3C), windows of `ws` = 16 (hat_s / m / l) or 8:
+    `ks = ws` = (shifted-)window self-attention of HAB, `ks = 1.5 ws` = overlapping cross-attention of OCAB
+    (hat_arch.py:168-216, 445-516)."""
 
     @staticmethod
-    def forward(ctx, qkv, table, heads, ks, shift, scale):
+    def forward(ctx, qkv, table, heads, ks, shift, scale, ws):
         lib = _C.load()
         qkv = _C.require_device(qkv, "qkv").contiguous()
         table = _C.require_device(table, "relative_position_bias_table").contiguous()
         B, H, W, C3 = qkv.shape
         C_ = C3 // 3
         out = _new((B, H, W, C_), qkv)
-        lse = _new((B * (H // 16) * (W // 16) * heads * 256,), qkv)
+        lse = _new((B * (H // ws) * (W // ws) * heads * ws * ws,), qkv)
         d = _C.FattnDesc(qkv=qkv.data_ptr(), rpb_table=table.data_ptr(), out=out.data_ptr(), lse=lse.data_ptr(),
-                         B=B, H=H, W=W, C=C_, heads=heads, ws=16, ks=ks, shift=shift, accumulate_rpb=0, scale=scale)
+                         B=B, H=H, W=W, C=C_, heads=heads, ws=ws, ks=ks, shift=shift, accumulate_rpb=0, scale=scale)
         _C.check(lib.neosr_flash_window_attention_fwd(d, _st()), "neosr_flash_window_attention_fwd")
         ctx.save_for_backward(qkv, table, out, lse)
-        ctx.meta = (B, H, W, C_, heads, ks, shift, scale)
+        ctx.meta = (B, H, W, C_, heads, ks, shift, scale, ws)
         return out
 
     @staticmethod
     def backward(ctx, g):
         lib = _C.load()
         qkv, table, out, lse = ctx.saved_tensors
-        B, H, W, C_, heads, ks, shift, scale = ctx.meta
+        B, H, W, C_, heads, ks, shift, scale, ws = ctx.meta
         g = g.contiguous()
         dqkv = torch.empty_like(qkv)
         dtab = torch.empty_like(table)
         d = _C.FattnDesc(qkv=qkv.data_ptr(), rpb_table=table.data_ptr(), out=out.data_ptr(), lse=lse.data_ptr(),
                          dout=g.data_ptr(), dqkv=dqkv.data_ptr(), d_rpb_table=dtab.data_ptr(), workspace=None,
-                         B=B, H=H, W=W, C=C_, heads=heads, ws=16, ks=ks, shift=shift, accumulate_rpb=0, scale=scale)
+                         B=B, H=H, W=W, C=C_, heads=heads, ws=ws, ks=ks, shift=shift, accumulate_rpb=0, scale=scale)
         wsp = torch.empty(lib.neosr_flash_window_attention_workspace_bytes(d) // 4, device=qkv.device,
                           dtype=torch.float32)
         d.workspace = wsp.data_ptr()
         _C.check(lib.neosr_flash_window_attention_bwd(d, _st()), "neosr_flash_window_attention_bwd")
-        return dqkv, dtab, None, None, None, None
+        return dqkv, dtab, None, None, None, None, None
 
 
-def flash_window_attention(qkv, table, heads, ks, shift, scale):
-    return FlashWindowAttention.apply(qkv, table, heads, ks, shift, scale)
+def flash_window_attention(qkv, table, heads, ks, shift, scale, ws=16):
+    return FlashWindowAttention.apply(qkv, table, heads, ks, shift, scale, ws)
 
 
 class Gelu(torch.autograd.Function):

@@ -177,6 +177,29 @@ def test_tiny_hat_net_vs_reference_fixture():
     assert worst[0] < 1e-3, worst
 
 
+def test_tiny_hat_window8_vs_reference_fixture():
+    """hat with window_size 8: HAB on 8x8 windows (shift 4, all nine mask regions), OCAB with 12x12 zero-padded key windows
+    (the <8, 8> / <8, 12> instantiations of the streaming attention kernels), forward + every gradient vs the reference"""
+    from neosr_amd.archs.hat_arch import hat
+
+    fix = load_golden("hat_w8.npz")
+    net = hat(img_size=16, embed_dim=24, depths=(2, 2), num_heads=(2, 2), window_size=8, compress_ratio=3,
+              squeeze_factor=6, mlp_ratio=2, drop_path_rate=0.0, upsampler="pixelshuffle", upscale=4)
+    assert list(net.state_dict().keys()) == [str(k) for k in fix["keys"]]
+    net.load_state_dict(group(fix, "p"), strict=False)
+    net = net.to(DEV).train()
+    x = T(fix["x"]).to(DEV).requires_grad_(True)
+    y = net(x)
+    (y * T(fix["r"]).to(DEV)).sum().backward()
+    assert rel_err(y, T(fix["y"])) < 1e-4
+    assert rel_err(x.grad, T(fix["gx"])) < 1e-3
+    named = dict(net.named_parameters())
+    worst = max((rel_err(named[k].grad, g), k) for k, g in group(fix, "g").items())
+    assert worst[0] < 1e-3, worst
+    with pytest.raises(Exception, match="window_size"):
+        hat(img_size=16, embed_dim=24, depths=(2,), num_heads=(2,), window_size=12, upsampler="pixelshuffle", upscale=4)
+
+
 def test_hat_l_forward_b1_vs_reference_fixture():
     """BASELINE configs[4] generator at full size: seeded init identical to the reference, forward at 64x64 LR"""
     from neosr_amd.archs import hat_arch as A

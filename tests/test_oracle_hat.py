@@ -75,6 +75,21 @@ def test_tiny_hat_forward_backward():
         assert rel_err(P[k].grad, g) < 2e-4, k
 
 
+def test_tiny_hat_window8_forward_backward():
+    """window_size 8 (shift 4, 12x12 overlapping key windows), two RHAGs, 16x24 tokens: the oracle against the reference run"""
+    fix = load_golden("hat_w8.npz")
+    P = group(fix, "p")
+    for v in P.values():
+        v.requires_grad_(True)
+    x = T(fix["x"]).requires_grad_(True)
+    y = ho.hat_forward(P, x, depths=(2, 2), num_heads=(2, 2), embed_dim=24, window_size=8)
+    assert rel_err(y, T(fix["y"])) < 1e-5
+    (y * T(fix["r"])).sum().backward()
+    assert rel_err(x.grad, T(fix["gx"])) < 1e-4
+    for k, g in group(fix, "g").items():
+        assert rel_err(P[k].grad, g) < 2e-4, k
+
+
 def _sums(sd):
     return np.array([float(v.double().sum()) for v in sd.values()])
 
