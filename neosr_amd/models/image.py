@@ -15,6 +15,8 @@ doing something else.
 
 from __future__ import annotations
 
+import math
+
 import sys
 from collections import OrderedDict
 from copy import deepcopy
@@ -23,7 +25,7 @@ from typing import Any
 import torch
 from torch import Tensor, nn
 
-from neosr_amd import optimizers
+from neosr_amd import _C, optimizers
 from neosr_amd.archs import build_network
 from neosr_amd.data.augmentations import apply_augment, resize_aa
 from neosr_amd.data.draws import LiveDraws
@@ -67,7 +69,7 @@ class EMAModel(nn.Module):
         return self._count == 0
 
 
-_UNSUPPORTED_TRAIN_FLAGS = ("eco", "wavelet_guided")
+_UNSUPPORTED_TRAIN_FLAGS = ("wavelet_guided",)
 _UNSUPPORTED_LOSSES = ("dists_opt", "ldl_opt", "ff_opt", "gw_opt")
 
 
@@ -106,6 +108,15 @@ class image(base):
         for key in _UNSUPPORTED_LOSSES:
             if train_opt.get(key):
                 raise NotImplementedError(f"train.{key}: no HIP implementation yet (next rows of SURVEY §8)")
+
+        # Empirical Centroid-oriented Optimization (image.py:136-142,236-238)
+        self.eco = train_opt.get("eco", False)
+        self.eco_schedule = train_opt.get("eco_schedule", "sigmoid")
+        self.eco_iters = train_opt.get("eco_iters", 80000)
+        self.eco_init = train_opt.get("eco_init", 15000)
+        self.pretrain = self.opt["path"].get("pretrain_network_g", None)
+        if self.eco:
+            logger.info("Using Empirical Centroid-oriented Optimization (ECO).")
 
         self.ema = train_opt.get("ema", -1)
         if self.ema > 0:
@@ -270,6 +281,33 @@ class image(base):
             ps = self._d_param_list = list(self.net_d.parameters())
         return ps
 
+    def eco_strategy(self, current_iter: int):
+        """`train.eco` (image.py:393-418, "Empirical Centroid-oriented Optimization", arXiv 2312.17526): a no-grad
+        prediction pulls the target towards what the network already produces — GT centroid (1-a) G(lq) + a gt, LQ centroid
+        (1-a) clamp(bicubic-antialias down(G(lq))) + a lq — and the step is taken on the prediction from the LQ centroid;
+        a follows a sigmoid (skewed at 0.25 eco_iters) or linear schedule."""
+        lib = _C.load()
+        if self.eco_schedule == "sigmoid":
+            a = 1 / (1 + math.exp(-1 * (10 * (current_iter / self.eco_iters - 0.25))))
+        else:
+            a = min(current_iter / self.eco_iters, 1.0)
+        with torch.no_grad():
+            if self._sync_g is not None:
+                armed, self._sync_g.armed = self._sync_g.armed, False
+            net_output = self.net_g(self.lq).contiguous()
+            if self._sync_g is not None:
+                self._sync_g.armed = armed
+            lq_scaled = resize_aa(net_output, net_output.shape[2] // self.scale, net_output.shape[3] // self.scale,
+                                  "bicubic", clamp=True)  # clamp(., 0, 1)
+            gt = self.gt.contiguous()
+            # p <- p + w (end - p):  (1-a) net_output + a gt   and   (1-a) lq_scaled + a lq
+            _C.check(lib.neosr_lerp(net_output.data_ptr(), gt.data_ptr(), net_output.numel(), float(a), _C.stream_ptr()),
+                     "neosr_lerp")
+            lq = self.lq.contiguous()
+            _C.check(lib.neosr_lerp(lq_scaled.data_ptr(), lq.data_ptr(), lq_scaled.numel(), float(a), _C.stream_ptr()),
+                     "neosr_lerp")
+        return self.net_g(lq_scaled), net_output
+
     def closure(self, current_iter: int):  # noqa: ARG002
         """image.py:427-625: G forward, weighted losses, G backward; then D real/fake forward+backward."""
         if self.net_d is not None:
@@ -283,7 +321,10 @@ class image(base):
 
         if self._sync_g is not None:  # buckets may go during backward only if this backward is the one stepped
             self._sync_g.armed = step_now and self.accum_iters == 1 and not self._sam_now
-        self.output = self.net_g(self.lq)
+        if self.eco and current_iter <= self.eco_iters and not (current_iter < self.eco_init and self.pretrain is None):
+            self.output, self.gt = self.eco_strategy(current_iter)  # image.py:441-446
+        else:
+            self.output = self.net_g(self.lq)
 
         l_g_total = torch.zeros(1, device=self.device)
         loss_dict = OrderedDict()

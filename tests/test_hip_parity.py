@@ -574,6 +574,30 @@ def test_image_model_trajectory_vs_reference_fixture(arch):
     assert int(esd["n_averaged"]) == 3
 
 
+def test_image_model_eco_trajectory_vs_reference_fixture():
+    """`train.eco` (image.py:393-418): 5 iterations around eco_init = 2 / eco_iters = 4 — a plain step, three ECO steps
+    (no-grad prediction, GT and LQ centroids, step on the prediction from the LQ centroid), a plain step — vs the reference"""
+    from neosr_amd.models import build_model
+    from neosr_amd.utils.options import parse_options
+    from tests.conftest import GOLDEN, ROOT
+
+    fix = load_golden("step_eco.npz")
+    opt, _ = parse_options(str(ROOT), True, argv=["-opt", str(GOLDEN / "golden_eco.toml")])
+    model = build_model(opt)
+    model.net_g.load_state_dict(group(fix, "init"))
+    for it in range(1, 6):
+        model.feed_data({"lq": torch.from_numpy(fix[f"lq{it}"]), "gt": torch.from_numpy(fix[f"gt{it}"])})
+        model.optimize_parameters(it)
+        log = model.get_current_log()
+        assert abs(log["l_g_pix"] - fix["log"][it - 1, 0]) < 1e-4 * fix["log"][it - 1, 0], it
+        assert rel_err(model.gt, torch.from_numpy(fix[f"gt_used{it}"])) < 1e-5, it  # the GT centroid of iterations 2-4
+        assert rel_err(model.output, torch.from_numpy(fix[f"out{it}"])) < 1e-3, it
+    final, ema = group(fix, "final"), group(fix, "ema")
+    sd, esd = model.net_g.state_dict(), model.net_g_ema.state_dict()
+    assert max(rel_err(sd[k], v) for k, v in final.items()) < 1e-3
+    assert max(rel_err(esd[k], v) for k, v in ema.items() if k != "n_averaged") < 1e-3
+
+
 def test_pack_many_equals_per_layer_packing():
     """neosr_conv3x3_pack_many (both image kinds, both modes, many layers per launch) writes exactly what the per-layer
     entry points write; the cached images of a layer stack are refreshed by one batched call after a parameter change"""

@@ -147,9 +147,9 @@ def test_unsupported_options_fail_loudly():
             self.opt = opt
             self.is_train = True
 
-    opt = {"train": {"eco": True, "optim_g": {"type": "adamw", "lr": 1e-4}}, "datasets": {"train": {}},
+    opt = {"train": {"wavelet_guided": True, "optim_g": {"type": "adamw", "lr": 1e-4}}, "datasets": {"train": {}},
            "scale": 4}
-    with pytest.raises(NotImplementedError, match="eco"):
+    with pytest.raises(NotImplementedError, match="wavelet_guided"):
         Dummy(opt).init_training_settings()
     # SAM is supported, but not together with gradient accumulation (image.py:251-257)
     opt = {"train": {"sam": "fsam", "optim_g": {"type": "adamw", "lr": 1e-4}},
