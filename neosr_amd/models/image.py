@@ -114,7 +114,7 @@ class image(base):
         self.eco_schedule = train_opt.get("eco_schedule", "sigmoid")
         self.eco_iters = train_opt.get("eco_iters", 80000)
         self.eco_init = train_opt.get("eco_init", 15000)
-        self.pretrain = self.opt["path"].get("pretrain_network_g", None)
+        self.pretrain = (self.opt.get("path") or {}).get("pretrain_network_g", None)
         if self.eco:
             logger.info("Using Empirical Centroid-oriented Optimization (ECO).")
 
