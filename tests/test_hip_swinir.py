@@ -72,6 +72,52 @@ def test_gemm_tn_weight_gradient_with_bias_sum(Mo, No, T_):
     assert torch.equal(gw2, first[0]) and rel_err(sep, refb) < 1e-5  # (two-stage column sum: other rounding order)
 
 
+def test_gemm_random_shapes_all_modes_and_epilogues():
+    """Seeded sweep over odd shapes: every GEMM kernel (128- and 64-row NT tiles with trimmed last chunk / skipped column
+    tile / LDS bias / prefetched residual, staged NN, register-fed and staged TN) and every epilogue against float64."""
+    from neosr_amd import _C
+    from neosr_amd.hip import transformer as tr
+
+    rng = np.random.default_rng(20260928)
+    g = torch.Generator().manual_seed(4)
+    for case in range(24):
+        M = int(rng.choice([4, 60, 128, 516, 1000, 4100, 9000, 20000]))
+        N = 4 * int(rng.integers(1, 150))
+        K = 4 * int(rng.integers(1, 100))
+        A, W = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g)
+        b, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+        rps = max(1, M // int(rng.integers(1, 5)))
+        rs = torch.rand(-(-M // rps), generator=g) + 0.5
+        Ad, Wd = A.to(DEV), W.to(DEV)
+        ref = A.double() @ W.double().t() + b.double()
+        mode = case % 3
+        if mode == 0:  # bias + DropPath row scale + residual
+            y = tr.gemm(_C.GEMM_NT, Ad, Wd, M, N, K, bias=b.to(DEV), res=res.to(DEV), row_scale=rs.to(DEV), rows_per_scale=rps)
+            want = ref * rs.double().repeat_interleave(rps)[:M, None] + res.double()
+        elif mode == 1:  # bias + GELU, pre-activation kept
+            aux = torch.empty(M, N, device=DEV)
+            y = tr.gemm(_C.GEMM_NT, Ad, Wd, M, N, K, bias=b.to(DEV), gelu=True, aux_out=aux)
+            want = torch.nn.functional.gelu(ref)
+            assert rel_err(aux, ref) < 1e-5, (case, M, N, K)
+        else:  # bare
+            y = tr.gemm(_C.GEMM_NT, Ad, Wd, M, N, K)
+            want = A.double() @ W.double().t()
+        assert rel_err(y, want) < 2e-5, (case, "NT", M, N, K)
+        G = torch.randn(M, N, generator=g)
+        Gd = G.to(DEV)
+        gx = tr.gemm(_C.GEMM_NN, Gd, Wd, M, K, N)
+        assert rel_err(gx, G.double() @ W.double()) < 1e-5, (case, "NN", M, N, K)
+        z = torch.randn(M, K, generator=g)
+        gz = tr.gemm(_C.GEMM_NN, Gd, Wd, M, K, N, aux_in=z.to(DEV))  # x GELU'(z)
+        zz = z.double().requires_grad_(True)
+        torch.nn.functional.gelu(zz).sum().backward()
+        assert rel_err(gz, (G.double() @ W.double()) * zz.grad) < 2e-5, (case, "NN gelu'", M, N, K)
+        gw, gb = tr._wgrad_pair(Gd, N, K, True)
+        tr.gemm(_C.GEMM_TN, Gd, Ad, N, K, M, out=gw, colsum_a=gb)
+        assert rel_err(gw, G.double().t() @ A.double()) < 1e-5, (case, "TN", M, N, K)
+        assert rel_err(gb, G.double().sum(0)) < 1e-5, (case, "TN bias", M, N, K)
+
+
 def test_gemm_weight_at_unaligned_arena_offset():
     """weights living at a 4-byte-aligned (not 16-byte) offset of the packed parameter arena"""
     from neosr_amd import _C
