@@ -20,6 +20,7 @@
 #include "common.h"
 #include "../../include/neosr_amd.h"
 #include "prof.h"
+#include "attn_wave.h"
 
 namespace {
 
@@ -665,7 +666,9 @@ extern "C" int neosr_flash_window_attention_fwd(const neosr_fattn_desc* d, void*
                      4.0 * (double)d->B * d->H * d->W * 4 * d->C);
   const dim3 grid(nblk), blk(256);
   hipStream_t st = (hipStream_t)stream;
-  if (d->ws == 16 && d->ks == 16) hipLaunchKernelGGL((flash_wattn_fwd_kernel<16, 16>), grid, blk, 0, st, *d);
+  static const bool streaming = getenv("NEOSR_FATTN_STREAMING") != nullptr;  // A/B switch
+  if (neosr_wattn::wave16_ok(*d) && !streaming) neosr_wattn::launch16_fwd(*d, stream);
+  else if (d->ws == 16 && d->ks == 16) hipLaunchKernelGGL((flash_wattn_fwd_kernel<16, 16>), grid, blk, 0, st, *d);
   else if (d->ws == 16) hipLaunchKernelGGL((flash_wattn_fwd_kernel<16, 24>), grid, blk, 0, st, *d);
   else if (d->ks == 8) hipLaunchKernelGGL((flash_wattn_fwd_kernel<8, 8>), grid, blk, 0, st, *d);
   else hipLaunchKernelGGL((flash_wattn_fwd_kernel<8, 12>), grid, blk, 0, st, *d);

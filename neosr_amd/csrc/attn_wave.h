@@ -6,4 +6,7 @@ namespace neosr_wattn {
 // head_dim <= 30: the 16 k-slots of a lane hold half a head row
 bool wave_ok(const neosr_wattn_desc& d);
 void launch_fwd(const neosr_wattn_desc& d, void* stream);
+// HAT 16 x 16 self-attention forward in the same style (ks == ws == 16, head_dim <= 30)
+bool wave16_ok(const neosr_fattn_desc& d);
+void launch16_fwd(const neosr_fattn_desc& d, void* stream);
 }  // namespace neosr_wattn

@@ -216,6 +216,139 @@ __global__ __launch_bounds__(256, 2) void wattn_wave_fwd_kernel(const neosr_watt
   }
 }
 
+// ------------------------------------------------------------------------------------ HAT: 16 x 16 windows (self)
+// Same construction for the (shifted-)window self-attention of HAT's HAB (hat_arch.py:168-216): unit = (window, head,
+// 32-query tile), 8 key tiles -> the whole 32 x 256 score block S^T lives in 128 accumulator registers, so there is no
+// online softmax and no LDS tile; K tiles are streamed as row operands, V as column operands in the register order
+// of P.  lse is stored in the layout of the streaming kernels ([(window, head)][256]) whose backward passes consume it.
+constexpr int W16 = 16, NB16 = 2 * W16 - 1, NBIN16 = NB16 * NB16, NKT = 8;
+
+struct Unit16 {
+  int b, Wy, Wx, head, nWy, nWx, wh;
+};
+
+__device__ __forceinline__ Unit16 decode16(const neosr_fattn_desc& d, int u) {
+  Unit16 w;
+  w.nWx = d.W / W16;
+  w.nWy = d.H / W16;
+  const int nW = w.nWy * w.nWx;
+  w.wh = u;
+  w.head = u % d.heads;
+  const int t = u / d.heads;
+  const int wi = t % nW;
+  w.b = t / nW;
+  w.Wy = wi / w.nWx;
+  w.Wx = wi - w.Wy * w.nWx;
+  return w;
+}
+
+__device__ __forceinline__ int region16(int c, int Wc, int nWc, int shift) {
+  return Wc == nWc - 1 ? (c < W16 - shift ? 1 : 2) : 0;
+}
+
+template <int HALF>
+__global__ __launch_bounds__(256, 2) void wattn16_wave_fwd_kernel(const neosr_fattn_desc d, int units) {
+  __shared__ float tabs[4][NBIN16 + 63];
+  const int lane = threadIdx.x & 63, l31 = lane & 31, lh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float* tab = tabs[wave];
+  const int hd = d.C / d.heads, ld = 3 * d.C;
+  constexpr int KS = HALF ? HALF : NS - 1;
+  const int stride = gridDim.x * 4;
+  const int dl = l31 < hd ? l31 : hd - 1;
+  for (int u8 = xcd_bid() * 4 + wave; u8 < 8 * units; u8 += stride) {
+    const int ti = u8 & 7;
+    const Unit16 w = decode16(d, u8 >> 3);
+    // token n of the window = (y, x) = (n >> 4, n & 15); a 32-token tile t is window rows 2 t, 2 t + 1
+    auto pix = [&](int n) {
+      const int Y = wrap(w.Wy * W16 + (n >> 4) + d.shift, d.H), X = wrap(w.Wx * W16 + (n & 15) + d.shift, d.W);
+      return (w.b * d.H + Y) * d.W + X;
+    };
+    float qf[NS];
+    load_rows<HALF>(d.qkv, ld, pix(32 * ti + l31), w.head * hd, hd, lh, d.scale, qf);
+    for (int n = lane; n < NBIN16; n += 64) tab[n] = d.rpb_table[n * d.heads + w.head];
+    // S^T tiles: rows (registers) = keys 32 tj + 8 g + 4 lh + r, column (lane) = query 32 ti + l31
+    f32x16 st[NKT];
+#pragma unroll
+    for (int tj = 0; tj < NKT; ++tj) {
+      float kf[NS];
+      load_rows<HALF>(d.qkv, ld, pix(32 * tj + l31), d.C + w.head * hd, hd, lh, 1.f, kf);
+      zero(st[tj]);
+#pragma unroll
+      for (int s = 0; s < KS; ++s) st[tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[s], qf[s], st[tj], 0, 0, 0);
+    }
+    // bias + mask, softmax over the 256 keys (registers + the other half-wave)
+    const bool masked = d.shift > 0 && (w.Wy == w.nWy - 1 || w.Wx == w.nWx - 1);
+    const int yi = 2 * ti + (l31 >> 4), xi = l31 & 15;
+    const float* tb = tab + (yi + W16 - 1) * NB16 + xi + W16 - 1 - 4 * lh;
+    const int ri = region16(yi, w.Wy, w.nWy, d.shift) * 3 + region16(xi, w.Wx, w.nWx, d.shift);
+    float m = -3.0e38f;
+#pragma unroll
+    for (int tj = 0; tj < NKT; ++tj)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int yj = 2 * tj + (g >> 1);
+        const int ryj = region16(yj, w.Wy, w.nWy, d.shift) * 3;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int xj0 = 8 * (g & 1) + r;  // + 4 lh
+          float sc = st[tj][4 * g + r] + tb[-(yj * NB16 + xj0)];
+          if (masked && ryj + region16(xj0 + 4 * lh, w.Wx, w.nWx, d.shift) != ri) sc -= 100.f;
+          st[tj][4 * g + r] = sc;
+          m = fmaxf(m, sc);
+        }
+      }
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int tj = 0; tj < NKT; ++tj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = __expf(st[tj][r] - m);
+        st[tj][r] = e;
+        sum += e;
+      }
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.f / sum;
+    if (d.lse && lh == 0) d.lse[(int64_t)w.wh * (W16 * W16) + 32 * ti + l31] = m + __logf(sum);
+
+    // O[i][d] = sum_j P[i][j] V[j][d]; V column operand: key (yj, xj) = (2 tj + (g >> 1), 8 (g & 1) + 4 lh + r)
+    int64_t xoff[2][4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xoff[h][r] = (int64_t)wrap(w.Wx * W16 + 8 * h + 4 * lh + r + d.shift, d.W);
+    auto rowb = [&](int y) { return ((int64_t)w.b * d.H + wrap(w.Wy * W16 + y + d.shift, d.H)) * d.W; };
+    const float* vb = d.qkv + 2 * d.C + w.head * hd + dl;
+    f32x16 o;
+    zero(o);
+#pragma unroll
+    for (int tj = 0; tj < NKT; ++tj) {
+      float vc[4][4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int64_t row = rowb(2 * tj + (g >> 1));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) vc[g][r] = vb[(row + xoff[g & 1][r]) * ld];
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          o = __builtin_amdgcn_mfma_f32_32x32x2f32(st[tj][4 * g + r] * inv, vc[g][r], o, 0, 0, 0);
+    }
+    if (l31 < hd) {
+      float* ob = d.out + w.head * hd + l31;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int64_t row = rowb(2 * ti + (g >> 1));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ob[(row + xoff[g & 1][r]) * d.C] = o[4 * g + r];
+      }
+    }
+  }
+}
+
 }  // namespace
 
 namespace neosr_wattn {
@@ -230,6 +363,20 @@ void launch_fwd(const neosr_wattn_desc& d, void* stream) {
     hipLaunchKernelGGL(wattn_wave_fwd_kernel<15>, dim3(nwg), dim3(256), 0, (hipStream_t)stream, d, units);
   else
     hipLaunchKernelGGL(wattn_wave_fwd_kernel<0>, dim3(nwg), dim3(256), 0, (hipStream_t)stream, d, units);
+}
+
+bool wave16_ok(const neosr_fattn_desc& d) {
+  return d.ws == W16 && d.ks == W16 && d.C % d.heads == 0 && d.C / d.heads <= 30;
+}
+
+void launch16_fwd(const neosr_fattn_desc& d, void* stream) {
+  const int units = d.B * (d.H / W16) * (d.W / W16) * d.heads;  // (window, head); 8 query tiles each
+  int nwg = (8 * units + 3) / 4;
+  if (nwg > 512) nwg = 512;
+  if (d.C / d.heads == 30)
+    hipLaunchKernelGGL(wattn16_wave_fwd_kernel<15>, dim3(nwg), dim3(256), 0, (hipStream_t)stream, d, units);
+  else
+    hipLaunchKernelGGL(wattn16_wave_fwd_kernel<0>, dim3(nwg), dim3(256), 0, (hipStream_t)stream, d, units);
 }
 
 }  // namespace neosr_wattn
