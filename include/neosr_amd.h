@@ -370,7 +370,9 @@ int neosr_spectral_norm_bwd(const float* gw, const float* w, const float* u, con
  * NT/NN epilogue, in this order: + bias[n]; aux_out = value (pre-activation kept for backward);
  * exact-erf GELU (gelu=1); * GELU'(aux_in[m,n]); * row_scale[m / rows_per_scale] (DropPath);
  * + res[m,n].  TN: fixed-order split-K through `workspace` (neosr_gemm_workspace_bytes), dense C,
- * C = accumulate ? C + result : result. */
+ * C = accumulate ? C + result : result; row_scale[k / rows_per_scale] multiplies ROW k of A (the DropPath
+ * scale of the incoming gradient dY — the weight and bias gradients of a dropped sample are zero) so that
+ * no scaled copy of dY is needed: NN takes the same scale in its epilogue. */
 typedef struct neosr_gemm_desc {
   const float* A;
   const float* B;

@@ -167,6 +167,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(const GemmArgs args) 
 
   // staging registers: A tile 128x32 floats = 4 float4 / thread, B tile 64x32 = 2 float4 / thread
   f32x4 ra[4], rb[2];
+  float rsc[4] = {1.f, 1.f, 1.f, 1.f};  // TN: row_scale[k / rows_per_scale] of the staged dY rows (DropPath)
   auto gload = [&](int k0) {
     if (MODE != 2) {
       // A rows m (contiguous along k): thread -> (row = tid/8 + 32 i, k4 = (tid%8)*4)
@@ -186,6 +187,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(const GemmArgs args) 
         const int kk = k0 + (tid >> 5) + 8 * i;
         const bool ok = kk < k_hi && m0 + m4 < M;
         ra[i] = *reinterpret_cast<const f32x4*>(ok ? d.A + (int64_t)kk * d.lda + m0 + m4 : gm_zero_page);
+        if (d.row_scale) rsc[i] = kk < k_hi ? d.row_scale[kk / d.rows_per_scale] : 0.f;
       }
     }
     if (MODE == 0) {
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(const GemmArgs args) 
       const int m4 = (tid & 31) << 2;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        *reinterpret_cast<f32x4*>(As + ((tid >> 5) + 8 * i) * LDM + m4) = ra[i];
+        *reinterpret_cast<f32x4*>(As + ((tid >> 5) + 8 * i) * LDM + m4) = d.row_scale ? ra[i] * rsc[i] : ra[i];
     }
     if (MODE == 0) {
       const int k4 = (tid & 7) << 2;
@@ -484,6 +486,10 @@ constexpr int RT_M = 96, RT_N = 64;
 #ifndef RT_OCC
 #define RT_OCC 1
 #endif
+// RS: row_scale[token / rows_per_scale] multiplies the dY rows (the DropPath scale of the incoming gradient, per sample):
+// rows_per_scale is a multiple of 32 and so is every run start, so a batch of 32 tokens has ONE scale — a scalar kept
+// beside each fragment batch, three v_mul per token pair.
+template <bool RS>
 __global__ __launch_bounds__(256, RT_OCC) void gemm_tn_reg_kernel(const GemmArgs args) {
   const neosr_gemm_desc& d = args.d;
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
@@ -533,10 +539,25 @@ __global__ __launch_bounds__(256, RT_OCC) void gemm_tn_reg_kernel(const GemmArgs
     av = __builtin_amdgcn_raw_buffer_load_b96(ra, ok ? oa : 0x7ffffff0, ta + p * sa, 0);
     bv = __builtin_amdgcn_raw_buffer_load_b64(rb, ok ? ob : 0x7ffffff0, tb + p * sb, 0);
   };
-  auto mm = [&](const frag3& av, const frag2& bv) {
+  // scale of the batch in a0 / a1 (sc0 / sc1); grp / left walk the scale groups without a division per batch
+  float sc0 = 1.f, sc1 = 1.f;
+  int grp = RS ? t_lo / d.rows_per_scale : 0, left = RS ? d.rows_per_scale - (t_lo - grp * d.rows_per_scale) : 0;
+  auto next_scale = [&]() {
+    float v = 1.f;
+    if (RS) {
+      v = d.row_scale[grp];
+      left -= 2 * RT_P;
+      if (left <= 0) {
+        ++grp;
+        left += d.rows_per_scale;
+      }
+    }
+    return v;
+  };
+  auto mm = [&](const frag3& av, const frag2& bv, float sc) {
 #pragma unroll
     for (int e1 = 0; e1 < 3; ++e1) {
-      const float a = __uint_as_float(av[e1]);
+      const float a = RS ? __uint_as_float(av[e1]) * sc : __uint_as_float(av[e1]);
 #pragma unroll
       for (int e2 = 0; e2 < 2; ++e2)
         acc[e1][e2] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(bv[e2]), a, acc[e1][e2], 0, 0, 0);
@@ -544,7 +565,8 @@ __global__ __launch_bounds__(256, RT_OCC) void gemm_tn_reg_kernel(const GemmArgs
     }
   };
   int ib = 0;  // index of the next batch to load
-  auto load = [&](frag3 (&ab)[RT_P], frag2 (&bb)[RT_P]) {
+  auto load = [&](frag3 (&ab)[RT_P], frag2 (&bb)[RT_P], float& sc) {
+    sc = next_scale();
     const bool full = ib < nfull;
     const int t0 = t_lo + ib * 2 * RT_P + lh;
 #pragma unroll
@@ -553,16 +575,18 @@ __global__ __launch_bounds__(256, RT_OCC) void gemm_tn_reg_kernel(const GemmArgs
     tb += RT_P * sb;
     ++ib;
   };
-  auto mac = [&](const frag3 (&ab)[RT_P], const frag2 (&bb)[RT_P]) {
+  auto mac = [&](const frag3 (&ab)[RT_P], const frag2 (&bb)[RT_P], float sc) {
 #pragma unroll
-    for (int p = 0; p < RT_P; ++p) mm(ab[p], bb[p]);
+    for (int p = 0; p < RT_P; ++p) mm(ab[p], bb[p], sc);
   };
   // steady state: multiply batch `cur` while refilling `nxt` (all full batches), the two loads of a pair issued
   // right behind the 6 MFMAs of the same slot so the matrix pipe never waits for an address burst
-  auto step = [&](const frag3 (&ca)[RT_P], const frag2 (&cb)[RT_P], frag3 (&na)[RT_P], frag2 (&nb_)[RT_P]) {
+  auto step = [&](const frag3 (&ca)[RT_P], const frag2 (&cb)[RT_P], float csc, frag3 (&na)[RT_P], frag2 (&nb_)[RT_P],
+                  float& nsc) {
+    nsc = next_scale();
 #pragma unroll
     for (int p = 0; p < RT_P; ++p) {
-      mm(ca[p], cb[p]);
+      mm(ca[p], cb[p], csc);
       ld(na[p], nb_[p], p, true, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -571,24 +595,24 @@ __global__ __launch_bounds__(256, RT_OCC) void gemm_tn_reg_kernel(const GemmArgs
     ++ib;
   };
   if (nb > 0) {
-    load(a0, b0);
+    load(a0, b0, sc0);
     while (ib + 2 <= nfull) {  // the next two batches to load are full ones
-      step(a0, b0, a1, b1);
-      step(a1, b1, a0, b0);
+      step(a0, b0, sc0, a1, b1, sc1);
+      step(a1, b1, sc1, a0, b0, sc0);
     }
     // a0 holds the last loaded batch; 0, 1 or 2 batches (one full and / or the ragged one) are left to load
     const int rem = nb - ib;
     if (rem == 0) {
-      mac(a0, b0);
+      mac(a0, b0, sc0);
     } else {
-      load(a1, b1);
-      mac(a0, b0);
+      load(a1, b1, sc1);
+      mac(a0, b0, sc0);
       if (rem == 2) {
-        load(a0, b0);
-        mac(a1, b1);
-        mac(a0, b0);
+        load(a0, b0, sc0);
+        mac(a1, b1, sc1);
+        mac(a0, b0, sc0);
       } else {
-        mac(a1, b1);
+        mac(a1, b1, sc1);
       }
     }
   }
@@ -754,7 +778,8 @@ extern "C" int neosr_gemm(const neosr_gemm_desc* dp, void* stream) {
     hipLaunchKernelGGL(gemm_mfma_kernel<1>, grid, dim3(256), 0, st, a);
   } else {
     NEOSR_CHECK(d.workspace, "gemm TN: workspace missing");
-    const bool reg = tn_reg_ok(d.M, d.N, d.K);
+    // (a row scale must be constant over the register kernel's 32-token batches)
+    const bool reg = tn_reg_ok(d.M, d.N, d.K) && (!d.row_scale || d.rows_per_scale % (2 * RT_P) == 0);
     if (reg) {
       a.ksplit_len = tn_reg_ksplit(d.M, d.N, d.K);
       a.tiles_m = ceil_div(d.M, RT_M);
@@ -777,8 +802,10 @@ extern "C" int neosr_gemm(const neosr_gemm_desc* dp, void* stream) {
     float* stage = d.workspace + (int64_t)nsplit * a.slab;
     grid.x = reg ? 8 * ceil_div(ceil_div(nsplit, 8) * a.tiles_m * a.tiles_n, 4)
                  : ceil_div(nsplit, 8) * 8 * a.tiles_m * a.tiles_n;
-    if (reg)
-      hipLaunchKernelGGL(gemm_tn_reg_kernel, grid, dim3(256), 0, st, a);
+    if (reg && d.row_scale)
+      hipLaunchKernelGGL(gemm_tn_reg_kernel<true>, grid, dim3(256), 0, st, a);
+    else if (reg)
+      hipLaunchKernelGGL(gemm_tn_reg_kernel<false>, grid, dim3(256), 0, st, a);
     else
       hipLaunchKernelGGL(gemm_mfma_kernel<2>, grid, dim3(256), 0, st, a);
     if (prof) neosr_prof_end(stream);

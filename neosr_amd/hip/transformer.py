@@ -99,16 +99,17 @@ class Linear(torch.autograd.Function):
         x2, w, rs = ctx.saved_tensors
         M, N, K, rps, has_b, has_res = ctx.meta
         g2 = _as2d(g)
-        gs = g2 if rs is None else row_scale(g2, rs, rps)
+        # the DropPath scale of the incoming gradient is applied inside the GEMMs (epilogue of the data gradient,
+        # operand rows of the weight gradient): no scaled copy of dY
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = gemm(_C.GEMM_NN, gs, w, M, K, N).view(*g.shape[:-1], K)
+            gx = gemm(_C.GEMM_NN, g2, w, M, K, N, row_scale=rs, rows_per_scale=rps).view(*g.shape[:-1], K)
         want_b = has_b and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            gw, gb = _wgrad_pair(gs, N, K, want_b)  # bias gradient rides in the weight-gradient GEMM
-            gemm(_C.GEMM_TN, gs, x2, N, K, M, out=gw, colsum_a=gb)
+            gw, gb = _wgrad_pair(g2, N, K, want_b)  # bias gradient rides in the weight-gradient GEMM
+            gemm(_C.GEMM_TN, g2, x2, N, K, M, out=gw, colsum_a=gb, row_scale=rs, rows_per_scale=rps)
         elif want_b:
-            gb = colsum(gs)
+            gb = colsum(g2 if rs is None else row_scale(g2, rs, rps))
         return gx, gw, gb, (g if has_res else None), None, None
 
 
@@ -143,11 +144,11 @@ class Mlp(torch.autograd.Function):
         x2, w1, w2, pre, h, rs = ctx.saved_tensors
         M, K, Hd, N, rps, has_res = ctx.meta
         g2 = _as2d(g)
-        gs = g2 if rs is None else row_scale(g2, rs, rps)
-        gw2, gb2 = _wgrad_pair(gs, N, Hd, True)  # bias gradients ride in the weight-gradient GEMMs
-        gemm(_C.GEMM_TN, gs, h, N, Hd, M, out=gw2, colsum_a=gb2)
-        gpre = gemm(_C.GEMM_NN, gs, w2, M, Hd, N, aux_in=pre)  # (g W2) * GELU'(pre)
-        gw1, gb1 = _wgrad_pair(gs, Hd, K, True)
+        gw2, gb2 = _wgrad_pair(g2, N, Hd, True)  # bias gradients ride in the weight-gradient GEMMs
+        # DropPath scale of g: operand rows of the fc2 weight gradient, epilogue of its data gradient
+        gemm(_C.GEMM_TN, g2, h, N, Hd, M, out=gw2, colsum_a=gb2, row_scale=rs, rows_per_scale=rps)
+        gpre = gemm(_C.GEMM_NN, g2, w2, M, Hd, N, aux_in=pre, row_scale=rs, rows_per_scale=rps)  # (g W2) GELU'(pre)
+        gw1, gb1 = _wgrad_pair(g2, Hd, K, True)
         gemm(_C.GEMM_TN, gpre, x2, Hd, K, M, out=gw1, colsum_a=gb1)
         gx = gemm(_C.GEMM_NN, gpre, w1, M, K, Hd).view(*g.shape[:-1], K) if ctx.needs_input_grad[0] else None
         return gx, gw1, gb1, gw2, gb2, (g if has_res else None), None, None

@@ -72,6 +72,38 @@ def test_gemm_tn_weight_gradient_with_bias_sum(Mo, No, T_):
     assert torch.equal(gw2, first[0]) and rel_err(sep, refb) < 1e-5  # (two-stage column sum: other rounding order)
 
 
+@pytest.mark.parametrize("Mo,No,T_,rps", [(180, 180, 4096 * 3, 4096), (540, 180, 2048 + 640, 256), (360, 180, 5000, 1000),
+                                         (128, 64, 777, 100), (180, 360, 4100, 32), (96, 64, 64, 32)])
+def test_gemm_tn_scales_gradient_rows_per_sample(Mo, No, T_, rps):
+    """DropPath in backward (arch_util.py:118-133 under autograd): dW = (s[t // rps] dY[t])^T X and db = sum_t s dY[t]
+    with the scale applied to the operand rows inside the TN GEMM — register-fed kernel when rps is a multiple of its
+    32-token batch (scale groups ending inside a run, ragged last group, dropped samples = exact zeros), staged kernel
+    otherwise — against a scaled copy through the same GEMM and float64; NN takes the same scale in its epilogue."""
+    from neosr_amd import _C
+    from neosr_amd.hip import transformer as tr
+
+    g = torch.Generator().manual_seed(Mo + No + T_ + rps)
+    dY, X = torch.randn(T_, Mo, generator=g), torch.randn(T_, No, generator=g)
+    ngrp = -(-T_ // rps)
+    sc = torch.where(torch.rand(ngrp, generator=g) < 0.3, torch.zeros(ngrp), torch.full((ngrp,), 1 / 0.7))
+    rows = sc.repeat_interleave(rps)[:T_, None]
+    ref, refb = (dY * rows).double().t() @ X.double(), (dY * rows).double().sum(0)
+    gw, gb = tr._wgrad_pair(dY.to(DEV), Mo, No, True)
+    tr.gemm(_C.GEMM_TN, dY.to(DEV), X.to(DEV), Mo, No, T_, out=gw, colsum_a=gb, row_scale=sc.to(DEV), rows_per_scale=rps)
+    assert rel_err(gw, ref) < 1e-5 and rel_err(gb, refb) < 1e-5
+    first = (gw.clone(), gb.clone())
+    tr.gemm(_C.GEMM_TN, dY.to(DEV), X.to(DEV), Mo, No, T_, out=gw, colsum_a=gb, row_scale=sc.to(DEV), rows_per_scale=rps)
+    assert torch.equal(gw, first[0]) and torch.equal(gb, first[1])
+    # the scaled copy through the unscaled GEMM: same products, the scale (0 or 1/keep) commutes with fp32 rounding
+    # only up to the last bit
+    gw2, gb2 = tr._wgrad_pair(dY.to(DEV), Mo, No, True)
+    tr.gemm(_C.GEMM_TN, (dY * rows).to(DEV), X.to(DEV), Mo, No, T_, out=gw2, colsum_a=gb2)
+    assert rel_err(gw, gw2.double().cpu()) < 1e-6 and rel_err(gb, gb2.double().cpu()) < 1e-6
+    W = torch.randn(Mo, No, generator=g)
+    gx = tr.gemm(_C.GEMM_NN, dY.to(DEV), W.to(DEV), T_, No, Mo, row_scale=sc.to(DEV), rows_per_scale=rps)
+    assert rel_err(gx, (dY * rows).double() @ W.double()) < 1e-5
+
+
 def test_gemm_random_shapes_all_modes_and_epilogues():
     """Seeded sweep over odd shapes: every GEMM kernel (128- and 64-row NT tiles with trimmed last chunk / skipped column
     tile / LDS bias / prefetched residual, staged NN, register-fed and staged TN) and every epilogue against float64."""
