@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_multi_kernel(const Wgrad
 //   * A operand = row i of G' dy G'^T for the lane's cout, B operand = row i of B^T d B for the lane's cin, both built in
 //     registers from the raw tiles; nothing transformed is ever stored;
 //   * raw tiles (4 x 34 input pixels x 32 cin, 2 x 32 gradient pixels x 32 cout) go global -> LDS with
-//     global_load_lds_dwordx4 into two 28 KB buffers, ONE barrier per unit.
+//     buffer_load_dwordx4 ... lds into two 25 KB buffers, ONE barrier per unit.
 // The 16 x 32 x 32 partial of a workgroup is summed over the splits in a fixed order and inverse-transformed by
 // conv3x3_wgrad_wino_reduce_kernel (run-to-run deterministic, like the direct path).
 constexpr int WW_XR = 4, WW_XC = 34;                 // raw input rows / columns of a unit
@@ -312,11 +312,6 @@ constexpr int WW_GF = 2 * 32 * 32;                   // gradient tile floats (8 
 constexpr int WW_BUF = WW_XF + WW_GF;                // 6400 floats = 25 KB; two buffers -> three workgroups per CU
 constexpr int WW_SLOTS = 768;                        // resident workgroups the split count aims at (3 per CU)
 constexpr int WW_PART = 16 * 1024;                   // floats per (pair, split) partial
-
-__device__ __forceinline__ void glds16g(const float* src, float* lds_dst) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                   (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
-}
 
 __global__ __launch_bounds__(256, 3) void conv3x3_wgrad_wino_kernel(const WgradMultiArgs args) {
   // two DISTINCT LDS objects: hipcc waits vmcnt(0) before any ds_read that may alias a pending LDS-DMA write, which
@@ -385,8 +380,12 @@ __global__ __launch_bounds__(256, 3) void conv3x3_wgrad_wino_kernel(const WgradM
     grel[i] = ((pix >> 5) * W + (pix & 31)) * d_g_cs + co0 + q4;
   }
 
-  const float* zp = wg_zero_page;
-  asm volatile("" : "+s"(zp));  // keep the zero page's address in SGPRs (else it is re-read through the GOT per use)
+  // LDS-DMA through BUFFER loads: base = the whole tensor, lane offset = unit origin (scalar) + the lane's fixed relative
+  // offset, and a granule outside the image / past K or N simply gets an out-of-range offset (the DMA writes zeros):
+  // two unsigned range checks, one add and one select per instruction, no pointers, no zero page, no branches.
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d_in), 0, args.B * Hin * Win * d_in_cs * 4, 0x00020000);
+  const auto rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d_g), 0, args.B * H * W * d_g_cs * 4, 0x00020000);
   auto issue = [&](int u, float* xb) {
     const int xx = u % units_x;
     const int r = u / units_x;
@@ -394,32 +393,35 @@ __global__ __launch_bounds__(256, 3) void conv3x3_wgrad_wino_kernel(const WgradM
     const int b = r / units_y;
     const int x0 = xx * 32, y0 = yy * 2;
     float* gb = xb + WW_XF;
-    const float* xbase = d_in + (((int64_t)b * Hin + (ups ? (y0 >> 1) : y0)) * Win + (ups ? (x0 >> 1) : x0)) * d_in_cs;
-    const float* gbase = d_g + (((int64_t)b * H + y0) * W + x0) * d_g_cs;
+    const int xbase = (((b * Hin + (ups ? (y0 >> 1) : y0)) * Win + (ups ? (x0 >> 1) : x0)) * d_in_cs) * 4;
+    const int gbase = (((b * H + y0) * W + x0) * d_g_cs) * 4;
 #pragma unroll
     for (int i = 0; i < WW_XROUNDS; ++i) {
-      if (i == WW_XROUNDS - 1 && wave != 0) break;  // granules 1024..1087
-      const int gy = y0 + xr[i], gx = x0 + xc[i];
-      const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;  // xr = -100000 for unused slots / channels >= K
-      const float* cand = xbase + xrel[i];  // unconditional: the select below is two v_cndmask, not a branch
-      glds16g(ok ? cand : zp, xb + (i * 4 + wave) * 256);
+      if (i == WW_XROUNDS - 1 && wv != 0) break;  // granules 1024..1087
+      // (xr = -100000 for unused slots / channels >= K: fails the unsigned row test)
+      const bool ok = ((unsigned)(y0 + xr[i]) < (unsigned)H) & ((unsigned)(x0 + xc[i]) < (unsigned)W);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(xb + (i * 4 + wv) * 256), 16,
+                                               ok ? xbase + xrel[i] * 4 : 0x7ffffff0, 0, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int pix = (i * 256 + tid) >> 3;
-      const bool ok = co_ok && y0 + (pix >> 5) < H && x0 + (pix & 31) < W;
-      const float* cand = gbase + grel[i];
-      glds16g(ok ? cand : zp, gb + (i * 4 + wave) * 256);
+      const bool ok = co_ok & (y0 + (pix >> 5) < H) & (x0 + (pix & 31) < W);  // (no short-circuit: one select)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (__attribute__((address_space(3))) void*)(gb + (i * 4 + wv) * 256), 16,
+                                               ok ? gbase + grel[i] * 4 : 0x7ffffff0, 0, 0, 0);
     }
   };
 
-  // this wave's row i = wave of the transforms
-  const int ra = wave == 0 ? 0 : 1, rb = wave == 3 ? 3 : 2;                      // input rows: t = sa x[ra] + sb x[rb]
-  const float sa = wave == 2 ? -1.f : 1.f, sb = (wave == 0 || wave == 3) ? -1.f : 1.f;
-  // gradient rows: g0 | g0 + g1 | g0 - g1 | -g1  as  r = ga * g[gr] + gbq * g[1]  (branch-free: waves 0 and 3 read row 1
-  // with a zero coefficient rather than diverge)
+  // this wave's row i = wave of the transforms, each as ONE fused multiply-add per element and an overall sign that is
+  // applied to the accumulators once, at the store:
+  //   input rows  x0 - x2 | x1 + x2 | -(x1 - x2) | x1 - x3      = sx * (x[ra] + sg * x[rb])
+  //   gradient    g0      | g0 + g1 | g0 - g1    | -g1          = sr * (g[gr] + gq * g[1])   (gq = 0 for waves 0, 3: they
+  //                                                                read row 1 with a zero coefficient rather than diverge)
+  const int ra = wave == 0 ? 0 : 1, rb = wave == 3 ? 3 : 2;
+  const float sg = (wave == 1) ? 1.f : -1.f;
   const int gr = wave == 3 ? 1 : 0;
-  const float ga = wave == 3 ? -1.f : 1.f, gbq = wave == 1 ? 1.f : (wave == 2 ? -1.f : 0.f);
+  const float gq = wave == 1 ? 1.f : (wave == 2 ? -1.f : 0.f);
+  const bool flip = (wave == 2) != (wave == 3);  // sx * sr = -1 for waves 2 and 3
 
   f32x16 acc[4];
 #pragma unroll
@@ -428,6 +430,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_wgrad_wino_kernel(const WgradM
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
   float bsum = 0.f;
 
+  const bool want_b = d.db && kt == 0;
   auto compute = [&](const float* buf) {
     const float* xb = buf + l31;
     const float* gb = buf + WW_XF + l31;
@@ -435,19 +438,21 @@ __global__ __launch_bounds__(256, 3) void conv3x3_wgrad_wino_kernel(const WgradM
     const float* xq = xb + (rb * WW_XC + lh * 16) * 32;
     const float* g0 = gb + (gr * 32 + lh * 16) * 32;
     const float* g1 = gb + (32 + lh * 16) * 32;
-    float t0 = sa * xa[0] + sb * xq[0];
-    float t1 = sa * xa[32] + sb * xq[32];
+    float t0 = __builtin_fmaf(sg, xq[0], xa[0]);
+    float t1 = __builtin_fmaf(sg, xq[32], xa[32]);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const float t2 = sa * xa[(2 * k + 2) * 32] + sb * xq[(2 * k + 2) * 32];
-      const float t3 = sa * xa[(2 * k + 3) * 32] + sb * xq[(2 * k + 3) * 32];
-      const float r0 = __builtin_fmaf(gbq, g1[(2 * k) * 32], ga * g0[(2 * k) * 32]);
-      const float r1 = __builtin_fmaf(gbq, g1[(2 * k + 1) * 32], ga * g0[(2 * k + 1) * 32]);
+      const float t2 = __builtin_fmaf(sg, xq[(2 * k + 2) * 32], xa[(2 * k + 2) * 32]);
+      const float t3 = __builtin_fmaf(sg, xq[(2 * k + 3) * 32], xa[(2 * k + 3) * 32]);
+      const float r0 = __builtin_fmaf(gq, g1[(2 * k) * 32], g0[(2 * k) * 32]);
+      const float r1 = __builtin_fmaf(gq, g1[(2 * k + 1) * 32], g0[(2 * k + 1) * 32]);
       bsum += r0 + r1;
+      // G' dy G'^T row: r0 | r0 + r1 | r0 - r1 | -r1 and B^T d B row: t0 - t2 | t1 + t2 | t2 - t1 | t1 - t3; the last
+      // pair as r1 (x) (t3 - t1)
       acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(r0, t0 - t2, acc[0], 0, 0, 0);
       acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(r0 + r1, t1 + t2, acc[1], 0, 0, 0);
       acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(r0 - r1, t2 - t1, acc[2], 0, 0, 0);
-      acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(-r1, t1 - t3, acc[3], 0, 0, 0);
+      acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(r1, t3 - t1, acc[3], 0, 0, 0);
       t0 = t2;
       t1 = t3;
     }
@@ -475,14 +480,15 @@ __global__ __launch_bounds__(256, 3) void conv3x3_wgrad_wino_kernel(const WgradM
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) part[j * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * lh) * 32] = acc[j][r];
+    for (int r = 0; r < 16; ++r)
+      part[j * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * lh) * 32] = flip ? -acc[j][r] : acc[j][r];
 
-  if (d.db && kt == 0) {  // sum of the gradient tile = (row 0 sums of wave 0) - (negated row 1 sums of wave 3)
+  if (want_b) {  // sum of the gradient tile = row 0 sums (wave 0: r = g0) + row 1 sums (wave 3: r = +g1 here)
     bsum += __shfl_xor(bsum, 32, 64);
     if (lh == 0 && (wave == 0 || wave == 3)) bred[(wave ? 32 : 0) + l31] = bsum;
     __syncthreads();
     if (tid < 32)
-      args.bpart[((int64_t)(args.btile_start[di] + ntile) * args.w_nsplit + s) * 32 + tid] = bred[tid] - bred[32 + tid];
+      args.bpart[((int64_t)(args.btile_start[di] + ntile) * args.w_nsplit + s) * 32 + tid] = bred[tid] + bred[32 + tid];
   }
 }
 
@@ -932,7 +938,12 @@ extern "C" int neosr_conv3x3_wgrad_multi(const neosr_wgrad_desc* ds, int32_t n, 
     s2d = s2d || ds[i].s2d_c > 0;
     plain = plain && !ds[i].g_mask && !ds[i].in_prelu && !ds[i].mask_slopes;
   }
-  if (fast && plain && !s2d && neosr_conv::wino_enabled()) {  // Winograd form (see conv3x3_wgrad_wino_kernel)
+  bool small = true;  // the Winograd kernel addresses a tensor through a buffer resource: 32-bit byte offsets
+  for (int i = 0; i < n; ++i) {
+    const int64_t pin = (int64_t)ds[i].B * (ds[i].ups ? (ds[i].H >> 1) * (ds[i].W >> 1) : ds[i].H * ds[i].W);
+    small = small && pin * ds[i].in_cs * 4 < (int64_t(1) << 31) && (int64_t)ds[i].B * ds[i].H * ds[i].W * ds[i].g_cs * 4 < (int64_t(1) << 31);
+  }
+  if (fast && plain && !s2d && small && neosr_conv::wino_enabled()) {  // Winograd form (see conv3x3_wgrad_wino_kernel)
     WgradMultiArgs w = a;
     const int P = a.pair_start[MAXD];
     w.bpart = workspace + (int64_t)P * a.w_nsplit * WW_PART;
