@@ -51,6 +51,8 @@ __device__ __forceinline__ void glds16w(const float* src, float* lds_dst) {
                                    (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 __device__ __forceinline__ f32x4 ld4f(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
 // Raw tile image in LDS (per 16-channel half): granule index = pix' * 4 + slot,
@@ -161,19 +163,29 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const ConvArgs arg
 #pragma unroll
     for (int s = 0; s < 8; ++s) dd[s] = ld4f(rbuf + (po[s] ^ (g << 3)));
   };
+  // The fp32 MFMA shares the SIMD's FMA lanes with ordinary vector instructions (they do not overlap: measured, the
+  // kernel's time is the SUM of both), so the transform is written on 2-wide vectors: v_pk_fma_f32 / v_pk_add_f32 do
+  // two elements per lane in the 4 cycles of one scalar instruction — 16 packed instead of 32 scalar per 16 MFMAs.
+  const f32x2 sg2 = {sg, sg};
   auto mac = [&](const f32x4 (&dd)[8], const f32x4 (&u)[4][2], int g) {
-    f32x4 t[4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+    for (int h = 0; h < 2; ++h) {
+      f32x2 t[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) t[s][e] = __builtin_fmaf(sg, dd[4 + s][e], dd[s][e]);
-    const f32x4 v0 = t[0] - t[2], v1 = t[1] + t[2], v2 = t[2] - t[1], v3 = t[1] - t[3];
+      for (int s = 0; s < 4; ++s) {
+        const f32x2 a = h ? __builtin_shufflevector(dd[s], dd[s], 2, 3) : __builtin_shufflevector(dd[s], dd[s], 0, 1);
+        const f32x2 q = h ? __builtin_shufflevector(dd[4 + s], dd[4 + s], 2, 3) : __builtin_shufflevector(dd[4 + s], dd[4 + s], 0, 1);
+        t[s] = __builtin_elementwise_fma(sg2, q, a);
+      }
+      const f32x2 v0 = t[0] - t[2], v1 = t[1] + t[2], v2 = t[2] - t[1], v3 = t[1] - t[3];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[0][g][e], v0[e], acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[1][g][e], v1[e], acc[1], 0, 0, 0);
-      acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[2][g][e], v2[e], acc[2], 0, 0, 0);
-      acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[3][g][e], v3[e], acc[3], 0, 0, 0);
+      for (int e2 = 0; e2 < 2; ++e2) {
+        const int e = 2 * h + e2;
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[0][g][e], v0[e2], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[1][g][e], v1[e2], acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[2][g][e], v2[e2], acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[3][g][e], v3[e2], acc[3], 0, 0, 0);
+      }
     }
   };
 
