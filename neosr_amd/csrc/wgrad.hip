@@ -428,9 +428,15 @@ __global__ __launch_bounds__(256, 3) void conv3x3_wgrad_wino_kernel(const WgradM
   for (int j = 0; j < 4; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-  float bsum = 0.f;
 
   const bool want_b = d.db && kt == 0;
+  // (fp32 MFMAs and ordinary vector instructions share the SIMD's FMA lanes, so every vector instruction saved is
+  // matrix time won: the row passes work on the PAIRS of adjacent columns that one ds_read2_b32 returns, with packed
+  // 2-wide instructions — (t2, t3) and (r0, r1) one v_pk_fma_f32 each, (t0 - t2, t1 - t3) one v_pk_add_f32; the last
+  // product is taken as r1 (x) (t1 - t3) and its accumulator's sign flipped at the store)
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const f32x2 sg2 = {sg, sg}, gq2 = {gq, gq};
+  f32x2 bs2 = {0.f, 0.f};
   auto compute = [&](const float* buf) {
     const float* xb = buf + l31;
     const float* gb = buf + WW_XF + l31;
@@ -438,23 +444,19 @@ __global__ __launch_bounds__(256, 3) void conv3x3_wgrad_wino_kernel(const WgradM
     const float* xq = xb + (rb * WW_XC + lh * 16) * 32;
     const float* g0 = gb + (gr * 32 + lh * 16) * 32;
     const float* g1 = gb + (32 + lh * 16) * 32;
-    float t0 = __builtin_fmaf(sg, xq[0], xa[0]);
-    float t1 = __builtin_fmaf(sg, xq[32], xa[32]);
+    auto pair = [](const float* p) { return f32x2{p[0], p[32]}; };
+    f32x2 P = __builtin_elementwise_fma(sg2, pair(xq), pair(xa));  // (t0, t1)
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const float t2 = __builtin_fmaf(sg, xq[(2 * k + 2) * 32], xa[(2 * k + 2) * 32]);
-      const float t3 = __builtin_fmaf(sg, xq[(2 * k + 3) * 32], xa[(2 * k + 3) * 32]);
-      const float r0 = __builtin_fmaf(gq, g1[(2 * k) * 32], g0[(2 * k) * 32]);
-      const float r1 = __builtin_fmaf(gq, g1[(2 * k + 1) * 32], g0[(2 * k + 1) * 32]);
-      bsum += r0 + r1;
-      // G' dy G'^T row: r0 | r0 + r1 | r0 - r1 | -r1 and B^T d B row: t0 - t2 | t1 + t2 | t2 - t1 | t1 - t3; the last
-      // pair as r1 (x) (t3 - t1)
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(r0, t0 - t2, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(r0 + r1, t1 + t2, acc[1], 0, 0, 0);
-      acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(r0 - r1, t2 - t1, acc[2], 0, 0, 0);
-      acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(r1, t3 - t1, acc[3], 0, 0, 0);
-      t0 = t2;
-      t1 = t3;
+      const f32x2 T = __builtin_elementwise_fma(sg2, pair(xq + (2 * k + 2) * 32), pair(xa + (2 * k + 2) * 32));  // (t2, t3)
+      const f32x2 R = __builtin_elementwise_fma(gq2, pair(g1 + (2 * k) * 32), pair(g0 + (2 * k) * 32));          // (r0, r1)
+      const f32x2 D = P - T;  // (t0 - t2, t1 - t3)
+      bs2 += R;
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(R.x, D.x, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(R.x + R.y, P.y + T.x, acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(R.x - R.y, T.x - P.y, acc[2], 0, 0, 0);
+      acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(R.y, D.y, acc[3], 0, 0, 0);
+      P = T;
     }
   };
 
@@ -480,10 +482,11 @@ __global__ __launch_bounds__(256, 3) void conv3x3_wgrad_wino_kernel(const WgradM
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
-      part[j * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * lh) * 32] = flip ? -acc[j][r] : acc[j][r];
+    for (int r = 0; r < 16; ++r)  // (position 3 of the row was accumulated with the opposite sign)
+      part[j * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * lh) * 32] = (flip != (j == 3)) ? -acc[j][r] : acc[j][r];
 
   if (want_b) {  // sum of the gradient tile = row 0 sums (wave 0: r = g0) + row 1 sums (wave 3: r = +g1 here)
+    float bsum = bs2.x + bs2.y;
     bsum += __shfl_xor(bsum, 32, 64);
     if (lh == 0 && (wave == 0 || wave == 3)) bred[(wave ? 32 : 0) + l31] = bsum;
     __syncthreads();
