@@ -363,7 +363,7 @@ __device__ __forceinline__ void recompute_p_ds(SharedBwd& S, int kq, int wave, i
 
 // (A) one workgroup per (window, head, query block): dQ, D = rowsum(dO * O), and the dS tiles
 template <int WS, int KS>
-__global__ __launch_bounds__(256) void flash_wattn_bwd_dq_kernel(const neosr_fattn_desc d, const BwdWs ws) {
+__global__ __launch_bounds__(256, KS > WS ? 2 : 1) void flash_wattn_bwd_dq_kernel(const neosr_fattn_desc d, const BwdWs ws) {
   using G = Geo<WS, KS>;
   __shared__ SharedBwd S;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
