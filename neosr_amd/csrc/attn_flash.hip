@@ -430,19 +430,27 @@ __global__ __launch_bounds__(256, KS > WS ? 2 : 1) void flash_wattn_bwd_dq_kerne
       constexpr int RQ = QB / WS, NB1 = 2 * WS - 1;
       static_assert((2 * RQ - 1) * NB1 <= 256, "one bin of the tile per thread");
       if (tid < (2 * RQ - 1) * NB1) {
+        // The pairs of bin (dy, dx) inside window rows (a, b) lie on ONE diagonal of that WS x WS sub-block:
+        // (xi, xj) = (xi0 + t, xj0 + t), t < WS - |dx| — a fixed start address per (thread, a) and a constant stride
+        // PS + 1, so the reads carry immediate offsets and validity is ONE predicate per t, shared by all a (t < len),
+        // plus one per a — 16 + 4 masks instead of the 64 per-pair masks that spilled 170 SGPRs in this kernel; a key
+        // row outside the tile is clamped for the address and its sum discarded.
         const int dyi = tid / NB1, dx = tid % NB1 - (WS - 1);
+        const int xi0 = dx > 0 ? dx : 0, xj0 = dx < 0 ? -dx : 0, len = WS - (dx < 0 ? -dx : dx);
         float s = 0.f;
 #pragma unroll
         for (int a = 0; a < RQ; ++a) {
           const int b = a - (dyi - (RQ - 1));  // key row of the tile paired with query row a
           const bool oky = b >= 0 && b < RQ;
+          const int bc = b < 0 ? 0 : (b >= RQ ? RQ - 1 : b);
+          const float* base = S.dS + (a * WS + xi0) * PS + bc * WS + xj0;
+          float sa = 0.f;
 #pragma unroll
-          for (int xi = 0; xi < WS; ++xi) {
-            const int xj = xi - dx;
-            const bool ok = oky && xj >= 0 && xj < WS;
-            const float v = S.dS[ok ? (a * WS + xi) * PS + b * WS + xj : 0];
-            s += ok ? v : 0.f;
+          for (int t = 0; t < WS; ++t) {
+            const float v = base[t * (PS + 1)];
+            sa += t < len ? v : 0.f;  // (a select, not a 0 / 1 factor: past the diagonal the read may hit anything)
           }
+          s += oky ? sa : 0.f;
         }
         const int dy = RQ * (w.qb - kb) - (RQ - 1) + dyi;
         if (dy > -WS && dy < WS) S.bins[(dy + WS - 1) * NB1 + dx + WS - 1] += s;
