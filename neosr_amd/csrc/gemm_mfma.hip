@@ -764,7 +764,10 @@ extern "C" int neosr_gemm(const neosr_gemm_desc* dp, void* stream) {
   if (d.mode == NEOSR_GEMM_NT && a.b_vec && !g_no_glds) {
     // 128-row tiles when they fill the chip's resident workgroup slots at least ~twice, else 64-row tiles
     static const int env64 = [] { const char* e = getenv("NEOSR_GEMM_BM64"); return e ? atoi(e) : -1; }();
-    const bool bm64 = env64 >= 0 ? env64 != 0 : a.tiles_m * a.tiles_n < g_bm64_below;
+    // (768 = 3 resident 128-row workgroups per CU: a launch whose last round is at most 60 % full — M = 16 384: N = 180 is
+    // half a round, N = 540 one and a half — runs faster as twice as many 64-row tiles; measured, tools/bench_linear.py)
+    const int t128 = a.tiles_m * a.tiles_n, tail = t128 % 768;
+    const bool bm64 = env64 >= 0 ? env64 != 0 : (t128 < g_bm64_below || (t128 < 2 * 768 && tail > 0 && tail <= 460));
     if (bm64) {
       a.tiles_m = ceil_div(d.M, BM2);
       grid.x = ceil_div(a.tiles_m * a.tiles_n, 8) * 8;
