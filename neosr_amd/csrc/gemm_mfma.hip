@@ -131,9 +131,12 @@ __device__ __forceinline__ void epilogue(const GemmArgs& args, const f32x16 (&ac
     }
 }
 
-// MODE 0 = NT, 1 = NN, 2 = TN
-template <int MODE>
+// MODE 0 = NT, 1 = NN, 2 = TN.  BMV = 64 (NT / NN only): 64-row tiles for launches that leave the last round of 128-row
+// tiles mostly empty (M = 16 384 tokens); the four waves then form a 2 x 2 grid of 32 x 32 tiles, one accumulator each.
+template <int MODE, int BMV = BM>
 __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(const GemmArgs args) {
+  static_assert(BMV == BM || (BMV == 64 && MODE != 2), "64-row tiles: NT / NN");
+  constexpr int NT = BMV == BM ? 2 : 1, AI = BMV / 32;
   const neosr_gemm_desc& d = args.d;
   __shared__ float lds[A_LDS + B_LDS];
   float* As = lds;          // [m][k]
@@ -157,7 +160,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(const GemmArgs args) 
     logical = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
     if (logical >= tiles) return;
   }
-  const int m0 = (logical / args.tiles_n) * BM, n0 = (logical % args.tiles_n) * BN;
+  const int m0 = (logical / args.tiles_n) * BMV, n0 = (logical % args.tiles_n) * BN;
   const int M = d.M, N = d.N;
   int k_lo = 0, k_hi = d.K;
   if (MODE == 2) {
@@ -173,7 +176,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(const GemmArgs args) 
       // A rows m (contiguous along k): thread -> (row = tid/8 + 32 i, k4 = (tid%8)*4)
       const int k4 = (tid & 7) << 2;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < AI; ++i) {
         const int m = m0 + (tid >> 3) + 32 * i;
         const bool ok = m < M && k0 + k4 < k_hi;
         ra[i] = *reinterpret_cast<const f32x4*>(ok ? d.A + (int64_t)m * d.lda + k0 + k4 : gm_zero_page);
@@ -214,7 +217,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(const GemmArgs args) 
     if (MODE != 2) {
       const int k4 = (tid & 7) << 2;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < AI; ++i) {
         float* p = As + ((tid >> 3) + 32 * i) * LDK + k4;
         p[0] = ra[i][0]; p[1] = ra[i][1]; p[2] = ra[i][2]; p[3] = ra[i][3];
       }
@@ -239,11 +242,12 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(const GemmArgs args) 
     }
   };
 
-  f32x16 acc[2];
+  f32x16 acc[NT];
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  const int wrow = BMV == BM ? wave * 32 : (wave & 1) * 32, wcol = BMV == BM ? 0 : (wave >> 1) * 32;
 
   // TN: the n-tile-0 workgroups also sum the columns of their A tile (= the bias gradient sum_rows dY)
   const bool do_colsum = MODE == 2 && args.colsum_part && n0 == 0 && tid < BM;
@@ -264,20 +268,20 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(const GemmArgs args) 
     // element (row r, k) of the staged A / B tile; strides are compile-time per MODE
     constexpr int a_rs = MODE == 2 ? 1 : LDK, a_ks = MODE == 2 ? LDM : 1;
     constexpr int b_rs = MODE == 0 ? LDK : 1, b_ks = MODE == 0 ? 1 : LDN;
-    const float* ap = As + (wave * 32 + l31) * a_rs + lh * a_ks;
-    const float* bp = Bs + l31 * b_rs + lh * b_ks;
+    const float* ap = As + (wrow + l31) * a_rs + lh * a_ks;
+    const float* bp = Bs + (wcol + l31) * b_rs + lh * b_ks;
 #pragma unroll
     for (int ks = 0; ks < BK / 2; ++ks) {
       const float a = ap[ks * 2 * a_ks];
-      const float b0 = bp[ks * 2 * b_ks], b1 = bp[32 * b_rs + ks * 2 * b_ks];
+      const float b0 = bp[ks * 2 * b_ks];
       // D = Bfrag x Afrag: rows i = column n of C, cols j = row m of C
       acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0, a, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b1, a, acc[1], 0, 0, 0);
+      if (NT == 2) acc[NT - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(bp[32 * b_rs + ks * 2 * b_ks], a, acc[NT - 1], 0, 0, 0);
     }
   }
 
   if (do_colsum && m0 + tid < M) args.colsum_part[(int64_t)split * args.slab + m0 + tid] = csum;
-  epilogue<MODE>(args, acc, m0, n0, split);
+  epilogue<MODE, NoPref, NT>(args, acc, m0, n0, split, nullptr, NoPref{}, BMV == BM ? -1 : wrow, wcol);
 }
 
 // NT GEMM with direct-to-LDS staging (global_load_lds_dwordx4): no staging VGPRs, no ds_write pass, two
@@ -778,7 +782,18 @@ extern "C" int neosr_gemm(const neosr_gemm_desc* dp, void* stream) {
   } else if (d.mode == NEOSR_GEMM_NT) {
     hipLaunchKernelGGL(gemm_mfma_kernel<0>, grid, dim3(256), 0, st, a);
   } else if (d.mode == NEOSR_GEMM_NN) {
-    hipLaunchKernelGGL(gemm_mfma_kernel<1>, grid, dim3(256), 0, st, a);
+    // (same last-round rule as the NT kernel; the staged kernel keeps 5 workgroups of 128 rows per CU resident)
+    static const int env64 = [] { const char* e = getenv("NEOSR_GEMM_NN64"); return e ? atoi(e) : -1; }();
+    const int t128 = a.tiles_m * a.tiles_n, tail = t128 % 768;
+    // ... and always under the GELU' epilogue (fc2's data gradient): half-size accumulators interleave that long
+    // vector epilogue with other workgroups' MFMAs (M = 32 768: 71.6 -> 62.9 us)
+    if (env64 >= 0 ? env64 != 0 : (d.aux_in || t128 < g_bm64_below || (t128 < 2 * 768 && tail > 0 && tail <= 460))) {
+      a.tiles_m = ceil_div(d.M, 64);
+      grid.x = ceil_div(a.tiles_m * a.tiles_n, 8) * 8;
+      hipLaunchKernelGGL((gemm_mfma_kernel<1, 64>), grid, dim3(256), 0, st, a);
+    } else {
+      hipLaunchKernelGGL(gemm_mfma_kernel<1>, grid, dim3(256), 0, st, a);
+    }
   } else {
     NEOSR_CHECK(d.workspace, "gemm TN: workspace missing");
     // (a row scale must be constant over the register kernel's 32-token batches)
