@@ -372,7 +372,9 @@ int neosr_spectral_norm_bwd(const float* gw, const float* w, const float* u, con
  * + res[m,n].  TN: fixed-order split-K through `workspace` (neosr_gemm_workspace_bytes), dense C,
  * C = accumulate ? C + result : result; row_scale[k / rows_per_scale] multiplies ROW k of A (the DropPath
  * scale of the incoming gradient dY — the weight and bias gradients of a dropped sample are zero) so that
- * no scaled copy of dY is needed: NN takes the same scale in its epilogue. */
+ * no scaled copy of dY is needed: NN takes the same scale in its epilogue.  TN with accumulate == 2 skips the
+ * split reduction: it returns -(number of splits) and leaves the partials [splits][M N (+ M)] in `workspace` for
+ * neosr_colsum_many (colsum_a, if given, must be C + M N). */
 typedef struct neosr_gemm_desc {
   const float* A;
   const float* B;
@@ -392,10 +394,24 @@ int neosr_gemm(const neosr_gemm_desc* d, void* stream);
 /* out[c] (+)= sum_r x[r, c]  (bias gradients); workspace >= 256*cols floats. */
 int neosr_colsum(const float* x, float* out, float* workspace, int32_t rows, int32_t cols, int32_t ld,
                  int32_t accumulate, void* stream);
+/* The same reduction for MANY matrices in one (two-stage: two) launch per 32 jobs, each job cut into row slabs and
+ * summed in exactly the order neosr_colsum uses.  None of the parameter-gradient sums of a transformer block
+ * (LayerNorm dgamma / dbeta partials, relative-position-bias bins, bias gradients) is needed before the optimizer:
+ * the backward pass queues them and runs this once at its end (the reference gets the same sums from ATen reductions
+ * inside each op's backward: swinir_arch.py:284-297 LayerNorm, :85-137 bias table).
+ * workspace >= neosr_colsum_many_workspace_floats(items, n) floats. */
+typedef struct neosr_colsum_item {
+  const float* x;
+  float* out;
+  int32_t rows, cols, ld, accumulate;
+} neosr_colsum_item;
+int64_t neosr_colsum_many_workspace_floats(const neosr_colsum_item* items, int32_t n);
+int neosr_colsum_many(const neosr_colsum_item* items, int32_t n, float* workspace, void* stream);
 /* nn.LayerNorm(C) over the last dim, eps 1e-5, biased variance (swinir_arch.py:284,297,960,1035).
  * fwd keeps (mean, rstd) per row in `stats` (2*rows floats).  bwd: dx, and dgamma/dbeta (+)= via a
  * fixed-order two-stage column reduction; workspace >= (2*1024 + 512)*C floats.  C <= 512.  One reduction launch
- * when dbeta == dgamma + C. */
+ * when dbeta == dgamma + C.  neosr_layernorm_bwd_res with dgamma == dbeta == NULL skips the reduction: it returns
+ * -(number of partial rows) and leaves the partials [rows][2 C] (dgamma | dbeta) at the start of `workspace`. */
 int neosr_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stats,
                         int64_t rows, int32_t C, float eps, void* stream);
 int neosr_layernorm_bwd(const float* dy, const float* x, const float* stats, const float* gamma,

@@ -193,6 +193,13 @@ class PackItem(C.Structure):
                 ("mode", C.c_int32), ("kind", C.c_int32)]
 
 
+class ColsumItem(C.Structure):
+    """neosr_colsum_item"""
+
+    _fields_ = [("x", C.c_void_p), ("out", C.c_void_p), ("rows", C.c_int32), ("cols", C.c_int32), ("ld", C.c_int32),
+                ("accumulate", C.c_int32)]
+
+
 class GemmDesc(C.Structure):
     """neosr_gemm_desc"""
 
@@ -303,6 +310,8 @@ SIGNATURES: dict[str, tuple] = {
     "neosr_gemm_workspace_bytes": (_i64, [C.POINTER(GemmDesc)]),
     "neosr_gemm": (C.c_int, [C.POINTER(GemmDesc), _vp]),
     "neosr_colsum": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "neosr_colsum_many_workspace_floats": (C.c_int64, [C.POINTER(ColsumItem), _i32]),
+    "neosr_colsum_many": (C.c_int, [C.POINTER(ColsumItem), _i32, _vp, _vp]),
     "neosr_layernorm_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp]),
     "neosr_layernorm_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     "neosr_layernorm_bwd_res": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),

@@ -522,7 +522,10 @@ extern "C" int neosr_layernorm_bwd(const float* dy, const float* x, const float*
 extern "C" int neosr_layernorm_bwd_res(const float* dy, const float* x, const float* stats, const float* gamma,
                                        const float* dres, float* dx, float* dgamma, float* dbeta, float* workspace,
                                        int64_t rows, int32_t C, int32_t accumulate, void* stream) {
-  NEOSR_CHECK(dy && x && stats && gamma && dx && dgamma && dbeta && workspace && rows > 0 && C > 0 &&
+  // dgamma == nullptr: leave the per-workgroup partials [return value][2 C] in `workspace` (dgamma | dbeta per row) for
+  // the caller to reduce later, batched with others (neosr_colsum_many); the return value is then the row count
+  const bool defer = !dgamma && !dbeta;
+  NEOSR_CHECK(dy && x && stats && gamma && dx && (defer || (dgamma && dbeta)) && workspace && rows > 0 && C > 0 &&
                   C <= LN_MAXI * 64, "layernorm_bwd: bad args");
   int nblk = (int)((rows + 15) / 16);  // >= 4 rows per wave
   if (nblk > 1024) nblk = 1024;
@@ -539,6 +542,7 @@ extern "C" int neosr_layernorm_bwd_res(const float* dy, const float* x, const fl
   }
 #undef LN_BWD
   NEOSR_LAUNCH_CHECK();
+  if (defer) return -nblk;  // (negative: not an error code)
   // per-workgroup partials [nblk][2][C] -> dgamma | dbeta; the column sums stage through the tail of
   // the workspace (behind the 2*1024*C partials)
   float* stage = workspace + (int64_t)2 * 1024 * C;

@@ -676,6 +676,49 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
   }
 }
 
+// Batched form of the same reduction (neosr_colsum_many): block b of the launch belongs to job j with
+// start[j] <= b < start[j + 1]; inside the job it is block (bx, by) of colsum_kernel's grid.
+constexpr int CSM_JOBS = 32;
+struct ColsumBatch {
+  const float* x[CSM_JOBS];
+  float* out[CSM_JOBS];
+  int rows[CSM_JOBS], cols[CSM_JOBS], ld[CSM_JOBS], rpb[CSM_JOBS], acc[CSM_JOBS], gx[CSM_JOBS];
+  int start[CSM_JOBS + 1];
+  int n;
+};
+__global__ __launch_bounds__(256) void colsum_many_kernel(const ColsumBatch bt) {
+  __shared__ float red[4][64];
+  int j = 0;
+#pragma unroll 1
+  for (int i = 1; i < bt.n; ++i)
+    if ((int)blockIdx.x >= bt.start[i]) j = i;
+  const int local = blockIdx.x - bt.start[j];
+  const int gx = bt.gx[j], bx = local % gx, by = local / gx;
+  const int rows = bt.rows[j], cols = bt.cols[j], ld = bt.ld[j], rpb = bt.rpb[j];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = bx * 64 + tx;
+  const int r0 = by * rpb, r1 = min(rows, r0 + rpb);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < cols) {
+    const float* p = bt.x[j] + c;
+    int r = r0 + ty;
+    for (; r + 12 < r1; r += 16) {
+      s0 += p[(int64_t)r * ld];
+      s1 += p[(int64_t)(r + 4) * ld];
+      s2 += p[(int64_t)(r + 8) * ld];
+      s3 += p[(int64_t)(r + 12) * ld];
+    }
+    for (; r < r1; r += 4) s0 += p[(int64_t)r * ld];
+  }
+  red[ty][tx] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (ty == 0 && c < cols) {
+    const float s = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+    float* o = bt.out[j] + (int64_t)by * cols + c;
+    *o = bt.acc[j] ? *o + s : s;
+  }
+}
+
 // split-K factor of the TN (weight-gradient) GEMM: the output is tiny (<= a few hundred rows and
 // columns) while K = B*H*W is huge, so the K range is cut until ~1024 workgroups exist (4 per CU),
 // never shorter than 4 chunks per workgroup
@@ -828,6 +871,12 @@ extern "C" int neosr_gemm(const neosr_gemm_desc* dp, void* stream) {
       hipLaunchKernelGGL(gemm_mfma_kernel<2>, grid, dim3(256), 0, st, a);
     if (prof) neosr_prof_end(stream);
     NEOSR_LAUNCH_CHECK();
+    // accumulate == 2: leave the [nsplit][slab] partials in the workspace for a batched reduction later
+    // (neosr_colsum_many: rows = nsplit = -return value, cols = ld = M N (+ M with colsum_a, which must follow C))
+    if (d.accumulate == 2) {
+      NEOSR_CHECK(!d.colsum_a || d.colsum_a == out + mn, "gemm TN: deferred reduction needs colsum_a right behind C");
+      return -nsplit;
+    }
     if (d.colsum_a == out + mn)
       return neosr_colsum(d.workspace, out, stage, nsplit, (int)a.slab, (int)a.slab, d.accumulate, stream);
     if (int rc = neosr_colsum(d.workspace, out, stage, nsplit, (int)mn, (int)a.slab, d.accumulate, stream)) return rc;
@@ -859,6 +908,73 @@ extern "C" int neosr_colsum(const float* x, float* out, float* workspace, int32_
     hipLaunchKernelGGL(colsum_kernel, dim3(gx, nblk), dim3(256), 0, st, x, workspace, rows, cols, ld, rpb, 0);
     hipLaunchKernelGGL(colsum_kernel, dim3(gx, 1), dim3(256), 0, st, workspace, out, nblk, cols, cols, nblk,
                        accumulate);
+  }
+  NEOSR_LAUNCH_CHECK();
+  return 0;
+}
+
+namespace {
+// row slabs of one job, exactly as neosr_colsum cuts them (same summation order as the unbatched call)
+inline void colsum_slabs(int rows, int cols, int& nblk, int& rpb) {
+  const int gx = ceil_div(cols, 64);
+  nblk = ceil_div(256, gx);
+  if (nblk < ceil_div(rows, 1024)) nblk = ceil_div(rows, 1024);
+  if (nblk > ceil_div(rows, 16)) nblk = ceil_div(rows, 16);
+  if (nblk > 256) nblk = 256;
+  if (nblk <= 1) {
+    nblk = 1;
+    rpb = rows;
+  } else {
+    rpb = ceil_div(ceil_div(rows, nblk), 4) * 4;
+    nblk = ceil_div(rows, rpb);
+  }
+}
+}  // namespace
+
+extern "C" int64_t neosr_colsum_many_workspace_floats(const neosr_colsum_item* items, int32_t n) {
+  int64_t tot = 64;
+  for (int i = 0; items && i < n; ++i) {
+    int nblk, rpb;
+    colsum_slabs(items[i].rows, items[i].cols, nblk, rpb);
+    if (nblk > 1) tot += (int64_t)nblk * items[i].cols;
+  }
+  return tot;
+}
+
+extern "C" int neosr_colsum_many(const neosr_colsum_item* items, int32_t n, float* workspace, void* stream) {
+  NEOSR_CHECK(items && n > 0 && workspace, "colsum_many: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  int64_t woff = 0;
+  for (int base = 0; base < n; base += CSM_JOBS) {
+    const int m = n - base < CSM_JOBS ? n - base : CSM_JOBS;
+    ColsumBatch a, b;  // stage 1 (all jobs), stage 2 (the jobs cut into row slabs)
+    a.n = m;
+    b.n = 0;
+    int sa = 0, sb = 0;
+    for (int i = 0; i < m; ++i) {
+      const neosr_colsum_item& it = items[base + i];
+      NEOSR_CHECK(it.x && it.out && it.rows > 0 && it.cols > 0 && it.ld >= it.cols, "colsum_many: bad item");
+      int nblk, rpb;
+      colsum_slabs(it.rows, it.cols, nblk, rpb);
+      const int gx = ceil_div(it.cols, 64);
+      float* part = workspace + woff;
+      a.x[i] = it.x; a.rows[i] = it.rows; a.cols[i] = it.cols; a.ld[i] = it.ld; a.rpb[i] = rpb; a.gx[i] = gx;
+      a.out[i] = nblk > 1 ? part : it.out;
+      a.acc[i] = nblk > 1 ? 0 : it.accumulate;
+      a.start[i] = sa;
+      sa += gx * nblk;
+      if (nblk > 1) {
+        const int k = b.n++;
+        b.x[k] = part; b.out[k] = it.out; b.rows[k] = nblk; b.cols[k] = it.cols; b.ld[k] = it.cols; b.rpb[k] = nblk;
+        b.gx[k] = gx; b.acc[k] = it.accumulate; b.start[k] = sb;
+        sb += gx;
+        woff += (int64_t)nblk * it.cols;
+      }
+    }
+    a.start[m] = sa;
+    b.start[b.n] = sb;
+    hipLaunchKernelGGL(colsum_many_kernel, dim3(sa), dim3(256), 0, st, a);
+    if (b.n) hipLaunchKernelGGL(colsum_many_kernel, dim3(sb), dim3(256), 0, st, b);
   }
   NEOSR_LAUNCH_CHECK();
   return 0;

@@ -8,6 +8,8 @@ torch is used for allocation and the autograd graph only; every FLOP runs in lib
 
 from __future__ import annotations
 
+import os
+
 import torch
 
 from neosr_amd import _C
@@ -26,7 +28,7 @@ def _new(shape, like):
 
 
 def gemm(mode, A, B, M, N, K, *, out=None, bias=None, res=None, aux_in=None, aux_out=None, row_scale=None,
-         rows_per_scale=0, gelu=False, accumulate=False, colsum_a=None):
+         rows_per_scale=0, gelu=False, accumulate=False, colsum_a=None, defer_to=None):
     """C = op(A) op(B) with the fused epilogue of `neosr_gemm` (include/neosr_amd.h). Dense operands.
     TN only: `colsum_a` (M floats) also receives sum_k A[k, :] (the bias gradient)."""
     lib = _C.load()
@@ -42,6 +44,14 @@ def gemm(mode, A, B, M, N, K, *, out=None, bias=None, res=None, aux_in=None, aux
     if mode == _C.GEMM_TN:
         ws = torch.empty(lib.neosr_gemm_workspace_bytes(d) // 4, device=A.device, dtype=torch.float32)
         d.workspace = ws.data_ptr()
+    if defer_to is not None:  # TN: queue the split reduction (see _defer_colsum); `out` must be _wgrad_pair's dW
+        d.accumulate = 2
+        rc = lib.neosr_gemm(d, _st())
+        if rc >= 0:
+            _C.check(rc or 1, "neosr_gemm")
+        slab = M * N + (M if colsum_a is not None else 0)
+        _defer_colsum(ws, -rc, slab, slab, out, defer_to)
+        return out
     _C.check(lib.neosr_gemm(d, _st()), "neosr_gemm")
     return out
 
@@ -71,6 +81,50 @@ def _wgrad_pair(like, n_out: int, k_in: int, want_bias: bool):
     return buf[: n_out * k_in].view(n_out, k_in), (buf[n_out * k_in:] if want_bias else None)
 
 
+# ------------------------------------------------------------------------------------------------
+# Deferred parameter-gradient reductions.  The per-workgroup partials of LayerNorm's dgamma / dbeta (and the other
+# fixed-order column sums of a block's backward) are not needed before the optimizer, so instead of two small launches
+# per layer the backward pass queues them and ONE batched call (`neosr_colsum_many`) at its end finishes all of them
+# and hands the results to `.grad` itself — the Function returns None for those inputs, so autograd never reads an
+# unfinished sum.  Only leaf tensors are deferred (a non-leaf weight needs its gradient inside the graph).
+_DEFERRED: list = []
+DEFER_REDUCTIONS = os.environ.get("NEOSR_AMD_DEFER_REDUCE", "1") != "0"
+
+
+def _can_defer(*params) -> bool:
+    # (not under hipGraph capture: the captured backward must contain its reductions)
+    return (DEFER_REDUCTIONS and all(p is not None and p.is_leaf and p.requires_grad for p in params)
+            and not torch.cuda.is_current_stream_capturing())
+
+
+def _defer_colsum(part, rows: int, cols: int, ld: int, out, targets) -> None:
+    """queue out[c] = sum_r part[r, c]; afterwards `targets` = [(leaf, view of out), ...] receive their gradients"""
+    if not _DEFERRED:
+        torch.autograd.Variable._execution_engine.queue_callback(_flush_deferred)  # noqa: SLF001
+    _DEFERRED.append((part, rows, cols, ld, out, targets))
+
+
+def _flush_deferred() -> None:
+    jobs = list(_DEFERRED)
+    _DEFERRED.clear()
+    if not jobs:
+        return
+    lib = _C.load()
+    items = (_C.ColsumItem * len(jobs))()
+    for it, (part, rows, cols, ld, out, _t) in zip(items, jobs):
+        it.x, it.out, it.rows, it.cols, it.ld, it.accumulate = part.data_ptr(), out.data_ptr(), rows, cols, ld, 0
+    ws = torch.empty(lib.neosr_colsum_many_workspace_floats(items, len(jobs)), device=jobs[0][0].device,
+                     dtype=torch.float32)
+    _C.check(lib.neosr_colsum_many(items, len(jobs), ws.data_ptr(), _st()), "neosr_colsum_many")
+    with torch.no_grad():
+        for *_x, targets in jobs:
+            for leaf, g in targets:
+                if leaf.grad is None:
+                    leaf.grad = g
+                else:
+                    leaf.grad += g
+
+
 def _as2d(x):
     x = _C.require_device(x, "x")
     if not x.is_contiguous():
@@ -85,6 +139,7 @@ class Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, res, rs, rows_per_scale):
         x2 = _as2d(x)
+        ctx.leaves = (w, b)
         w = _C.require_device(w, "weight").contiguous()
         M, K = x2.shape
         N = w.shape[0]
@@ -107,7 +162,13 @@ class Linear(torch.autograd.Function):
         want_b = has_b and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             gw, gb = _wgrad_pair(g2, N, K, want_b)  # bias gradient rides in the weight-gradient GEMM
-            gemm(_C.GEMM_TN, g2, x2, N, K, M, out=gw, colsum_a=gb, row_scale=rs, rows_per_scale=rps)
+            wl, bl = ctx.leaves
+            if _can_defer(wl, *((bl,) if want_b else ())):
+                gemm(_C.GEMM_TN, g2, x2, N, K, M, out=gw, colsum_a=gb, row_scale=rs, rows_per_scale=rps,
+                     defer_to=[(wl, gw)] + ([(bl, gb)] if want_b else []))
+                gw = gb = None
+            else:
+                gemm(_C.GEMM_TN, g2, x2, N, K, M, out=gw, colsum_a=gb, row_scale=rs, rows_per_scale=rps)
         elif want_b:
             gb = colsum(g2 if rs is None else row_scale(g2, rs, rps))
         return gx, gw, gb, (g if has_res else None), None, None
@@ -125,6 +186,7 @@ class Mlp(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, res, rs, rows_per_scale):
         x2 = _as2d(x)
+        ctx.leaves = (w1, b1, w2, b2)
         w1 = _C.require_device(w1, "fc1.weight").contiguous()
         w2 = _C.require_device(w2, "fc2.weight").contiguous()
         M, K = x2.shape
@@ -145,11 +207,18 @@ class Mlp(torch.autograd.Function):
         M, K, Hd, N, rps, has_res = ctx.meta
         g2 = _as2d(g)
         gw2, gb2 = _wgrad_pair(g2, N, Hd, True)  # bias gradients ride in the weight-gradient GEMMs
-        # DropPath scale of g: operand rows of the fc2 weight gradient, epilogue of its data gradient
-        gemm(_C.GEMM_TN, g2, h, N, Hd, M, out=gw2, colsum_a=gb2, row_scale=rs, rows_per_scale=rps)
-        gpre = gemm(_C.GEMM_NN, g2, w2, M, Hd, N, aux_in=pre, row_scale=rs, rows_per_scale=rps)  # (g W2) GELU'(pre)
         gw1, gb1 = _wgrad_pair(g2, Hd, K, True)
-        gemm(_C.GEMM_TN, gpre, x2, Hd, K, M, out=gw1, colsum_a=gb1)
+        l1, lb1, l2, lb2 = ctx.leaves
+        # (split reductions of both weight gradients queued for the batched pass at the end of backward when all four
+        # parameters are leaves)
+        defer = _can_defer(l1, lb1, l2, lb2) and all(ctx.needs_input_grad[1:5])
+        # DropPath scale of g: operand rows of the fc2 weight gradient, epilogue of its data gradient
+        gemm(_C.GEMM_TN, g2, h, N, Hd, M, out=gw2, colsum_a=gb2, row_scale=rs, rows_per_scale=rps,
+             defer_to=[(l2, gw2), (lb2, gb2)] if defer else None)
+        gpre = gemm(_C.GEMM_NN, g2, w2, M, Hd, N, aux_in=pre, row_scale=rs, rows_per_scale=rps)  # (g W2) GELU'(pre)
+        gemm(_C.GEMM_TN, gpre, x2, Hd, K, M, out=gw1, colsum_a=gb1, defer_to=[(l1, gw1), (lb1, gb1)] if defer else None)
+        if defer:
+            gw1 = gb1 = gw2 = gb2 = None
         gx = gemm(_C.GEMM_NN, gpre, w1, M, K, Hd).view(*g.shape[:-1], K) if ctx.needs_input_grad[0] else None
         return gx, gw1, gb1, gw2, gb2, (g if has_res else None), None, None
 
@@ -209,6 +278,7 @@ class ResidualLayerNorm(torch.autograd.Function):
         _C.check(lib.neosr_layernorm_fwd(x2.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
                                          stats.data_ptr(), rows, C_, eps, _st()), "neosr_layernorm_fwd")
         ctx.save_for_backward(x2, gamma, stats)
+        ctx.gamma_leaf, ctx.beta_leaf = gamma, beta
         return x.view_as(x), y.view(x.shape)
 
     @staticmethod
@@ -224,6 +294,13 @@ class ResidualLayerNorm(torch.autograd.Function):
         dgb = _new((2 * C_,), x2)  # dgamma | dbeta adjacent: one reduction launch
         dg, db = dgb[:C_], dgb[C_:]
         ws = _new(((2 * 1024 + 512) * C_,), x2)
+        if _can_defer(ctx.gamma_leaf, ctx.beta_leaf):
+            rc = lib.neosr_layernorm_bwd_res(g2.data_ptr(), x2.data_ptr(), stats.data_ptr(), gamma.data_ptr(), _p(gs2),
+                                             dx.data_ptr(), None, None, ws.data_ptr(), rows, C_, 0, _st())
+            if rc >= 0:
+                _C.check(rc or 1, "neosr_layernorm_bwd_res")
+            _defer_colsum(ws, -rc, 2 * C_, 2 * C_, dgb, [(ctx.gamma_leaf, dg), (ctx.beta_leaf, db)])
+            return dx.view(g.shape), None, None, None
         _C.check(lib.neosr_layernorm_bwd_res(g2.data_ptr(), x2.data_ptr(), stats.data_ptr(), gamma.data_ptr(),
                                              _p(gs2), dx.data_ptr(), dg.data_ptr(), db.data_ptr(), ws.data_ptr(),
                                              rows, C_, 0, _st()), "neosr_layernorm_bwd_res")

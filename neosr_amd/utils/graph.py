@@ -21,11 +21,15 @@ def graph_train_forward(net: torch.nn.Module, sample: torch.Tensor) -> None:
         raise RuntimeError("graph_train_forward: capture the network in train mode")
     eager = net.forward
     shape, dtype = tuple(sample.shape), sample.dtype
+    from neosr_amd.hip import transformer
+
     layers.FORCE_REPACK_IN_CAPTURE = True
+    defer, transformer.DEFER_REDUCTIONS = transformer.DEFER_REDUCTIONS, False  # warm-up uses autograd.grad on the parameters
     try:
         torch.cuda.make_graphed_callables(net, (sample,))
     finally:
         layers.FORCE_REPACK_IN_CAPTURE = False
+        transformer.DEFER_REDUCTIONS = defer
     graphed = net.forward
 
     def forward(x):

@@ -104,6 +104,65 @@ def test_gemm_tn_scales_gradient_rows_per_sample(Mo, No, T_, rps):
     assert rel_err(gx, (dY * rows).double() @ W.double()) < 1e-5
 
 
+def test_colsum_many_equals_single_calls_bitwise():
+    """The batched reduction (one launch pair per 32 jobs) cuts every job into the row slabs `neosr_colsum` uses: same
+    bits; 40 jobs of every size class (single slab, slabbed narrow matrices, wide split-K slabs, strided rows)."""
+    from neosr_amd import _C
+    from neosr_amd.hip import transformer as tr
+
+    lib = _C.load()
+    g = torch.Generator().manual_seed(11)
+    shapes = [(1024, 360, 360), (256, 5766, 5766), (56, 97380, 97380), (3, 64, 64), (1, 4, 4), (700, 180, 360),
+              (17, 1000, 1024), (43, 33, 40)] * 5
+    xs = [torch.randn(r, ld, generator=g).to(DEV) for (r, c, ld) in shapes]
+    outs = [torch.empty(c, device=DEV) for (r, c, ld) in shapes]
+    items = (_C.ColsumItem * len(shapes))()
+    for it, x, o, (r, c, ld) in zip(items, xs, outs, shapes):
+        it.x, it.out, it.rows, it.cols, it.ld, it.accumulate = x.data_ptr(), o.data_ptr(), r, c, ld, 0
+    ws = torch.empty(lib.neosr_colsum_many_workspace_floats(items, len(shapes)), device=DEV)
+    _C.check(lib.neosr_colsum_many(items, len(shapes), ws.data_ptr(), None), "neosr_colsum_many")
+    for x, o, (r, c, ld) in zip(xs, outs, shapes):
+        ref = torch.empty(c, device=DEV)
+        w1 = torch.empty(256 * c + 64, device=DEV)
+        _C.check(lib.neosr_colsum(x.data_ptr(), ref.data_ptr(), w1.data_ptr(), r, c, ld, 0, None), "neosr_colsum")
+        assert torch.equal(o, ref)
+        assert rel_err(o, x[:, :c].double().sum(0)) < 1e-5
+
+
+def test_deferred_parameter_gradient_reductions_equal_immediate_ones(monkeypatch):
+    """LayerNorm dgamma / dbeta and the Linear / Mlp weight + bias gradients with their reductions queued to the end of
+    backward (returned as None, handed to `.grad` by the flush) against the immediate path: identical bits, `.grad`
+    accumulation over two backward passes included, non-leaf parameters untouched (they keep the immediate path)."""
+    from neosr_amd.hip import transformer as tr
+
+    g = torch.Generator().manual_seed(5)
+    M, Cc = 4096 + 96, 180
+    x0 = torch.randn(2, M // 2, Cc, generator=g).to(DEV)
+    P = {k: v.to(DEV) for k, v in dict(
+        g1=torch.randn(Cc, generator=g), b1=torch.randn(Cc, generator=g), w=torch.randn(540, Cc, generator=g) * .05,
+        wb=torch.randn(540, generator=g), f1=torch.randn(360, 540, generator=g) * .05, fb1=torch.randn(360, generator=g),
+        f2=torch.randn(Cc, 360, generator=g) * .05, fb2=torch.randn(Cc, generator=g)).items()}
+    rs = (torch.rand(2, generator=g) < 0.7).float().to(DEV) / 0.7
+
+    def run(defer, scale_w):
+        monkeypatch.setattr(tr, "DEFER_REDUCTIONS", defer)
+        p = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+        x = x0.clone().requires_grad_(True)
+        for rep in range(2):  # second pass accumulates into existing .grad
+            w = p["w"] * 2.0 if scale_w else p["w"]  # non-leaf weight: must stay on the immediate path
+            sc, n = tr.residual_layer_norm(x, p["g1"], p["b1"])
+            h = tr.linear(n, w, p["wb"])
+            y = tr.mlp(h, p["f1"], p["fb1"], p["f2"], p["fb2"], res=sc, rs=rs, rows_per_scale=M // 2)
+            (y * (1.0 + rep)).sum().backward()
+        assert not tr._DEFERRED
+        return [x.grad] + [p[k].grad for k in sorted(p)]
+
+    for scale_w in (False, True):
+        a, b = run(True, scale_w), run(False, scale_w)
+        for u, v in zip(a, b):
+            assert u is not None and torch.equal(u, v)
+
+
 def test_gemm_random_shapes_all_modes_and_epilogues():
     """Seeded sweep over odd shapes: every GEMM kernel (128- and 64-row NT tiles with trimmed last chunk / skipped column
     tile / LDS bias / prefetched residual, staged NN, register-fed and staged TN) and every epilogue against float64."""
