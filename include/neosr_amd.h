@@ -446,6 +446,9 @@ typedef struct neosr_wattn_desc {
   float scale;
 } neosr_wattn_desc;
 int neosr_window_attention_fwd(const neosr_wattn_desc* d, void* stream);
+/* bwd with accumulate_rpb == 2 (here and in neosr_flash_window_attention_bwd, self-attention form): the bias-table
+ * partials stay in the workspace — [B nW][bins heads] at its start here, [B nW ws^2/64][bins heads] at float offset
+ * B nW heads ws^2 there — and the call returns -(rows) for neosr_colsum_many. */
 int neosr_window_attention_bwd(const neosr_wattn_desc* d, void* stream);
 /* Window attention of HAT on the fused qkv matrix [B*H*W, 3*C] in image order, windows of ws = 16 (hat_s / m / l) or 8:
  *   ks == ws:     (shifted-)window self-attention of HAB (hat_arch.py:168-216 inside :299-351), rel-pos

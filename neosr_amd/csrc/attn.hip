@@ -586,6 +586,9 @@ extern "C" int neosr_window_attention_bwd(const neosr_wattn_desc* d, void* strea
   NEOSR_LAUNCH_CHECK();
   // d_table[bin][head] (+)= column sums of the [nbw][bin*heads + head] per-window matrix (fixed order)
   const int cols = NB * d->heads;
+  // accumulate_rpb == 2: leave the [nbw][cols] partials at the start of the workspace for a batched reduction
+  // (neosr_colsum_many); returns -(rows)
+  if (d->accumulate_rpb == 2) return -nbw;
   return neosr_colsum(d->workspace, d->d_rpb_table, d->workspace + (int64_t)nbw * cols, nbw, cols, cols,
                       d->accumulate_rpb, stream);
 }

@@ -635,6 +635,9 @@ int launch_bwd(const neosr_fattn_desc& d, hipStream_t st) {
   }
   if (G::SELF) {  // bias gradient: fixed-order column sums of the per-(window, query block) bin partials
     const int cols = G::NBINS * d.heads;
+    // accumulate_rpb == 2: leave the [bw NQB][cols] partials (at float offset bw heads ws^2 of the workspace) for a
+    // batched reduction (neosr_colsum_many); returns -(rows)
+    if (d.accumulate_rpb == 2) return -(bw * G::NQB);
     return neosr_colsum(d.workspace + ws.ds_full, d.d_rpb_table, d.workspace + ws.stage, bw * G::NQB, cols, cols,
                         d.accumulate_rpb, (void*)st);
   }

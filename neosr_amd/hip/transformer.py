@@ -319,6 +319,7 @@ class WindowAttention(torch.autograd.Function):
     @staticmethod
     def forward(ctx, qkv, table, heads, ws, shift, scale):
         lib = _C.load()
+        ctx.table_leaf = table
         qkv = _C.require_device(qkv, "qkv").contiguous()
         table = _C.require_device(table, "relative_position_bias_table").contiguous()
         B, H, W, C3 = qkv.shape
@@ -342,11 +343,17 @@ class WindowAttention(torch.autograd.Function):
         dqkv = torch.empty_like(qkv)
         dtab = torch.empty_like(table)
         wsp = _new(((B * nW + 256) * heads * (2 * ws - 1) ** 2,), qkv)
+        defer = _can_defer(ctx.table_leaf)
         d = _C.WattnDesc(qkv=qkv.data_ptr(), rpb_table=table.data_ptr(), out=out.data_ptr(), lse=lse.data_ptr(),
                          dout=g.data_ptr(), dqkv=dqkv.data_ptr(), d_rpb_table=dtab.data_ptr(),
                          workspace=wsp.data_ptr(), B=B, H=H, W=W, C=C_, heads=heads, ws=ws, shift=shift,
-                         accumulate_rpb=0, scale=scale)
-        _C.check(lib.neosr_window_attention_bwd(d, _st()), "neosr_window_attention_bwd")
+                         accumulate_rpb=2 if defer else 0, scale=scale)
+        rc = lib.neosr_window_attention_bwd(d, _st())
+        if defer and rc < 0:  # bias-table partials [rows][bins * heads] at the start of the workspace
+            cols = heads * (2 * ws - 1) ** 2
+            _defer_colsum(wsp, -rc, cols, cols, dtab, [(ctx.table_leaf, dtab)])
+            return dqkv, None, None, None, None, None
+        _C.check(rc, "neosr_window_attention_bwd")
         return dqkv, dtab, None, None, None, None
 
 
@@ -409,6 +416,7 @@ class FlashWindowAttention(torch.autograd.Function):
     @staticmethod
     def forward(ctx, qkv, table, heads, ks, shift, scale, ws):
         lib = _C.load()
+        ctx.table_leaf = table
         qkv = _C.require_device(qkv, "qkv").contiguous()
         table = _C.require_device(table, "relative_position_bias_table").contiguous()
         B, H, W, C3 = qkv.shape
@@ -436,7 +444,16 @@ class FlashWindowAttention(torch.autograd.Function):
         wsp = torch.empty(lib.neosr_flash_window_attention_workspace_bytes(d) // 4, device=qkv.device,
                           dtype=torch.float32)
         d.workspace = wsp.data_ptr()
-        _C.check(lib.neosr_flash_window_attention_bwd(d, _st()), "neosr_flash_window_attention_bwd")
+        defer = ks == ws and _can_defer(ctx.table_leaf)  # (the overlapping form gathers its bins from a dense sum)
+        if defer:
+            d.accumulate_rpb = 2
+        rc = lib.neosr_flash_window_attention_bwd(d, _st())
+        if defer and rc < 0:
+            cols = heads * (2 * ws - 1) ** 2
+            part = wsp[B * (H // ws) * (W // ws) * heads * ws * ws:]
+            _defer_colsum(part, -rc, cols, cols, dtab, [(ctx.table_leaf, dtab)])
+            return dqkv, None, None, None, None, None, None
+        _C.check(rc, "neosr_flash_window_attention_bwd")
         return dqkv, dtab, None, None, None, None, None
 
 
