@@ -99,9 +99,16 @@ def _can_defer(*params) -> bool:
 
 def _defer_colsum(part, rows: int, cols: int, ld: int, out, targets) -> None:
     """queue out[c] = sum_r part[r, c]; afterwards `targets` = [(leaf, view of out), ...] receive their gradients"""
-    if not _DEFERRED:
-        torch.autograd.Variable._execution_engine.queue_callback(_flush_deferred)  # noqa: SLF001
+    # one callback per producing backward call, the first one to run does all the work: a backward pass that died with
+    # an exception leaves jobs behind without having run its callbacks, and "register when the queue is empty" would
+    # then never register again (`reset_deferred` drops such leftovers at the start of a training step)
+    torch.autograd.Variable._execution_engine.queue_callback(_flush_deferred)  # noqa: SLF001
     _DEFERRED.append((part, rows, cols, ld, out, targets))
+
+
+def reset_deferred() -> None:
+    """Drop reductions queued by a backward pass that did not finish (models call this before each step)."""
+    _DEFERRED.clear()
 
 
 def _flush_deferred() -> None:

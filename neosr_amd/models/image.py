@@ -387,6 +387,9 @@ class image(base):
         return l_g_total
 
     def optimize_parameters(self, current_iter: int) -> None:
+        from neosr_amd.hip import transformer as _tr
+
+        _tr.reset_deferred()  # (reductions queued by a backward pass that raised)
         self.n_accumulated += 1
         if self.n_accumulated >= self.accum_iters:
             self.n_accumulated = 0
