@@ -93,6 +93,10 @@ typedef struct neosr_conv_desc {
   const float* w_wino;      /* optional Winograd F(2x2,3x3) image of the same weights (neosr_conv3x3_pack_wino):
                                launches that qualify for w_pack and have no ups / s2d_c / PReLU take the Winograd
                                kernel (16/36 of the multiplications; same epilogue); see neosr_set_winograd */
+  const float* w_wino4;     /* optional Winograd F(4x4,3x3) image of the same weights (neosr_conv3x3_pack_wino4): under
+                               neosr_set_winograd(2) (the default) launches that would take w_wino and do not upsample
+                               take the F(4x4,3x3) kernel instead (36 multiplications per 4x4 output tile and channel
+                               pair instead of 144 direct / 64 with F(2x2,3x3); same epilogue) */
 } neosr_conv_desc;
 
 int neosr_conv3x3(const neosr_conv_desc* d, void* stream);
@@ -111,9 +115,18 @@ int neosr_conv3x3_pack_weights(const float* w, int32_t w_cout, int32_t w_cin, in
 int64_t neosr_conv3x3_pack_wino_bytes(int32_t N, int32_t K);
 int neosr_conv3x3_pack_wino(const float* w, int32_t w_cout, int32_t w_cin, int32_t mode, float* dst, void* stream);
 int neosr_set_winograd(int on);
+/* Winograd F(4x4, 3x3) image (conv_wino4.hip): [ceil(N/32)][ceil(K/32)][pos 36][k parity 2][cout block 2][k quad 4]
+ * [cout 16][4] floats, element (G g G^T)[pos] (6x6, points 0, +-1, +-2, inf; evaluated in float64 and rounded once) of the
+ * (n, k) pair the direct image addresses (mode FWD / DGRAD), zero padded.  fp32 products and sums; the larger transforms
+ * amplify rounding ~10x more than F(2x2,3x3): ~5e-6 of the output scale against a float64 convolution.
+ * neosr_set_winograd: 0 = direct kernels, 1 = F(2x2,3x3) wherever w_wino is given, 2 (default; env NEOSR_AMD_WINOGRAD)
+ * = F(4x4,3x3) wherever w_wino4 is given, else as 1. */
+int64_t neosr_conv3x3_pack_wino4_bytes(int32_t N, int32_t K);
+int neosr_conv3x3_pack_wino4(const float* w, int32_t w_cout, int32_t w_cin, int32_t mode, float* dst, void* stream);
 /* Both images of MANY weight tensors in ceil(n / 24) launches per image kind (the per-layer calls above cost one launch
  * each: a transformer generator with ~160 convolutions re-packs 4 images per layer after every optimizer step).
- * `items` is a HOST array; kind 0 = direct image (neosr_conv3x3_pack_weights), 1 = Winograd image. */
+ * `items` is a HOST array; kind 0 = direct image (neosr_conv3x3_pack_weights), 1 = Winograd F(2x2,3x3) image,
+ * 2 = Winograd F(4x4,3x3) image. */
 typedef struct neosr_pack_item {
   const float* w;
   float* dst;

@@ -60,6 +60,7 @@ class ConvDesc(C.Structure):
         ("s2d_c", C.c_int32),
         ("reserved0", C.c_int32),
         ("w_wino", C.c_void_p),
+        ("w_wino4", C.c_void_p),
     ]
 
 
@@ -255,6 +256,8 @@ SIGNATURES: dict[str, tuple] = {
     "neosr_set_winograd": (C.c_int, [C.c_int]),
     "neosr_conv3x3_pack_wino_bytes": (_i64, [_i32, _i32]),
     "neosr_conv3x3_pack_wino": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp]),
+    "neosr_conv3x3_pack_wino4_bytes": (_i64, [_i32, _i32]),
+    "neosr_conv3x3_pack_wino4": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp]),
     "neosr_conv3x3_pack_many": (C.c_int, [C.POINTER(PackItem), _i32, _vp]),
     "neosr_conv3x3_wgrad_workspace_bytes": (_i64, [_i32, _i32, _i32, _i32, _i32]),
     "neosr_conv3x3_wgrad": (C.c_int, [C.POINTER(WgradDesc), _vp]),

@@ -407,6 +407,9 @@ extern "C" int neosr_conv3x3(const neosr_conv_desc* dp, void* stream) {
   // Winograd F(2x2,3x3) form of the same launch (conv_wino.hip)
   const bool use_wino = use_pack && d.w_wino && ((uintptr_t)d.w_wino % 16 == 0) && d.s2d_c == 0 &&
                         d.act != NEOSR_ACT_PRELU && neosr_conv::wino_enabled();
+  // ... or its F(4x4,3x3) form (conv_wino4.hip): same conditions, nearest-upsampled inputs stay with F(2x2,3x3)
+  const bool use_wino4 = use_pack && d.w_wino4 && ((uintptr_t)d.w_wino4 % 16 == 0) && d.s2d_c == 0 && !d.ups &&
+                         d.act != NEOSR_ACT_PRELU && neosr_conv::wino_mode() == 2;
   const bool prof = neosr_prof_on();
   if (prof) {
     const double px = (double)d.B * d.H * d.W;
@@ -422,7 +425,9 @@ extern "C" int neosr_conv3x3(const neosr_conv_desc* dp, void* stream) {
   a.scalar_in = thin_k && !al_in;
   const bool thin_n = plain_in && d.N <= 4 && d.K >= 8 && (d.K % 4 == 0) && al_mk && !d.res1 && !d.res2 &&
                       !d.accumulate && !d.out_mask && d.act != NEOSR_ACT_PRELU;
-  if (use_wino) {
+  if (use_wino4) {
+    launch_wino4(a, st);
+  } else if (use_wino) {
     launch_wino(a, st);
   } else if (use_pack) {
     launch_glds(a, grid, st);

@@ -34,6 +34,13 @@ inline int64_t wino_image_floats(int N, int K) {
   return (int64_t)((N + 31) / 32) * ((K + 15) / 16) * WINO_IMG_FLOATS;
 }
 
+// Winograd F(4x4,3x3) image (conv_wino4.hip): [nblk][chunk 32 k][pos 36][k parity 2][cout block 2][k quad 4][cout 16][4]
+// floats, element = (G g G^T)[pos] (6x6, computed in float64); 144 KB per (n-block, chunk)
+constexpr int WINO4_IMG_FLOATS = 36 * 2 * 2 * 256;
+inline int64_t wino4_image_floats(int N, int K) {
+  return (int64_t)((N + 31) / 32) * ((K + 31) / 32) * WINO4_IMG_FLOATS;
+}
+
 constexpr int BATCH = 24;  // images per launch (passed by value as kernel arguments: 3.4 KB)
 struct Batch {
   Image im[BATCH];
@@ -42,5 +49,6 @@ struct Batch {
 // `images` is a HOST array; ceil(n / BATCH) launches, nothing is copied to the device.
 int launch(const Image* images, int n, void* stream);
 int launch_wino(const Image* images, int n, void* stream);  // same descriptors, Winograd images
+int launch_wino4(const Image* images, int n, void* stream); // same descriptors, Winograd F(4x4,3x3) images
 
 }  // namespace neosr_pack

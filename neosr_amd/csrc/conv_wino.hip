@@ -374,21 +374,24 @@ __global__ __launch_bounds__(256) void conv_pack_wino_kernel(const neosr_pack::B
     *reinterpret_cast<float4*>(dst + pos * 512) = make_float4(u[pos][0], u[pos][1], u[pos][2], u[pos][3]);
 }
 
-int g_wino = -1;  // -1: read NEOSR_AMD_WINOGRAD on first use (default on)
+int g_wino = -1;  // -1: read NEOSR_AMD_WINOGRAD on first use (default 2: F(4x4,3x3) where an image is given)
 
 }  // namespace
 
-bool neosr_conv::wino_enabled() {
+int neosr_conv::wino_mode() {
   if (g_wino < 0) {
     const char* e = getenv("NEOSR_AMD_WINOGRAD");
-    g_wino = (e && atoi(e) == 0) ? 0 : 1;
+    const int v = e ? atoi(e) : 2;
+    g_wino = v <= 0 ? 0 : (v == 1 ? 1 : 2);
   }
-  return g_wino != 0;
+  return g_wino;
 }
 
+bool neosr_conv::wino_enabled() { return wino_mode() != 0; }
+
 extern "C" int neosr_set_winograd(int on) {
-  const int prev = neosr_conv::wino_enabled() ? 1 : 0;
-  g_wino = on ? 1 : 0;
+  const int prev = neosr_conv::wino_mode();
+  g_wino = on <= 0 ? 0 : (on == 1 ? 1 : 2);
   return prev;
 }
 
@@ -446,7 +449,7 @@ extern "C" int neosr_conv3x3_pack_wino(const float* w, int32_t w_cout, int32_t w
 
 extern "C" int neosr_conv3x3_pack_many(const neosr_pack_item* items, int32_t n, void* stream) {
   NEOSR_CHECK(items && n > 0, "conv3x3_pack_many: bad arguments");
-  std::vector<neosr_pack::Image> direct, wino;
+  std::vector<neosr_pack::Image> direct, wino, wino4;
   for (int i = 0; i < n; ++i) {
     const neosr_pack_item& it = items[i];
     NEOSR_CHECK(it.w && it.dst && it.w_cout > 0 && it.w_cin > 0, "conv3x3_pack_many: bad item");
@@ -464,11 +467,13 @@ extern "C" int neosr_conv3x3_pack_many(const neosr_pack_item* items, int32_t n, 
     im.seg[0].k_lo = 0;
     im.seg[0].k_cnt = im.K;
     im.seg[0].n_lo = 0;
-    (it.kind ? wino : direct).push_back(im);
+    (it.kind == 2 ? wino4 : it.kind ? wino : direct).push_back(im);
   }
   if (!direct.empty())
     if (int rc = neosr_pack::launch(direct.data(), (int)direct.size(), stream)) return rc;
   if (!wino.empty())
     if (int rc = neosr_pack::launch_wino(wino.data(), (int)wino.size(), stream)) return rc;
+  if (!wino4.empty())
+    if (int rc = neosr_pack::launch_wino4(wino4.data(), (int)wino4.size(), stream)) return rc;
   return 0;
 }

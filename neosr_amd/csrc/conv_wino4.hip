@@ -1,0 +1,456 @@
+// conv_wino4.hip — Winograd F(4x4, 3x3) form of the 3x3 / stride 1 / pad 1 convolution for gfx950 (fp32, MFMA).
+//
+// Same launches and the same epilogue contract as conv3x3_wino_kernel (conv_wino.hip: the RDB trunk's forward and
+// gather-form backward-data convolutions, neosr/archs/esrgan_arch.py:82-142 and their autograd backward), but a 4x4
+// output tile costs 36 multiplications per (channel pair) instead of 4 x 16 = 64 with F(2x2,3x3) or 144 in the direct
+// form:
+//
+//   Y(4x4) = A^T [ sum_k U_k (.) V_k ] A,   U = G g G^T (6x6 per (cin, cout), float64 -> fp32, neosr_conv3x3_pack_wino4),
+//   V = B^T d B (6x6 per (tile, cin)),  d = the 6x6 input patch of the tile (Lavin & Gray 2016, points 0, +-1, +-2, inf)
+//
+// MI355X mapping.  A workgroup of TWELVE waves owns 16 x 16 output pixels (4 x 4 Winograd tiles) and 32 output channels;
+// at B = 16 a 64 x 64 launch is then 256 workgroups = one per CU, three waves per SIMD.  Each of the 36 transform
+// positions is an independent 16 tiles x 32 cout x K GEMM on v_mfma_f32_16x16x4_f32 (two 16-cout blocks):
+//   * wave (i, kp) OWNS ROW i of the 6x6 transform for the channels of k-parity kp (the first / second 16 channels of
+//     every 32-channel chunk): 6 positions x 2 cout blocks = 12 accumulators of 4 registers; the two k-parities are
+//     summed in the accumulator exchange at the end;
+//   * lane = (tile = lane & 15, k quad = lane >> 4) is the B-fragment owner: it reads the 3-4 patch rows of ITS tile that
+//     row i of B^T needs as 16-byte channel quads from the raw LDS tile, runs the column pass (3 FMAs per element) and the
+//     row pass (12 per channel) in registers and feeds the 6 x 4 results straight into MFMAs — the transformed input
+//     never exists in memory;
+//   * the A operand (U of position (i, j), 4 channels, cout = lane & 15) is one 16-byte buffer load of the packed image
+//     per (position, cout block) and chunk: every wave streams ITS twelve 1 KB rows, L2 resident (all workgroups of a
+//     launch read the same image), refilled in two halves right behind the MFMAs that consumed them;
+//   * LDS holds the raw 18 x 18 x 32-channel tile (two buffers, 45 KB each, `buffer_load ... lds`, out-of-image granules
+//     get an out-of-range offset = zeros); pixel slots are parity-split and the channel quad XOR-swizzled so that every
+//     ds_read_b128 lane group hits 16 distinct 16-byte bank groups (see q_off);
+//   * the loop is skewed across the one barrier per chunk: the MFMAs of positions (i, 3..5) of chunk c are issued AFTER
+//     the barrier that releases chunk c + 1, in front of that chunk's transform, and the three waves of a SIMD run at
+//     three static priorities — one wave's transform (vector instructions) lies beside another's MFMAs instead of all
+//     twelve waves transforming at once behind the barrier.
+// Exact fp32 products and sums in the Winograd summation order; the F(4x4) transforms amplify rounding ~10x more than
+// F(2x2): ~5e-6 of the output scale against the float64 convolution (tests: <= 1e-4 at kernel level; north_star allows
+// 1e-3).  neosr_set_winograd(1) keeps F(2x2,3x3) for every launch, neosr_set_winograd(0) the direct kernel.
+#include <cstring>
+#include <vector>
+#include <stdlib.h>
+#include "conv_common.h"
+#include "conv_pack.h"
+
+using namespace neosr_conv;
+
+namespace {
+
+constexpr int QT = 16;                 // output pixels per workgroup side
+constexpr int QR = QT + 2;             // raw tile side 18
+constexpr int QSLOTS = 360;            // pixel slots of a raw buffer: 180 even (rows 0-7, 16, 17) + 180 odd (rows 8-15; 36 unused)
+constexpr int QGRAN = QSLOTS * 8;      // 16-byte granules per 32-channel chunk = 2880 = 45 wave-level DMA instructions
+constexpr int QES = 36;                // tile stride (floats) of the accumulator exchange image
+constexpr int QEXF = 6 * 4 * 16 * QES; // one k-parity half of the exchange image: [row 6][b 4][tile 16][cout 32 (+4)] = 13824 floats
+constexpr int QBUF = QEXF;             // floats per LDS object (raw buffer needs 360 * 32 = 11520)
+static_assert(QSLOTS * 32 <= QBUF, "raw buffer must fit its LDS object");
+constexpr int QU_CHUNK = neosr_pack::WINO4_IMG_FLOATS;  // 36 pos x 2 kp x 2 cout blocks x 256 floats = 144 KB per 32 channels
+
+typedef __attribute__((address_space(3))) void* lds_void;
+
+__device__ __forceinline__ f32x4 ld4f(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 splat(float v) { return (f32x4){v, v, v, v}; }
+__device__ __forceinline__ f32x4 fma4(f32x4 a, f32x4 b, f32x4 c) { return __builtin_elementwise_fma(a, b, c); }
+
+// Raw tile image: pixel (y, x) of the 18 x 18 tile, channel quad q (0..7) of the chunk lives at float offset
+//   32 * slot(y, x) + 4 * (q ^ swz(y, x)),   slot = 2 * (yy * 18 + x) + odd,  odd = 1 for rows 8..15 (yy = y - 8),
+//   else 0 with yy = y (rows 0..7) or y - 8 (rows 16, 17);  swz = ((x >> 2) & 3) | (((y >> 2) & 1) << 2).
+// A ds_read_b128 lane group holds the 16 tiles once each (k quad fixed per tile row); their pixels (4 ty + r, 4 tx + c)
+// differ in (slot parity, (y >> 2) & 1, (x >> 2) & 3) = 16 distinct 16-byte bank groups for every patch position.
+__device__ __forceinline__ int q_slot(int y, int x) {
+  const int odd = (y >= 8 && y < 16) ? 1 : 0;
+  const int yy = y < 8 ? y : y - 8;
+  return 2 * (yy * QR + x) + odd;
+}
+__device__ __forceinline__ int q_swz(int y, int x) { return ((x >> 2) & 3) | (((y >> 2) & 1) << 2); }
+__device__ __forceinline__ int q_off(int y, int x, int q) { return 32 * q_slot(y, x) + 4 * (q ^ q_swz(y, x)); }
+
+__global__ __attribute__((amdgpu_flat_work_group_size(768, 768), amdgpu_waves_per_eu(3, 3)))
+void conv3x3_wino4_kernel(const ConvArgs args) {
+  const neosr_conv_desc& d = args.d;
+  // two DISTINCT LDS objects: raw buffers during the loop, the two k-parity halves of the exchange image afterwards
+  __shared__ __attribute__((aligned(1024))) float ldsA[QBUF];
+  __shared__ __attribute__((aligned(1024))) float ldsB[QBUF];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ti = wave >> 1, kp = wave & 1;   // transform row, channel parity
+  const int t16 = lane & 15, kq = lane >> 4;
+  const int tyi = t16 >> 2, txi = t16 & 3;
+  // waves w, w + 4, w + 8 share a SIMD: three static priorities (see the header)
+  if (wave >= 8) __builtin_amdgcn_s_setprio(2);
+  else if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+
+  int bid = xcd_tile(blockIdx.x, gridDim.x, args.xcd);
+  const int tx = bid % args.tiles_x;
+  bid /= args.tiles_x;
+  const int ty = bid % args.tiles_y;
+  const int b = bid / args.tiles_y;
+  const int x0 = tx * QT, y0 = ty * QT;
+  const int n0 = blockIdx.y * 32;
+  const int H = d.H, W = d.W, K = d.K;
+  const int Hin = d.ups ? (H >> 1) : H, Win = d.ups ? (W >> 1) : W;
+  const int nchunks = (K + 31) >> 5;
+
+  // ---- DMA granules of this thread: round r, G = r * 768 + tid -> slot G >> 3, LDS quad G & 7
+  const auto rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.in) + (int64_t)b * Hin * Win * d.in_cs, 0,
+                                                     ((Hin * Win - 1) * d.in_cs + K) * 4, 0x00020000);
+  // (granule geometry as a function of (round, thread): also re-evaluated by the ragged last chunk, so that no register
+  // besides the offset is carried through the loop)
+  auto gran = [&](int r, int& q4) -> int {
+    const int G = r * 768 + tid;
+    const int P = G >> 3, sl = G & 7;
+    const int odd = P & 1, idx = P >> 1;
+    const int yy = idx / QR, x = idx - yy * QR;
+    const int y = odd ? yy + 8 : (yy < 8 ? yy : yy + 8);
+    const bool used = G < QGRAN && (odd ? yy < 8 : yy < 10);
+    const int q = sl ^ q_swz(y, x);
+    const int gy = y0 + y - 1, gx = x0 + x - 1;
+    q4 = q << 2;
+    if (used && gy >= 0 && gy < H && gx >= 0 && gx < W) {
+      const int sy = d.ups ? (gy >> 1) : gy, sx = d.ups ? (gx >> 1) : gx;
+      return ((sy * Win + sx) * d.in_cs + (q << 2)) * 4;
+    }
+    return 0x7ffffff0;
+  };
+  int in_off[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    int q4;
+    in_off[r] = gran(r, q4);
+  }
+  auto issue = [&](int c, float* buf) {
+    const int c0 = c * 32;
+    if (c0 + 32 <= K) {  // uniform
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (r == 3 && wave >= 9) break;  // granules 2304 .. 2879: waves 0-8
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_void)(buf + (r * 12 + wave) * 256), 16, in_off[r], c0 * 4, 0, 0);
+      }
+    } else {  // ragged last chunk: channel quads past K get zeros
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (r == 3 && wave >= 9) break;
+        int q4;
+        const int o = gran(r, q4);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_void)(buf + (r * 12 + wave) * 256), 16,
+                                                 c0 + q4 < K ? o : 0x7ffffff0, c0 * 4, 0, 0);
+      }
+    }
+  };
+
+  // ---- patch rows of this wave: t = g * (aq * d[r1] + d[r3]) + (ap * d[r2] + d[r4]); rows 0 / 5: t = 4 d[r1] + (-5 d[r2] + d[r4])
+  //   row 0: 4 d0 - 5 d2 + d4            rows 1, 2: (d4 - 4 d2) +- (d3 - 4 d1)
+  //   row 5: 4 d1 - 5 d3 + d5            rows 3, 4: (d4 - d2) +- 2 (d3 - d1)
+  const bool three = ti == 0 || ti == 5;
+  const int r1 = ti == 0 ? 0 : 1;
+  const int r2 = ti == 5 ? 3 : 2;
+  const int r3 = 3;                       // unused by rows 0 / 5
+  const int r4 = ti == 5 ? 5 : 4;
+  const float ap = three ? -5.f : (ti <= 2 ? -4.f : -1.f);
+  const float aq = ap;                    // (d3 + aq d1) uses the same factor as (d4 + ap d2) for rows 1-4
+  const float gm = three ? 4.f : (ti == 1 ? 1.f : ti == 2 ? -1.f : ti == 3 ? 2.f : -2.f);
+  // LDS float offsets of (row rk, column 0 / column 4) of this lane's patch; columns c & 3 are +64 floats each
+  const int qq = 4 * kp + kq;
+  int pa[4][2];
+  {
+    const int rows[4] = {r1, r2, r3, r4};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int cs = 0; cs < 2; ++cs) pa[k][cs] = q_off(4 * tyi + rows[k], 4 * txi + 4 * cs, qq);
+  }
+
+  // ---- U image of this n-block: [chunk][pos 36][kp 2][cout block 2][k quad 4][cout 16][4] floats
+  const auto ru = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(d.w_wino4) + (int64_t)blockIdx.y * nchunks * QU_CHUNK, 0, nchunks * QU_CHUNK * 4, 0x00020000);
+  const int u_lane = lane * 16;
+  const int u_wave = ((ti * 6) * 4 + kp * 2) * 1024;
+  typedef decltype(__builtin_amdgcn_raw_buffer_load_b128(ru, 0, 0, 0)) u32x4_t;
+  auto load_u3 = [&](int c, int j0, f32x4 (&u)[3][2]) {   // positions (ti, j0 .. j0 + 2) of chunk c
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(ru, u_lane + nb * 1024, c * (QU_CHUNK * 4) + u_wave + (j0 + j) * 4096, 0);
+        u[j][nb] = __builtin_bit_cast(f32x4, v);
+      }
+  };
+
+  f32x4 acc[6][2];
+#pragma unroll
+  for (int j = 0; j < 6; ++j)
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) acc[j][nb] = splat(0.f);
+
+  auto mac3 = [&](int j0, const f32x4 (&v)[3], const f32x4 (&u)[3][2]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+          acc[j0 + j][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[j][nb][e], v[j][e], acc[j0 + j][nb], 0, 0, 0);
+  };
+
+  // column pass (row ti of B^T d) then row pass ((B^T d) B) for the lane's four channels
+  auto transform = [&](const float* rb, f32x4 (&vlo)[3], f32x4 (&vhi)[3]) {
+    f32x4 t[6];
+    const f32x4 ap4 = splat(ap), aq4 = splat(aq), gm4 = splat(gm);
+    if (three) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        const int o = (c & 3) * 64;
+        const f32x4 da = ld4f(rb + pa[0][c >> 2] + o), db = ld4f(rb + pa[1][c >> 2] + o), dc = ld4f(rb + pa[3][c >> 2] + o);
+        t[c] = fma4(gm4, da, fma4(ap4, db, dc));
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        const int o = (c & 3) * 64;
+        const f32x4 d1 = ld4f(rb + pa[0][c >> 2] + o), d2 = ld4f(rb + pa[1][c >> 2] + o);
+        const f32x4 d3 = ld4f(rb + pa[2][c >> 2] + o), d4 = ld4f(rb + pa[3][c >> 2] + o);
+        t[c] = fma4(gm4, fma4(aq4, d1, d3), fma4(ap4, d2, d4));
+      }
+    }
+    const f32x4 m4 = splat(-4.f), m5 = splat(-5.f), p4 = splat(4.f), p2 = splat(2.f), m2 = splat(-2.f);
+    const f32x4 a = fma4(m4, t[2], t[4]), bq = fma4(m4, t[1], t[3]);
+    const f32x4 cc = t[4] - t[2], dd = t[3] - t[1];
+    vlo[0] = fma4(p4, t[0], fma4(m5, t[2], t[4]));
+    vlo[1] = a + bq;
+    vlo[2] = a - bq;
+    vhi[0] = fma4(p2, dd, cc);
+    vhi[1] = fma4(m2, dd, cc);
+    vhi[2] = fma4(p4, t[1], fma4(m5, t[3], t[5]));
+  };
+
+  f32x4 ulo[3][2], uhi[3][2], vlo[3], vhi[3];
+  issue(0, ldsA);
+  load_u3(0, 0, ulo);
+  __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
+  __syncthreads();
+  for (int c = 0; c < nchunks; ++c) {
+    const float* rb = (c & 1) ? ldsB : ldsA;
+    if (c > 0) mac3(3, vhi, uhi);  // positions (ti, 3..5) of chunk c - 1
+    __builtin_amdgcn_sched_barrier(0);
+    // (hipcc's wait for the U registers above is vmcnt(0) across the loop back edge: the DMA of the next chunk is therefore
+    // requested BEHIND those MFMAs, not in front of them — it still has the transform and 24 MFMAs to land)
+    if (c + 1 < nchunks) issue(c + 1, (c & 1) ? ldsA : ldsB);
+    __builtin_amdgcn_sched_barrier(0);
+    transform(rb, vlo, vhi);
+    __builtin_amdgcn_sched_barrier(0);
+    load_u3(c, 3, uhi);            // (their U registers are free during the transform: requested only now)
+    __builtin_amdgcn_sched_barrier(0);
+    mac3(0, vlo, ulo);
+    __builtin_amdgcn_sched_barrier(0);
+    if (c + 1 < nchunks) {
+      load_u3(c + 1, 0, ulo);
+      // chunk c + 1 has landed (the twelve U loads issued behind it may stay in flight) ...
+      __builtin_amdgcn_s_waitcnt(0x0f7c);  // vmcnt(12)
+    }
+    __syncthreads();  // ... for every wave, and every wave is done reading buffer c & 1
+  }
+  mac3(3, vhi, uhi);
+  __builtin_amdgcn_s_setprio(0);
+
+  // ---- epilogue operands of thread (tile, b, cout quad) — waves 0-7 — requested now: their latency hides under the row
+  // pass, the exchange and its barrier
+  const bool fin = wave < 8;
+  const int cq = (tid & 7) << 2, eb = (tid >> 3) & 3, et = (tid >> 5) & 15;
+  const int chq = n0 + cq;
+  const bool ch_ok = fin && chq < d.N;
+  const int cs0 = ch_ok ? chq : 0;
+  f32x4 bias = splat(0.f);
+  float s_uni = 1.f;
+  if (d.act == ACT_LRELU) s_uni = d.slope;
+  else if (d.act == ACT_RELU) s_uni = 0.f;
+  const int ey = y0 + 4 * (et >> 2), ex = x0 + 4 * (et & 3) + eb;
+  bool okp[4];
+  int64_t pixp[4];
+  f32x4 e1[4], e2[4], e0[4], mk[4];
+  if (fin) {
+    if (d.bias) bias = ld4f(d.bias + cs0);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int py = ey + a;
+      okp[a] = ch_ok && py < H && ex < W;
+      pixp[a] = okp[a] ? ((int64_t)b * H + py) * W + ex : 0;
+      e1[a] = e2[a] = e0[a] = splat(0.f);
+      mk[a] = splat(1.f);
+      if (d.res1) e1[a] = ld4f((okp[a] && chq < d.res1_nch) ? d.res1 + pixp[a] * d.res1_cs + chq : g_zero_page);
+      if (d.res2) e2[a] = ld4f((okp[a] && chq < d.res2_nch) ? d.res2 + pixp[a] * d.res2_cs + chq : g_zero_page);
+      if (d.accumulate) e0[a] = ld4f(okp[a] ? d.out + pixp[a] * d.out_cs + chq : g_zero_page);
+      if (d.out_mask) mk[a] = ld4f(okp[a] ? d.out_mask + pixp[a] * d.out_mask_cs + chq : g_zero_page);
+    }
+  }
+
+  // ---- output transform, row pass IN THE WAVE: X[i][b] = sum_j M[i][j] A[j][b],
+  //   A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+  // exchange image (k-parity kp in its own LDS object): [ti][b][tile][cout], register e of acc[.][nb] <-> cout 16 nb + 4 kq + e
+  {
+    float* ex_img = kp ? ldsB : ldsA;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      const f32x4 s1 = acc[1][nb] + acc[2][nb], d1 = acc[1][nb] - acc[2][nb];
+      const f32x4 s2 = acc[3][nb] + acc[4][nb], d2 = acc[3][nb] - acc[4][nb];
+      const f32x4 x0v = (acc[0][nb] + s1) + s2;
+      const f32x4 x1v = fma4(splat(2.f), d2, d1);
+      const f32x4 x2v = fma4(splat(4.f), s2, s1);
+      const f32x4 x3v = fma4(splat(8.f), d2, d1) + acc[5][nb];
+      float* p = ex_img + ((ti * 4) * 16 + t16) * QES + 16 * nb + 4 * kq;
+      *reinterpret_cast<f32x4*>(p) = x0v;
+      *reinterpret_cast<f32x4*>(p + 16 * QES) = x1v;
+      *reinterpret_cast<f32x4*>(p + 32 * QES) = x2v;
+      *reinterpret_cast<f32x4*>(p + 48 * QES) = x3v;
+    }
+  }
+  __syncthreads();
+  if (!fin) return;
+
+  // ---- column pass (+ the k-parity sum) and epilogue: Y[a][b] = sum_i A^T[a][i] X[i][b]
+  f32x4 xi[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int o = ((i * 4 + eb) * 16 + et) * QES + cq;
+    xi[i] = ld4f(ldsA + o) + ld4f(ldsB + o);
+  }
+  f32x4 y[4];
+  {
+    const f32x4 s1 = xi[1] + xi[2], d1 = xi[1] - xi[2], s2 = xi[3] + xi[4], d2 = xi[3] - xi[4];
+    y[0] = (xi[0] + s1) + s2;
+    y[1] = fma4(splat(2.f), d2, d1);
+    y[2] = fma4(splat(4.f), s2, s1);
+    y[3] = fma4(splat(8.f), d2, d1) + xi[5];
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float t = y[a][e] + bias[e];
+      t = t > 0.f ? t : t * s_uni;
+      t = t * d.alpha + e1[a][e];
+      t = t * d.alpha2 + e2[a][e];
+      t += e0[a][e];
+      o[e] = mk[a][e] > 0.f ? t : t * d.out_mask_slope;
+    }
+    *reinterpret_cast<f32x4*>(okp[a] ? d.out + pixp[a] * d.out_cs + chq : g_trash + (tid & 255) * 4) = o;
+  }
+}
+
+// U = G g G^T of every (cin, cout) pair of an image, in float64, rounded once:
+//   dst[nblk][chunk 32 k][pos = i * 6 + j][kp 2][cout block 2][k quad 4][cout 16][4]
+// one thread per (n-block, chunk, k quad 0..7, n 0..31) loads the 4 x 9 taps of its four channels and writes 36 granules.
+__global__ __launch_bounds__(256) void conv_pack_wino4_kernel(const neosr_pack::Batch batch) {
+  const neosr_pack::Image& im = batch.im[blockIdx.y];
+  const int nch = (im.K + 31) >> 5, nblk = (im.N + 31) >> 5;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= nblk * nch * 256) return;
+  const int n32 = t & 31, q = (t >> 5) & 7;
+  const int rest = t >> 8;
+  const int chunk = rest % nch, nb = rest / nch;
+  const int n = nb * 32 + n32, k0 = chunk * 32 + q * 4;
+  float g[4][9];
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) g[e][tap] = 0.f;
+  if (n < im.N && k0 < im.K) {
+    for (int s = 0; s < im.nseg; ++s) {
+      const neosr_pack::Seg& sg = im.seg[s];
+      if (k0 < sg.k_lo || k0 >= sg.k_lo + sg.k_cnt) continue;
+      const int kk = k0 - sg.k_lo;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (kk + e >= sg.k_cnt) break;
+        const float* src = im.mode == NEOSR_CONV_FWD ? sg.w + ((int64_t)(sg.n_lo + n) * sg.w_cin + kk + e) * 9
+                                                     : sg.w + ((int64_t)(kk + e) * sg.w_cin + sg.n_lo + n) * 9;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) g[e][tap] = src[im.mode == NEOSR_CONV_FWD ? tap : 8 - tap];
+      }
+    }
+  }
+  // rows of G: (1/4, 0, 0), (-1/6, -1/6, -1/6), (-1/6, 1/6, -1/6), (1/24, 1/12, 1/6), (1/24, -1/12, 1/6), (0, 0, 1)
+  const double G0[6] = {0.25, -1.0 / 6, -1.0 / 6, 1.0 / 24, 1.0 / 24, 0.0};
+  const double G1[6] = {0.0, -1.0 / 6, 1.0 / 6, 1.0 / 12, -1.0 / 12, 0.0};
+  const double G2[6] = {0.0, -1.0 / 6, -1.0 / 6, 1.0 / 6, 1.0 / 6, 1.0};
+  float* dst = im.dst + ((int64_t)(nb * nch + chunk) * QU_CHUNK) + ((q >> 2) * 2 + (n32 >> 4)) * 256 + ((q & 3) * 16 + (n32 & 15)) * 4;
+  double cg[4][3][6];  // (g G^T)[a][j] per channel
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int j = 0; j < 6; ++j)
+        cg[e][a][j] = G0[j] * (double)g[e][a * 3] + G1[j] * (double)g[e][a * 3 + 1] + G2[j] * (double)g[e][a * 3 + 2];
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      float4 v;
+      v.x = (float)(G0[i] * cg[0][0][j] + G1[i] * cg[0][1][j] + G2[i] * cg[0][2][j]);
+      v.y = (float)(G0[i] * cg[1][0][j] + G1[i] * cg[1][1][j] + G2[i] * cg[1][2][j]);
+      v.z = (float)(G0[i] * cg[2][0][j] + G1[i] * cg[2][1][j] + G2[i] * cg[2][2][j]);
+      v.w = (float)(G0[i] * cg[3][0][j] + G1[i] * cg[3][1][j] + G2[i] * cg[3][2][j]);
+      *reinterpret_cast<float4*>(dst + (i * 6 + j) * 1024) = v;
+    }
+}
+
+}  // namespace
+
+void neosr_conv::launch_wino4(const ConvArgs& a, hipStream_t st) {
+  ConvArgs w = a;
+  w.tiles_x = ceil_div(a.d.W, QT);
+  w.tiles_y = ceil_div(a.d.H, QT);
+  dim3 grid(w.tiles_x * w.tiles_y * a.d.B, ceil_div(a.d.N, 32));
+  hipLaunchKernelGGL(conv3x3_wino4_kernel, grid, dim3(768), 0, st, w);
+}
+
+int neosr_pack::launch_wino4(const Image* images, int n, void* stream) {
+  NEOSR_CHECK(images && n > 0, "conv pack (winograd 4x4): bad arguments");
+  for (int i0 = 0; i0 < n; i0 += BATCH) {
+    const int cnt = n - i0 < BATCH ? n - i0 : BATCH;
+    Batch bt;
+    memset(&bt, 0, sizeof(bt));
+    int64_t thr = 0;
+    for (int i = 0; i < cnt; ++i) {
+      bt.im[i] = images[i0 + i];
+      const int64_t g = wino4_image_floats(bt.im[i].N, bt.im[i].K) / 144;  // one thread per 36 granules
+      thr = g > thr ? g : thr;
+    }
+    dim3 grid((unsigned)((thr + 255) / 256), cnt);
+    hipLaunchKernelGGL(conv_pack_wino4_kernel, grid, dim3(256), 0, (hipStream_t)stream, bt);
+  }
+  NEOSR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int64_t neosr_conv3x3_pack_wino4_bytes(int32_t N, int32_t K) {
+  if (N <= 0 || K <= 0) return -1;
+  return neosr_pack::wino4_image_floats(N, K) * 4;
+}
+
+extern "C" int neosr_conv3x3_pack_wino4(const float* w, int32_t w_cout, int32_t w_cin, int32_t mode, float* dst,
+                                        void* stream) {
+  NEOSR_CHECK(w && dst && w_cout > 0 && w_cin > 0, "conv3x3_pack_wino4: bad arguments");
+  NEOSR_CHECK(mode == NEOSR_CONV_FWD || mode == NEOSR_CONV_DGRAD, "conv3x3_pack_wino4: bad mode");
+  NEOSR_CHECK((uintptr_t)dst % 16 == 0, "conv3x3_pack_wino4: dst must be 16-byte aligned");
+  neosr_pack::Image im;
+  memset(&im, 0, sizeof(im));
+  im.dst = dst;
+  im.mode = mode;
+  im.N = mode == NEOSR_CONV_FWD ? w_cout : w_cin;
+  im.K = mode == NEOSR_CONV_FWD ? w_cin : w_cout;
+  im.nseg = 1;
+  im.seg[0].w = w;
+  im.seg[0].w_cin = w_cin;
+  im.seg[0].k_lo = 0;
+  im.seg[0].k_cnt = im.K;
+  im.seg[0].n_lo = 0;
+  return neosr_pack::launch_wino4(&im, 1, stream);
+}

@@ -8,6 +8,7 @@
 // backward.
 #include "common.h"
 #include "conv_pack.h"
+namespace neosr_conv { int wino_mode(); }  // conv_wino.hip: 0 direct, 1 F(2x2,3x3), 2 F(4x4,3x3)
 #include "../../include/neosr_amd.h"
 #include <stdlib.h>
 #include <string.h>
@@ -85,6 +86,9 @@ struct RrdbLayout {
   // direct + Winograd images of conv_body / conv_up1 / conv_up2 / conv_hr (forward) and of their backward-data
   float *tail_pf, *tail_wf, *tail_pd, *tail_wd;
   int64_t tail_p, tail_w;  // floats per image
+  // Winograd F(4x4,3x3) images (conv_wino4.hip), same indexing; only the set the current neosr_set_winograd mode uses is packed
+  float *wwino4_f, *wwino4_d, *tail_w4f, *tail_w4d;
+  int64_t w4f_off[5], w4d_off[5], w4f_total, w4d_total, tail_w4;
   int64_t total;
 };
 
@@ -181,6 +185,23 @@ RrdbLayout rrdb_layout(const neosr_rrdbnet_cfg& c, void* ws) {
     L.tail_wf = b.take(4 * L.tail_w);
     L.tail_pd = c.training ? b.take(4 * L.tail_p) : nullptr;
     L.tail_wd = c.training ? b.take(4 * L.tail_w) : nullptr;
+    o = 0;
+    for (int k = 0; k < 5; ++k) {
+      L.w4f_off[k] = o;
+      o += neosr_pack::wino4_image_floats(k < 4 ? G : F, F + k * G);
+    }
+    L.w4f_total = o;
+    o = 0;
+    for (int j = 0; j < 5; ++j) {
+      L.w4d_off[j] = o;
+      o += neosr_pack::wino4_image_floats(j == 0 ? F : G, F + (j == 0 ? 4 : 4 - j) * G);
+    }
+    L.w4d_total = o;
+    L.wwino4_f = b.take(3 * L.NB * L.w4f_total);
+    L.wwino4_d = c.training ? b.take(3 * L.NB * L.w4d_total) : nullptr;
+    L.tail_w4 = neosr_pack::wino4_image_floats(F, F);
+    L.tail_w4f = b.take(4 * L.tail_w4);
+    L.tail_w4d = c.training ? b.take(4 * L.tail_w4) : nullptr;
   }
   L.total = ((b.off + 255) & ~(int64_t)255);
   return L;
@@ -273,7 +294,10 @@ int rrdb_pack_tail(const RrdbLayout& L, const float* const* P, int mode, void* s
   }
   RUN(neosr_pack::launch(imgs, 4, st));
   for (int i = 0; i < 4; ++i) imgs[i].dst = (mode == NEOSR_CONV_FWD ? L.tail_wf : L.tail_wd) + i * L.tail_w;
-  return neosr_pack::launch_wino(imgs, 4, st);
+  RUN(neosr_pack::launch_wino(imgs, 4, st));  // (the nearest-upsampled forward launches keep F(2x2,3x3) in every mode)
+  if (neosr_conv::wino_mode() != 2) return 0;
+  for (int i = 0; i < 4; ++i) imgs[i].dst = (mode == NEOSR_CONV_FWD ? L.tail_w4f : L.tail_w4d) + i * L.tail_w4;
+  return neosr_pack::launch_wino4(imgs, 4, st);
 }
 
 int rrdb_pack_fwd(const RrdbLayout& L, const float* const* P, void* st) {
@@ -294,8 +318,11 @@ int rrdb_pack_fwd(const RrdbLayout& L, const float* const* P, void* st) {
     }
   RUN(neosr_pack::launch(imgs.data(), (int)imgs.size(), st));
   for (int i = 0; i < 3 * L.NB; ++i)
-    for (int k = 0; k < 5; ++k) imgs[i * 5 + k].dst = L.wwino_f + i * L.wf_total + L.wf_off[k];
-  return neosr_pack::launch_wino(imgs.data(), (int)imgs.size(), st);
+    for (int k = 0; k < 5; ++k)
+      imgs[i * 5 + k].dst = neosr_conv::wino_mode() == 2 ? L.wwino4_f + i * L.w4f_total + L.w4f_off[k]
+                                                        : L.wwino_f + i * L.wf_total + L.wf_off[k];
+  return neosr_conv::wino_mode() == 2 ? neosr_pack::launch_wino4(imgs.data(), (int)imgs.size(), st)
+                                      : neosr_pack::launch_wino(imgs.data(), (int)imgs.size(), st);
 }
 
 int rrdb_pack_dgrad(const RrdbLayout& L, const float* const* P, void* st) {
@@ -324,8 +351,11 @@ int rrdb_pack_dgrad(const RrdbLayout& L, const float* const* P, void* st) {
     }
   RUN(neosr_pack::launch(imgs.data(), (int)imgs.size(), st));
   for (int i = 0; i < 3 * L.NB; ++i)
-    for (int j = 0; j < 5; ++j) imgs[i * 5 + j].dst = L.wwino_d + i * L.wd_total + L.wd_off[j];
-  return neosr_pack::launch_wino(imgs.data(), (int)imgs.size(), st);
+    for (int j = 0; j < 5; ++j)
+      imgs[i * 5 + j].dst = neosr_conv::wino_mode() == 2 ? L.wwino4_d + i * L.w4d_total + L.w4d_off[j]
+                                                        : L.wwino_d + i * L.wd_total + L.wd_off[j];
+  return neosr_conv::wino_mode() == 2 ? neosr_pack::launch_wino4(imgs.data(), (int)imgs.size(), st)
+                                      : neosr_pack::launch_wino(imgs.data(), (int)imgs.size(), st);
 }
 
 }  // namespace
@@ -365,6 +395,7 @@ extern "C" int neosr_rrdbnet_forward(const neosr_rrdbnet_cfg* c, const float* co
     for (int r = 0; r < 3; ++r) {
       const float* pk = L.wpack_f + (int64_t)(3 * n + r) * L.pf_total;
       const float* wk = L.wwino_f + (int64_t)(3 * n + r) * L.wf_total;
+      const float* wk4 = L.wwino4_f + (int64_t)(3 * n + r) * L.w4f_total;
       for (int h = 0; h < nhalf; ++h) {
         const int b0 = (int)((int64_t)B * h / nhalf), nb = (int)((int64_t)B * (h + 1) / nhalf) - b0;
         void* sh = h ? (void*)ax->sc[h] : st;
@@ -376,6 +407,7 @@ extern "C" int neosr_rrdbnet_forward(const neosr_rrdbnet_cfg* c, const float* co
           d.w = P[p_rdb(n, r, k)]; d.bias = P[p_rdb(n, r, k) + 1]; d.w_cout = G; d.w_cin = F + k * G;
           d.w_pack = pk + L.pf_off[k];
           d.w_wino = wk + L.wf_off[k];
+          d.w_wino4 = wk4 + L.w4f_off[k];
           d.out = A + F + k * G; d.out_cs = CC; d.N = G;
           d.act = NEOSR_ACT_LRELU; d.slope = 0.2f;
           RUN(neosr_conv3x3(&d, sh));
@@ -385,6 +417,7 @@ extern "C" int neosr_rrdbnet_forward(const neosr_rrdbnet_cfg* c, const float* co
         d.w = P[p_rdb(n, r, 4)]; d.bias = P[p_rdb(n, r, 4) + 1]; d.w_cout = F; d.w_cin = CC;
         d.w_pack = pk + L.pf_off[4];
         d.w_wino = wk + L.wf_off[4];
+        d.w_wino4 = wk4 + L.w4f_off[4];
         const bool last = (n == L.NB - 1 && r == 2);
         d.out = last ? L.trunk + po * F : L.act[act_idx(L, 3 * n + r + 1)] + po * CC;
         d.out_cs = last ? F : CC;
@@ -406,7 +439,7 @@ extern "C" int neosr_rrdbnet_forward(const neosr_rrdbnet_cfg* c, const float* co
     neosr_conv_desc d = conv_base(B, H, W);
     d.in = L.trunk; d.in_cs = F; d.K = F;
     d.w = P[p_tail(L, 0)]; d.bias = P[p_tail(L, 0) + 1]; d.w_cout = F; d.w_cin = F;
-    d.w_pack = L.tail_pf; d.w_wino = L.tail_wf;
+    d.w_pack = L.tail_pf; d.w_wino = L.tail_wf; d.w_wino4 = L.tail_w4f;
     d.out = L.fea; d.out_cs = F; d.N = F;
     d.res1 = L.act[0]; d.res1_cs = CC; d.res1_nch = F;
     RUN(neosr_conv3x3(&d, st));
@@ -415,7 +448,7 @@ extern "C" int neosr_rrdbnet_forward(const neosr_rrdbnet_cfg* c, const float* co
     neosr_conv_desc d = conv_base(B, 2 * H, 2 * W);
     d.ups = 1; d.in = L.fea; d.in_cs = F; d.K = F;
     d.w = P[p_tail(L, 1)]; d.bias = P[p_tail(L, 1) + 1]; d.w_cout = F; d.w_cin = F;
-    d.w_pack = L.tail_pf + L.tail_p; d.w_wino = L.tail_wf + L.tail_w;
+    d.w_pack = L.tail_pf + L.tail_p; d.w_wino = L.tail_wf + L.tail_w; d.w_wino4 = L.tail_w4f + L.tail_w4;
     d.out = L.u1; d.out_cs = F; d.N = F; d.act = NEOSR_ACT_LRELU; d.slope = 0.2f;
     RUN(neosr_conv3x3(&d, st));
   }
@@ -423,7 +456,7 @@ extern "C" int neosr_rrdbnet_forward(const neosr_rrdbnet_cfg* c, const float* co
     neosr_conv_desc d = conv_base(B, 4 * H, 4 * W);
     d.ups = 1; d.in = L.u1; d.in_cs = F; d.K = F;
     d.w = P[p_tail(L, 2)]; d.bias = P[p_tail(L, 2) + 1]; d.w_cout = F; d.w_cin = F;
-    d.w_pack = L.tail_pf + 2 * L.tail_p; d.w_wino = L.tail_wf + 2 * L.tail_w;
+    d.w_pack = L.tail_pf + 2 * L.tail_p; d.w_wino = L.tail_wf + 2 * L.tail_w; d.w_wino4 = L.tail_w4f + 2 * L.tail_w4;
     d.out = L.u2; d.out_cs = F; d.N = F; d.act = NEOSR_ACT_LRELU; d.slope = 0.2f;
     RUN(neosr_conv3x3(&d, st));
   }
@@ -431,7 +464,7 @@ extern "C" int neosr_rrdbnet_forward(const neosr_rrdbnet_cfg* c, const float* co
     neosr_conv_desc d = conv_base(B, 4 * H, 4 * W);
     d.in = L.u2; d.in_cs = F; d.K = F;
     d.w = P[p_tail(L, 3)]; d.bias = P[p_tail(L, 3) + 1]; d.w_cout = F; d.w_cin = F;
-    d.w_pack = L.tail_pf + 3 * L.tail_p; d.w_wino = L.tail_wf + 3 * L.tail_w;
+    d.w_pack = L.tail_pf + 3 * L.tail_p; d.w_wino = L.tail_wf + 3 * L.tail_w; d.w_wino4 = L.tail_w4f + 3 * L.tail_w4;
     d.out = L.hr; d.out_cs = F; d.N = F; d.act = NEOSR_ACT_LRELU; d.slope = 0.2f;
     RUN(neosr_conv3x3(&d, st));
   }
@@ -507,7 +540,7 @@ int rrdb_backward_impl(const neosr_rrdbnet_cfg* c, const float* const* P, float*
     d.mode = NEOSR_CONV_DGRAD;
     d.in = L.g_hr; d.in_cs = F; d.K = F;
     d.w = P[p_tail(L, 3)]; d.w_cout = F; d.w_cin = F;
-    d.w_pack = L.tail_pd + 3 * L.tail_p; d.w_wino = L.tail_wd + 3 * L.tail_w;
+    d.w_pack = L.tail_pd + 3 * L.tail_p; d.w_wino = L.tail_wd + 3 * L.tail_w; d.w_wino4 = L.tail_w4d + 3 * L.tail_w4;
     d.out = L.g_u2; d.out_cs = F; d.N = F;
     d.out_mask = L.u2; d.out_mask_cs = F; d.out_mask_slope = 0.2f;
     RUN(neosr_conv3x3(&d, st));
@@ -521,7 +554,7 @@ int rrdb_backward_impl(const neosr_rrdbnet_cfg* c, const float* const* P, float*
     d.mode = NEOSR_CONV_DGRAD;
     d.in = L.g_u2; d.in_cs = F; d.K = F;
     d.w = P[p_tail(L, 2)]; d.w_cout = F; d.w_cin = F;
-    d.w_pack = L.tail_pd + 2 * L.tail_p; d.w_wino = L.tail_wd + 2 * L.tail_w;
+    d.w_pack = L.tail_pd + 2 * L.tail_p; d.w_wino = L.tail_wd + 2 * L.tail_w; d.w_wino4 = L.tail_w4d + 2 * L.tail_w4;
     d.out = L.g_up2in; d.out_cs = F; d.N = F;
     RUN(neosr_conv3x3(&d, st));
     RUN(neosr_pool2x2_sum_masked(L.g_up2in, L.g_u1, L.u1, B, H2, W2, F, F, F, F, 0.2f, st));
@@ -535,7 +568,7 @@ int rrdb_backward_impl(const neosr_rrdbnet_cfg* c, const float* const* P, float*
     d.mode = NEOSR_CONV_DGRAD;
     d.in = L.g_u1; d.in_cs = F; d.K = F;
     d.w = P[p_tail(L, 1)]; d.w_cout = F; d.w_cin = F;
-    d.w_pack = L.tail_pd + L.tail_p; d.w_wino = L.tail_wd + L.tail_w;
+    d.w_pack = L.tail_pd + L.tail_p; d.w_wino = L.tail_wd + L.tail_w; d.w_wino4 = L.tail_w4d + L.tail_w4;
     d.out = L.g_up1in; d.out_cs = F; d.N = F;
     RUN(neosr_conv3x3(&d, st));
     RUN(neosr_pool2x2_sum(L.g_up1in, L.g_fea, B, H, W, F, F, F, 0, st));
@@ -549,7 +582,7 @@ int rrdb_backward_impl(const neosr_rrdbnet_cfg* c, const float* const* P, float*
     d.mode = NEOSR_CONV_DGRAD;
     d.in = L.g_fea; d.in_cs = F; d.K = F;
     d.w = P[p_tail(L, 0)]; d.w_cout = F; d.w_cin = F;
-    d.w_pack = L.tail_pd; d.w_wino = L.tail_wd;
+    d.w_pack = L.tail_pd; d.w_wino = L.tail_wd; d.w_wino4 = L.tail_w4d;
     d.out = L.gb[0]; d.out_cs = CC; d.N = F;  // = g5 of the last RDB
     RUN(neosr_conv3x3(&d, st));
   }
@@ -578,6 +611,7 @@ int rrdb_backward_impl(const neosr_rrdbnet_cfg* c, const float* const* P, float*
       if (r == 2) dOut = L.gb[gbi];
       const float* pk = L.wpack_d + (int64_t)(3 * n + r) * L.pd_total;
       const float* wk = L.wwino_d + (int64_t)(3 * n + r) * L.wd_total;
+      const float* wk4 = L.wwino4_d + (int64_t)(3 * n + r) * L.w4d_total;
       for (int h = 0; h < nhalf; ++h) {
         const int b0 = (int)((int64_t)B * h / nhalf), nb = (int)((int64_t)B * (h + 1) / nhalf) - b0;
         void* sh = h ? (void*)ax->sc[h] : st;
@@ -591,6 +625,7 @@ int rrdb_backward_impl(const neosr_rrdbnet_cfg* c, const float* const* P, float*
           d.in = GB; d.in_cs = CC; d.K = F + (4 - j) * G;
           d.w_pack = pk + L.pd_off[j];
           d.w_wino = wk + L.wd_off[j];
+          d.w_wino4 = wk4 + L.w4d_off[j];
           d.out = GB + g_off(F, G, j); d.out_cs = CC; d.N = G;
           d.out_mask = A + F + (j - 1) * G; d.out_mask_cs = CC; d.out_mask_slope = 0.2f;
           RUN(neosr_conv3x3(&d, sh));
@@ -602,6 +637,7 @@ int rrdb_backward_impl(const neosr_rrdbnet_cfg* c, const float* const* P, float*
           d.in = GB; d.in_cs = CC; d.K = CC;
           d.w_pack = pk + L.pd_off[0];
           d.w_wino = wk + L.wd_off[0];
+          d.w_wino4 = wk4 + L.w4d_off[0];
           d.out = NG; d.out_cs = CC; d.N = F;
           d.alpha = 0.2f; d.res1 = GB; d.res1_cs = CC; d.res1_nch = F;
           if (r == 2) d.alpha2 = 0.2f;

@@ -30,7 +30,8 @@ def _cs(t: torch.Tensor) -> int:
 def conv3x3(x, w, bias=None, *, out=None, n_out=None, mode=CONV_FWD, ups=False, act=ACT_NONE,
             slope=0.0, prelu=None, alpha=1.0, res1=None, res1_nch=None, alpha2=1.0, res2=None,
             res2_nch=None, accumulate=False, in_mask=None, mask_slope=1.0, mask_slopes=None,
-            in_prelu=None, k_in=None, w_pack=None, out_mask=None, out_mask_slope=1.0, s2d_c=0, w_wino=None):
+            in_prelu=None, k_in=None, w_pack=None, out_mask=None, out_mask_slope=1.0, s2d_c=0, w_wino=None,
+            w_wino4=None):
     """out = epilogue(conv3x3(x', w)).  See ``neosr_conv3x3`` in include/neosr_amd.h."""
     lib = _C.load()
     _C.require_device(x, "x")
@@ -75,6 +76,7 @@ def conv3x3(x, w, bias=None, *, out=None, n_out=None, mode=CONV_FWD, ups=False, 
     d.mask_slope, d.slope, d.alpha, d.alpha2 = mask_slope, slope, alpha, alpha2
     d.w_pack = _ptr(w_pack)
     d.w_wino = _ptr(w_wino)
+    d.w_wino4 = _ptr(w_wino4)
     d.s2d_c = int(s2d_c)
     if out_mask is not None:
         d.out_mask = out_mask.data_ptr()
@@ -109,6 +111,20 @@ def conv3x3_pack_wino(w, mode=CONV_FWD):
     dst = torch.empty(nbytes // 4, device=w.device, dtype=torch.float32)
     _C.check(lib.neosr_conv3x3_pack_wino(w.data_ptr(), cout, cin, mode, dst.data_ptr(), _C.stream_ptr()),
              "neosr_conv3x3_pack_wino")
+    return dst
+
+
+def conv3x3_pack_wino4(w, mode=CONV_FWD):
+    """Winograd F(4x4,3x3) image of ``w`` (``neosr_conv3x3_pack_wino4``), for `conv3x3(..., w_pack=, w_wino4=)`."""
+    lib = _C.load()
+    _C.require_device(w, "w")
+    assert w.is_contiguous() and w.shape[2:] == (3, 3)
+    cout, cin = w.shape[0], w.shape[1]
+    N, K = (cout, cin) if mode == CONV_FWD else (cin, cout)
+    nbytes = lib.neosr_conv3x3_pack_wino4_bytes(N, K)
+    dst = torch.empty(nbytes // 4, device=w.device, dtype=torch.float32)
+    _C.check(lib.neosr_conv3x3_pack_wino4(w.data_ptr(), cout, cin, mode, dst.data_ptr(), _C.stream_ptr()),
+             "neosr_conv3x3_pack_wino4")
     return dst
 
 
