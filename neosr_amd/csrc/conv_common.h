@@ -28,6 +28,7 @@ struct ConvArgs {
   int tiles_x, tiles_y;
   int scalar_in;                 // thin-K kernel: the input's channel stride / base is not 16-byte friendly
   int xcd;                       // 1: XCD-aware tile order (see xcd_tile)
+  int tx_shift, ty_shift;        // log2 of tiles_x / tiles_y when both are powers of two, else -1 (F(4x4,3x3) kernel)
   unsigned long long* timeline;  // debug only (NEOSR_TIMELINE builds)
 };
 

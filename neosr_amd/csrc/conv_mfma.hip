@@ -384,6 +384,7 @@ extern "C" int neosr_conv3x3(const neosr_conv_desc* dp, void* stream) {
   a.tiles_x = ceil_div(d.W, TW);
   a.tiles_y = ceil_div(d.H, TH);
   a.scalar_in = 0;
+  a.tx_shift = a.ty_shift = -1;
   a.timeline = g_timeline;
   a.xcd = neosr_conv::xcd_enabled() ? 1 : 0;
   const bool al_in = (d.in_cs % 4 == 0) && ((uintptr_t)d.in % 16 == 0);

@@ -62,13 +62,49 @@ __device__ __forceinline__ f32x4 fma4(f32x4 a, f32x4 b, f32x4 c) { return __buil
 //   else 0 with yy = y (rows 0..7) or y - 8 (rows 16, 17);  swz = ((x >> 2) & 3) | (((y >> 2) & 1) << 2).
 // A ds_read_b128 lane group holds the 16 tiles once each (k quad fixed per tile row); their pixels (4 ty + r, 4 tx + c)
 // differ in (slot parity, (y >> 2) & 1, (x >> 2) & 3) = 16 distinct 16-byte bank groups for every patch position.
-__device__ __forceinline__ int q_slot(int y, int x) {
+constexpr __host__ __device__ int q_slot(int y, int x) {
   const int odd = (y >= 8 && y < 16) ? 1 : 0;
   const int yy = y < 8 ? y : y - 8;
   return 2 * (yy * QR + x) + odd;
 }
-__device__ __forceinline__ int q_swz(int y, int x) { return ((x >> 2) & 3) | (((y >> 2) & 1) << 2); }
-__device__ __forceinline__ int q_off(int y, int x, int q) { return 32 * q_slot(y, x) + 4 * (q ^ q_swz(y, x)); }
+constexpr __host__ __device__ int q_swz(int y, int x) { return ((x >> 2) & 3) | (((y >> 2) & 1) << 2); }
+constexpr __host__ __device__ int q_off(int y, int x, int q) { return 32 * q_slot(y, x) + 4 * (q ^ q_swz(y, x)); }
+// rows of the 6 x 6 patch that row ti of B^T d reads (see the column pass in the kernel); k = 2 is unused by rows 0 / 5
+constexpr __host__ __device__ int q_row(int ti, int k) {
+  return k == 0 ? (ti == 0 ? 0 : 1) : k == 1 ? (ti == 5 ? 3 : 2) : k == 2 ? 3 : (ti == 5 ? 5 : 4);
+}
+
+// Launch-invariant per-thread geometry, evaluated at COMPILE time (with twelve waves per CU the address set-up of the
+// prologue was issue-bound: ~450 vector instructions per wave before the first load could leave):
+//   gran[tid][r]   DMA granule G = r * 768 + tid -> y | x << 8 | channel quad << 16 | (slot exists) << 24
+//   pa[wave][lane] LDS float offsets of (patch row k, column block cs) of the lane's tile, k-quad and the wave's parity
+struct QTables {
+  int gran[768][4];
+  int pa[12][64][8];
+};
+constexpr QTables q_make_tables() {
+  QTables t{};
+  for (int tid = 0; tid < 768; ++tid)
+    for (int r = 0; r < 4; ++r) {
+      const int G = r * 768 + tid;
+      const int P = G >> 3, sl = G & 7;
+      const int odd = P & 1, idx = P >> 1;
+      const int yy = idx / QR, x = idx - yy * QR;
+      const int y = odd ? yy + 8 : (yy < 8 ? yy : yy + 8);
+      const bool used = G < QGRAN && (odd ? yy < 8 : yy < 10);
+      const int q = sl ^ q_swz(y, x);
+      t.gran[tid][r] = used ? (y | (x << 8) | (q << 16) | (1 << 24)) : 0;
+    }
+  for (int w = 0; w < 12; ++w)
+    for (int l = 0; l < 64; ++l) {
+      const int ti = w >> 1, kp = w & 1, t16 = l & 15, kq = l >> 4;
+      for (int k = 0; k < 4; ++k)
+        for (int cs = 0; cs < 2; ++cs)
+          t.pa[w][l][k * 2 + cs] = q_off(4 * (t16 >> 2) + q_row(ti, k), 4 * (t16 & 3) + 4 * cs, 4 * kp + kq);
+    }
+  return t;
+}
+static __device__ const QTables g_qt = q_make_tables();
 
 __global__ __attribute__((amdgpu_flat_work_group_size(768, 768), amdgpu_waves_per_eu(3, 3)))
 void conv3x3_wino4_kernel(const ConvArgs args) {
@@ -81,16 +117,31 @@ void conv3x3_wino4_kernel(const ConvArgs args) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ti = wave >> 1, kp = wave & 1;   // transform row, channel parity
   const int t16 = lane & 15, kq = lane >> 4;
-  const int tyi = t16 >> 2, txi = t16 & 3;
   // waves w, w + 4, w + 8 share a SIMD: three static priorities (see the header)
+#ifndef W4_NOPRIO
   if (wave >= 8) __builtin_amdgcn_s_setprio(2);
   else if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
+  TL_MARK(0);
+
+  // table rows of this thread (requested first: their latency hides under the scalar set-up)
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  const i32x4 gtab = *reinterpret_cast<const i32x4*>(g_qt.gran[tid]);
+  const i32x4 pa_lo = *reinterpret_cast<const i32x4*>(g_qt.pa[wave][lane]);
+  const i32x4 pa_hi = *reinterpret_cast<const i32x4*>(g_qt.pa[wave][lane] + 4);
 
   int bid = xcd_tile(blockIdx.x, gridDim.x, args.xcd);
-  const int tx = bid % args.tiles_x;
-  bid /= args.tiles_x;
-  const int ty = bid % args.tiles_y;
-  const int b = bid / args.tiles_y;
+  int tx, ty, b;
+  if (args.tx_shift >= 0 && args.ty_shift >= 0) {  // power-of-two tile grid (64 / 128 / 256-pixel maps): no integer division
+    tx = bid & (args.tiles_x - 1);
+    ty = (bid >> args.tx_shift) & (args.tiles_y - 1);
+    b = bid >> (args.tx_shift + args.ty_shift);
+  } else {
+    tx = bid % args.tiles_x;
+    bid /= args.tiles_x;
+    ty = bid % args.tiles_y;
+    b = bid / args.tiles_y;
+  }
   const int x0 = tx * QT, y0 = ty * QT;
   const int n0 = blockIdx.y * 32;
   const int H = d.H, W = d.W, K = d.K;
@@ -100,29 +151,19 @@ void conv3x3_wino4_kernel(const ConvArgs args) {
   // ---- DMA granules of this thread: round r, G = r * 768 + tid -> slot G >> 3, LDS quad G & 7
   const auto rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.in) + (int64_t)b * Hin * Win * d.in_cs, 0,
                                                      ((Hin * Win - 1) * d.in_cs + K) * 4, 0x00020000);
-  // (granule geometry as a function of (round, thread): also re-evaluated by the ragged last chunk, so that no register
-  // besides the offset is carried through the loop)
-  auto gran = [&](int r, int& q4) -> int {
-    const int G = r * 768 + tid;
-    const int P = G >> 3, sl = G & 7;
-    const int odd = P & 1, idx = P >> 1;
-    const int yy = idx / QR, x = idx - yy * QR;
-    const int y = odd ? yy + 8 : (yy < 8 ? yy : yy + 8);
-    const bool used = G < QGRAN && (odd ? yy < 8 : yy < 10);
-    const int q = sl ^ q_swz(y, x);
+  auto gran = [&](int e, int& q4) -> int {  // byte offset of a table entry's granule in this sample (or out of range)
+    const int y = e & 0xff, x = (e >> 8) & 0xff;
     const int gy = y0 + y - 1, gx = x0 + x - 1;
-    q4 = q << 2;
-    if (used && gy >= 0 && gy < H && gx >= 0 && gx < W) {
-      const int sy = d.ups ? (gy >> 1) : gy, sx = d.ups ? (gx >> 1) : gx;
-      return ((sy * Win + sx) * d.in_cs + (q << 2)) * 4;
-    }
-    return 0x7ffffff0;
+    q4 = (e >> 14) & 0x3fc;   // 4 * channel quad
+    const bool ok = (e >> 24) && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+    const int sy = d.ups ? (gy >> 1) : gy, sx = d.ups ? (gx >> 1) : gx;
+    return ok ? ((sy * Win + sx) * d.in_cs + q4) * 4 : 0x7ffffff0;
   };
   int in_off[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     int q4;
-    in_off[r] = gran(r, q4);
+    in_off[r] = gran(gtab[r], q4);
   }
   auto issue = [&](int c, float* buf) {
     const int c0 = c * 32;
@@ -132,12 +173,13 @@ void conv3x3_wino4_kernel(const ConvArgs args) {
         if (r == 3 && wave >= 9) break;  // granules 2304 .. 2879: waves 0-8
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_void)(buf + (r * 12 + wave) * 256), 16, in_off[r], c0 * 4, 0, 0);
       }
-    } else {  // ragged last chunk: channel quads past K get zeros
+    } else {  // ragged last chunk: channel quads past K get zeros (the table row is re-read: no register is carried for it)
+      const i32x4 g2 = *reinterpret_cast<const volatile i32x4*>(g_qt.gran[tid]);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         if (r == 3 && wave >= 9) break;
         int q4;
-        const int o = gran(r, q4);
+        const int o = gran(g2[r], q4);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_void)(buf + (r * 12 + wave) * 256), 16,
                                                  c0 + q4 < K ? o : 0x7ffffff0, c0 * 4, 0, 0);
       }
@@ -148,23 +190,11 @@ void conv3x3_wino4_kernel(const ConvArgs args) {
   //   row 0: 4 d0 - 5 d2 + d4            rows 1, 2: (d4 - 4 d2) +- (d3 - 4 d1)
   //   row 5: 4 d1 - 5 d3 + d5            rows 3, 4: (d4 - d2) +- 2 (d3 - d1)
   const bool three = ti == 0 || ti == 5;
-  const int r1 = ti == 0 ? 0 : 1;
-  const int r2 = ti == 5 ? 3 : 2;
-  const int r3 = 3;                       // unused by rows 0 / 5
-  const int r4 = ti == 5 ? 5 : 4;
   const float ap = three ? -5.f : (ti <= 2 ? -4.f : -1.f);
   const float aq = ap;                    // (d3 + aq d1) uses the same factor as (d4 + ap d2) for rows 1-4
   const float gm = three ? 4.f : (ti == 1 ? 1.f : ti == 2 ? -1.f : ti == 3 ? 2.f : -2.f);
-  // LDS float offsets of (row rk, column 0 / column 4) of this lane's patch; columns c & 3 are +64 floats each
-  const int qq = 4 * kp + kq;
-  int pa[4][2];
-  {
-    const int rows[4] = {r1, r2, r3, r4};
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-#pragma unroll
-      for (int cs = 0; cs < 2; ++cs) pa[k][cs] = q_off(4 * tyi + rows[k], 4 * txi + 4 * cs, qq);
-  }
+  // LDS float offsets of (row q_row(ti, k), column 0 / column 4) of this lane's patch; columns c & 3 are +64 floats each
+  const int pa[4][2] = {{pa_lo[0], pa_lo[1]}, {pa_lo[2], pa_lo[3]}, {pa_hi[0], pa_hi[1]}, {pa_hi[2], pa_hi[3]}};
 
   // ---- U image of this n-block: [chunk][pos 36][kp 2][cout block 2][k quad 4][cout 16][4] floats
   const auto ru = __builtin_amdgcn_make_buffer_rsrc(
@@ -195,11 +225,23 @@ void conv3x3_wino4_kernel(const ConvArgs args) {
       for (int j = 0; j < 3; ++j)
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb)
+#ifdef W4_NOMFMA
+          acc[j0 + j][nb][e] += u[j][nb][e] * v[j][e];
+#else
           acc[j0 + j][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[j][nb][e], v[j][e], acc[j0 + j][nb], 0, 0, 0);
+#endif
   };
 
   // column pass (row ti of B^T d) then row pass ((B^T d) B) for the lane's four channels
   auto transform = [&](const float* rb, f32x4 (&vlo)[3], f32x4 (&vhi)[3]) {
+#ifdef W4_NOTRANSFORM
+    {
+      const f32x4 da = ld4f(rb + pa[0][0]);
+      vlo[0] = da; vlo[1] = da + splat(1.f); vlo[2] = da + splat(2.f);
+      vhi[0] = da + splat(3.f); vhi[1] = da + splat(4.f); vhi[2] = da + splat(5.f);
+      return;
+    }
+#endif
     f32x4 t[6];
     const f32x4 ap4 = splat(ap), aq4 = splat(aq), gm4 = splat(gm);
     if (three) {
@@ -230,38 +272,58 @@ void conv3x3_wino4_kernel(const ConvArgs args) {
   };
 
   f32x4 ulo[3][2], uhi[3][2], vlo[3], vhi[3];
+  TL_MARK(56);
   issue(0, ldsA);
-  load_u3(0, 0, ulo);
-  __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
+  TL_MARK(57);
+  __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): chunk 0 has landed
+  TL_MARK(58);
   __syncthreads();
+  TL_MARK(1);
+  // (the first U loads leave only now: in front of the barrier they would queue ahead of the late waves' DMA pieces in
+  // the CU's one address path — 16 cycles per 1 KB instruction —; they land under the first transform)
+  load_u3(0, 0, ulo);
   for (int c = 0; c < nchunks; ++c) {
     const float* rb = (c & 1) ? ldsB : ldsA;
     if (c > 0) mac3(3, vhi, uhi);  // positions (ti, 3..5) of chunk c - 1
+    TL_MARK(2 + 4 * c);
     __builtin_amdgcn_sched_barrier(0);
     // (hipcc's wait for the U registers above is vmcnt(0) across the loop back edge: the DMA of the next chunk is therefore
     // requested BEHIND those MFMAs, not in front of them — it still has the transform and 24 MFMAs to land)
+#ifndef W4_NODMA
     if (c + 1 < nchunks) issue(c + 1, (c & 1) ? ldsA : ldsB);
+#endif
     __builtin_amdgcn_sched_barrier(0);
     transform(rb, vlo, vhi);
     __builtin_amdgcn_sched_barrier(0);
+    TL_MARK(3 + 4 * c);
+#ifdef W4_NOULOAD
+    if (c == 0)
+#endif
     load_u3(c, 3, uhi);            // (their U registers are free during the transform: requested only now)
     __builtin_amdgcn_sched_barrier(0);
     mac3(0, vlo, ulo);
     __builtin_amdgcn_sched_barrier(0);
     if (c + 1 < nchunks) {
+#ifndef W4_NOULOAD
       load_u3(c + 1, 0, ulo);
+#endif
       // chunk c + 1 has landed (the twelve U loads issued behind it may stay in flight) ...
+      TL_MARK(4 + 4 * c);
       __builtin_amdgcn_s_waitcnt(0x0f7c);  // vmcnt(12)
     }
     __syncthreads();  // ... for every wave, and every wave is done reading buffer c & 1
+    TL_MARK(5 + 4 * c);
   }
   mac3(3, vhi, uhi);
   __builtin_amdgcn_s_setprio(0);
+  TL_MARK(60);
 
-  // ---- epilogue operands of thread (tile, b, cout quad) — waves 0-7 — requested now: their latency hides under the row
+  // ---- epilogue operands of thread (tile, b, cout quad) — eight of the twelve waves — requested now: their latency hides under the row
   // pass, the exchange and its barrier
-  const bool fin = wave < 8;
-  const int cq = (tid & 7) << 2, eb = (tid >> 3) & 3, et = (tid >> 5) & 15;
+  // (waves 4-11: the two higher priorities leave the loop first, so their address arithmetic and loads run beside the
+  // last MFMAs of waves 0-3)
+  const bool fin = wave >= 4;
+  const int cq = (tid & 7) << 2, eb = (tid >> 3) & 3, et = ((tid - 256) >> 5) & 15;
   const int chq = n0 + cq;
   const bool ch_ok = fin && chq < d.N;
   const int cs0 = ch_ok ? chq : 0;
@@ -270,22 +332,51 @@ void conv3x3_wino4_kernel(const ConvArgs args) {
   if (d.act == ACT_LRELU) s_uni = d.slope;
   else if (d.act == ACT_RELU) s_uni = 0.f;
   const int ey = y0 + 4 * (et >> 2), ex = x0 + 4 * (et & 3) + eb;
-  bool okp[4];
-  int64_t pixp[4];
-  f32x4 e1[4], e2[4], e0[4], mk[4];
-  if (fin) {
-    if (d.bias) bias = ld4f(d.bias + cs0);
+  // BUFFER loads / stores with 32-bit byte offsets: a pixel outside the image (or a channel quad past N / past a
+  // residual's width) gets an out-of-range offset — loads return zeros, stores are dropped; no 64-bit pointer selects,
+  // no zero / trash pages, no exec-masked branches (the host routes tensors of 2 GB and more to the F(2x2) kernel)
+  const int pix0 = (b * H + ey) * W + ex;
+  const bool col_ok = ch_ok && ex < W;
+  bool okr[4];
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      const int py = ey + a;
-      okp[a] = ch_ok && py < H && ex < W;
-      pixp[a] = okp[a] ? ((int64_t)b * H + py) * W + ex : 0;
-      e1[a] = e2[a] = e0[a] = splat(0.f);
-      mk[a] = splat(1.f);
-      if (d.res1) e1[a] = ld4f((okp[a] && chq < d.res1_nch) ? d.res1 + pixp[a] * d.res1_cs + chq : g_zero_page);
-      if (d.res2) e2[a] = ld4f((okp[a] && chq < d.res2_nch) ? d.res2 + pixp[a] * d.res2_cs + chq : g_zero_page);
-      if (d.accumulate) e0[a] = ld4f(okp[a] ? d.out + pixp[a] * d.out_cs + chq : g_zero_page);
-      if (d.out_mask) mk[a] = ld4f(okp[a] ? d.out_mask + pixp[a] * d.out_mask_cs + chq : g_zero_page);
+  for (int a = 0; a < 4; ++a) okr[a] = col_ok && ey + a < H;
+  typedef decltype(__builtin_amdgcn_raw_buffer_load_b128(ru, 0, 0, 0)) raw4_t;
+  // byte offset of (pixel row a, channel quad) in a tensor of channel stride cs: one multiplication per tensor, the rows
+  // are a uniform step apart (cheap select operands: the compiler keeps them v_cndmask, not branches)
+  auto offs = [&](int cs, bool ok_ch, int (&o)[4]) {
+    const int base = (pix0 * cs + chq) * 4, step = W * cs * 4;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) o[a] = (okr[a] && ok_ch) ? base + a * step : 0x7ffffff8;
+  };
+  auto load4 = [&](const float* p, const int (&o)[4], f32x4 (&v)[4]) {
+    const auto rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, 0x7ffffff0, 0x00020000);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) v[a] = __builtin_bit_cast(f32x4, (raw4_t)__builtin_amdgcn_raw_buffer_load_b128(rr, o[a], 0, 0));
+  };
+  const auto r_out = __builtin_amdgcn_make_buffer_rsrc(d.out, 0, 0x7ffffff0, 0x00020000);
+  int o_out[4];
+  offs(d.out_cs, true, o_out);
+  f32x4 e1[4], e2[4], e0[4], mk[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    e1[a] = e2[a] = e0[a] = splat(0.f);
+    mk[a] = splat(1.f);
+  }
+  if (fin) {
+    int o[4];
+    if (d.bias) bias = ld4f(d.bias + cs0);
+    if (d.res1) {
+      offs(d.res1_cs, chq < d.res1_nch, o);
+      load4(d.res1, o, e1);
+    }
+    if (d.res2) {
+      offs(d.res2_cs, chq < d.res2_nch, o);
+      load4(d.res2, o, e2);
+    }
+    if (d.accumulate) load4(d.out, o_out, e0);
+    if (d.out_mask) {  // (an out-of-range lane reads zeros: its result is dropped by the store anyway)
+      offs(d.out_mask_cs, true, o);
+      load4(d.out_mask, o, mk);
     }
   }
 
@@ -309,8 +400,17 @@ void conv3x3_wino4_kernel(const ConvArgs args) {
       *reinterpret_cast<f32x4*>(p + 48 * QES) = x3v;
     }
   }
+  TL_MARK(59);
   __syncthreads();
+  TL_MARK(61);
   if (!fin) return;
+  // (opaque touch: keeps the first USE of the epilogue operands — hipcc would otherwise turn the mask into SGPR booleans
+  // right behind its loads, i.e. wait for all of them in front of the row pass)
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    asm volatile("" : "+v"(mk[a]), "+v"(e0[a]));
+    asm volatile("" : "+v"(e1[a]), "+v"(e2[a]));
+  }
 
   // ---- column pass (+ the k-parity sum) and epilogue: Y[a][b] = sum_i A^T[a][i] X[i][b]
   f32x4 xi[6];
@@ -327,6 +427,7 @@ void conv3x3_wino4_kernel(const ConvArgs args) {
     y[2] = fma4(splat(4.f), s2, s1);
     y[3] = fma4(splat(8.f), d2, d1) + xi[5];
   }
+  TL_MARK(62);
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
     f32x4 o;
@@ -339,8 +440,9 @@ void conv3x3_wino4_kernel(const ConvArgs args) {
       t += e0[a][e];
       o[e] = mk[a][e] > 0.f ? t : t * d.out_mask_slope;
     }
-    *reinterpret_cast<f32x4*>(okp[a] ? d.out + pixp[a] * d.out_cs + chq : g_trash + (tid & 255) * 4) = o;
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(raw4_t, o), r_out, o_out[a], 0, 0);
   }
+  TL_MARK(63);
 }
 
 // U = G g G^T of every (cin, cout) pair of an image, in float64, rounded once:
@@ -407,6 +509,9 @@ void neosr_conv::launch_wino4(const ConvArgs& a, hipStream_t st) {
   ConvArgs w = a;
   w.tiles_x = ceil_div(a.d.W, QT);
   w.tiles_y = ceil_div(a.d.H, QT);
+  auto lg2 = [](int v) { int s = 0; while ((1 << s) < v) ++s; return (1 << s) == v ? s : -1; };
+  w.tx_shift = lg2(w.tiles_x);
+  w.ty_shift = lg2(w.tiles_y);
   dim3 grid(w.tiles_x * w.tiles_y * a.d.B, ceil_div(a.d.N, 32));
   hipLaunchKernelGGL(conv3x3_wino4_kernel, grid, dim3(768), 0, st, w);
 }

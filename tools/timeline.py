@@ -101,7 +101,47 @@ def run_wino(name, H, W, K, N, CC, B=16):
         print(f" wave{wv}: " + " ".join(row))
 
 
+def run_wino4(name, H, W, K, N, CC, B=16):
+    """F(4x4,3x3) kernel (12 waves): marks = start, first barrier, per 32-channel chunk (hi MFMAs of the previous chunk done,
+    transform done, lo MFMAs + refill issued, barrier passed), last hi MFMAs, exchange barrier, end"""
+    lib = _C.load()
+    x = torch.randn(B, H, W, CC, device="cuda")
+    w = torch.randn(N, K, 3, 3, device="cuda") * 0.05
+    pack, wino = ops.conv3x3_pack_weights(w), ops.conv3x3_pack_wino4(w)
+    out = torch.empty(B, H, W, N, device="cuda")
+    tl = torch.zeros(12 * 64, dtype=torch.int64, device="cuda")
+    for _ in range(3):
+        ops.conv3x3(x, w, None, out=out, k_in=K, w_pack=pack, w_wino4=wino)
+    torch.cuda.synchronize()
+    lib.neosr_debug_set_timeline(tl.data_ptr())
+    ops.conv3x3(x, w, None, out=out, k_in=K, w_pack=pack, w_wino4=wino)
+    torch.cuda.synchronize()
+    lib.neosr_debug_set_timeline(None)
+    t = tl.cpu().view(12, 64)
+    nchunks = (K + 31) // 32
+    t0 = int(t[:, 0].min())
+    print(f"== winograd F(4x4) {name}: K={K} N={N} chunks={nchunks}  (cycles; per chunk: hiMFMA | transform | loMFMA | wait+barrier)")
+    for wv in range(12):
+        r = t[wv]
+        base = int(r[0])
+        row = [f"start+{base - t0} setup@{int(r[56]) - base} issued@{int(r[57]) - base} landed@{int(r[58]) - base} first_bar@{int(r[1]) - base}"]
+        prev = int(r[1]) - base
+        for c in range(nchunks):
+            a, b_, m, bar = (int(r[2 + 4 * c + j]) - base for j in range(4))
+            if c + 1 == nchunks:
+                row.append(f"[c{c} {a - prev} | {b_ - a} | lo+bar {bar - b_}]")
+            else:
+                row.append(f"[c{c} {a - prev} | {b_ - a} | {m - b_} | {bar - m}]")
+            prev = bar
+        row.append(f"last_hi@{int(r[60]) - base} exch_written@{int(r[59]) - base} exch_bar@{int(r[61]) - base} colpass@{int(r[62]) - base} end@{int(r[63]) - base}")
+        print(f" wave{wv:2d}: " + " ".join(row))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "wino4":
+        run_wino4("rdb.conv1", 64, 64, 64, 32, 192)
+        run_wino4("rdb.conv4", 64, 64, 160, 32, 192)
+        raise SystemExit
     if len(sys.argv) > 1 and sys.argv[1] == "wino":
         run_wino("rdb.conv1", 64, 64, 64, 32, 192)
         run_wino("rdb.conv4", 64, 64, 160, 32, 192)
