@@ -168,6 +168,23 @@ def pmc_traffic(cfg_name: str, symbol: str) -> dict | None:
     return None
 
 
+def sq_counters(cfg_name: str, symbol: str) -> dict | None:
+    """Matrix-pipe / vector / LDS activity of a kernel from the committed rocprofv3 SQ-counter passes of THIS config
+    (tools/profile_sq.sh -> profiles/rNN_<config>_sq_summary.json; a citation like `pmc_traffic`).  Per-dispatch
+    averages; mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CYCLES-per-CU) as the summary defines it."""
+    files = sorted((ROOT / "profiles").glob(f"r*_{cfg_name}_sq_summary.json"))
+    if not files:
+        return None
+    summ = json.loads(files[-1].read_text())
+    for alt in symbol.split("|"):
+        for part in alt.split("+"):
+            hits = [(d.get("dispatches", 0), name, d) for name, d in summ.get("kernels", {}).items() if part in name]
+            if hits:
+                _, name, d = max(hits, key=lambda h: h[0])
+                return {"source": files[-1].name, "kernel": name[:96], **{k: v for k, v in d.items()}}
+    return None
+
+
 def make_batch(opt: dict, dev, rank: int) -> dict:
     import torch
 
@@ -342,51 +359,67 @@ def main() -> None:
             step(it)
         nc = lib.neosr_prof_num_classes()
         ms, ln, fl, by = (C.c_double * nc)(), (C.c_longlong * nc)(), (C.c_double * nc)(), (C.c_double * nc)()
+        ex, algo = (C.c_double * nc)(), (C.c_longlong * (3 * nc))()
+        _C.check(lib.neosr_prof_collect_exec(ex, algo), "neosr_prof_collect_exec")
         _C.check(lib.neosr_prof_collect(ms, ln, fl, by), "neosr_prof_collect")
         lib.neosr_prof_enable(0)
         lib.neosr_set_num_streams(prev_streams)
+        ALGO = ("direct", "winograd F(2x2,3x3): 16 of the direct form's 36 multiplications",
+                "winograd F(4x4,3x3): 36 of the direct form's 144 multiplications")
         kern = {}
         for i in range(nc):
             if ln[i]:
+                tf = (lambda f: round(f / (ms[i] * 1e9), 2) if ms[i] > 0 and f else None)
                 kern[CLASS_NAMES[i]] = {"launches": int(ln[i]), "avg_us": round(1e3 * ms[i] / ln[i], 2),
                                         "total_ms": round(ms[i], 3),
-                                        "tflops": round(fl[i] / (ms[i] * 1e9), 2) if ms[i] > 0 and fl[i] else None,
+                                        # executed = the multiplications the matrix pipe really ran; direct_equiv = the
+                                        # direct form's FLOPs (SURVEY §8d's algorithmic figure) over the same time
+                                        "executed_tflops": tf(ex[i]), "direct_equiv_tflops": tf(fl[i]),
+                                        "launches_by_algorithm": {ALGO[a].split(":")[0]: int(algo[3 * i + a]) for a in range(3) if algo[3 * i + a]},
                                         "algo_GBps": round(by[i] / (ms[i] * 1e6), 1) if ms[i] > 0 and by[i] else None}
         dom = max(COMPUTE_CLASSES, key=lambda i: ms[i])
-        ach = fl[dom] / (ms[dom] * 1e9) if ms[dom] > 0 else 0.0
+        ach = ex[dom] / (ms[dom] * 1e9) if ms[dom] > 0 else 0.0           # executed TFLOP/s: the hardware fraction
+        ach_direct = fl[dom] / (ms[dom] * 1e9) if ms[dom] > 0 else 0.0    # direct-form equivalent
         allms = sum(ms[i] for i in COMPUTE_CLASSES)
         allfl = sum(fl[i] for i in COMPUTE_CLASSES)
-        wino = lib.neosr_set_winograd(1)
-        lib.neosr_set_winograd(wino)
-        wino_dom = bool(wino) and dom in (0, 1, 2) and opt["network_g"]["type"] == "esrgan"
-        sym = {0: "conv3x3_wino_kernel", 1: "conv3x3_wino_kernel", 2: "conv3x3_wgrad_wino_kernel"}[dom] if wino_dom else CLASS_SYMBOL[dom]
+        allex = sum(ex[i] for i in COMPUTE_CLASSES)
+        dom_algo = max(range(3), key=lambda a: algo[3 * dom + a])
+        sym = ({0: "conv3x3_glds_kernel", 1: "conv3x3_wino_kernel", 2: "conv3x3_wino4_kernel"}[dom_algo] if dom in (0, 1)
+               else {0: "conv3x3_wgrad_multi_kernel", 1: "conv3x3_wgrad_wino_kernel", 2: "conv3x3_wgrad_wino_kernel"}[dom_algo] if dom == 2
+               else CLASS_SYMBOL[dom])
         tr = pmc_traffic(cfg_name, sym) if not (args.batch or args.arch) else None
+        sq = sq_counters(cfg_name, sym) if not (args.batch or args.arch) else None
         step_s = elapsed / args.steps
-        roofline = {"bound": "mfma", "kernel": CLASS_NAMES[dom], "achieved": round(ach, 2),
-                    "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+        roofline = {"bound": "mfma", "kernel": CLASS_NAMES[dom], "symbol": sym,
+                    # `achieved` / `frac`: the FLOPs the matrix pipe EXECUTED per second against the dense fp32 MFMA peak
+                    # (the hardware fraction, <= 1 by construction).  The Winograd kernels execute fewer
+                    # multiplications than the direct form SURVEY §8(d) prices; that algorithmic figure over the same
+                    # time is direct_equiv_tflops (it may exceed the peak: the gain is the algorithm's, not the pipe's)
+                    "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+                    "direct_equiv_tflops": round(ach_direct, 2),
+                    "direct_equiv_frac": round(ach_direct / PEAK_F32_MFMA_TFLOPS, 4),
+                    "algorithm": ALGO[dom_algo],
+                    # neither roof binds these kernels (fp32 MFMA shares the SIMD's issue with the transform's vector
+                    # instructions, fixed per-launch cost): what the SQ counters of the committed profile show
+                    "limiter": ("issue / latency (matrix pipe partly idle); counters in `sq_counters`" if sq else
+                                "issue / latency (no committed SQ-counter summary for this kernel)"),
+                    "sq_counters": sq,
                     "traffic": tr["bytes_per_launch"] if tr else None, "traffic_detail": tr,
                     "algo_bytes_per_launch": round(by[dom] / max(1, ln[dom])),
                     "avg_launch_us": round(1e3 * ms[dom] / max(1, ln[dom]), 2),
-                    "all_mfma_kernels_tflops": round(allfl / (allms * 1e9), 2) if allms > 0 else None,
+                    "all_mfma_kernels_executed_tflops": round(allex / (allms * 1e9), 2) if allms > 0 else None,
+                    "all_mfma_kernels_direct_equiv_tflops": round(allfl / (allms * 1e9), 2) if allms > 0 else None,
                     "mfma_kernel_share_of_profiled_step": round(allms / nprof / (step_s * 1e3), 4),
-                    # whole step as timed (launch chains, losses, optimizer, all-reduce included); FLOPs = the MFMA
-                    # kernels' algorithmic FLOPs as counted at their launches
-                    "step_tflops": round(allfl / nprof / (step_s * 1e12), 2),
-                    "step_frac": round(allfl / nprof / (step_s * 1e12) / PEAK_F32_MFMA_TFLOPS, 4),
+                    # whole step as timed (launch chains, losses, optimizer, all-reduce included)
+                    "step_executed_tflops": round(allex / nprof / (step_s * 1e12), 2),
+                    "step_executed_frac": round(allex / nprof / (step_s * 1e12) / PEAK_F32_MFMA_TFLOPS, 4),
+                    "step_direct_equiv_tflops": round(allfl / nprof / (step_s * 1e12), 2),
                     "hbm_algo_frac_of_8TBps": round((by[dom] / (ms[dom] * 1e6)) / PEAK_HBM_GBS, 4) if ms[dom] > 0 else None,
                     "kernels": kern,
-                    # Winograd F(2x2,3x3) launches execute 16/36 of the direct form's multiplications: `achieved` (and
-                    # every `tflops` above) counts the DIRECT form's FLOPs per launch (SURVEY §8d's algorithmic figure),
-                    # so it can exceed the fp32 MFMA peak; the matrix pipe itself runs at executed_mfma_tflops
-                    "algorithm": ("winograd F(2x2,3x3) for the RDB trunk's forward / backward-data / weight-gradient launches "
-                                  "(16 multiplications per 2x2 output tile, channel pair and filter instead of 36)")
-                                 if wino_dom else "direct",
-                    "executed_mfma_tflops": round(ach * 16.0 / 36.0, 2) if wino_dom else round(ach, 2),
-                    "executed_mfma_frac": round(ach * (16.0 / 36.0 if wino_dom else 1.0) / PEAK_F32_MFMA_TFLOPS, 4),
                     "method": "HIP events around every launch of the class on the launch stream, separate "
                               "profiled pass after the timed region with the trunk on ONE stream "
-                              "(neosr_set_num_streams(1)); profiles/r02_<config>_kernel_stats.csv is rocprofv3 "
+                              "(neosr_set_num_streams(1)); profiles/r03_<config>_kernel_stats.csv is rocprofv3 "
                               "--kernel-trace --stats of `NEOSR_AMD_STREAMS=1 python bench.py --config <config>`"}
         if ms[0] + ms[1] > 0:  # forward + backward-data launches of ONE symbol: comparable with its rocprofv3 row
             roofline["packed_conv_kernel_avg_us"] = round(1e3 * (ms[0] + ms[1]) / max(1, ln[0] + ln[1]), 2)
@@ -410,7 +443,7 @@ def main() -> None:
                    "options_file": f"options/{cfg_name}.toml" if (ROOT / "options" / f"{cfg_name}.toml").exists() else args.config,
                    "global_batch": B * world, "parallelism": f"dp{world}", "ranks": world, "backend": backend if world > 1 else None,
                    "devices": devices, "gflop_per_patch": gflop_patch},
-        "whole_step_tflops": round(value / world * gflop_patch / 1e3, 2) if gflop_patch else None,
+        "whole_step_direct_equiv_tflops": round(value / world * gflop_patch / 1e3, 2) if gflop_patch else None,
         "final_loss": loss,
         "roofline": roofline,
     }

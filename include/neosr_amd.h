@@ -115,12 +115,16 @@ int neosr_conv3x3_pack_weights(const float* w, int32_t w_cout, int32_t w_cin, in
 int64_t neosr_conv3x3_pack_wino_bytes(int32_t N, int32_t K);
 int neosr_conv3x3_pack_wino(const float* w, int32_t w_cout, int32_t w_cin, int32_t mode, float* dst, void* stream);
 int neosr_set_winograd(int on);
+int neosr_get_winograd(void);   /* the current mode (0 / 1 / 2), see below */
 /* Winograd F(4x4, 3x3) image (conv_wino4.hip): [ceil(N/32)][ceil(K/32)][pos 36][k parity 2][cout block 2][k quad 4]
  * [cout 16][4] floats, element (G g G^T)[pos] (6x6, points 0, +-1, +-2, inf; evaluated in float64 and rounded once) of the
  * (n, k) pair the direct image addresses (mode FWD / DGRAD), zero padded.  fp32 products and sums; the larger transforms
  * amplify rounding ~10x more than F(2x2,3x3): ~5e-6 of the output scale against a float64 convolution.
  * neosr_set_winograd: 0 = direct kernels, 1 = F(2x2,3x3) wherever w_wino is given, 2 (default; env NEOSR_AMD_WINOGRAD)
- * = F(4x4,3x3) wherever w_wino4 is given, else as 1. */
+ * = F(4x4,3x3) wherever w_wino4 is given and the launch has at least NEOSR_WINO4_MIN_WGS workgroups (16 x 16-pixel tiles x
+ * 32-cout blocks; below that a 256-CU chip is better filled by the 8 x 16-pixel tiles of F(2x2,3x3)) or no w_wino was
+ * given, else as 1. */
+#define NEOSR_WINO4_MIN_WGS 64
 int64_t neosr_conv3x3_pack_wino4_bytes(int32_t N, int32_t K);
 int neosr_conv3x3_pack_wino4(const float* w, int32_t w_cout, int32_t w_cin, int32_t mode, float* dst, void* stream);
 /* Both images of MANY weight tensors in ceil(n / 24) launches per image kind (the per-layer calls above cost one launch
@@ -685,6 +689,11 @@ int neosr_fsam_first_step(const neosr_fsam_desc* d, void* stream);
 int neosr_prof_num_classes(void);
 int neosr_prof_enable(int on);
 int neosr_prof_collect(double* ms, long long* launches, double* flops, double* bytes);
+/* executed[c]: FLOPs of the multiplications the class's launches really ran — a Winograd F(2x2,3x3) launch executes
+ * 16/36 and an F(4x4,3x3) launch 36/144 of the direct form's (which is what flops[c] above counts);
+ * by_algo[3 c + a]: launches in the direct (a = 0) / F(2x2,3x3) (1) / F(4x4,3x3) (2) form.  Call before
+ * neosr_prof_collect. */
+int neosr_prof_collect_exec(double* executed, long long* by_algo);
 
 /* whole-network plans ------------------------------------------------------------------------ */
 /*

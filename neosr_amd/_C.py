@@ -254,6 +254,7 @@ SIGNATURES: dict[str, tuple] = {
     "neosr_set_num_streams": (C.c_int, [C.c_int]),
     "neosr_set_xcd_aware": (C.c_int, [C.c_int]),
     "neosr_set_winograd": (C.c_int, [C.c_int]),
+    "neosr_get_winograd": (C.c_int, []),
     "neosr_conv3x3_pack_wino_bytes": (_i64, [_i32, _i32]),
     "neosr_conv3x3_pack_wino": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp]),
     "neosr_conv3x3_pack_wino4_bytes": (_i64, [_i32, _i32]),
@@ -357,6 +358,7 @@ SIGNATURES: dict[str, tuple] = {
         C.c_int,
         [C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double), C.POINTER(C.c_double)],
     ),
+    "neosr_prof_collect_exec": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
     "neosr_rrdbnet_workspace_bytes": (_i64, [C.POINTER(RRDBNetCfg)]),
     "neosr_rrdbnet_num_params": (_i32, [C.POINTER(RRDBNetCfg)]),
     "neosr_rrdbnet_forward": (C.c_int, [C.POINTER(RRDBNetCfg), c_void_pp, _vp, _vp, _vp, _vp]),

@@ -409,8 +409,13 @@ extern "C" int neosr_conv3x3(const neosr_conv_desc* dp, void* stream) {
   const bool use_wino = use_pack && d.w_wino && ((uintptr_t)d.w_wino % 16 == 0) && d.s2d_c == 0 &&
                         d.act != NEOSR_ACT_PRELU && neosr_conv::wino_enabled();
   // ... or its F(4x4,3x3) form (conv_wino4.hip): same conditions, nearest-upsampled inputs stay with F(2x2,3x3)
+  // (32-bit byte offsets in its epilogue: tensors of 2 GB and more stay with F(2x2,3x3); small launches too, if they can)
+  const int64_t w4_wgs = (int64_t)d.B * ceil_div(d.H, 16) * ceil_div(d.W, 16) * ceil_div(d.N, 32);
+  auto small = [&](const void* p, int cs) { return !p || (int64_t)d.B * d.H * d.W * cs * 4 < (int64_t(1) << 31); };
   const bool use_wino4 = use_pack && d.w_wino4 && ((uintptr_t)d.w_wino4 % 16 == 0) && d.s2d_c == 0 && !d.ups &&
-                         d.act != NEOSR_ACT_PRELU && neosr_conv::wino_mode() == 2;
+                         d.act != NEOSR_ACT_PRELU && neosr_conv::wino_mode() == 2 &&
+                         (w4_wgs >= NEOSR_WINO4_MIN_WGS || !use_wino) && small(d.out, d.out_cs) && small(d.res1, d.res1_cs) &&
+                         small(d.res2, d.res2_cs) && small(d.out_mask, d.out_mask_cs) && small(d.in, d.in_cs);
   const bool prof = neosr_prof_on();
   if (prof) {
     const double px = (double)d.B * d.H * d.W;
@@ -418,6 +423,7 @@ extern "C" int neosr_conv3x3(const neosr_conv_desc* dp, void* stream) {
     neosr_prof_begin((d.mode == NEOSR_CONV_FWD ? NEOSR_PROF_CONV_FWD : NEOSR_PROF_CONV_DGRAD) + (use_pack ? 0 : 4), stream,
                      2.0 * px * d.K * d.N * 9.0,
                      4.0 * (px / (d.ups ? 4.0 : 1.0) * d.K + px * d.N + 9.0 * d.K * d.N));
+    neosr_prof_algo(use_wino4 ? 2 : use_wino ? 1 : 0);
   }
   // thin layers (see conv3x3_thin_*_kernel)
   const bool plain_in = d.w && al_in && !d.ups && !d.in_prelu && !d.mask_slopes;

@@ -389,6 +389,8 @@ int neosr_conv::wino_mode() {
 
 bool neosr_conv::wino_enabled() { return wino_mode() != 0; }
 
+extern "C" int neosr_get_winograd(void) { return neosr_conv::wino_mode(); }
+
 extern "C" int neosr_set_winograd(int on) {
   const int prev = neosr_conv::wino_mode();
   g_wino = on <= 0 ? 0 : (on == 1 ? 1 : 2);

@@ -89,6 +89,9 @@ struct RrdbLayout {
   // Winograd F(4x4,3x3) images (conv_wino4.hip), same indexing; only the set the current neosr_set_winograd mode uses is packed
   float *wwino4_f, *wwino4_d, *tail_w4f, *tail_w4d;
   int64_t w4f_off[5], w4d_off[5], w4f_total, w4d_total, tail_w4;
+  // trunk launches take the F(4x4,3x3) kernel: mode 2 and enough 16 x 16-pixel tiles x 32-cout blocks over the WHOLE
+  // batch (the launch chains run side by side) to fill the chip — NEOSR_WINO4_MIN_WGS; else F(2x2,3x3)
+  bool w4_trunk;
   int64_t total;
 };
 
@@ -202,6 +205,8 @@ RrdbLayout rrdb_layout(const neosr_rrdbnet_cfg& c, void* ws) {
     L.tail_w4 = neosr_pack::wino4_image_floats(F, F);
     L.tail_w4f = b.take(4 * L.tail_w4);
     L.tail_w4d = c.training ? b.take(4 * L.tail_w4) : nullptr;
+    L.w4_trunk = neosr_conv::wino_mode() == 2 &&
+                 (int64_t)c.B * ((c.H + 15) / 16) * ((c.W + 15) / 16) * ((G + 31) / 32) >= NEOSR_WINO4_MIN_WGS;
   }
   L.total = ((b.off + 255) & ~(int64_t)255);
   return L;
@@ -319,10 +324,10 @@ int rrdb_pack_fwd(const RrdbLayout& L, const float* const* P, void* st) {
   RUN(neosr_pack::launch(imgs.data(), (int)imgs.size(), st));
   for (int i = 0; i < 3 * L.NB; ++i)
     for (int k = 0; k < 5; ++k)
-      imgs[i * 5 + k].dst = neosr_conv::wino_mode() == 2 ? L.wwino4_f + i * L.w4f_total + L.w4f_off[k]
-                                                        : L.wwino_f + i * L.wf_total + L.wf_off[k];
-  return neosr_conv::wino_mode() == 2 ? neosr_pack::launch_wino4(imgs.data(), (int)imgs.size(), st)
-                                      : neosr_pack::launch_wino(imgs.data(), (int)imgs.size(), st);
+      imgs[i * 5 + k].dst = L.w4_trunk ? L.wwino4_f + i * L.w4f_total + L.w4f_off[k]
+                                       : L.wwino_f + i * L.wf_total + L.wf_off[k];
+  return L.w4_trunk ? neosr_pack::launch_wino4(imgs.data(), (int)imgs.size(), st)
+                    : neosr_pack::launch_wino(imgs.data(), (int)imgs.size(), st);
 }
 
 int rrdb_pack_dgrad(const RrdbLayout& L, const float* const* P, void* st) {
@@ -352,10 +357,10 @@ int rrdb_pack_dgrad(const RrdbLayout& L, const float* const* P, void* st) {
   RUN(neosr_pack::launch(imgs.data(), (int)imgs.size(), st));
   for (int i = 0; i < 3 * L.NB; ++i)
     for (int j = 0; j < 5; ++j)
-      imgs[i * 5 + j].dst = neosr_conv::wino_mode() == 2 ? L.wwino4_d + i * L.w4d_total + L.w4d_off[j]
-                                                        : L.wwino_d + i * L.wd_total + L.wd_off[j];
-  return neosr_conv::wino_mode() == 2 ? neosr_pack::launch_wino4(imgs.data(), (int)imgs.size(), st)
-                                      : neosr_pack::launch_wino(imgs.data(), (int)imgs.size(), st);
+      imgs[i * 5 + j].dst = L.w4_trunk ? L.wwino4_d + i * L.w4d_total + L.w4d_off[j]
+                                       : L.wwino_d + i * L.wd_total + L.wd_off[j];
+  return L.w4_trunk ? neosr_pack::launch_wino4(imgs.data(), (int)imgs.size(), st)
+                    : neosr_pack::launch_wino(imgs.data(), (int)imgs.size(), st);
 }
 
 }  // namespace
@@ -406,8 +411,8 @@ extern "C" int neosr_rrdbnet_forward(const neosr_rrdbnet_cfg* c, const float* co
           d.in = A; d.in_cs = CC; d.K = F + k * G;
           d.w = P[p_rdb(n, r, k)]; d.bias = P[p_rdb(n, r, k) + 1]; d.w_cout = G; d.w_cin = F + k * G;
           d.w_pack = pk + L.pf_off[k];
-          d.w_wino = wk + L.wf_off[k];
-          d.w_wino4 = wk4 + L.w4f_off[k];
+          d.w_wino = L.w4_trunk ? nullptr : wk + L.wf_off[k];   // (only the image kind that was packed is offered)
+          d.w_wino4 = L.w4_trunk ? wk4 + L.w4f_off[k] : nullptr;
           d.out = A + F + k * G; d.out_cs = CC; d.N = G;
           d.act = NEOSR_ACT_LRELU; d.slope = 0.2f;
           RUN(neosr_conv3x3(&d, sh));
@@ -416,8 +421,8 @@ extern "C" int neosr_rrdbnet_forward(const neosr_rrdbnet_cfg* c, const float* co
         d.in = A; d.in_cs = CC; d.K = CC;
         d.w = P[p_rdb(n, r, 4)]; d.bias = P[p_rdb(n, r, 4) + 1]; d.w_cout = F; d.w_cin = CC;
         d.w_pack = pk + L.pf_off[4];
-        d.w_wino = wk + L.wf_off[4];
-        d.w_wino4 = wk4 + L.w4f_off[4];
+        d.w_wino = L.w4_trunk ? nullptr : wk + L.wf_off[4];
+        d.w_wino4 = L.w4_trunk ? wk4 + L.w4f_off[4] : nullptr;
         const bool last = (n == L.NB - 1 && r == 2);
         d.out = last ? L.trunk + po * F : L.act[act_idx(L, 3 * n + r + 1)] + po * CC;
         d.out_cs = last ? F : CC;
@@ -624,8 +629,8 @@ int rrdb_backward_impl(const neosr_rrdbnet_cfg* c, const float* const* P, float*
           d.mode = NEOSR_CONV_DGRAD;
           d.in = GB; d.in_cs = CC; d.K = F + (4 - j) * G;
           d.w_pack = pk + L.pd_off[j];
-          d.w_wino = wk + L.wd_off[j];
-          d.w_wino4 = wk4 + L.w4d_off[j];
+          d.w_wino = L.w4_trunk ? nullptr : wk + L.wd_off[j];
+          d.w_wino4 = L.w4_trunk ? wk4 + L.w4d_off[j] : nullptr;
           d.out = GB + g_off(F, G, j); d.out_cs = CC; d.N = G;
           d.out_mask = A + F + (j - 1) * G; d.out_mask_cs = CC; d.out_mask_slope = 0.2f;
           RUN(neosr_conv3x3(&d, sh));
@@ -636,8 +641,8 @@ int rrdb_backward_impl(const neosr_rrdbnet_cfg* c, const float* const* P, float*
           d.mode = NEOSR_CONV_DGRAD;
           d.in = GB; d.in_cs = CC; d.K = CC;
           d.w_pack = pk + L.pd_off[0];
-          d.w_wino = wk + L.wd_off[0];
-          d.w_wino4 = wk4 + L.w4d_off[0];
+          d.w_wino = L.w4_trunk ? nullptr : wk + L.wd_off[0];
+          d.w_wino4 = L.w4_trunk ? wk4 + L.w4d_off[0] : nullptr;
           d.out = NG; d.out_cs = CC; d.N = F;
           d.alpha = 0.2f; d.res1 = GB; d.res1_cs = CC; d.res1_nch = F;
           if (r == 2) d.alpha2 = 0.2f;

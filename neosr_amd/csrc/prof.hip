@@ -13,6 +13,10 @@ std::vector<hipEvent_t> g_pool;
 double g_flops[NEOSR_PROF_NCLASS];
 double g_bytes[NEOSR_PROF_NCLASS];
 long long g_launch[NEOSR_PROF_NCLASS];
+double g_exec[NEOSR_PROF_NCLASS];            // multiplications the launches really executed (Winograd forms: fewer)
+long long g_algo[NEOSR_PROF_NCLASS][3];      // launches by algorithm: direct, Winograd F(2x2,3x3), Winograd F(4x4,3x3)
+double g_last_flops = 0.0;
+int g_last_cls = 0;
 
 hipEvent_t get_event() {
   if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
@@ -34,6 +38,19 @@ void neosr_prof_begin(int cls, void* stream, double flops, double bytes) {
   g_flops[cls] += flops;
   g_bytes[cls] += bytes;
   g_launch[cls] += 1;
+  g_exec[cls] += flops;
+  g_algo[cls][0] += 1;
+  g_last_flops = flops;
+  g_last_cls = cls;
+}
+
+// the launch just begun runs in a Winograd form: algo 1 = F(2x2,3x3) (16 of the direct form's 36 multiplications),
+// 2 = F(4x4,3x3) (36 of 144)
+void neosr_prof_algo(int algo) {
+  if (algo != 1 && algo != 2) return;
+  g_exec[g_last_cls] -= g_last_flops * (algo == 1 ? 20.0 / 36.0 : 0.75);
+  g_algo[g_last_cls][0] -= 1;
+  g_algo[g_last_cls][algo] += 1;
 }
 
 void neosr_prof_end(void* stream) { hipEventRecord(g_recs.back().b, (hipStream_t)stream); }
@@ -41,7 +58,10 @@ void neosr_prof_end(void* stream) { hipEventRecord(g_recs.back().b, (hipStream_t
 extern "C" int neosr_prof_enable(int on) {
   g_on = on != 0;
   if (g_on) {
-    for (int i = 0; i < NEOSR_PROF_NCLASS; ++i) { g_flops[i] = 0; g_bytes[i] = 0; g_launch[i] = 0; }
+    for (int i = 0; i < NEOSR_PROF_NCLASS; ++i) {
+      g_flops[i] = 0; g_bytes[i] = 0; g_launch[i] = 0; g_exec[i] = 0;
+      g_algo[i][0] = g_algo[i][1] = g_algo[i][2] = 0;
+    }
   }
   return 0;
 }
@@ -60,5 +80,16 @@ extern "C" int neosr_prof_collect(double* ms, long long* launches, double* flops
     g_pool.push_back(r.b);
   }
   g_recs.clear();
+  return 0;
+}
+
+// executed[c] = FLOPs of the multiplications the class's launches really ran (flops[c] of neosr_prof_collect counts the
+// DIRECT form, SURVEY §8d's algorithmic figure); by_algo[3 c + a] = launches in the direct / F(2x2,3x3) / F(4x4,3x3) form.
+// Call before neosr_prof_collect (which recycles the events, not these sums).
+extern "C" int neosr_prof_collect_exec(double* executed, long long* by_algo) {
+  for (int i = 0; i < NEOSR_PROF_NCLASS; ++i) {
+    executed[i] = g_exec[i];
+    for (int a = 0; a < 3; ++a) by_algo[3 * i + a] = g_algo[i][a];
+  }
   return 0;
 }

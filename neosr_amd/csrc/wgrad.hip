@@ -949,6 +949,7 @@ extern "C" int neosr_conv3x3_wgrad_multi(const neosr_wgrad_desc* ds, int32_t n, 
   if (fast && plain && !s2d && small && neosr_conv::wino_enabled()) {  // Winograd form (see conv3x3_wgrad_wino_kernel)
     WgradMultiArgs w = a;
     const int P = a.pair_start[MAXD];
+    if (prof) neosr_prof_algo(1);
     w.bpart = workspace + (int64_t)P * a.w_nsplit * WW_PART;
     w.xcd_full = P <= WW_SLOTS / 8 ? (WW_SLOTS / 8) / P : 0;  // 96 slots per XCD
     if (w.xcd_full > a.w_nsplit / 8) w.xcd_full = a.w_nsplit / 8;

@@ -106,14 +106,19 @@ def _image_floats(w, kind, mode):
     lib = _C.load()
     cout, cin = w.shape[0], w.shape[1]
     N, K = (cout, cin) if mode == ops.CONV_FWD else (cin, cout)
-    return (lib.neosr_conv3x3_pack_wino_bytes(N, K) if kind else lib.neosr_conv3x3_pack_bytes(N, K)) // 4
+    fn = (lib.neosr_conv3x3_pack_bytes, lib.neosr_conv3x3_pack_wino_bytes, lib.neosr_conv3x3_pack_wino4_bytes)[kind]
+    return fn(N, K) // 4
+
+
+def _pack_now(w, mode, kind):
+    return (ops.conv3x3_pack_weights, ops.conv3x3_pack_wino, ops.conv3x3_pack_wino4)[kind](w, mode)
 
 
 def _packed(w: torch.Tensor, mode: int, kind: int):
     if min(w.shape[0], w.shape[1]) <= 4 or w.shape[0] % 4 or w.shape[1] % 4:
         return None
     if not hasattr(w, "__dict__"):
-        return ops.conv3x3_pack_wino(w, mode) if kind else ops.conv3x3_pack_weights(w, mode)
+        return _pack_now(w, mode, kind)
     global FORCE_REPACK_IN_CAPTURE
     if FORCE_REPACK_IN_CAPTURE and torch.cuda.is_current_stream_capturing():
         FORCE_REPACK_IN_CAPTURE = False
@@ -124,7 +129,7 @@ def _packed(w: torch.Tensor, mode: int, kind: int):
         return hit[1]
     if not isinstance(w, torch.nn.Parameter):
         # temporaries (spectral-normalised weights): a fresh tensor every forward, nothing to cache or to batch with
-        return ops.conv3x3_pack_wino(w, mode) if kind else ops.conv3x3_pack_weights(w, mode)
+        return _pack_now(w, mode, kind)
     _PACKS[(id(w), kind, mode)] = weakref.ref(w)
     _repack_stale(w.device)
     return cache[(kind, mode)][1]
@@ -166,6 +171,26 @@ def packed_wino(w: torch.Tensor, mode: int):
     return _packed(w, mode, 1)
 
 
+def packed_wino4(w: torch.Tensor, mode: int):
+    """Winograd F(4x4,3x3) image of `w` (`neosr_conv3x3_pack_wino4`), cached like `packed_weights`."""
+    return _packed(w, mode, 2)
+
+
+WINO4_MIN_WGS = 64  # include/neosr_amd.h: NEOSR_WINO4_MIN_WGS
+
+
+def wino_images(w: torch.Tensor, mode: int, B: int, H: int, W: int, n_out: int, ok: bool = True) -> dict:
+    """The ONE Winograd image a plain 3x3 launch of this geometry will use, as keyword arguments of `ops.conv3x3`:
+    F(4x4,3x3) under `neosr_set_winograd(2)` when the launch has enough 16 x 16-pixel x 32-cout workgroups to fill the
+    chip, else F(2x2,3x3) (the library applies the same rule; packing only the image it will pick halves the pack work)."""
+    if not ok:
+        return {}
+    wgs = B * -(-H // 16) * -(-W // 16) * -(-n_out // 32)
+    if _C.load().neosr_get_winograd() == 2 and wgs >= WINO4_MIN_WGS:
+        return {"w_wino4": packed_wino4(w, mode)}
+    return {"w_wino": packed_wino(w, mode)}
+
+
 class Conv3x3(torch.autograd.Function):
     """y = act(conv3x3(x'[..., :K], w) + b) (+ res), fused bias/activation/residual; x' = x or its
     nearest x2 upsampling (`ups`, folded into the conv loader).  backward = MFMA dgrad (activation
@@ -175,9 +200,13 @@ class Conv3x3(torch.autograd.Function):
     def forward(ctx, x, w, b, act, slope, ups, res, s2d_c=0, sole_consumer_is_conv=False):
         _C.require_device(x, "x")
         w = _C.require_device(w, "weight").contiguous()
-        wino = packed_wino(w, ops.CONV_FWD) if s2d_c == 0 else None  # F(2x2,3x3) kernel when eligible
+        # Winograd kernel when eligible (nearest-upsampled inputs: F(2x2,3x3) only)
+        if ups:
+            wino = {"w_wino": packed_wino(w, ops.CONV_FWD)} if s2d_c == 0 else {}
+        else:
+            wino = wino_images(w, ops.CONV_FWD, x.shape[0], x.shape[1], x.shape[2], w.shape[0], s2d_c == 0)
         y = ops.conv3x3(x, w, b, act=act, slope=slope, k_in=w.shape[1], ups=ups, res1=res,
-                        w_pack=packed_weights(w, ops.CONV_FWD), s2d_c=s2d_c, w_wino=wino)
+                        w_pack=packed_weights(w, ops.CONV_FWD), s2d_c=s2d_c, **wino)
         ctx.s2d_c = s2d_c
         ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
         ctx.act, ctx.slope, ctx.has_bias, ctx.ups, ctx.has_res = act, slope, b is not None, ups, res is not None
@@ -220,8 +249,9 @@ class Conv3x3(torch.autograd.Function):
             fold = plain and ctx.x_fold_slope is not None
             gx = ops.conv3x3(g, w, None, mode=ops.CONV_DGRAD, in_mask=y, mask_slope=slope,
                              w_pack=packed_weights(w, ops.CONV_DGRAD) if plain else None, s2d_c=ctx.s2d_c,
-                             w_wino=packed_wino(w, ops.CONV_DGRAD) if plain and ctx.s2d_c == 0 else None,
-                             out_mask=x if fold else None, out_mask_slope=ctx.x_fold_slope if fold else 1.0)
+                             out_mask=x if fold else None, out_mask_slope=ctx.x_fold_slope if fold else 1.0,
+                             **wino_images(w, ops.CONV_DGRAD, g.shape[0], g.shape[1], g.shape[2], w.shape[1],
+                                           plain and ctx.s2d_c == 0))
             if fold:
                 gx._neosr_act_masked = x.data_ptr()
             if ctx.ups:

@@ -157,7 +157,9 @@ def test_full_size_generator_properties(arch):
     _, ga = _fwd_bwd(net, x[:h].contiguous(), g1[:h].contiguous())
     _, gb = _fwd_bwd(net, x[h:].contiguous(), g1[h:].contiguous())
     worst = max(rel_err(p + q, r) for p, q, r in zip(ga, gb, a))
-    assert worst < 2e-4, worst
+    # (re-association only; 5e-4: the F(4x4,3x3) convolutions round ~10x coarser than F(2x2,3x3), 3.2e-4 observed on
+    # hat_l's smallest gradients, 1.1e-4 before them — north_star allows 1e-3)
+    assert worst < 5e-4, worst
     # backward is linear in the upstream gradient
     _, b = _fwd_bwd(net, x, g2)
     _, c = _fwd_bwd(net, x, 0.5 * g1 - 2.0 * g2)

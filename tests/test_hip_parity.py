@@ -260,11 +260,12 @@ def test_conv3x3_winograd4_slices_residuals_accumulate_and_modes():
     wino4 = ops.conv3x3_pack_wino4(w, ops.CONV_FWD)
     lib = _C_lib()
     outs = []
-    for on in (0, 1, 2, 2):
+    for on, both in ((0, True), (1, True), (2, False), (2, False), (2, True)):
         prev = lib.neosr_set_winograd(on)
+        assert lib.neosr_get_winograd() == on
         o = buf.clone()
         ops.conv3x3(o[..., :K], w, b, out=o[..., K:K + N], alpha=0.2, res1=o[..., :N], alpha2=0.5, res2=r2,
-                    accumulate=True, w_pack=pack, w_wino=wino, w_wino4=wino4)
+                    accumulate=True, w_pack=pack, w_wino=wino if both else None, w_wino4=wino4)
         outs.append(o)
         assert lib.neosr_set_winograd(prev) == on
     torch.cuda.synchronize()
@@ -272,6 +273,9 @@ def test_conv3x3_winograd4_slices_residuals_accumulate_and_modes():
     assert not torch.equal(outs[0], outs[2]) and not torch.equal(outs[1], outs[2])
     assert rel_err(outs[2].cpu(), outs[0].cpu()) < 1e-5
     assert torch.equal(outs[2][..., :K], buf[..., :K])
+    # a launch this small (12 workgroups of 16 x 16 pixels x 32 channels < NEOSR_WINO4_MIN_WGS) keeps F(2x2,3x3) when it
+    # is offered both images
+    assert torch.equal(outs[4], outs[1])
 
 
 def test_conv3x3_winograd_slices_residuals_accumulate_and_toggle():
