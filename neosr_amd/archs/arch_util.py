@@ -80,7 +80,9 @@ class DropPathBank:
         if self._keep is None or self._keep.device != device:
             self._keep = torch.tensor([1.0 - p for p in self.probs], dtype=torch.float32, device=device).view(-1, 1)
         rows = torch.bernoulli(self._keep.expand(-1, b))
-        self._rows = rows.div_(self._keep)
+        # (a site with drop_prob == 1 keeps nothing: its scale stays 0 like the per-site path / the reference's
+        # `keep_prob > 0` guard, instead of 0 / 0)
+        self._rows = rows.div_(self._keep.clamp_min(torch.finfo(torch.float32).tiny))
 
     def end(self, training: bool) -> None:
         if training and not self.recorded:

@@ -230,7 +230,9 @@ class Conv3x3(torch.autograd.Function):
         x, w, y = ctx.saved_tensors
         g = g.contiguous()
         slope = ctx.slope if ctx.act == ACT_LRELU else 0.0
-        if y is not None and getattr(g, "_neosr_act_masked", None) == y.data_ptr():
+        # (the tag is only honoured while the tensor is exactly what the consumer wrote: autograd's input buffer may add
+        # further contributions IN PLACE into a tagged tensor it holds the last reference to — that bumps `_version`)
+        if y is not None and getattr(g, "_neosr_act_masked", None) == (y.data_ptr(), g._version):
             y = None  # the consumer's backward-data epilogue already multiplied g by act'(y) (below)
         if y is not None and (ctx.s2d_c == 0 or _S2D_PREMASK):
             # producer-side activation derivative: g <- g * act'(y) in ONE elementwise pass, so that neither the
@@ -253,7 +255,7 @@ class Conv3x3(torch.autograd.Function):
                              **wino_images(w, ops.CONV_DGRAD, g.shape[0], g.shape[1], g.shape[2], w.shape[1],
                                            plain and ctx.s2d_c == 0))
             if fold:
-                gx._neosr_act_masked = x.data_ptr()
+                gx._neosr_act_masked = (x.data_ptr(), gx._version)
             if ctx.ups:
                 gx = ops.pool2x2_sum(gx)
             if x.shape[3] > gx.shape[3]:  # conv read a channel prefix of a wider buffer

@@ -88,7 +88,19 @@ def _wgrad_pair(like, n_out: int, k_in: int, want_bias: bool):
 # and hands the results to `.grad` itself — the Function returns None for those inputs, so autograd never reads an
 # unfinished sum.  Only leaf tensors are deferred (a non-leaf weight needs its gradient inside the graph).
 _DEFERRED: list = []
+_DEFERRED_BYTES = 0
 DEFER_REDUCTIONS = os.environ.get("NEOSR_AMD_DEFER_REDUCE", "1") != "0"
+# A queued job pins the WHOLE workspace its partials live in (a view keeps the storage alive: ~100 MB per HAB of hat_l at
+# B = 4, the split-K slabs of every Linear) until it is flushed, so the queue is bounded: it is flushed from inside the
+# backward pass once it holds DEFER_MAX_JOBS jobs (the launch batch of `neosr_colsum_many`) or DEFER_MAX_BYTES of pinned
+# workspaces, whichever comes first — peak memory no longer grows with the depth of the network.
+DEFER_MAX_JOBS = 32
+DEFER_MAX_BYTES = 1 << 30
+
+
+def _task_id() -> int:
+    fn = getattr(torch._C, "_current_graph_task_id", None)  # noqa: SLF001
+    return fn() if fn is not None else -1
 
 
 def _can_defer(*params) -> bool:
@@ -99,33 +111,49 @@ def _can_defer(*params) -> bool:
 
 def _defer_colsum(part, rows: int, cols: int, ld: int, out, targets) -> None:
     """queue out[c] = sum_r part[r, c]; afterwards `targets` = [(leaf, view of out), ...] receive their gradients"""
-    # one callback per producing backward call, the first one to run does all the work: a backward pass that died with
-    # an exception leaves jobs behind without having run its callbacks, and "register when the queue is empty" would
-    # then never register again (`reset_deferred` drops such leftovers at the start of a training step)
+    global _DEFERRED_BYTES
+    task = _task_id()
+    if _DEFERRED and _DEFERRED[0][6] != task:
+        # jobs of ANOTHER backward pass: it died with an exception before its final callback ran.  Their partials must
+        # not leak into this pass's gradients
+        reset_deferred()
+    # one callback per producing backward call, the first one to run does all the work (a pass that dies never runs its
+    # callbacks, so "register only when the queue is empty" could strand jobs)
     torch.autograd.Variable._execution_engine.queue_callback(_flush_deferred)  # noqa: SLF001
-    _DEFERRED.append((part, rows, cols, ld, out, targets))
+    _DEFERRED.append((part, rows, cols, ld, out, targets, task, torch.cuda.current_stream()))
+    _DEFERRED_BYTES += part.untyped_storage().nbytes()
+    if len(_DEFERRED) >= DEFER_MAX_JOBS or _DEFERRED_BYTES >= DEFER_MAX_BYTES:
+        _flush_deferred()
 
 
 def reset_deferred() -> None:
     """Drop reductions queued by a backward pass that did not finish (models call this before each step)."""
+    global _DEFERRED_BYTES
     _DEFERRED.clear()
+    _DEFERRED_BYTES = 0
 
 
 def _flush_deferred() -> None:
+    global _DEFERRED_BYTES
     jobs = list(_DEFERRED)
     _DEFERRED.clear()
+    _DEFERRED_BYTES = 0
     if not jobs:
         return
     lib = _C.load()
+    cur = torch.cuda.current_stream()
+    for s in {j[7] for j in jobs}:  # partials produced on another stream (a backward node's forward stream): order after it
+        if s != cur:
+            cur.wait_stream(s)
     items = (_C.ColsumItem * len(jobs))()
-    for it, (part, rows, cols, ld, out, _t) in zip(items, jobs):
+    for it, (part, rows, cols, ld, out, *_r) in zip(items, jobs):
         it.x, it.out, it.rows, it.cols, it.ld, it.accumulate = part.data_ptr(), out.data_ptr(), rows, cols, ld, 0
     ws = torch.empty(lib.neosr_colsum_many_workspace_floats(items, len(jobs)), device=jobs[0][0].device,
                      dtype=torch.float32)
     _C.check(lib.neosr_colsum_many(items, len(jobs), ws.data_ptr(), _st()), "neosr_colsum_many")
     with torch.no_grad():
-        for *_x, targets in jobs:
-            for leaf, g in targets:
+        for job in jobs:
+            for leaf, g in job[5]:
                 if leaf.grad is None:
                     leaf.grad = g
                 else:
