@@ -125,6 +125,11 @@ int neosr_get_winograd(void);   /* the current mode (0 / 1 / 2), see below */
  * 32-cout blocks; below that a 256-CU chip is better filled by the 8 x 16-pixel tiles of F(2x2,3x3)) or no w_wino was
  * given, else as 1. */
 #define NEOSR_WINO4_MIN_WGS 64
+/* The F(4x4,3x3) kernel has two workgroup shapes, 32 or 64 output channels (launches with N > 32), chosen per launch by a
+ * fill estimate over the 256 CUs.  They sum the channel chunks in different orders (results differ by rounding, ~1e-6), so a
+ * network's output bits can depend on the batch size the way a vendor library's algorithm choice does.
+ * neosr_set_wino4_n64: -1 = by the estimate (default), 0 = always 32, 1 = 64 whenever N > 32; returns the previous mode. */
+int neosr_set_wino4_n64(int mode);
 int64_t neosr_conv3x3_pack_wino4_bytes(int32_t N, int32_t K);
 int neosr_conv3x3_pack_wino4(const float* w, int32_t w_cout, int32_t w_cin, int32_t mode, float* dst, void* stream);
 /* Both images of MANY weight tensors in ceil(n / 24) launches per image kind (the per-layer calls above cost one launch

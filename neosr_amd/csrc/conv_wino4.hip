@@ -106,29 +106,34 @@ constexpr QTables q_make_tables() {
 }
 static __device__ const QTables g_qt = q_make_tables();
 
+// N64 = false: the workgroup owns 32 output channels, wave (ti, kp) the channels of k-parity kp of every chunk (see the
+// header).  N64 = true (launches with more than 32 output channels): the workgroup owns SIXTY-FOUR output channels and
+// wave (ti, ch) the 32 channels of cout half ch for BOTH k-parities, one after the other (two sub-chunks per barrier) —
+// the raw tile is staged once for 64 channels instead of twice, one prologue / epilogue per 2 x the matrix work, and
+// the accumulator exchange needs no k-parity sum.
+template <bool N64>
 __global__ __attribute__((amdgpu_flat_work_group_size(768, 768), amdgpu_waves_per_eu(3, 3)))
 void conv3x3_wino4_kernel(const ConvArgs args) {
   const neosr_conv_desc& d = args.d;
-  // two DISTINCT LDS objects: raw buffers during the loop, the two k-parity halves of the exchange image afterwards
+  // two DISTINCT LDS objects: raw buffers during the loop, the two halves of the exchange image afterwards
   __shared__ __attribute__((aligned(1024))) float ldsA[QBUF];
   __shared__ __attribute__((aligned(1024))) float ldsB[QBUF];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ti = wave >> 1, kp = wave & 1;   // transform row, channel parity
+  const int ti = wave >> 1, sel = wave & 1;   // transform row; channel parity (N64: cout half)
   const int t16 = lane & 15, kq = lane >> 4;
   // waves w, w + 4, w + 8 share a SIMD: three static priorities (see the header)
-#ifndef W4_NOPRIO
   if (wave >= 8) __builtin_amdgcn_s_setprio(2);
   else if (wave >= 4) __builtin_amdgcn_s_setprio(1);
-#endif
   TL_MARK(0);
 
   // table rows of this thread (requested first: their latency hides under the scalar set-up)
   typedef int i32x4 __attribute__((ext_vector_type(4)));
   const i32x4 gtab = *reinterpret_cast<const i32x4*>(g_qt.gran[tid]);
-  const i32x4 pa_lo = *reinterpret_cast<const i32x4*>(g_qt.pa[wave][lane]);
-  const i32x4 pa_hi = *reinterpret_cast<const i32x4*>(g_qt.pa[wave][lane] + 4);
+  const int prow = N64 ? (wave & ~1) : wave;   // N64: the k-parity 0 row; parity 1 = the same offsets with bit 4 flipped
+  const i32x4 pa_lo = *reinterpret_cast<const i32x4*>(g_qt.pa[prow][lane]);
+  const i32x4 pa_hi = *reinterpret_cast<const i32x4*>(g_qt.pa[prow][lane] + 4);
 
   int bid = xcd_tile(blockIdx.x, gridDim.x, args.xcd);
   int tx, ty, b;
@@ -143,7 +148,8 @@ void conv3x3_wino4_kernel(const ConvArgs args) {
     b = bid / args.tiles_y;
   }
   const int x0 = tx * QT, y0 = ty * QT;
-  const int n0 = blockIdx.y * 32;
+  constexpr int NW = N64 ? 64 : 32;           // output channels per workgroup
+  const int n0 = blockIdx.y * NW;
   const int H = d.H, W = d.W, K = d.K;
   const int Hin = d.ups ? (H >> 1) : H, Win = d.ups ? (W >> 1) : W;
   const int nchunks = (K + 31) >> 5;
@@ -196,13 +202,16 @@ void conv3x3_wino4_kernel(const ConvArgs args) {
   // LDS float offsets of (row q_row(ti, k), column 0 / column 4) of this lane's patch; columns c & 3 are +64 floats each
   const int pa[4][2] = {{pa_lo[0], pa_lo[1]}, {pa_lo[2], pa_lo[3]}, {pa_hi[0], pa_hi[1]}, {pa_hi[2], pa_hi[3]}};
 
-  // ---- U image of this n-block: [chunk][pos 36][kp 2][cout block 2][k quad 4][cout 16][4] floats
+  // ---- U image of this wave's 32-cout block: [chunk][pos 36][kp 2][cout block 2][k quad 4][cout 16][4] floats
+  const int nblk = N64 ? 2 * (int)blockIdx.y + sel : (int)blockIdx.y;
+  const bool blk_ok = nblk * 32 < d.N;   // (N64, N % 64 == 32: the upper half of the last workgroup has no channels)
   const auto ru = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(d.w_wino4) + (int64_t)blockIdx.y * nchunks * QU_CHUNK, 0, nchunks * QU_CHUNK * 4, 0x00020000);
+      const_cast<float*>(d.w_wino4) + (int64_t)(blk_ok ? nblk : 0) * nchunks * QU_CHUNK, 0, blk_ok ? nchunks * QU_CHUNK * 4 : 0,
+      0x00020000);
   const int u_lane = lane * 16;
-  const int u_wave = ((ti * 6) * 4 + kp * 2) * 1024;
   typedef decltype(__builtin_amdgcn_raw_buffer_load_b128(ru, 0, 0, 0)) u32x4_t;
-  auto load_u3 = [&](int c, int j0, f32x4 (&u)[3][2]) {   // positions (ti, j0 .. j0 + 2) of chunk c
+  auto load_u3 = [&](int c, int kp, int j0, f32x4 (&u)[3][2]) {   // positions (ti, j0 .. j0 + 2), k-parity kp of chunk c
+    const int u_wave = ((ti * 6) * 4 + kp * 2) * 1024;
 #pragma unroll
     for (int j = 0; j < 3; ++j)
 #pragma unroll
@@ -225,38 +234,28 @@ void conv3x3_wino4_kernel(const ConvArgs args) {
       for (int j = 0; j < 3; ++j)
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb)
-#ifdef W4_NOMFMA
-          acc[j0 + j][nb][e] += u[j][nb][e] * v[j][e];
-#else
           acc[j0 + j][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[j][nb][e], v[j][e], acc[j0 + j][nb], 0, 0, 0);
-#endif
   };
 
-  // column pass (row ti of B^T d) then row pass ((B^T d) B) for the lane's four channels
-  auto transform = [&](const float* rb, f32x4 (&vlo)[3], f32x4 (&vhi)[3]) {
-#ifdef W4_NOTRANSFORM
-    {
-      const f32x4 da = ld4f(rb + pa[0][0]);
-      vlo[0] = da; vlo[1] = da + splat(1.f); vlo[2] = da + splat(2.f);
-      vhi[0] = da + splat(3.f); vhi[1] = da + splat(4.f); vhi[2] = da + splat(5.f);
-      return;
-    }
-#endif
+  // column pass (row ti of B^T d) then row pass ((B^T d) B) for the lane's four channels; xr = 16 selects k-parity 1 of
+  // the N64 kernel (channel quad q ^ 4: bit 4 of the swizzled float offset)
+  auto transform = [&](const float* rb, int xr, f32x4 (&vlo)[3], f32x4 (&vhi)[3]) {
     f32x4 t[6];
     const f32x4 ap4 = splat(ap), aq4 = splat(aq), gm4 = splat(gm);
     if (three) {
 #pragma unroll
       for (int c = 0; c < 6; ++c) {
         const int o = (c & 3) * 64;
-        const f32x4 da = ld4f(rb + pa[0][c >> 2] + o), db = ld4f(rb + pa[1][c >> 2] + o), dc = ld4f(rb + pa[3][c >> 2] + o);
+        const f32x4 da = ld4f(rb + (pa[0][c >> 2] ^ xr) + o), db = ld4f(rb + (pa[1][c >> 2] ^ xr) + o);
+        const f32x4 dc = ld4f(rb + (pa[3][c >> 2] ^ xr) + o);
         t[c] = fma4(gm4, da, fma4(ap4, db, dc));
       }
     } else {
 #pragma unroll
       for (int c = 0; c < 6; ++c) {
         const int o = (c & 3) * 64;
-        const f32x4 d1 = ld4f(rb + pa[0][c >> 2] + o), d2 = ld4f(rb + pa[1][c >> 2] + o);
-        const f32x4 d3 = ld4f(rb + pa[2][c >> 2] + o), d4 = ld4f(rb + pa[3][c >> 2] + o);
+        const f32x4 d1 = ld4f(rb + (pa[0][c >> 2] ^ xr) + o), d2 = ld4f(rb + (pa[1][c >> 2] ^ xr) + o);
+        const f32x4 d3 = ld4f(rb + (pa[2][c >> 2] ^ xr) + o), d4 = ld4f(rb + (pa[3][c >> 2] ^ xr) + o);
         t[c] = fma4(gm4, fma4(aq4, d1, d3), fma4(ap4, d2, d4));
       }
     }
@@ -281,35 +280,41 @@ void conv3x3_wino4_kernel(const ConvArgs args) {
   TL_MARK(1);
   // (the first U loads leave only now: in front of the barrier they would queue ahead of the late waves' DMA pieces in
   // the CU's one address path — 16 cycles per 1 KB instruction —; they land under the first transform)
-  load_u3(0, 0, ulo);
+  load_u3(0, N64 ? 0 : sel, 0, ulo);
   for (int c = 0; c < nchunks; ++c) {
     const float* rb = (c & 1) ? ldsB : ldsA;
-    if (c > 0) mac3(3, vhi, uhi);  // positions (ti, 3..5) of chunk c - 1
+    if (c > 0) mac3(3, vhi, uhi);  // positions (ti, 3..5) of the previous (sub-)chunk
     TL_MARK(2 + 4 * c);
     __builtin_amdgcn_sched_barrier(0);
     // (hipcc's wait for the U registers above is vmcnt(0) across the loop back edge: the DMA of the next chunk is therefore
     // requested BEHIND those MFMAs, not in front of them — it still has the transform and 24 MFMAs to land)
-#ifndef W4_NODMA
     if (c + 1 < nchunks) issue(c + 1, (c & 1) ? ldsA : ldsB);
-#endif
     __builtin_amdgcn_sched_barrier(0);
-    transform(rb, vlo, vhi);
+    transform(rb, 0, vlo, vhi);
     __builtin_amdgcn_sched_barrier(0);
     TL_MARK(3 + 4 * c);
-#ifdef W4_NOULOAD
-    if (c == 0)
-#endif
-    load_u3(c, 3, uhi);            // (their U registers are free during the transform: requested only now)
+    load_u3(c, N64 ? 0 : sel, 3, uhi);   // (their U registers are free during the transform: requested only now)
     __builtin_amdgcn_sched_barrier(0);
     mac3(0, vlo, ulo);
     __builtin_amdgcn_sched_barrier(0);
+    if (N64) {  // second k-parity of the same raw chunk, no barrier in between
+      load_u3(c, 1, 0, ulo);
+      __builtin_amdgcn_sched_barrier(0);
+      mac3(3, vhi, uhi);
+      __builtin_amdgcn_sched_barrier(0);
+      transform(rb, 16, vlo, vhi);
+      __builtin_amdgcn_sched_barrier(0);
+      load_u3(c, 1, 3, uhi);
+      __builtin_amdgcn_sched_barrier(0);
+      mac3(0, vlo, ulo);
+      __builtin_amdgcn_sched_barrier(0);
+    }
     if (c + 1 < nchunks) {
-#ifndef W4_NOULOAD
-      load_u3(c + 1, 0, ulo);
-#endif
-      // chunk c + 1 has landed (the twelve U loads issued behind it may stay in flight) ...
+      load_u3(c + 1, N64 ? 0 : sel, 0, ulo);
+      // chunk c + 1 has landed (the U loads issued behind it — 12, N64: 24 — may stay in flight) ...
       TL_MARK(4 + 4 * c);
-      __builtin_amdgcn_s_waitcnt(0x0f7c);  // vmcnt(12)
+      if (N64) __builtin_amdgcn_s_waitcnt(0x4f78);  // vmcnt(24)
+      else __builtin_amdgcn_s_waitcnt(0x0f7c);      // vmcnt(12)
     }
     __syncthreads();  // ... for every wave, and every wave is done reading buffer c & 1
     TL_MARK(5 + 4 * c);
@@ -318,73 +323,81 @@ void conv3x3_wino4_kernel(const ConvArgs args) {
   __builtin_amdgcn_s_setprio(0);
   TL_MARK(60);
 
-  // ---- epilogue operands of thread (tile, b, cout quad) — eight of the twelve waves — requested now: their latency hides under the row
-  // pass, the exchange and its barrier
-  // (waves 4-11: the two higher priorities leave the loop first, so their address arithmetic and loads run beside the
-  // last MFMAs of waves 0-3)
-  const bool fin = wave >= 4;
-  const int cq = (tid & 7) << 2, eb = (tid >> 3) & 3, et = ((tid - 256) >> 5) & 15;
-  const int chq = n0 + cq;
-  const bool ch_ok = fin && chq < d.N;
-  const int cs0 = ch_ok ? chq : 0;
-  f32x4 bias = splat(0.f);
-  float s_uni = 1.f;
-  if (d.act == ACT_LRELU) s_uni = d.slope;
-  else if (d.act == ACT_RELU) s_uni = 0.f;
-  const int ey = y0 + 4 * (et >> 2), ex = x0 + 4 * (et & 3) + eb;
+  // ---- epilogue: thread (tile, b, cout quad) of eight of the twelve waves (4-11: the two higher priorities leave the
+  // loop first, so their address arithmetic and loads run beside the last MFMAs of waves 0-3) finishes 4 pixels (one
+  // column of a tile) x 4 channels; N64: two such units (tiles et and et + 8) one after the other.
   // BUFFER loads / stores with 32-bit byte offsets: a pixel outside the image (or a channel quad past N / past a
   // residual's width) gets an out-of-range offset — loads return zeros, stores are dropped; no 64-bit pointer selects,
   // no zero / trash pages, no exec-masked branches (the host routes tensors of 2 GB and more to the F(2x2) kernel)
-  const int pix0 = (b * H + ey) * W + ex;
-  const bool col_ok = ch_ok && ex < W;
-  bool okr[4];
-#pragma unroll
-  for (int a = 0; a < 4; ++a) okr[a] = col_ok && ey + a < H;
+  const bool fin = wave >= 4;
+  const int cq = N64 ? (tid & 15) << 2 : (tid & 7) << 2;
+  const int eb = N64 ? (tid >> 4) & 3 : (tid >> 3) & 3;
+  const int et0 = N64 ? ((tid - 256) >> 6) & 7 : ((tid - 256) >> 5) & 15;
+  const int chq = n0 + cq;
+  const bool ch_ok = fin && chq < d.N;
+  f32x4 bias = splat(0.f);
+  if (fin && d.bias) bias = ld4f(d.bias + (ch_ok ? chq : 0));
+  float s_uni = 1.f;
+  if (d.act == ACT_LRELU) s_uni = d.slope;
+  else if (d.act == ACT_RELU) s_uni = 0.f;
   typedef decltype(__builtin_amdgcn_raw_buffer_load_b128(ru, 0, 0, 0)) raw4_t;
-  // byte offset of (pixel row a, channel quad) in a tensor of channel stride cs: one multiplication per tensor, the rows
-  // are a uniform step apart (cheap select operands: the compiler keeps them v_cndmask, not branches)
-  auto offs = [&](int cs, bool ok_ch, int (&o)[4]) {
-    const int base = (pix0 * cs + chq) * 4, step = W * cs * 4;
-#pragma unroll
-    for (int a = 0; a < 4; ++a) o[a] = (okr[a] && ok_ch) ? base + a * step : 0x7ffffff8;
-  };
-  auto load4 = [&](const float* p, const int (&o)[4], f32x4 (&v)[4]) {
-    const auto rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, 0x7ffffff0, 0x00020000);
-#pragma unroll
-    for (int a = 0; a < 4; ++a) v[a] = __builtin_bit_cast(f32x4, (raw4_t)__builtin_amdgcn_raw_buffer_load_b128(rr, o[a], 0, 0));
-  };
   const auto r_out = __builtin_amdgcn_make_buffer_rsrc(d.out, 0, 0x7ffffff0, 0x00020000);
-  int o_out[4];
-  offs(d.out_cs, true, o_out);
-  f32x4 e1[4], e2[4], e0[4], mk[4];
+  struct Epi {
+    int o_out[4];
+    f32x4 e1[4], e2[4], e0[4], mk[4];
+  };
+  auto epi_load = [&](int et, Epi& E) {
+    const int ey = y0 + 4 * (et >> 2), ex = x0 + 4 * (et & 3) + eb;
+    const int pix0 = (b * H + ey) * W + ex;
+    const bool col_ok = ch_ok && ex < W;
+    bool okr[4];
 #pragma unroll
-  for (int a = 0; a < 4; ++a) {
-    e1[a] = e2[a] = e0[a] = splat(0.f);
-    mk[a] = splat(1.f);
-  }
-  if (fin) {
+    for (int a = 0; a < 4; ++a) okr[a] = col_ok && ey + a < H;
+    // byte offset of (pixel row a, channel quad) in a tensor of channel stride cs: one multiplication per tensor, the
+    // rows are a uniform step apart (cheap select operands: the compiler keeps them v_cndmask, not branches)
+    auto offs = [&](int cs, bool ok_ch, int (&o)[4]) {
+      const int base = (pix0 * cs + chq) * 4, step = W * cs * 4;
+#pragma unroll
+      for (int a = 0; a < 4; ++a) o[a] = (okr[a] && ok_ch) ? base + a * step : 0x7ffffff8;
+    };
+    auto load4 = [&](const float* p, const int (&o)[4], f32x4 (&v)[4]) {
+      const auto rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, 0x7ffffff0, 0x00020000);
+#pragma unroll
+      for (int a = 0; a < 4; ++a) v[a] = __builtin_bit_cast(f32x4, (raw4_t)__builtin_amdgcn_raw_buffer_load_b128(rr, o[a], 0, 0));
+    };
+    offs(d.out_cs, true, E.o_out);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      E.e1[a] = E.e2[a] = E.e0[a] = splat(0.f);
+      E.mk[a] = splat(1.f);
+    }
     int o[4];
-    if (d.bias) bias = ld4f(d.bias + cs0);
     if (d.res1) {
       offs(d.res1_cs, chq < d.res1_nch, o);
-      load4(d.res1, o, e1);
+      load4(d.res1, o, E.e1);
     }
     if (d.res2) {
       offs(d.res2_cs, chq < d.res2_nch, o);
-      load4(d.res2, o, e2);
+      load4(d.res2, o, E.e2);
     }
-    if (d.accumulate) load4(d.out, o_out, e0);
+    if (d.accumulate) load4(d.out, E.o_out, E.e0);
     if (d.out_mask) {  // (an out-of-range lane reads zeros: its result is dropped by the store anyway)
       offs(d.out_mask_cs, true, o);
-      load4(d.out_mask, o, mk);
+      load4(d.out_mask, o, E.mk);
     }
-  }
+  };
+  Epi E0;
+  if (fin) epi_load(et0, E0);
 
   // ---- output transform, row pass IN THE WAVE: X[i][b] = sum_j M[i][j] A[j][b],
   //   A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
-  // exchange image (k-parity kp in its own LDS object): [ti][b][tile][cout], register e of acc[.][nb] <-> cout 16 nb + 4 kq + e
+  // exchange image [ti][b][tile][cout]; register e of acc[.][nb] <-> cout 16 nb + 4 kq + e (N64: + 32 ch).  !N64: k-parity
+  // kp in its own LDS object (tile stride 36); N64: rows 0-2 in the first object, 3-5 in the second (tile stride 68)
+  constexpr int ES = N64 ? 68 : QES;
+  static_assert(3 * 4 * 16 * 68 <= QBUF, "N64 exchange half must fit its LDS object");
   {
-    float* ex_img = kp ? ldsB : ldsA;
+    float* ex_img = N64 ? (ti >= 3 ? ldsB : ldsA) : (sel ? ldsB : ldsA);
+    const int er = N64 ? (ti >= 3 ? ti - 3 : ti) : ti;
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
       const f32x4 s1 = acc[1][nb] + acc[2][nb], d1 = acc[1][nb] - acc[2][nb];
@@ -393,54 +406,66 @@ void conv3x3_wino4_kernel(const ConvArgs args) {
       const f32x4 x1v = fma4(splat(2.f), d2, d1);
       const f32x4 x2v = fma4(splat(4.f), s2, s1);
       const f32x4 x3v = fma4(splat(8.f), d2, d1) + acc[5][nb];
-      float* p = ex_img + ((ti * 4) * 16 + t16) * QES + 16 * nb + 4 * kq;
+      float* p = ex_img + ((er * 4) * 16 + t16) * ES + (N64 ? 32 * sel : 0) + 16 * nb + 4 * kq;
       *reinterpret_cast<f32x4*>(p) = x0v;
-      *reinterpret_cast<f32x4*>(p + 16 * QES) = x1v;
-      *reinterpret_cast<f32x4*>(p + 32 * QES) = x2v;
-      *reinterpret_cast<f32x4*>(p + 48 * QES) = x3v;
+      *reinterpret_cast<f32x4*>(p + 16 * ES) = x1v;
+      *reinterpret_cast<f32x4*>(p + 32 * ES) = x2v;
+      *reinterpret_cast<f32x4*>(p + 48 * ES) = x3v;
     }
   }
   TL_MARK(59);
   __syncthreads();
   TL_MARK(61);
   if (!fin) return;
-  // (opaque touch: keeps the first USE of the epilogue operands — hipcc would otherwise turn the mask into SGPR booleans
-  // right behind its loads, i.e. wait for all of them in front of the row pass)
-#pragma unroll
-  for (int a = 0; a < 4; ++a) {
-    asm volatile("" : "+v"(mk[a]), "+v"(e0[a]));
-    asm volatile("" : "+v"(e1[a]), "+v"(e2[a]));
-  }
 
   // ---- column pass (+ the k-parity sum) and epilogue: Y[a][b] = sum_i A^T[a][i] X[i][b]
-  f32x4 xi[6];
+  auto epi_finish = [&](int et, Epi& E) {
+    // (opaque touch: keeps the first USE of the epilogue operands behind the exchange — hipcc would otherwise turn the mask
+    // into SGPR booleans right behind its loads, i.e. wait for all of them in front of the row pass)
 #pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    const int o = ((i * 4 + eb) * 16 + et) * QES + cq;
-    xi[i] = ld4f(ldsA + o) + ld4f(ldsB + o);
-  }
-  f32x4 y[4];
-  {
-    const f32x4 s1 = xi[1] + xi[2], d1 = xi[1] - xi[2], s2 = xi[3] + xi[4], d2 = xi[3] - xi[4];
-    y[0] = (xi[0] + s1) + s2;
-    y[1] = fma4(splat(2.f), d2, d1);
-    y[2] = fma4(splat(4.f), s2, s1);
-    y[3] = fma4(splat(8.f), d2, d1) + xi[5];
-  }
-  TL_MARK(62);
-#pragma unroll
-  for (int a = 0; a < 4; ++a) {
-    f32x4 o;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float t = y[a][e] + bias[e];
-      t = t > 0.f ? t : t * s_uni;
-      t = t * d.alpha + e1[a][e];
-      t = t * d.alpha2 + e2[a][e];
-      t += e0[a][e];
-      o[e] = mk[a][e] > 0.f ? t : t * d.out_mask_slope;
+    for (int a = 0; a < 4; ++a) {
+      asm volatile("" : "+v"(E.mk[a]), "+v"(E.e0[a]));
+      asm volatile("" : "+v"(E.e1[a]), "+v"(E.e2[a]));
     }
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(raw4_t, o), r_out, o_out[a], 0, 0);
+    f32x4 xi[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      if (N64) {
+        xi[i] = ld4f((i >= 3 ? ldsB : ldsA) + (((i >= 3 ? i - 3 : i) * 4 + eb) * 16 + et) * ES + cq);
+      } else {
+        const int o = ((i * 4 + eb) * 16 + et) * ES + cq;
+        xi[i] = ld4f(ldsA + o) + ld4f(ldsB + o);
+      }
+    }
+    f32x4 y[4];
+    {
+      const f32x4 s1 = xi[1] + xi[2], d1 = xi[1] - xi[2], s2 = xi[3] + xi[4], d2 = xi[3] - xi[4];
+      y[0] = (xi[0] + s1) + s2;
+      y[1] = fma4(splat(2.f), d2, d1);
+      y[2] = fma4(splat(4.f), s2, s1);
+      y[3] = fma4(splat(8.f), d2, d1) + xi[5];
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float t = y[a][e] + bias[e];
+        t = t > 0.f ? t : t * s_uni;
+        t = t * d.alpha + E.e1[a][e];
+        t = t * d.alpha2 + E.e2[a][e];
+        t += E.e0[a][e];
+        o[e] = E.mk[a][e] > 0.f ? t : t * d.out_mask_slope;
+      }
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(raw4_t, o), r_out, E.o_out[a], 0, 0);
+    }
+  };
+  TL_MARK(62);
+  epi_finish(et0, E0);
+  if (N64) {
+    Epi E1;
+    epi_load(et0 + 8, E1);
+    epi_finish(et0 + 8, E1);
   }
   TL_MARK(63);
 }
@@ -505,6 +530,20 @@ __global__ __launch_bounds__(256) void conv_pack_wino4_kernel(const neosr_pack::
 
 }  // namespace
 
+// launch chains of the caller that run side by side (nets.hip: the two half-batch chains of the RRDB trunk): the fill
+// estimate below counts their workgroups together.  Host-side hint only — results never depend on it.
+int neosr_conv::g_wino4_concurrency = 1;
+
+namespace {
+int g_n64 = -1;  // -1: by the fill estimate (default); 0: never; 1: whenever the launch has more than 32 output channels
+}
+
+extern "C" int neosr_set_wino4_n64(int mode) {
+  const int prev = g_n64;
+  g_n64 = mode < 0 ? -1 : (mode ? 1 : 0);
+  return prev;
+}
+
 void neosr_conv::launch_wino4(const ConvArgs& a, hipStream_t st) {
   ConvArgs w = a;
   w.tiles_x = ceil_div(a.d.W, QT);
@@ -512,8 +551,17 @@ void neosr_conv::launch_wino4(const ConvArgs& a, hipStream_t st) {
   auto lg2 = [](int v) { int s = 0; while ((1 << s) < v) ++s; return (1 << s) == v ? s : -1; };
   w.tx_shift = lg2(w.tiles_x);
   w.ty_shift = lg2(w.tiles_y);
-  dim3 grid(w.tiles_x * w.tiles_y * a.d.B, ceil_div(a.d.N, 32));
-  hipLaunchKernelGGL(conv3x3_wino4_kernel, grid, dim3(768), 0, st, w);
+  // 64 output channels per workgroup when that fills the 256 CUs at least as well: a 64-channel workgroup runs ~1.75x as
+  // long as a 32-channel one (twice the matrix work, one prologue / epilogue / raw tile), workgroups go one per CU
+  const int64_t tiles = (int64_t)w.tiles_x * w.tiles_y * a.d.B * (g_wino4_concurrency > 0 ? g_wino4_concurrency : 1);
+  const int64_t r32 = (tiles * ceil_div(a.d.N, 32) + 255) / 256, r64 = (tiles * ceil_div(a.d.N, 64) + 255) / 256;
+  if (a.d.N > 32 && (g_n64 < 0 ? 7 * r64 <= 4 * r32 : g_n64 == 1)) {
+    dim3 grid(w.tiles_x * w.tiles_y * a.d.B, ceil_div(a.d.N, 64));
+    hipLaunchKernelGGL(conv3x3_wino4_kernel<true>, grid, dim3(768), 0, st, w);
+  } else {
+    dim3 grid(w.tiles_x * w.tiles_y * a.d.B, ceil_div(a.d.N, 32));
+    hipLaunchKernelGGL(conv3x3_wino4_kernel<false>, grid, dim3(768), 0, st, w);
+  }
 }
 
 int neosr_pack::launch_wino4(const Image* images, int n, void* stream) {

@@ -8,7 +8,10 @@
 // backward.
 #include "common.h"
 #include "conv_pack.h"
-namespace neosr_conv { int wino_mode(); }  // conv_wino.hip: 0 direct, 1 F(2x2,3x3), 2 F(4x4,3x3)
+namespace neosr_conv {
+int wino_mode();                  // conv_wino.hip: 0 direct, 1 F(2x2,3x3), 2 F(4x4,3x3)
+extern int g_wino4_concurrency;   // conv_wino4.hip: launch chains running side by side (fill estimate of the F(4x4) kernel)
+}
 #include "../../include/neosr_amd.h"
 #include <stdlib.h>
 #include <string.h>
@@ -66,6 +69,13 @@ neosr_wgrad_desc wgrad_base(int B, int H, int W) {
     if (int rc__ = (expr)) return rc__; \
   } while (0)
 
+// the F(4x4,3x3) kernel's fill estimate counts the workgroups of `n` launch chains together while this is alive
+struct ChainHint {
+  int prev;
+  explicit ChainHint(int n) : prev(neosr_conv::g_wino4_concurrency) { neosr_conv::g_wino4_concurrency = n; }
+  ~ChainHint() { neosr_conv::g_wino4_concurrency = prev; }
+};
+
 // ------------------------------------------------------------------------------ RRDBNet
 struct RrdbLayout {
   int B, H, W, Cin, Cout, F, G, NB, CC, cin_cs, cout_cs, nact;
@@ -92,6 +102,9 @@ struct RrdbLayout {
   // trunk launches take the F(4x4,3x3) kernel: mode 2 and enough 16 x 16-pixel tiles x 32-cout blocks over the WHOLE
   // batch (the launch chains run side by side) to fill the chip — NEOSR_WINO4_MIN_WGS; else F(2x2,3x3)
   bool w4_trunk;
+  // the trunk launches can still reach the direct-to-LDS kernel (Winograd switched off, or buffers of 2 GB and more that
+  // the F(4x4) kernel's 32-bit offsets refuse): only then are the direct images worth packing
+  bool direct_trunk;
   int64_t total;
 };
 
@@ -207,6 +220,7 @@ RrdbLayout rrdb_layout(const neosr_rrdbnet_cfg& c, void* ws) {
     L.tail_w4d = c.training ? b.take(4 * L.tail_w4) : nullptr;
     L.w4_trunk = neosr_conv::wino_mode() == 2 &&
                  (int64_t)c.B * ((c.H + 15) / 16) * ((c.W + 15) / 16) * ((G + 31) / 32) >= NEOSR_WINO4_MIN_WGS;
+    L.direct_trunk = neosr_conv::wino_mode() == 0 || (int64_t)c.B * c.H * c.W * L.CC * 4 >= (int64_t(1) << 31);
   }
   L.total = ((b.off + 255) & ~(int64_t)255);
   return L;
@@ -321,7 +335,7 @@ int rrdb_pack_fwd(const RrdbLayout& L, const float* const* P, void* st) {
       im.seg[0].w_cin = im.K;
       im.seg[0].k_cnt = im.K;
     }
-  RUN(neosr_pack::launch(imgs.data(), (int)imgs.size(), st));
+  if (L.direct_trunk) RUN(neosr_pack::launch(imgs.data(), (int)imgs.size(), st));
   for (int i = 0; i < 3 * L.NB; ++i)
     for (int k = 0; k < 5; ++k)
       imgs[i * 5 + k].dst = L.w4_trunk ? L.wwino4_f + i * L.w4f_total + L.w4f_off[k]
@@ -354,7 +368,7 @@ int rrdb_pack_dgrad(const RrdbLayout& L, const float* const* P, void* st) {
       }
       im.nseg = ns;
     }
-  RUN(neosr_pack::launch(imgs.data(), (int)imgs.size(), st));
+  if (L.direct_trunk) RUN(neosr_pack::launch(imgs.data(), (int)imgs.size(), st));
   for (int i = 0; i < 3 * L.NB; ++i)
     for (int j = 0; j < 5; ++j)
       imgs[i * 5 + j].dst = L.w4_trunk ? L.wwino4_d + i * L.w4d_total + L.w4d_off[j]
@@ -396,6 +410,8 @@ extern "C" int neosr_rrdbnet_forward(const neosr_rrdbnet_cfg* c, const float* co
     NEOSR_HIP(hipEventRecord(ax->fork, (hipStream_t)st));
     for (int h = 1; h < nhalf; ++h) NEOSR_HIP(hipStreamWaitEvent(ax->sc[h], ax->fork, 0));
   }
+  {
+  ChainHint hint(nhalf);
   for (int n = 0; n < L.NB; ++n) {
     for (int r = 0; r < 3; ++r) {
       const float* pk = L.wpack_f + (int64_t)(3 * n + r) * L.pf_total;
@@ -434,6 +450,7 @@ extern "C" int neosr_rrdbnet_forward(const neosr_rrdbnet_cfg* c, const float* co
         RUN(neosr_conv3x3(&d, sh));
       }
     }
+  }
   }
   if (ax)
     for (int h = 1; h < nhalf; ++h) {
@@ -611,6 +628,8 @@ int rrdb_backward_impl(const neosr_rrdbnet_cfg* c, const float* const* P, float*
   int gbi = 0, t = 0;
   const float* dOut = nullptr;  // gradient wrt the output of the current RRDB (g5 slot of its last RDB)
   float* prev = nullptr;
+  {
+  ChainHint hint(nhalf);
   for (int n = L.NB - 1; n >= 0; --n) {
     for (int r = 2; r >= 0; --r, ++t) {
       if (r == 2) dOut = L.gb[gbi];
@@ -675,6 +694,7 @@ int rrdb_backward_impl(const neosr_rrdbnet_cfg* c, const float* const* P, float*
       prev = L.gb[(gbi + 1) & 3];
       gbi = (gbi + 1) & 3;
     }
+  }
   }
   if (ax) {
     for (int h = 1; h < nhalf; ++h) {

@@ -36,15 +36,30 @@ def test_full_size_batch_independence_and_determinism(net):
     y, grads = _fwd_bwd(net, x, gy)
     y2, grads2 = _fwd_bwd(net, x, gy)
     assert torch.equal(y, y2) and all(torch.equal(a, b) for a, b in zip(grads, grads2))   # three streams, fixed order
-    # every sample's output depends on that sample alone: two half batches reproduce the full batch bit for bit
+    # every sample's output depends on that sample alone: two half batches reproduce the full batch — to rounding, not
+    # bit for bit, by default: the launch geometry picks the workgroup shape of the F(4x4,3x3) kernel (32 or 64 output
+    # channels, another summation order over the channel chunks), like a vendor library's algorithm choice
     with torch.no_grad():
         ya, yb = net(x[:8].contiguous()), net(x[8:].contiguous())
-    assert torch.equal(torch.cat((ya, yb)), y)
-    # and the parameter gradient is the sum over samples (re-association only)
-    _, ga = _fwd_bwd(net, x[:8].contiguous(), gy[:8].contiguous())
-    _, gb = _fwd_bwd(net, x[8:].contiguous(), gy[8:].contiguous())
-    worst = max(rel_err(a + b, c) for a, b, c in zip(ga, gb, grads))
-    assert worst < 1e-4, worst
+    assert rel_err(torch.cat((ya, yb)), y) < 1e-5
+    # with the shape pinned the halves ARE the full batch bit for bit, and the parameter gradient is the sum over samples
+    # up to re-association (with different forward bits a few LeakyReLU masks near zero flip, which moves gradients by
+    # ~1e-3: a conditioning effect, not an arithmetic one — DESIGN.md §6)
+    from neosr_amd import _C
+    lib = _C.load()
+    for mode in (0, 1):
+        prev = lib.neosr_set_wino4_n64(mode)
+        try:
+            y, grads = _fwd_bwd(net, x, gy)
+            with torch.no_grad():
+                ya, yb = net(x[:8].contiguous()), net(x[8:].contiguous())
+            assert torch.equal(torch.cat((ya, yb)), y)
+            _, ga = _fwd_bwd(net, x[:8].contiguous(), gy[:8].contiguous())
+            _, gb = _fwd_bwd(net, x[8:].contiguous(), gy[8:].contiguous())
+            worst = max(rel_err(a + b, c) for a, b, c in zip(ga, gb, grads))
+            assert worst < 1e-4, (mode, worst)
+        finally:
+            lib.neosr_set_wino4_n64(prev)
 
 
 def test_full_size_backward_is_linear_in_the_upstream_gradient(net):

@@ -203,7 +203,8 @@ def test_conv3x3_winograd_fwd_and_dgrad(B, H, W, K, N):
 
 
 @pytest.mark.parametrize("B,H,W,K,N", PACK_CASES + [(1, 13, 21, 96, 12), (3, 8, 16, 128, 32), (2, 64, 64, 192, 64),
-                                                   (1, 16, 16, 16, 32), (2, 35, 50, 48, 40)])
+                                                   (1, 16, 16, 16, 32), (2, 35, 50, 48, 40), (1, 24, 40, 64, 96),
+                                                   (2, 16, 32, 180, 180)])
 def test_conv3x3_winograd4_fwd_and_dgrad(B, H, W, K, N):
     """Winograd F(4x4,3x3) kernel (w_wino4, neosr_set_winograd(2)) against autograd in float64, both modes, the same
     epilogues as the direct-to-LDS kernel; sizes that are not multiples of the 16-pixel tile, ragged K / N, K not a
