@@ -2,6 +2,7 @@
 """Config-shaped golden fixtures, produced by RUNNING THE REFERENCE on CPU (build container only):
 
     python tests/golden/gen_golden_cfgs.py swinir_medium   -> cfg3_swinir_medium.npz
+    python tests/golden/gen_golden_cfgs.py hat_l           -> cfg4_hat_l.npz
     python tests/golden/gen_golden_cfgs.py cfg3            -> step_cfg3.npz   (+ golden_cfg3.toml)
     python tests/golden/gen_golden_cfgs.py cfg2            -> step_cfg2.npz   (+ golden_cfg2.toml)
     python tests/golden/gen_golden_cfgs.py cfg4            -> step_cfg4.npz   (+ golden_cfg4.toml)
@@ -10,6 +11,9 @@
                           perturbation so that biases / LN affines are non-trivial), one 64x64 LR patch, forward
                           + backward of sum(y * r): y, dL/dx, per-parameter gradient checksums and a handful of
                           full gradient tensors.  drop_path_rate = 0 (DropPath draws from the global RNG).
+  cfg4_hat_l.npz          BASELINE configs[4]'s generator AS NAMED: `hat_l()` in train mode, the same recipe (seeded init +
+                          perturbation, one 64x64 LR patch, forward + backward of sum(y * r)): y, dL/dx, gradient
+                          checksums of all 1710 parameters and a dozen full gradient tensors (HAB / OCAB / CAB / convs).
   step_cfg3.npz           configs[3]'s COMBINATION at reduced width: `image` model, swinir_small, L1 + VGG19
                           perceptual (seeded weights), adan_sf, clip, EMA — 2 iterations.
   step_cfg2.npz           configs[2]'s combination: `otf` model, feed_data with EVERY random draw recorded ->
@@ -133,6 +137,7 @@ criterion = "chc"
 """ + LOGGER,
 }
 TOMLS["swinir_medium"] = TOMLS["cfg3"]
+TOMLS["hat_l"] = TOMLS["cfg4"]
 
 SAMPLE_G = {  # a few full tensors of the big generators (the rest is pinned by per-tensor checksums)
     "swinir_small": ["conv_first.weight", "layers.0.residual_group.blocks.1.attn.relative_position_bias_table",
@@ -190,6 +195,51 @@ def gen_swinir_medium() -> None:
               "conv_before_upsample.0.weight", "upsample.2.bias", "conv_last.weight"):
         A[f"gfull/{k}"] = grads[k].numpy().copy()
     save("cfg3_swinir_medium.npz", **A)
+
+
+def gen_hat_l() -> None:
+    from neosr.archs import hat_arch as HA
+
+    for seed in range(1024, 1124):
+        torch.manual_seed(seed)
+        net = HA.hat_l(drop_path_rate=0.0)
+        sgen = torch.Generator().manual_seed(9000 + seed)
+        with torch.no_grad():
+            for p in net.parameters():
+                p.add_(torch.randn(p.shape, generator=sgen) * 0.02)
+        x = torch.rand(1, 3, 64, 64, generator=sgen).requires_grad_(True)
+        closest = [float("inf")]
+        hooks = [m.register_forward_pre_hook(lambda _m, a: closest.__setitem__(0, min(closest[0], float(a[0].abs().min()))))
+                 for m in net.modules() if isinstance(m, (torch.nn.LeakyReLU, torch.nn.ReLU))]
+        net.train()
+        y = net(x)
+        for h in hooks:
+            h.remove()
+        print(f"hat_l: seed {seed} closest LeakyReLU / ReLU input to zero {closest[0]:.2e}")
+        if closest[0] > 2e-7:  # see gen_golden_swinir.py: the derivative jumps at 0
+            break
+    else:
+        raise RuntimeError("no well-conditioned draw found")
+    r = torch.randn(y.shape, generator=sgen)
+    (y * r).sum().backward()
+    A = {"seed": np.int64(seed), "x": x.detach().numpy(), "r": r.numpy(), "y": y.detach().numpy(),
+         "gx": x.grad.numpy().copy()}
+    keys, s, a = checksums(dict(net.named_parameters()))
+    A["p/keys"], A["p/sum"], A["p/abs"] = keys, s, a
+    grads = {k: v.grad for k, v in net.named_parameters()}
+    A["g/sum"] = np.array([float(grads[str(k)].double().sum()) for k in keys])
+    A["g/abs"] = np.array([float(grads[str(k)].double().abs().sum()) for k in keys])
+    A["g/l2"] = np.array([float(grads[str(k)].double().norm()) for k in keys])
+    for k in ("conv_first.weight", "layers.0.residual_group.blocks.0.attn.qkv.weight",
+              "layers.0.residual_group.blocks.1.attn.relative_position_bias_table",
+              "layers.3.residual_group.blocks.2.conv_block.cab.0.weight",
+              "layers.3.residual_group.blocks.2.conv_block.cab.3.attention.1.weight",
+              "layers.5.residual_group.overlap_attn.relative_position_bias_table",
+              "layers.5.residual_group.overlap_attn.qkv.weight", "layers.7.residual_group.blocks.5.mlp.fc1.bias",
+              "layers.11.residual_group.blocks.5.attn.proj.weight", "layers.11.conv.weight",
+              "layers.6.residual_group.blocks.3.norm2.weight", "upsample.2.bias", "conv_last.weight"):
+        A[f"gfull/{k}"] = grads[k].numpy().copy()
+    save("cfg4_hat_l.npz", **A)
 
 
 def gen_step(name: str, opt) -> None:
@@ -293,11 +343,14 @@ def main() -> None:
     name = sys.argv[1]
     tmp = Path(tempfile.mkdtemp()) / f"golden_{name}.toml"
     tmp.write_text(TOMLS[name])
-    if name != "swinir_medium":
+    if name not in ("swinir_medium", "hat_l"):
         (HERE / f"golden_{name}.toml").write_text(TOMLS[name])
     install_reference(str(tmp))
     if name == "swinir_medium":
         gen_swinir_medium()
+        return
+    if name == "hat_l":
+        gen_hat_l()
         return
     from neosr.utils.options import parse_options
 

@@ -67,6 +67,41 @@ def test_swinir_medium_forward_backward_vs_reference_fixture():
         assert rel_err(P[k[len("gfull/"):]].grad, T(fix[k])) < 1e-3, k
 
 
+def test_hat_l_forward_backward_vs_reference_fixture():
+    """BASELINE configs[4]'s generator AS NAMED, at full width (dim 180, 6 heads, 12 x (6 HAB + OCAB)): forward AND backward
+    of the HIP path against the reference's own run (cfg4_hat_l.npz): y, dL/dx, the gradient of every one of the 1710
+    parameters (norm + sum) and a dozen full gradient tensors across HAB / OCAB / CAB / convolutions."""
+    from neosr_amd.archs import hat_arch as A
+
+    fix = load_golden("cfg4_hat_l.npz")
+    seed = int(fix["seed"])
+    torch.manual_seed(seed)
+    net = A.hat_l(upscale=4, drop_path_rate=0.0)
+    sgen = torch.Generator().manual_seed(9000 + seed)
+    with torch.no_grad():
+        for p in net.parameters():
+            p.add_(torch.randn(p.shape, generator=sgen) * 0.02)
+    keys = [str(k) for k in fix["p/keys"]]
+    P = dict(net.named_parameters())
+    assert keys == list(P)
+    np.testing.assert_allclose(np.array([float(P[k].double().sum()) for k in keys]), fix["p/sum"], rtol=1e-6, atol=1e-5)
+    net = net.to(DEV).train()
+    x = T(fix["x"]).to(DEV).requires_grad_(True)
+    y = net(x)
+    assert rel_err(y, T(fix["y"])) < 1e-4
+    y.backward(T(fix["r"]).to(DEV))
+    assert rel_err(x.grad, T(fix["gx"])) < 1e-3
+    P = dict(net.named_parameters())
+    l2 = np.array([float(P[k].grad.double().norm()) for k in keys])
+    bad = np.abs(l2 - fix["g/l2"]) > 1e-3 * fix["g/l2"] + 1e-7
+    assert not bad.any(), [(keys[i], l2[i], fix["g/l2"][i]) for i in np.nonzero(bad)[0]][:5]
+    s = np.array([float(P[k].grad.double().sum()) for k in keys])
+    bad = np.abs(s - fix["g/sum"]) > 1e-3 * fix["g/abs"] + 1e-7
+    assert not bad.any(), [keys[i] for i in np.nonzero(bad)[0]][:5]
+    for k in [f for f in fix if f.startswith("gfull/")]:
+        assert rel_err(P[k[len("gfull/"):]].grad, T(fix[k])) < 1e-3, k
+
+
 # ---------------------------------------------------------------------------------------------- config combinations
 @pytest.mark.parametrize("name", ["cfg3", "cfg2", "cfg4"])
 def test_config_combination_trajectory_vs_reference_fixture(name):
@@ -213,6 +248,50 @@ def test_full_size_config2_step_b32_deterministic_and_finite():
     assert runs[0][0] == runs[1][0]
     assert all(torch.equal(a, b) for a, b in zip(runs[0][1], runs[1][1]))
     assert all(torch.equal(a, b) for a, b in zip(runs[0][2], runs[1][2]))
+
+
+def test_full_size_config2_otf_feed_b32_deterministic_and_in_range():
+    """configs[2] AS NAMED — `model_type = "otf"` at batch 32: the whole on-device degradation feed (512x512 GT, live draws:
+    blur / resize / noise / JPEG twice, sinc, crop, pair pool) chained into the full G / D step, twice from the same seeds.
+    No reference replay at this size (tests/test_hip_degrade.py and the cfg2 trajectory do that at fixture size): the
+    size-independent properties — LQ / GT shapes and range, every log entry finite, bit-identical LQ, logs and final
+    weights across the two runs."""
+    import bench
+    from neosr_amd.models import build_model
+    from neosr_amd.utils.options import parse_options, set_global_opt
+
+    runs = []
+    for _ in range(2):
+        opt, _a = parse_options(str(ROOT), True, argv=["-opt", str(ROOT / "options" / "bench_esrgan_otf_gan.toml")])
+        assert opt["model_type"] == "otf" and opt["datasets"]["train"]["batch_size"] == 32
+        opt["datasets"]["train"].update(opt.get("degradations", {}))   # what train.py:69-70 does for the otf dataset
+        set_global_opt(opt)
+        torch.manual_seed(1024)
+        random.seed(1024)
+        np.random.seed(1024)
+        model = build_model(opt)
+        batch = bench.make_batch(opt, torch.device(DEV), 0)
+        assert batch["gt"].shape == (32, 3, 512, 512)
+        lqs = []
+        for it in (1, 2):
+            model.feed_data(batch)
+            assert model.lq.shape == (32, 3, 64, 64) and model.gt.shape == (32, 3, 256, 256)
+            assert float(model.lq.min()) >= 0.0 and float(model.lq.max()) <= 1.0
+            assert float(model.gt.min()) >= 0.0 and float(model.gt.max()) <= 1.0
+            assert float(model.lq.std()) > 1e-3   # (a degraded image, not a constant)
+            lqs.append(model.lq.detach().clone())
+            model.optimize_parameters(it)
+        log = model.get_current_log()
+        assert all(np.isfinite(v) for v in log.values()), log
+        torch.cuda.synchronize()
+        runs.append((log, lqs, [p.detach().clone() for p in model.net_g.parameters()],
+                     [p.detach().clone() for p in model.net_d.parameters()]))
+        del model, batch
+        torch.cuda.empty_cache()
+    assert runs[0][0] == runs[1][0]
+    assert all(torch.equal(a, b) for a, b in zip(runs[0][1], runs[1][1]))
+    assert all(torch.equal(a, b) for a, b in zip(runs[0][2], runs[1][2]))
+    assert all(torch.equal(a, b) for a, b in zip(runs[0][3], runs[1][3]))
 
 
 # ---------------------------------------------------------------------------------------------- compile = true

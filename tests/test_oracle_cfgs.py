@@ -12,6 +12,7 @@ import pytest
 import torch
 
 from oracle import gan_oracle as gorc
+from oracle import hat_oracle as horc
 from oracle import swinir_oracle as sorc
 from oracle.step_oracle import ConfigTrainer
 from tests.conftest import GOLDEN, ROOT, group, load_draws, load_golden, rel_err
@@ -116,6 +117,37 @@ def test_swinir_medium_oracle_forward_backward_vs_reference():
     x = T(fix["x"]).requires_grad_(True)
     cfg = dict(sorc.VARIANTS["swinir_medium"], upscale=4)
     y = sorc.swinir_forward(P, x, **cfg)
+    assert rel_err(y, T(fix["y"])) < 1e-5
+    (y * T(fix["r"])).sum().backward()
+    assert rel_err(x.grad, T(fix["gx"])) < 1e-4
+    l2 = np.array([float(P[k].grad.double().norm()) for k in keys])
+    np.testing.assert_allclose(l2, fix["g/l2"], rtol=1e-4, atol=1e-7)
+    for k in [f for f in fix if f.startswith("gfull/")]:
+        assert rel_err(P[k[len("gfull/"):]].grad, T(fix[k])) < 1e-4, k
+
+
+@pytest.mark.skipif(torch.get_num_threads() < 4, reason="hat_l forward + backward on CPU wants a few threads")
+def test_hat_l_oracle_forward_backward_vs_reference():
+    """configs[4]'s generator as named (hat_l, train mode, drop_path_rate 0): seeded init + seeded perturbation rebuilt
+    here, then y, dx and every parameter gradient (checksums for all 1710, full tensors for a sample) against the
+    reference run (cfg4_hat_l.npz, gen_golden_cfgs.py hat_l)."""
+    from neosr_amd.archs import hat_arch as A
+
+    fix = load_golden("cfg4_hat_l.npz")
+    seed = int(fix["seed"])
+    torch.manual_seed(seed)
+    net = A.hat_l(upscale=4, drop_path_rate=0.0)
+    sgen = torch.Generator().manual_seed(9000 + seed)
+    with torch.no_grad():
+        for p in net.parameters():
+            p.add_(torch.randn(p.shape, generator=sgen) * 0.02)
+    P = OrderedDict((k, v.detach().clone().requires_grad_(True)) for k, v in net.named_parameters())
+    keys = [str(k) for k in fix["p/keys"]]
+    assert keys == list(P)
+    np.testing.assert_allclose(np.array([float(P[k].double().sum()) for k in keys]), fix["p/sum"], rtol=1e-6, atol=1e-5)
+    x = T(fix["x"]).requires_grad_(True)
+    cfg = {k: v for k, v in horc.VARIANTS["hat_l"].items() if k not in ("compress_ratio", "squeeze_factor")}
+    y = horc.hat_forward(P, x, upscale=4, **cfg)
     assert rel_err(y, T(fix["y"])) < 1e-5
     (y * T(fix["r"])).sum().backward()
     assert rel_err(x.grad, T(fix["gx"])) < 1e-4
