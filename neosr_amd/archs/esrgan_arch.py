@@ -49,6 +49,7 @@ class RRDB(nn.Module):
 
 @ARCH_REGISTRY.register()
 class esrgan(HipNet):
+    plan_sends_grad_buckets = True   # models/image.py: the C++ backward plan reduces arena suffixes itself (GradSync marks)
     def __init__(self, num_in_ch: int = 3, num_out_ch: int = 3, scale: int | None = None,
                  num_feat: int = 64, num_block: int = 23, num_grow_ch: int = 32) -> None:
         super().__init__()

@@ -96,6 +96,9 @@ DEFER_REDUCTIONS = os.environ.get("NEOSR_AMD_DEFER_REDUCE", "1") != "0"
 # workspaces, whichever comes first — peak memory no longer grows with the depth of the network.
 DEFER_MAX_JOBS = 32
 DEFER_MAX_BYTES = 1 << 30
+# Set by the model on data-parallel runs (GradSync.grads_ready): the flush writes `.grad` outside autograd, so no
+# post-accumulate hook fires for these parameters — the gradient exchange is told here that they are final.
+GRADS_READY = None
 
 
 def _task_id() -> int:
@@ -158,6 +161,8 @@ def _flush_deferred() -> None:
                     leaf.grad = g
                 else:
                     leaf.grad += g
+    if GRADS_READY is not None:
+        GRADS_READY([leaf for job in jobs for leaf, _g in job[5]])
 
 
 def _as2d(x):

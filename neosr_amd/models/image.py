@@ -15,6 +15,8 @@ doing something else.
 
 from __future__ import annotations
 
+import os
+
 import math
 
 import sys
@@ -166,6 +168,12 @@ class image(base):
         if self.opt["dist"]:
             self._sync_g = GradSync()
             self.net_g._neosr_grad_sync = self._sync_g  # noqa: SLF001
+            if not getattr(self.net_g, "plan_sends_grad_buckets", False) and os.environ.get("NEOSR_AMD_DDP_HOOKS", "1") != "0":
+                # layer-composed generator (SwinIR, HAT, compact): DDP-style buckets driven by gradient hooks
+                from neosr_amd.hip import transformer as _tr
+
+                self._sync_g.attach(list(self.net_g.parameters()))
+                _tr.GRADS_READY = self._sync_g.grads_ready
             if self.net_d is not None:
                 self._sync_d = GradSync()
 
@@ -262,12 +270,13 @@ class image(base):
         phase and D's exchange overlaps G's optimizer step."""
         params = optimizer.param_groups[0]["params"]
         if self.opt["dist"]:
-            flat = flat_grad_of(params)
-            if flat is None:
-                flat = pack_grads(params)
-                for p, off in zip(params, arena_layout(params)[0]):
-                    p.grad = flat[off : off + p.numel()].view_as(p)
-            sync.start(flat)
+            if not sync.end_backward():   # (hook-driven exchange: every bucket is already on the communication stream)
+                flat = flat_grad_of(params)
+                if flat is None:
+                    flat = pack_grads(params)
+                    for p, off in zip(params, arena_layout(params)[0]):
+                        p.grad = flat[off : off + p.numel()].view_as(p)
+                sync.start(flat)
             if self._sam_now:  # the closure runs again inside fsam.step: finish this exchange first
                 sync.finish()
             optimizer.set_grad_scale(1.0 / self.opt["world_size"])
@@ -358,6 +367,8 @@ class image(base):
             loss_dict["l_g_gan"] = l_g_gan
         loss_dict["l_g_total"] = l_g_total
         l_g_total = l_g_total / self.accum_iters
+        if self._sync_g is not None:
+            self._sync_g.arm_backward()   # hook-driven buckets leave from inside this backward (no-op for the RRDB plan)
         l_g_total.backward()
         if step_now:
             self._sync_grads(self.sam_optimizer_g if self._sam_now else self.optimizer_g, self._sync_g)

@@ -9,10 +9,16 @@ a communication stream waits on the event and reduces that suffix while the earl
 xGMI is point-to-point (7 links, ring collectives are per-link bound): a handful of 15-25 MB messages, not
 DDP's many small ones.  The 1/world_size is folded into the fused optimizer kernel (`set_grad_scale`).
 
-Networks whose gradients arrive tensor by tensor (U-Net-SN, SwinIR, HAT: layer-composed) are reduced after
-their backward, but still asynchronously: `start()` only enqueues, `finish()` is called right before that
-network's optimizer step, so the exchange of G overlaps the whole discriminator phase and the exchange of D
-overlaps the generator's optimizer step.
+Networks whose gradients arrive tensor by tensor (SwinIR, HAT, compact generators: layer-composed) get DDP's own
+mechanism, rebuilt around the flat arena (`attach`): the parameter arena is cut into a few contiguous buckets;
+post-accumulate hooks (and the deferred-reduction flush of hip/transformer.py, which writes `.grad` outside autograd)
+count the parameters of a bucket that have their gradient; the moment a bucket is complete its gradients are packed into
+the persistent gradient arena by ONE `cat`, the parameters' `.grad` are re-pointed at the arena, an event is recorded and
+the communication stream all-reduces that slice — while backward is still working on the earlier layers.  What is not
+complete when backward returns (unused parameters) goes with `start()`.  The discriminator (two backward passes per
+step) and accumulating / SAM steps are reduced after backward, but still asynchronously: `start()` only enqueues,
+`finish()` is called right before that network's optimizer step, so the exchange of G overlaps the whole discriminator
+phase and the exchange of D overlaps the generator's optimizer step.
 """
 
 from __future__ import annotations
@@ -37,6 +43,19 @@ class GradSync:
         self._flat: torch.Tensor | None = None
         self._lo = 0                # [self._lo, numel) of self._flat is already being reduced
         self.buckets: list[tuple[int, int]] = []  # (lo, hi) element ranges of the last exchange, in issue order
+        # hook-driven buckets of a layer-composed network (attach)
+        self._params: list = []
+        self._offs: list[int] = []
+        self._total = 0
+        self._arena: torch.Tensor | None = None
+        self._bucket_of: dict[int, int] = {}          # id(param) -> bucket
+        self._bucket_params: list[list[int]] = []     # bucket -> parameter indices
+        self._bucket_range: list[tuple[int, int]] = []
+        self._pending: list[int] = []
+        self._sent: list[bool] = []
+        self._seen: set[int] = set()
+        self._live = False                            # a hook-driven exchange is in progress for this backward
+        self.in_backward_buckets = 0                  # buckets issued from inside the last backward (tests / bench)
 
     # -- plan side ------------------------------------------------------------------------------------
     def mark_blocks(self, num_block: int) -> list[int]:
@@ -72,6 +91,104 @@ class GradSync:
         else:
             self._works.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, async_op=True))
 
+    # -- hook-driven buckets (layer-composed networks) --------------------------------------------------
+    def attach(self, params, n_buckets: int = 4) -> None:
+        """Register the hooks on `params` (one network, arena order = `named_parameters()` order)."""
+        from neosr_amd.hip.nets import arena_layout
+
+        self._params = [p for p in params]
+        offs, total = arena_layout(self._params)
+        self._offs, self._total = list(offs), int(total)
+        # contiguous buckets of roughly equal size, cut at parameter boundaries
+        target = max(1, total // n_buckets)
+        self._bucket_params, self._bucket_range, cur, lo = [], [], [], 0
+        for i, p in enumerate(self._params):
+            cur.append(i)
+            end = self._offs[i + 1] if i + 1 < len(self._params) else total
+            if end - lo >= target and len(self._bucket_params) < n_buckets - 1:
+                self._bucket_params.append(cur)
+                self._bucket_range.append((lo, end))
+                cur, lo = [], end
+        if cur:
+            self._bucket_params.append(cur)
+            self._bucket_range.append((lo, total))
+        self._bucket_of = {id(self._params[i]): b for b, idx in enumerate(self._bucket_params) for i in idx}
+        for p in self._params:
+            if p.requires_grad:
+                p.register_post_accumulate_grad_hook(self._on_grad)
+
+    def _on_grad(self, p) -> None:
+        if self._live:
+            self.grads_ready((p,))
+
+    def arm_backward(self) -> None:
+        """Call right before the backward whose gradients will be stepped (model: `armed` and hooks attached)."""
+        if not self._params or not self.armed:
+            self._live = False
+            return
+        self.finish()
+        if self._arena is None or self._arena.device != self._params[0].device:
+            self._arena = torch.zeros(self._total, device=self._params[0].device, dtype=torch.float32)
+        self._flat, self._lo, self.buckets = self._arena, self._total, []
+        self._pending = [sum(1 for i in idx if self._params[i].requires_grad) for idx in self._bucket_params]
+        self._sent = [False] * len(self._bucket_params)
+        self._seen = set()
+        self._live, self.in_backward_buckets = True, 0
+        self.armed = True
+
+    def grads_ready(self, leaves) -> None:
+        """`.grad` of these parameters is final for this backward (hook, or the deferred-reduction flush)."""
+        if not self._live:
+            return
+        for p in leaves:
+            b = self._bucket_of.get(id(p))
+            # (the engine also runs the post-accumulate hook of a leaf whose Function returned None — the deferred
+            # reductions deliver that gradient later, outside autograd —: a notification counts once, and only when
+            # the gradient is there)
+            if b is None or p.grad is None or id(p) in self._seen:
+                continue
+            self._seen.add(id(p))
+            self._pending[b] -= 1
+            if self._pending[b] == 0 and not self._sent[b]:
+                self._send_bucket(b)
+                self.in_backward_buckets += 1
+
+    def _send_bucket(self, b: int) -> None:
+        lo, hi = self._bucket_range[b]
+        idx = self._bucket_params[b]
+        parts, pos = [], lo
+        for i in idx:
+            p = self._params[i]
+            off = self._offs[i]
+            if off > pos:
+                parts.append(self._arena.new_zeros(off - pos))
+            g = p.grad
+            parts.append(g.reshape(-1) if g is not None else self._arena.new_zeros(p.numel()))
+            pos = off + p.numel()
+        if hi > pos:
+            parts.append(self._arena.new_zeros(hi - pos))
+        torch.cat(parts, out=self._arena[lo:hi])
+        for i in idx:  # the optimizer and the all-reduce see ONE buffer: no second copy
+            p = self._params[i]
+            p.grad = self._arena[self._offs[i] : self._offs[i] + p.numel()].view_as(p)
+        self._sent[b] = True
+        event = None
+        if self.comm is not None and self._arena.is_cuda:
+            event = torch.cuda.Event()
+            event.record()
+        self._issue(lo, hi, event)
+
+    def end_backward(self) -> bool:
+        """After the armed backward: send what the hooks left (parameters without a gradient).  True if this network's
+        exchange was hook-driven (then `start()` has nothing left to do)."""
+        if not self._live:
+            return False
+        for b in range(len(self._bucket_params)):
+            if not self._sent[b]:
+                self._send_bucket(b)
+        self._live, self._lo = False, 0
+        return True
+
     # -- model side -----------------------------------------------------------------------------------
     def start(self, flat: torch.Tensor, bucket_elems: int = 16 << 20) -> None:
         """Enqueue the reduction of whatever part of `flat` is not in flight yet (all of it for layer-composed
@@ -97,3 +214,4 @@ class GradSync:
         self._works = []
         self._flat = None
         self.armed = False
+        self._live = False

@@ -64,6 +64,42 @@ def _worker(rank: int, world: int, port: int, q) -> None:
     gs.start(flat3)
     gs.finish()
     ok = ok and torch.allclose(flat3, full.sum(0), atol=1e-5) and gs.buckets == [(0, 100_003)]
+    # hook-driven buckets of a layer-composed network (GradSync.attach: what SwinIR / HAT generators use): a small torch
+    # model, per-rank half batches; buckets leave from inside backward in reverse arena order, `.grad` ends up as views of
+    # ONE arena holding the SUM over ranks, and SUM / world equals the big-batch gradient
+    torch.manual_seed(5)
+    net = torch.nn.Sequential(torch.nn.Linear(24, 64), torch.nn.GELU(), torch.nn.Linear(64, 64), torch.nn.GELU(),
+                              torch.nn.Linear(64, 8))
+    X = torch.randn(2 * world, 24, generator=g)
+    params = list(net.parameters())
+    gs2 = GradSync(device="cpu")
+    gs2.attach(params, n_buckets=3)
+    sent_inside = []
+    for step in range(2):  # the second step re-uses the arena
+        for p in params:
+            p.grad = None
+        gs2.armed = True
+        gs2.arm_backward()
+        net(X[2 * rank : 2 * rank + 2]).square().sum().backward()
+        sent_inside.append(gs2.in_backward_buckets)
+        assert gs2.end_backward()
+        gs2.finish()
+    ref = torch.nn.Sequential(*[type(m)(m.in_features, m.out_features) if isinstance(m, torch.nn.Linear) else type(m)()
+                                for m in net])
+    ref.load_state_dict(net.state_dict())
+    ref(X).square().sum().backward()
+    from neosr_amd.hip.nets import flat_grad_of
+
+    flat_g = flat_grad_of(params)
+    ok = ok and flat_g is not None and sent_inside == [2, 2] and len(gs2.buckets) == 2   # (cut at parameter boundaries)
+    ok = ok and gs2.buckets[0][1] == flat_g.numel() and sorted(gs2.buckets)[0][0] == 0   # last layers first
+    ok = ok and all(torch.allclose(p.grad, rp.grad, rtol=1e-5, atol=1e-6) for p, rp in zip(params, ref.parameters()))
+    gs2.armed = False   # accumulation / SAM steps: the hooks stay silent, the model falls back to start()
+    for p in params:
+        p.grad = None
+    gs2.arm_backward()
+    net(X[2 * rank : 2 * rank + 2]).square().sum().backward()
+    ok = ok and not gs2.end_backward() and flat_grad_of(params) is None
     q.put((rank, bool(ok), float(flat.sum())))
     dist.destroy_process_group()
 

@@ -93,7 +93,7 @@ TWO_RANK = textwrap.dedent("""
             return model
         return model
 
-    for cfg in ("golden_esrgan.toml", "golden_gan.toml"):
+    for cfg in ("golden_esrgan.toml", "golden_gan.toml", "golden_cfg3.toml"):
         m = run(cfg, True)
         init_g = {{k: v.detach().clone() for k, v in m.net_g.state_dict().items()}}
         init_d = {{k: v.detach().clone() for k, v in m.net_d.state_dict().items()}} if m.net_d is not None else None
@@ -103,6 +103,9 @@ TWO_RANK = textwrap.dedent("""
             m.optimize_parameters(it)
             if cfg == "golden_esrgan.toml":   # the RRDB plan sent 2 buckets during backward + the head afterwards
                 assert len(m._sync_g.buckets) >= 2, m._sync_g.buckets
+            if cfg == "golden_cfg3.toml":     # swinir_small (layer-composed): hook-driven buckets left DURING backward
+                assert m._sync_g.in_backward_buckets >= 2, (m._sync_g.in_backward_buckets, m._sync_g.buckets)
+                assert sorted(m._sync_g.buckets)[0][0] == 0 and len(m._sync_g.buckets) >= 3
         log = m.get_current_log()
         torch.cuda.synchronize()
         # every rank holds the same parameters, EMA and buffers, bit for bit
@@ -125,6 +128,12 @@ TWO_RANK = textwrap.dedent("""
             for k in rlog:
                 assert abs(log[k] - rlog[k]) <= 2e-4 * max(1.0, abs(rlog[k])), (cfg, k, log[k], rlog[k])
             for (k, a), b in zip(m.net_g.state_dict().items(), ref.net_g.state_dict().values()):
+                if cfg == "golden_cfg3.toml" and a.is_floating_point():
+                    # adan_sf on zero-initialised biases / LayerNorm shifts: two steps leave values of ~5e-5 whose
+                    # normalised updates amplify rounding (8e-3 RELATIVE on a 5e-5 tensor = 4e-7 absolute, identical
+                    # with and without the hook-driven buckets) -> norm-relative 2e-4 OR 2e-6 absolute
+                    assert rel_err(a, b) < 2e-4 or float((a - b).abs().max()) <= 2e-6, (cfg, "net_g", k, rel_err(a, b))
+                    continue
                 assert rel_err(a, b) < 2e-4, (cfg, "net_g", k, rel_err(a, b))
             if init_d is not None:
                 for (k, a), b in zip(m.net_d.state_dict().items(), ref.net_d.state_dict().values()):
