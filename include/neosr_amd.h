@@ -94,7 +94,7 @@ typedef struct neosr_conv_desc {
                                launches that qualify for w_pack and have no ups / s2d_c / PReLU take the Winograd
                                kernel (16/36 of the multiplications; same epilogue); see neosr_set_winograd */
   const float* w_wino4;     /* optional Winograd F(4x4,3x3) image of the same weights (neosr_conv3x3_pack_wino4): under
-                               neosr_set_winograd(2) (the default) launches that would take w_wino and do not upsample
+                               neosr_set_winograd(2) (the default) launches that would take w_wino
                                take the F(4x4,3x3) kernel instead (36 multiplications per 4x4 output tile and channel
                                pair instead of 144 direct / 64 with F(2x2,3x3); same epilogue) */
 } neosr_conv_desc;

@@ -408,11 +408,11 @@ extern "C" int neosr_conv3x3(const neosr_conv_desc* dp, void* stream) {
   // Winograd F(2x2,3x3) form of the same launch (conv_wino.hip)
   const bool use_wino = use_pack && d.w_wino && ((uintptr_t)d.w_wino % 16 == 0) && d.s2d_c == 0 &&
                         d.act != NEOSR_ACT_PRELU && neosr_conv::wino_enabled();
-  // ... or its F(4x4,3x3) form (conv_wino4.hip): same conditions, nearest-upsampled inputs stay with F(2x2,3x3)
+  // ... or its F(4x4,3x3) form (conv_wino4.hip): same conditions (nearest-upsampled inputs are gathered by its DMA addresses too)
   // (32-bit byte offsets in its epilogue: tensors of 2 GB and more stay with F(2x2,3x3); small launches too, if they can)
   const int64_t w4_wgs = (int64_t)d.B * ceil_div(d.H, 16) * ceil_div(d.W, 16) * ceil_div(d.N, 32);
   auto small = [&](const void* p, int cs) { return !p || (int64_t)d.B * d.H * d.W * cs * 4 < (int64_t(1) << 31); };
-  const bool use_wino4 = use_pack && d.w_wino4 && ((uintptr_t)d.w_wino4 % 16 == 0) && d.s2d_c == 0 && !d.ups &&
+  const bool use_wino4 = use_pack && d.w_wino4 && ((uintptr_t)d.w_wino4 % 16 == 0) && d.s2d_c == 0 &&
                          d.act != NEOSR_ACT_PRELU && neosr_conv::wino_mode() == 2 &&
                          (w4_wgs >= NEOSR_WINO4_MIN_WGS || !use_wino) && small(d.out, d.out_cs) && small(d.res1, d.res1_cs) &&
                          small(d.res2, d.res2_cs) && small(d.out_mask, d.out_mask_cs) && small(d.in, d.in_cs);

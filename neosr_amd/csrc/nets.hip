@@ -313,7 +313,7 @@ int rrdb_pack_tail(const RrdbLayout& L, const float* const* P, int mode, void* s
   }
   RUN(neosr_pack::launch(imgs, 4, st));
   for (int i = 0; i < 4; ++i) imgs[i].dst = (mode == NEOSR_CONV_FWD ? L.tail_wf : L.tail_wd) + i * L.tail_w;
-  RUN(neosr_pack::launch_wino(imgs, 4, st));  // (the nearest-upsampled forward launches keep F(2x2,3x3) in every mode)
+  RUN(neosr_pack::launch_wino(imgs, 4, st));  // (small launches — e.g. B = 1 — fall back to F(2x2,3x3): both kinds are kept)
   if (neosr_conv::wino_mode() != 2) return 0;
   for (int i = 0; i < 4; ++i) imgs[i].dst = (mode == NEOSR_CONV_FWD ? L.tail_w4f : L.tail_w4d) + i * L.tail_w4;
   return neosr_pack::launch_wino4(imgs, 4, st);

@@ -200,11 +200,9 @@ class Conv3x3(torch.autograd.Function):
     def forward(ctx, x, w, b, act, slope, ups, res, s2d_c=0, sole_consumer_is_conv=False):
         _C.require_device(x, "x")
         w = _C.require_device(w, "weight").contiguous()
-        # Winograd kernel when eligible (nearest-upsampled inputs: F(2x2,3x3) only)
-        if ups:
-            wino = {"w_wino": packed_wino(w, ops.CONV_FWD)} if s2d_c == 0 else {}
-        else:
-            wino = wino_images(w, ops.CONV_FWD, x.shape[0], x.shape[1], x.shape[2], w.shape[0], s2d_c == 0)
+        # Winograd kernel when eligible (a nearest-upsampled input is gathered by the kernels' DMA addresses)
+        up = 2 if ups else 1
+        wino = wino_images(w, ops.CONV_FWD, x.shape[0], up * x.shape[1], up * x.shape[2], w.shape[0], s2d_c == 0)
         y = ops.conv3x3(x, w, b, act=act, slope=slope, k_in=w.shape[1], ups=ups, res1=res,
                         w_pack=packed_weights(w, ops.CONV_FWD), s2d_c=s2d_c, **wino)
         ctx.s2d_c = s2d_c

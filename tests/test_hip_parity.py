@@ -246,6 +246,30 @@ def test_conv3x3_winograd4_fwd_and_dgrad(B, H, W, K, N):
         lib.neosr_set_winograd(prev)
 
 
+def test_conv3x3_winograd4_nearest_upsampled_input():
+    """nearest x2 upsampling folded into the F(4x4,3x3) kernel's DMA addresses (esrgan_arch.py:207-212 conv_up1 / conv_up2)"""
+    from neosr_amd.hip import ops
+
+    g = torch.Generator().manual_seed(31)
+    B, H, W, K, N = 2, 12, 20, 64, 64
+    x = torch.randn(B, K, H, W, generator=g)
+    w = torch.randn(N, K, 3, 3, generator=g) * 0.1
+    b = torch.randn(N, generator=g)
+    ref = F.leaky_relu(F.conv2d(F.interpolate(x.double(), scale_factor=2, mode="nearest"), w.double(), b.double(), padding=1), 0.2)
+    wd = w.to(DEV)
+    lib = _C_lib()
+    prev = lib.neosr_set_winograd(2)
+    try:
+        out = ops.conv3x3(_nhwc(x), wd, b.to(DEV), ups=True, act=ops.ACT_LRELU, slope=0.2,
+                          w_pack=ops.conv3x3_pack_weights(wd, ops.CONV_FWD), w_wino4=ops.conv3x3_pack_wino4(wd, ops.CONV_FWD))
+        direct = ops.conv3x3(_nhwc(x), wd, b.to(DEV), ups=True, act=ops.ACT_LRELU, slope=0.2)
+    finally:
+        lib.neosr_set_winograd(prev)
+    torch.cuda.synchronize()
+    assert out.shape == (B, 2 * H, 2 * W, N) and not torch.equal(out, direct)
+    assert rel_err(_nchw(out), ref) < 1e-4
+
+
 def test_conv3x3_winograd4_slices_residuals_accumulate_and_modes():
     """prefix-K read of a wide buffer, slice write, two residuals, accumulate through the F(4x4,3x3) kernel;
     neosr_set_winograd(0 / 1 / 2) routes the same descriptor to the direct / F(2x2) / F(4x4) kernel"""
