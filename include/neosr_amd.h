@@ -130,6 +130,9 @@ int neosr_get_winograd(void);   /* the current mode (0 / 1 / 2), see below */
  * network's output bits can depend on the batch size the way a vendor library's algorithm choice does.
  * neosr_set_wino4_n64: -1 = by the estimate (default), 0 = always 32, 1 = 64 whenever N > 32; returns the previous mode. */
 int neosr_set_wino4_n64(int mode);
+/* Weight gradient of the 32-channel-tile path: 1 (default; env NEOSR_AMD_WGRAD4) = the F(4x4-tile) Winograd form when
+ * neosr_get_winograd() == 2, 0 = the F(2x2) form.  Returns the previous setting. */
+int neosr_set_wgrad4(int on);
 int64_t neosr_conv3x3_pack_wino4_bytes(int32_t N, int32_t K);
 int neosr_conv3x3_pack_wino4(const float* w, int32_t w_cout, int32_t w_cin, int32_t mode, float* dst, void* stream);
 /* Both images of MANY weight tensors in ceil(n / 24) launches per image kind (the per-layer calls above cost one launch

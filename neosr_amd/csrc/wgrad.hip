@@ -17,11 +17,12 @@
 // neosr/archs/esrgan_arch.py:109-116,196-214 and neosr/archs/compact_arch.py:76-79.
 #include "common.h"
 #include "prof.h"
+#include <stdlib.h>
 #include <string.h>
 #include <type_traits>
 #include "../../include/neosr_amd.h"
 
-namespace neosr_conv { bool xcd_enabled(); bool wino_enabled(); }
+namespace neosr_conv { bool xcd_enabled(); bool wino_enabled(); int wino_mode(); }
 
 namespace {
 
@@ -54,6 +55,7 @@ struct WgradMultiArgs {
   int xcd, xcd_full, xcd_q;
   // Winograd path (conv3x3_wgrad_wino_kernel): units of 2 rows x 32 columns, its own split of them
   int w_units_x, w_units_y, w_nunits, w_units_per_split, w_nsplit;
+  unsigned long long* timeline;  // debug only (NEOSR_TIMELINE builds)
 };
 
 __device__ __forceinline__ float4 ld4(const float* p, bool vec, int c, int C) {
@@ -569,6 +571,347 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_wino_reduce_kernel(const Wg
 }
 
 // ---------------------------------------------------------------------------------------------
+// Winograd F(3x3 taps <- 4x4 gradient tile (*) 6x6 input patch) form of the weight gradient (round 3):
+//   dW(3x3) = C [ sum over tiles and batch of (G'' dy G''^T) (.) (B^T d B) ] C^T
+//   B^T: the 6x6 matrix of conv_wino4.hip (points 0, +-1, +-2, inf); G'' = rows (1,0,0,0), (1,1,1,1), (1,-1,1,-1),
+//   (1,2,4,8), (1,-2,4,-8), (0,0,0,1) — the F(3,4) filter transform with its row scales s = (1/4, -1/6, -1/6, 1/24, 1/24, 1)
+//   taken out; C = A'^T diag(s), A'^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 1]  (checked against the direct sum in
+//   float64: experiments/wgrad43_check.py).  36 multiplications per (4x4 tile, cout, cin) instead of 64 with the
+//   F(2x2) form above and 144 direct.
+// Same (pair, split) decomposition, XCD pinning and bias partials as the kernels above; MFMA reduction index = tile.
+//   * the 36 positions are dealt 9 per wave: wave 0 = row 0 + (1, 0..2), wave 1 = row 2 + (1, 3..5), wave 2 = row 3 +
+//     (4, 0..2), wave 3 = row 5 + (4, 3..5) — every wave runs the column pass for TWO rows of both transforms (waves 1, 2:
+//     the row pairs {1,2} / {3,4} share their even / odd parts, 4 FMAs per element and row pair) and the row pass for one
+//     full row and one half row; 9 accumulators of 16 registers;
+//   * unit = 4 rows x 16 columns of gradient pixels = 4 tiles; lanes lh = 0 / 1 walk the left / right two tiles, so the
+//     row-combined columns 4, 5 of a lane's first patch are columns 0, 1 of its second; lane = channel, and both raw
+//     tiles are stored [row][column-in-half][half][32 channels] so a ds_read_b32 of the wave touches 64 consecutive
+//     floats (6 x 10 x 2 input pixels x 32 cin — columns 8, 9 twice —, 4 x 8 x 2 gradient pixels x 32 cout; buffer-load
+//     DMA, two 24 KB buffers, one barrier per unit);
+//   * the inverse transform runs IN the kernel: each wave contracts its positions with C along j, the 8 row parts cross
+//     LDS once per output column b, and the workgroup writes a plain 9-tap partial — 36 KB instead of the 64 KB of
+//     16-position partials, summed over the splits by conv3x3_wgrad_reduce_kernel (fixed order: deterministic).
+constexpr int W4_XF = 4 * 256 * 4;                    // input region: 4 workgroup-wide DMA rounds (16 KB), 960 granules used
+constexpr int W4_XSLOTS = 6 * 10 * 2;                 // pixel slots of the input tile
+constexpr int W4_GF = 4 * 16 * 32;                    // gradient tile floats (8 KB) = 2 DMA rounds
+constexpr int W4_BUF = W4_XF + W4_GF;                 // 6144 floats = 24 KB; two buffers, two workgroups per CU
+constexpr int W4_SLOTS = 512;
+static_assert(W4_BUF >= 4096, "a buffer holds four 32 x 32 row parts of the exchange");
+
+#ifdef NEOSR_TIMELINE  // debug builds: clock64 marks of workgroup (0, 0), see tools/timeline.py
+#define W4_TL(slot)                                                                                  \
+  do {                                                                                               \
+    if (args.timeline && blockIdx.x == 0 && blockIdx.y == 0 && (threadIdx.x & 63) == 0)              \
+      args.timeline[(threadIdx.x >> 6) * 64 + (slot)] = clock64();                                   \
+  } while (0)
+#define W4_TLU(j) do { const int it_ = (u - u_lo) >> 1; if (it_ < 10) W4_TL(2 + 6 * it_ + (j)); } while (0)
+#else
+#define W4_TL(slot) do {} while (0)
+#define W4_TLU(j) do {} while (0)
+#endif
+
+typedef float w4_f32x2 __attribute__((ext_vector_type(2)));
+
+template <bool EDGE, bool HI>
+__device__ __forceinline__ void wgrad_w4_body(const WgradMultiArgs& args, const neosr_wgrad_desc& d, int di, int pair, int s,
+                                              int ntile, int kt, float* ldsA, float* ldsB, float* bred) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int co0 = ntile * 32, ci0 = kt * 32;
+  const float* __restrict__ d_in = d.in;
+  const float* __restrict__ d_g = d.g;
+  const int d_in_cs = d.in_cs, d_g_cs = d.g_cs, d_K = d.K, d_N = d.N;
+  const int ups = args.ups, units_x = args.w_units_x, units_y = args.w_units_y;
+  const int H = args.H, W = args.W;
+  const int Hin = ups ? (H >> 1) : H, Win = ups ? (W >> 1) : W;
+  const int u_lo = s * args.w_units_per_split;
+  const int u_hi = min(args.w_nunits, u_lo + args.w_units_per_split);
+
+  // DMA granules.  Input rounds i = 0..3: granule G = i*256 + tid -> slot G >> 3 = 2 * (row * 10 + cc) + h (< 120, the
+  // rest unused: zeros), image column cc + 8 h, channel quad G & 7; gradient rounds i = 0, 1: slot = 2 * (row * 8 + cc) + h.
+  const int q4 = (tid & 7) << 2;
+  const bool ci_ok = ci0 + q4 < d_K, co_ok = co0 + q4 < d_N;
+  int xr[4], xc[4], xrel[4], gy[2], gx[2], grel[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int slot = (i * 256 + tid) >> 3;
+    const int h = slot & 1, rc = slot >> 1;
+    const int r = rc / 10, c = rc - r * 10 + 8 * h;
+    xr[i] = (slot < W4_XSLOTS && ci_ok) ? r - 1 : -100000;
+    xc[i] = c - 1;
+    const int ry = ups ? ((r - 1) >> 1) : r - 1, rxx = ups ? ((c - 1) >> 1) : c - 1;
+    xrel[i] = (ry * Win + rxx) * d_in_cs + ci0 + q4;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int slot = (i * 256 + tid) >> 3;
+    const int h = slot & 1, rc = slot >> 1;
+    gy[i] = co_ok ? (rc >> 3) : 100000;
+    gx[i] = (rc & 7) + 8 * h;
+    grel[i] = ((rc >> 3) * W + gx[i]) * d_g_cs + co0 + q4;
+  }
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d_in), 0, args.B * Hin * Win * d_in_cs * 4, 0x00020000);
+  const auto rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d_g), 0, args.B * H * W * d_g_cs * 4, 0x00020000);
+  auto issue = [&](int u, int u_end, float* xb) {
+    const int xx = u % units_x;
+    const int r = u / units_x;
+    const int yy = r % units_y;
+    const int b = r / units_y;
+    const int x0 = xx * 16, y0 = u < u_end ? yy * 4 : 0x100000;  // past the end: every row out of range
+    float* gb = xb + W4_XF;
+    const int xbase = (((b * Hin + (ups ? (y0 >> 1) : y0)) * Win + (ups ? (x0 >> 1) : x0)) * d_in_cs) * 4;
+    const int gbase = (((b * H + y0) * W + x0) * d_g_cs) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool ok = ((unsigned)(y0 + xr[i]) < (unsigned)H) & ((unsigned)(x0 + xc[i]) < (unsigned)W);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(xb + (i * 4 + wv) * 256), 16,
+                                               ok ? xbase + xrel[i] * 4 : 0x7ffffff0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const bool ok = (y0 + gy[i] < H) & (x0 + gx[i] < W);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (__attribute__((address_space(3))) void*)(gb + (i * 4 + wv) * 256), 16,
+                                               ok ? gbase + grel[i] * 4 : 0x7ffffff0, 0, 0, 0);
+    }
+  };
+
+  // per-wave constants:
+  //   inner waves (1: rows F = 2, H = 1; 2: F = 3, H = 4):  x: p = d4 + al d2, q = d3 + al d1, tF = p + gF q, tH = p + gH q
+  //                                                          g: e = g0 + be g2, o = g1 + be g3, rF = e + dF o, rH = e + dH o
+  //   edge waves (0: F = 0, H = 1; 3: F = 5, H = 4):          x: tF = 4 d[xa] - 5 d[xa + 2] + d[xa + 4]; tH as above
+  //                                                          g: rF = g0 | g3; rH as above
+  constexpr bool LOW = EDGE != HI;               // waves 0, 1
+  constexpr float al = LOW ? -4.f : -1.f;
+  constexpr float gH = LOW ? 1.f : -2.f;
+  constexpr float gF = LOW ? -1.f : 2.f;         // (inner only)
+  constexpr float be = LOW ? 1.f : 4.f;
+  constexpr float dH = LOW ? 1.f : -2.f;
+  constexpr float dF = LOW ? -1.f : 2.f;         // (inner only)
+  constexpr int xa = HI ? 1 : 0;                 // (edge only) first row of the three-term row
+  constexpr bool glast = HI;                     // (edge only) gradient row copied: 0 | 3
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int j = 0; j < 9; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  const bool want_b = d.db && kt == 0 && wave == 0;
+  float bsum = 0.f;
+
+  // The transforms run on column PAIRS in packed fp32 (v_pk_fma_f32): a ds_read2st64_b32 returns the columns (c, c + 1)
+  // of one row in a register pair.  Column pass of one input column pair (rows F and H of B^T d):
+  auto ld2 = [](const float* p) { return w4_f32x2{p[0], p[64]}; };
+  auto xcol2 = [&](const float* xp, w4_f32x2& f, w4_f32x2& h) {
+    const w4_f32x2 d1 = ld2(xp + 640), d2 = ld2(xp + 2 * 640), d3 = ld2(xp + 3 * 640), d4 = ld2(xp + 4 * 640);
+    const w4_f32x2 p = __builtin_elementwise_fma(w4_f32x2{al, al}, d2, d4), q = __builtin_elementwise_fma(w4_f32x2{al, al}, d1, d3);
+    h = __builtin_elementwise_fma(w4_f32x2{gH, gH}, q, p);
+    if (EDGE) {
+      const w4_f32x2 dA = ld2(xp + xa * 640), dB = ld2(xp + (xa + 2) * 640), dC = ld2(xp + (xa + 4) * 640);
+      f = __builtin_elementwise_fma(w4_f32x2{4.f, 4.f}, dA, __builtin_elementwise_fma(w4_f32x2{-5.f, -5.f}, dB, dC));
+    } else {
+      f = __builtin_elementwise_fma(w4_f32x2{gF, gF}, q, p);
+    }
+  };
+  auto compute = [&](const float* buf) {
+    const float* xb = buf + lane;            // + (row * 10 + cc) * 64
+    const float* gb = buf + W4_XF + lane;    // + (row * 8 + cc) * 64
+    w4_f32x2 fR, fQ, fP, hR, hQ, hP;            // row-combined columns (0,1), (2,3), (4,5) of rows F / H
+    xcol2(xb, fP, hP);                       // columns 0, 1 of the first patch enter as the "carried" pair
+#pragma unroll 1
+    for (int st = 0; st < 2; ++st) {
+      const float* xs = xb + st * 256;
+      const float* gs = gb + st * 256;
+      // ---- input: column pass for the new patch columns (the walk keeps columns 4, 5 as the next tile's 0, 1)
+      fR = fP; hR = hP;
+      xcol2(xs + 2 * 64, fQ, hQ);
+      xcol2(xs + 4 * 64, fP, hP);
+      // ---- input: row passes.  v0 = 4 t0 - 5 t2 + t4, v5 = 4 t1 - 5 t3 + t5;  a = t4 - 4 t2, b = t3 - 4 t1: v1, v2 = a +- b;
+      //      c = t4 - t2, d = t3 - t1: v3, v4 = c +- 2 d
+      float vF[6], vH[3];
+      {
+        const w4_f32x2 v05 = __builtin_elementwise_fma(w4_f32x2{4.f, 4.f}, fR, __builtin_elementwise_fma(w4_f32x2{-5.f, -5.f}, fQ, fP));
+        const w4_f32x2 ac = __builtin_elementwise_fma(w4_f32x2{-4.f, -1.f}, fQ.xx, fP.xx);
+        const w4_f32x2 bd = __builtin_elementwise_fma(w4_f32x2{-4.f, -1.f}, fR.yy, fQ.yy);
+        const w4_f32x2 v13 = __builtin_elementwise_fma(w4_f32x2{1.f, 2.f}, bd, ac);
+        const w4_f32x2 v24 = __builtin_elementwise_fma(w4_f32x2{-1.f, -2.f}, bd, ac);
+        vF[0] = v05.x; vF[5] = v05.y; vF[1] = v13.x; vF[3] = v13.y; vF[2] = v24.x; vF[4] = v24.y;
+      }
+      if (!HI) {
+        const float a = fmaf(-4.f, hQ.x, hP.x), bq = fmaf(-4.f, hR.y, hQ.y);
+        const w4_f32x2 v12 = __builtin_elementwise_fma(w4_f32x2{1.f, -1.f}, w4_f32x2{bq, bq}, w4_f32x2{a, a});
+        vH[0] = fmaf(4.f, hR.x, fmaf(-5.f, hQ.x, hP.x));
+        vH[1] = v12.x; vH[2] = v12.y;
+      } else {
+        const float cc = hP.x - hQ.x, dd = hQ.y - hR.y;
+        const w4_f32x2 v34 = __builtin_elementwise_fma(w4_f32x2{2.f, -2.f}, w4_f32x2{dd, dd}, w4_f32x2{cc, cc});
+        vH[0] = v34.x; vH[1] = v34.y;
+        vH[2] = fmaf(4.f, hR.y, fmaf(-5.f, hQ.y, hP.y));
+      }
+      // ---- gradient: column pass (rows F, H of G'' dy) for the tile's two column pairs, then the row passes
+      w4_f32x2 rFa, rFb, rHa, rHb;
+#pragma unroll
+      for (int cp = 0; cp < 2; ++cp) {
+        const float* gp = gs + cp * 128;
+        const w4_f32x2 g0 = ld2(gp), g1 = ld2(gp + 512), g2 = ld2(gp + 2 * 512), g3 = ld2(gp + 3 * 512);
+        const w4_f32x2 e = __builtin_elementwise_fma(w4_f32x2{be, be}, g2, g0), o = __builtin_elementwise_fma(w4_f32x2{be, be}, g3, g1);
+        const w4_f32x2 rh = __builtin_elementwise_fma(w4_f32x2{dH, dH}, o, e);
+        const w4_f32x2 rf = EDGE ? (glast ? g3 : g0) : __builtin_elementwise_fma(w4_f32x2{dF, dF}, o, e);
+        if (cp == 0) { rFa = rf; rHa = rh; } else { rFb = rf; rHb = rh; }
+        if (EDGE && !HI) {
+          if (want_b) { const w4_f32x2 t = (g0 + g1) + (g2 + g3); bsum += t.x + t.y; }
+        }
+      }
+      float uF[6], uH[3];
+      {
+        const w4_f32x2 eo1 = rFa + rFb, eo2 = __builtin_elementwise_fma(w4_f32x2{4.f, 4.f}, rFb, rFa);
+        const w4_f32x2 u12 = __builtin_elementwise_fma(w4_f32x2{1.f, -1.f}, eo1.yy, eo1.xx);
+        const w4_f32x2 u34 = __builtin_elementwise_fma(w4_f32x2{2.f, -2.f}, eo2.yy, eo2.xx);
+        uF[0] = rFa.x; uF[1] = u12.x; uF[2] = u12.y; uF[3] = u34.x; uF[4] = u34.y; uF[5] = rFb.y;
+      }
+      if (!HI) {
+        const w4_f32x2 eo1 = rHa + rHb;
+        const w4_f32x2 u12 = __builtin_elementwise_fma(w4_f32x2{1.f, -1.f}, eo1.yy, eo1.xx);
+        uH[0] = rHa.x; uH[1] = u12.x; uH[2] = u12.y;
+      } else {
+        const w4_f32x2 eo2 = __builtin_elementwise_fma(w4_f32x2{4.f, 4.f}, rHb, rHa);
+        const w4_f32x2 u34 = __builtin_elementwise_fma(w4_f32x2{2.f, -2.f}, eo2.yy, eo2.xx);
+        uH[0] = u34.x; uH[1] = u34.y; uH[2] = rHb.y;
+      }
+#pragma unroll
+      for (int j = 0; j < 6; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(uF[j], vF[j], acc[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) acc[6 + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(uH[j], vH[j], acc[6 + j], 0, 0, 0);
+    }
+  };
+
+  // units run in pairs (buffer A, buffer B); a unit index past the split's end loads zeros (no contribution), which keeps
+  // the loop a single straight-line body — the accumulators stay in place
+  W4_TL(0);
+  if (u_lo < u_hi) {
+    issue(u_lo, u_hi, ldsA);
+    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
+    __syncthreads();
+    W4_TL(1);
+    for (int u = u_lo; u < u_hi; u += 2) {
+      issue(u + 1, u_hi, ldsB);
+      W4_TLU(0);
+      compute(ldsA);
+      W4_TLU(1);
+      __builtin_amdgcn_s_waitcnt(0x0f70);
+      __syncthreads();
+      W4_TLU(2);
+      issue(u + 2, u_hi, ldsA);
+      W4_TLU(3);
+      compute(ldsB);
+      W4_TLU(4);
+      __builtin_amdgcn_s_waitcnt(0x0f70);
+      __syncthreads();
+      W4_TLU(5);
+    }
+  }
+  W4_TL(62);
+
+  // ---- inverse transform.  C[b][j] = A'^T[b][j] s_j:  b = 0: (1/4, -1/6, -1/6, 1/24, 1/24, 0)
+  //                                                      b = 1: (0, -1/6, 1/6, 1/12, -1/12, 0)   b = 2: (0, -1/6, -1/6, 1/6, 1/6, 1)
+  // row parts in LDS: part 2 w = full row of wave w, 2 w + 1 = its half row (rows 1 and 4 arrive in two halves)
+  constexpr float S6 = 1.f / 6.f, S12 = 1.f / 12.f, S24 = 1.f / 24.f;
+  float* outp = args.part + ((int64_t)pair * args.nsplit + s) * WG_TILE;
+  float* pF = (wave < 2 ? ldsA : ldsB) + ((2 * wave) & 3) * 1024 + l31;
+  float* pH = (wave < 2 ? ldsA : ldsB) + ((2 * wave + 1) & 3) * 1024 + l31;
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    const float c0 = b == 0 ? 0.25f : 0.f;
+    const float c1 = -S6, c2 = b == 1 ? S6 : -S6;
+    const float c3 = b == 0 ? S24 : (b == 1 ? S12 : S6), c4 = b == 0 ? S24 : (b == 1 ? -S12 : S6);
+    const float c5 = b == 2 ? 1.f : 0.f;
+    if (b) __syncthreads();  // the combine of column b - 1 is done reading
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      float xf = c1 * acc[1][r] + c2 * acc[2][r] + c3 * acc[3][r] + c4 * acc[4][r];
+      if (b == 0) xf += c0 * acc[0][r];
+      if (b == 2) xf += c5 * acc[5][r];
+      float xh;
+      if (!HI) {
+        xh = c1 * acc[7][r] + c2 * acc[8][r];
+        if (b == 0) xh += c0 * acc[6][r];
+      } else {
+        xh = c3 * acc[6][r] + c4 * acc[7][r];
+        if (b == 2) xh += c5 * acc[8][r];
+      }
+      pF[i * 32] = xf;
+      pH[i * 32] = xh;
+    }
+    __syncthreads();
+    {
+      // rows: X0 = part 0, X1 = parts 1 + 3, X2 = part 2 (ldsA);  X3 = part 4, X4 = parts 5 + 7, X5 = part 6 (ldsB)
+      const int e = tid * 4;
+      const f32x4 x0 = *reinterpret_cast<const f32x4*>(ldsA + e);
+      const f32x4 x1 = *reinterpret_cast<const f32x4*>(ldsA + 1024 + e) + *reinterpret_cast<const f32x4*>(ldsA + 3072 + e);
+      const f32x4 x2 = *reinterpret_cast<const f32x4*>(ldsA + 2048 + e);
+      const f32x4 x3 = *reinterpret_cast<const f32x4*>(ldsB + e);
+      const f32x4 x4 = *reinterpret_cast<const f32x4*>(ldsB + 1024 + e) + *reinterpret_cast<const f32x4*>(ldsB + 3072 + e);
+      const f32x4 x5 = *reinterpret_cast<const f32x4*>(ldsB + 2048 + e);
+      const f32x4 s12 = x1 + x2, d12 = x2 - x1, s34 = x3 + x4, d34 = x3 - x4;
+      const f32x4 w0 = 0.25f * x0 - S6 * s12 + S24 * s34;
+      const f32x4 w1v = S6 * d12 + S12 * d34;
+      const f32x4 w2 = S6 * (s34 - s12) + x5;
+      *reinterpret_cast<f32x4*>(outp + (0 * 3 + b) * 1024 + e) = w0;
+      *reinterpret_cast<f32x4*>(outp + (1 * 3 + b) * 1024 + e) = w1v;
+      *reinterpret_cast<f32x4*>(outp + (2 * 3 + b) * 1024 + e) = w2;
+    }
+  }
+
+  if (d.db && kt == 0) {
+    if (wave == 0) {
+      bsum += __shfl_xor(bsum, 32, 64);
+      if (lh == 0) bred[l31] = bsum;
+    }
+    __syncthreads();
+    if (tid < 32) args.bpart[((int64_t)(args.btile_start[di] + ntile) * args.nsplit + s) * 32 + tid] = bred[tid];
+  }
+  W4_TL(63);
+}
+
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_wino4_kernel(const WgradMultiArgs args) {
+  __shared__ __attribute__((aligned(1024))) float ldsA[W4_BUF];
+  __shared__ __attribute__((aligned(1024))) float ldsB[W4_BUF];
+  __shared__ float bred[32];
+  int pair = blockIdx.x, s = blockIdx.y;
+  if (args.xcd) {  // XCD-pinned order, see conv3x3_wgrad_multi_kernel
+    const int P = args.pair_start[MAXD];
+    const int x = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int pinned = args.xcd_full * P;
+    if (q < pinned) {
+      s = x * args.xcd_full + q / P;
+      pair = q % P;
+    } else {
+      const int r = x * (args.xcd_q - pinned) + (q - pinned);
+      s = 8 * args.xcd_full + r / P;
+      pair = r % P;
+      if (s >= args.nsplit) return;
+    }
+  }
+  int di = 0;
+#pragma unroll
+  for (int i = 1; i < MAXD; ++i)
+    if (i < args.ndesc && pair >= args.pair_start[i]) di = i;
+  const neosr_wgrad_desc& d = args.d[di];
+  const int local = pair - args.pair_start[di];
+  const int nkt = args.nkt[di];
+  const int ntile = local / nkt, kt = local - ntile * nkt;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // wave 0: edge rows (0, 1 lo), 1: inner (2, 1 hi), 2: inner (3, 4 lo), 3: edge (5, 4 hi)
+  if (wave == 0) wgrad_w4_body<true, false>(args, d, di, pair, s, ntile, kt, ldsA, ldsB, bred);
+  else if (wave == 1) wgrad_w4_body<false, true>(args, d, di, pair, s, ntile, kt, ldsA, ldsB, bred);
+  else if (wave == 2) wgrad_w4_body<false, false>(args, d, di, pair, s, ntile, kt, ldsA, ldsB, bred);
+  else wgrad_w4_body<true, true>(args, d, di, pair, s, ntile, kt, ldsA, ldsB, bred);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Thin layers (3 or 1 channels on one side: conv_first / conv_last, U-Net conv0 / conv9): the 32 x 32
 // tile above would compute 10x zeros.  Here v_mfma_f32_4x4x1_16b_f32 takes ONE pixel per instruction:
 // the 4 rows of every 4x4 block are the thin side's channels t, the 64 columns (16 blocks x 4) are 64
@@ -870,8 +1213,36 @@ int64_t thin_ws_floats(const neosr_wgrad_desc& d) {
   return (int64_t)groups * THIN_WGS * THIN_PART + (int64_t)THIN_WGS * 64 * groups + 64;
 }
 
+// unit / split geometry of conv3x3_wgrad_wino4_kernel (units of 4 rows x 16 columns); overwrites nsplit
+void w4_geometry(WgradMultiArgs& w) {
+  const int P = w.pair_start[MAXD];
+  w.w_units_x = ceil_div(w.W, 16);
+  w.w_units_y = ceil_div(w.H, 4);
+  w.w_nunits = w.w_units_x * w.w_units_y * w.B;
+  int wsplit = W4_SLOTS / P;
+  if (wsplit < 1) wsplit = 1;
+  if (wsplit > w.w_nunits) wsplit = w.w_nunits;
+  w.w_units_per_split = ceil_div(w.w_nunits, wsplit);
+  w.nsplit = ceil_div(w.w_nunits, w.w_units_per_split);
+}
+
+int g_wgrad4 = -1;  // F(4x4-tile) weight gradient: -1 = read NEOSR_AMD_WGRAD4 (default on)
+bool wgrad4_enabled() {
+  if (g_wgrad4 < 0) {
+    const char* e = getenv("NEOSR_AMD_WGRAD4");
+    g_wgrad4 = (e && e[0] == '0') ? 0 : 1;
+  }
+  return g_wgrad4 == 1;
+}
+
 int64_t ws_floats(const WgradMultiArgs& a) {
   int64_t w = (int64_t)a.pair_start[MAXD] * a.nsplit * WG_TILE + (int64_t)a.btile_start[MAXD] * a.nsplit * 32 + 64;
+  {
+    WgradMultiArgs w4 = a;
+    w4_geometry(w4);
+    const int64_t t = (int64_t)a.pair_start[MAXD] * w4.nsplit * WG_TILE + (int64_t)a.btile_start[MAXD] * w4.nsplit * 32 + 64;
+    if (t > w) w = t;
+  }
   const int64_t ww = (int64_t)a.pair_start[MAXD] * a.w_nsplit * WW_PART + (int64_t)a.btile_start[MAXD] * a.w_nsplit * 32 + 64;
   if (ww > w) w = ww;  // the Winograd path keeps 16 positions per partial
   if (thin_ok(a.d, a.ndesc)) {
@@ -882,6 +1253,18 @@ int64_t ws_floats(const WgradMultiArgs& a) {
 }
 
 }  // namespace
+
+unsigned long long* g_wgrad_timeline = nullptr;
+extern "C" int neosr_debug_set_wgrad_timeline(void* dev_buf) {
+  g_wgrad_timeline = (unsigned long long*)dev_buf;
+  return 0;
+}
+
+extern "C" int neosr_set_wgrad4(int on) {
+  const int prev = wgrad4_enabled() ? 1 : 0;
+  g_wgrad4 = on ? 1 : 0;
+  return prev;
+}
 
 extern "C" int64_t neosr_conv3x3_wgrad_multi_workspace_bytes(const neosr_wgrad_desc* ds, int32_t n) {
   WgradMultiArgs a;
@@ -945,6 +1328,26 @@ extern "C" int neosr_conv3x3_wgrad_multi(const neosr_wgrad_desc* ds, int32_t n, 
   for (int i = 0; i < n; ++i) {
     const int64_t pin = (int64_t)ds[i].B * (ds[i].ups ? (ds[i].H >> 1) * (ds[i].W >> 1) : ds[i].H * ds[i].W);
     small = small && pin * ds[i].in_cs * 4 < (int64_t(1) << 31) && (int64_t)ds[i].B * ds[i].H * ds[i].W * ds[i].g_cs * 4 < (int64_t(1) << 31);
+  }
+  if (fast && plain && !s2d && small && neosr_conv::wino_mode() == 2 && wgrad4_enabled()) {  // conv3x3_wgrad_wino4_kernel
+    WgradMultiArgs w = a;
+    const int P = a.pair_start[MAXD];
+    if (prof) neosr_prof_algo(2);
+    w4_geometry(w);
+    w.timeline = g_wgrad_timeline;
+    w.bpart = workspace + (int64_t)P * w.nsplit * WG_TILE;
+    w.xcd_full = P <= W4_SLOTS / 8 ? (W4_SLOTS / 8) / P : 0;
+    if (w.xcd_full > w.nsplit / 8) w.xcd_full = w.nsplit / 8;
+    w.xcd_q = w.xcd_full * P + ceil_div((w.nsplit - 8 * w.xcd_full) * P, 8);
+    const dim3 wgrid = w.xcd ? dim3(8 * w.xcd_q) : dim3(P, w.nsplit);
+    hipLaunchKernelGGL(conv3x3_wgrad_wino4_kernel, wgrid, dim3(256), 0, st, w);
+    if (prof) neosr_prof_end(stream);
+    NEOSR_LAUNCH_CHECK();
+    if (prof) neosr_prof_begin(NEOSR_PROF_WGRAD_REDUCE, stream, 0.0, 0.0);
+    hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3(WG_TILE / 64, P), dim3(256), 0, st, w);
+    if (prof) neosr_prof_end(stream);
+    NEOSR_LAUNCH_CHECK();
+    return 0;
   }
   if (fast && plain && !s2d && small && neosr_conv::wino_enabled()) {  // Winograd form (see conv3x3_wgrad_wino_kernel)
     WgradMultiArgs w = a;

@@ -392,6 +392,73 @@ def test_wgrad_thin_layers_vs_autograd(B, H, W, K, N):
     assert torch.equal(dw, dw2) and torch.equal(db, db2)  # fixed-order reductions
 
 
+WGRAD4_CASES = [
+    # B, H, W, K, N, ups
+    (2, 12, 20, 16, 8, 0), (1, 9, 37, 20, 44, 0), (1, 64, 64, 64, 32, 0), (2, 33, 47, 96, 64, 0), (1, 5, 3, 32, 32, 0),
+    (3, 16, 16, 160, 32, 0), (2, 6, 10, 8, 12, 1), (1, 32, 48, 64, 64, 1), (1, 4, 16, 32, 32, 0), (1, 7, 100, 36, 68, 0),
+]
+
+
+@pytest.mark.parametrize("B,H,W,K,N,ups", WGRAD4_CASES)
+def test_wgrad_winograd4_vs_autograd_float64(B, H, W, K, N, ups):
+    """F(4x4-tile) weight-gradient kernel (neosr_set_winograd(2) + neosr_set_wgrad4(1)) against autograd in float64:
+    ragged units, K / N that are no multiple of 32, nearest-upsampled input; its error is ~8e-7 of the gradient's norm
+    (the F(2x2) form: ~2e-7); run-to-run bit-identical; neosr_set_wgrad4(0) routes the same call to the F(2x2) kernel"""
+    from neosr_amd import _C
+    from neosr_amd.hip import ops
+
+    lib = _C.load()
+    g = torch.Generator().manual_seed(B * 7 + N)
+    x = torch.randn(B, K, H // 2 if ups else H, W // 2 if ups else W, generator=g, dtype=torch.float64)
+    w = (torch.randn(N, K, 3, 3, generator=g, dtype=torch.float64) * 0.1).requires_grad_(True)
+    b = torch.randn(N, generator=g, dtype=torch.float64).requires_grad_(True)
+    xin = F.interpolate(x, scale_factor=2, mode="nearest") if ups else x
+    y = F.conv2d(xin, w, b, padding=1)
+    gy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(gy)
+    xs, gs = _nhwc(x.float()), _nhwc(gy.float())
+    prev_mode = lib.neosr_set_winograd(2)
+    prev = lib.neosr_set_wgrad4(1)
+    try:
+        dw, db = ops.conv3x3_wgrad(xs, gs, N, K, ups=bool(ups))
+        dw2, db2 = ops.conv3x3_wgrad(xs, gs, N, K, ups=bool(ups))
+        assert lib.neosr_set_wgrad4(0) == 1
+        dw_f2, db_f2 = ops.conv3x3_wgrad(xs, gs, N, K, ups=bool(ups))
+        torch.cuda.synchronize()
+    finally:
+        lib.neosr_set_wgrad4(prev)
+        lib.neosr_set_winograd(prev_mode)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)
+    assert rel_err(dw.cpu().double(), w.grad) < 2e-6
+    assert rel_err(db.cpu().double(), b.grad) < 1e-6
+    assert rel_err(dw_f2.cpu().double(), w.grad) < 1e-6
+    assert not torch.equal(dw, dw_f2)  # a different kernel ran
+
+
+def test_wgrad_winograd4_prefix_read_slice_accumulate_scale():
+    """prefix-K read of a wider activation buffer, gradient = channel slice of a wider buffer, accumulate, scale"""
+    from neosr_amd import _C
+    from neosr_amd.hip import ops
+
+    lib = _C.load()
+    g = torch.Generator().manual_seed(5)
+    xw = torch.randn(2, 24, 40, 96, generator=g).to(DEV)
+    gy = torch.randn(2, 24, 40, 64, generator=g).to(DEV)[..., :32]
+    wref = torch.zeros(32, 64, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xw[..., :64].permute(0, 3, 1, 2).double().cpu(), wref, None, padding=1).backward(
+        gy.permute(0, 3, 1, 2).double().cpu())
+    prev_mode = lib.neosr_set_winograd(2)
+    prev = lib.neosr_set_wgrad4(1)
+    try:
+        dw0 = torch.ones(32, 64, 3, 3, device=DEV)
+        dw, _ = ops.conv3x3_wgrad(xw, gy, 32, 64, dw=dw0, want_bias=False, accumulate=True, scale=0.5)
+        torch.cuda.synchronize()
+    finally:
+        lib.neosr_set_wgrad4(prev)
+        lib.neosr_set_winograd(prev_mode)
+    assert rel_err(dw.cpu().double() - 1.0, 0.5 * wref.grad) < 2e-6
+
+
 def test_wgrad_upsampled_input():
     from neosr_amd.hip import ops
 
