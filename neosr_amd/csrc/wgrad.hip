@@ -594,7 +594,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_wino_reduce_kernel(const Wg
 constexpr int W4_XF = 4 * 256 * 4;                    // input region: 4 workgroup-wide DMA rounds (16 KB), 960 granules used
 constexpr int W4_XSLOTS = 6 * 10 * 2;                 // pixel slots of the input tile
 constexpr int W4_GF = 4 * 16 * 32;                    // gradient tile floats (8 KB) = 2 DMA rounds
-constexpr int W4_BUF = W4_XF + W4_GF;                 // 6144 floats = 24 KB; two buffers, two workgroups per CU
+constexpr int W4_BUF = W4_XF + W4_GF;                 // 6144 floats = 24 KB; three buffers, two workgroups per CU (144 KB)
 constexpr int W4_SLOTS = 512;
 static_assert(W4_BUF >= 4096, "a buffer holds four 32 x 32 row parts of the exchange");
 
@@ -604,17 +604,29 @@ static_assert(W4_BUF >= 4096, "a buffer holds four 32 x 32 row parts of the exch
     if (args.timeline && blockIdx.x == 0 && blockIdx.y == 0 && (threadIdx.x & 63) == 0)              \
       args.timeline[(threadIdx.x >> 6) * 64 + (slot)] = clock64();                                   \
   } while (0)
-#define W4_TLU(j) do { const int it_ = (u - u_lo) >> 1; if (it_ < 10) W4_TL(2 + 6 * it_ + (j)); } while (0)
+#define W4_TLU(j) do { const int it_ = (u - u_lo) / 3; if (it_ < 10) W4_TL(2 + 6 * it_ + (j)); } while (0)
 #else
 #define W4_TL(slot) do {} while (0)
 #define W4_TLU(j) do {} while (0)
 #endif
 
+typedef int w4_i32x4 __attribute__((ext_vector_type(4)));
+
+// One LDS-DMA round (64 lanes x 16 bytes -> 1 KB at lds_addr) as inline assembly: with three unit buffers in flight the
+// rounds of two units are outstanding at a barrier, and hipcc's wait-count pass (which cannot tell the generations of one
+// buffer apart across the loop back-edge) turns every vmcnt(6) into vmcnt(0).  Hidden from it, the waits below stand as written.
+__device__ __forceinline__ void w4_dma16(w4_i32x4 rsrc, unsigned lds_addr, int voff, int soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+               :
+               : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
+               : "memory", "m0");
+}
+
 typedef float w4_f32x2 __attribute__((ext_vector_type(2)));
 
 template <bool EDGE, bool HI>
 __device__ __forceinline__ void wgrad_w4_body(const WgradMultiArgs& args, const neosr_wgrad_desc& d, int di, int pair, int s,
-                                              int ntile, int kt, float* ldsA, float* ldsB, float* bred) {
+                                              int ntile, int kt, float* ldsA, float* ldsB, float* ldsC, float* bred) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
@@ -630,51 +642,77 @@ __device__ __forceinline__ void wgrad_w4_body(const WgradMultiArgs& args, const 
 
   // DMA granules.  Input rounds i = 0..3: granule G = i*256 + tid -> slot G >> 3 = 2 * (row * 10 + cc) + h (< 120, the
   // rest unused: zeros), image column cc + 8 h, channel quad G & 7; gradient rounds i = 0, 1: slot = 2 * (row * 8 + cc) + h.
+  // A granule's byte offset inside its unit never changes (xvo / gvo; the unit's origin goes into the scalar offset), and
+  // whether it falls outside the image depends only on which border the unit touches: bit 0 = above the first unit row,
+  // 1 = below the image in the last unit row, 2 = left of the first unit column, 3 = right of the image in the last one,
+  // 4 = every granule (units past the split's end load zeros).  Interior units issue the six loads with no vector work.
   const int q4 = (tid & 7) << 2;
   const bool ci_ok = ci0 + q4 < d_K, co_ok = co0 + q4 < d_N;
-  int xr[4], xc[4], xrel[4], gy[2], gx[2], grel[2];
+  const int ylast0 = (units_y - 1) * 4, xlast0 = (units_x - 1) * 16;
+  const int xbias = (Win + 1) * d_in_cs * 4;  // the resource starts this many bytes early: offsets of row / column -1 stay >= 0
+  constexpr int OOB = 0x7ffffff0;
+  int xvo[4], xbits[4], gvo[2], gbits[2];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int slot = (i * 256 + tid) >> 3;
     const int h = slot & 1, rc = slot >> 1;
     const int r = rc / 10, c = rc - r * 10 + 8 * h;
-    xr[i] = (slot < W4_XSLOTS && ci_ok) ? r - 1 : -100000;
-    xc[i] = c - 1;
     const int ry = ups ? ((r - 1) >> 1) : r - 1, rxx = ups ? ((c - 1) >> 1) : c - 1;
-    xrel[i] = (ry * Win + rxx) * d_in_cs + ci0 + q4;
+    xvo[i] = (slot < W4_XSLOTS && ci_ok) ? ((ry * Win + rxx) * d_in_cs + ci0 + q4) * 4 + xbias : OOB;
+    xbits[i] = 16 | (r == 0 ? 1 : 0) | (ylast0 + r - 1 >= H ? 2 : 0) | (c == 0 ? 4 : 0) | (xlast0 + c - 1 >= W ? 8 : 0);
   }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int slot = (i * 256 + tid) >> 3;
     const int h = slot & 1, rc = slot >> 1;
-    gy[i] = co_ok ? (rc >> 3) : 100000;
-    gx[i] = (rc & 7) + 8 * h;
-    grel[i] = ((rc >> 3) * W + gx[i]) * d_g_cs + co0 + q4;
+    const int gy = rc >> 3, gx = (rc & 7) + 8 * h;
+    gvo[i] = co_ok ? ((gy * W + gx) * d_g_cs + co0 + q4) * 4 : OOB;
+    gbits[i] = 16 | (ylast0 + gy >= H ? 2 : 0) | (xlast0 + gx >= W ? 8 : 0);
   }
   const int wv = __builtin_amdgcn_readfirstlane(wave);
-  const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d_in), 0, args.B * Hin * Win * d_in_cs * 4, 0x00020000);
-  const auto rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d_g), 0, args.B * H * W * d_g_cs * 4, 0x00020000);
-  auto issue = [&](int u, int u_end, float* xb) {
-    const int xx = u % units_x;
-    const int r = u / units_x;
-    const int yy = r % units_y;
-    const int b = r / units_y;
-    const int x0 = xx * 16, y0 = u < u_end ? yy * 4 : 0x100000;  // past the end: every row out of range
-    float* gb = xb + W4_XF;
-    const int xbase = (((b * Hin + (ups ? (y0 >> 1) : y0)) * Win + (ups ? (x0 >> 1) : x0)) * d_in_cs) * 4;
-    const int gbase = (((b * H + y0) * W + x0) * d_g_cs) * 4;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const bool ok = ((unsigned)(y0 + xr[i]) < (unsigned)H) & ((unsigned)(x0 + xc[i]) < (unsigned)W);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(xb + (i * 4 + wv) * 256), 16,
-                                               ok ? xbase + xrel[i] * 4 : 0x7ffffff0, 0, 0, 0);
+  // raw buffer resources (base, stride 0, num_records bytes, DATA_FORMAT = 32 bit); the input's starts xbias bytes early
+  auto make_rsrc = [](const void* p, int bytes) {
+    const unsigned long long a = (unsigned long long)p;
+    return w4_i32x4{(int)(unsigned)a, (int)((unsigned)(a >> 32) & 0xffffu), bytes, 0x00020000};
+  };
+  const w4_i32x4 rx = make_rsrc(reinterpret_cast<const char*>(d_in) - xbias, args.B * Hin * Win * d_in_cs * 4 + xbias);
+  const w4_i32x4 rg = make_rsrc(d_g, args.B * H * W * d_g_cs * 4);
+  auto lds_addr = [](const float* p) { return (unsigned)(unsigned long long)(const __attribute__((address_space(3))) float*)p; };
+  // the unit the next issue() loads: (ixx, iyy, ib) walk x-fastest from u_lo
+  int iu = u_lo, ixx, iyy, ib;
+  {
+    ixx = u_lo % units_x;
+    const int r = u_lo / units_x;
+    iyy = r % units_y;
+    ib = r / units_y;
+  }
+  int dvo[6], dxbase = 0, dgbase = 0;  // the unit being loaded: per-granule voffsets, scalar origins
+  auto issue_prep = [&]() {
+    const int x0 = ixx * 16, y0 = iyy * 4;
+    const int inval = (iyy == 0 ? 1 : 0) | (iyy == units_y - 1 ? 2 : 0) | (ixx == 0 ? 4 : 0) | (ixx == units_x - 1 ? 8 : 0) |
+                      (iu < u_hi ? 0 : 16);
+    dxbase = iu < u_hi ? (((ib * Hin + (ups ? (y0 >> 1) : y0)) * Win + (ups ? (x0 >> 1) : x0)) * d_in_cs) * 4 : 0;
+    dgbase = iu < u_hi ? (((ib * H + y0) * W + x0) * d_g_cs) * 4 : 0;
+    ++iu;
+    if (++ixx == units_x) {
+      ixx = 0;
+      if (++iyy == units_y) { iyy = 0; ++ib; }
     }
+    if (inval == 0) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const bool ok = (y0 + gy[i] < H) & (x0 + gx[i] < W);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (__attribute__((address_space(3))) void*)(gb + (i * 4 + wv) * 256), 16,
-                                               ok ? gbase + grel[i] * 4 : 0x7ffffff0, 0, 0, 0);
+      for (int i = 0; i < 4; ++i) dvo[i] = xvo[i];
+      dvo[4] = gvo[0];
+      dvo[5] = gvo[1];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dvo[i] = (xbits[i] & inval) ? OOB : xvo[i];
+      dvo[4] = (gbits[0] & inval) ? OOB : gvo[0];
+      dvo[5] = (gbits[1] & inval) ? OOB : gvo[1];
     }
+  };
+  auto issue_one = [&](float* xb, int i) {  // granule round i of the prepared unit: 0..3 input, 4, 5 gradient
+    if (i < 4) w4_dma16(rx, lds_addr(xb + (i * 4 + wv) * 256), dvo[i], dxbase);
+    else w4_dma16(rg, lds_addr(xb + W4_XF + ((i - 4) * 4 + wv) * 256), dvo[i], dgbase);
   };
 
   // per-wave constants:
@@ -683,6 +721,7 @@ __device__ __forceinline__ void wgrad_w4_body(const WgradMultiArgs& args, const 
   //   edge waves (0: F = 0, H = 1; 3: F = 5, H = 4):          x: tF = 4 d[xa] - 5 d[xa + 2] + d[xa + 4]; tH as above
   //                                                          g: rF = g0 | g3; rH as above
   constexpr bool LOW = EDGE != HI;               // waves 0, 1
+  constexpr int WV = EDGE ? (HI ? 3 : 0) : (HI ? 1 : 2);  // = wave
   constexpr float al = LOW ? -4.f : -1.f;
   constexpr float gH = LOW ? 1.f : -2.f;
   constexpr float gF = LOW ? -1.f : 2.f;         // (inner only)
@@ -698,120 +737,166 @@ __device__ __forceinline__ void wgrad_w4_body(const WgradMultiArgs& args, const 
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-  const bool want_b = d.db && kt == 0 && wave == 0;
-  float bsum = 0.f;
+  const bool want_b = d.db && kt == 0;
+  w4_f32x2 bsum2 = {0.f, 0.f};
 
   // The transforms run on column PAIRS in packed fp32 (v_pk_fma_f32): a ds_read2st64_b32 returns the columns (c, c + 1)
-  // of one row in a register pair.  Column pass of one input column pair (rows F and H of B^T d):
+  // of one row in a register pair.
   auto ld2 = [](const float* p) { return w4_f32x2{p[0], p[64]}; };
-  auto xcol2 = [&](const float* xp, w4_f32x2& f, w4_f32x2& h) {
-    const w4_f32x2 d1 = ld2(xp + 640), d2 = ld2(xp + 2 * 640), d3 = ld2(xp + 3 * 640), d4 = ld2(xp + 4 * 640);
-    const w4_f32x2 p = __builtin_elementwise_fma(w4_f32x2{al, al}, d2, d4), q = __builtin_elementwise_fma(w4_f32x2{al, al}, d1, d3);
-    h = __builtin_elementwise_fma(w4_f32x2{gH, gH}, q, p);
+  // MFMA operands of the step transformed last: the products are issued one step late, right after the next step's LDS
+  // reads, so the reads' latency and the transforms of the co-resident wave run under the matrix pipe's 9 x 16 passes
+  float uF[6], vF[6], uH[3], vH[3];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) uF[j] = vF[j] = 0.f;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) uH[j] = vH[j] = 0.f;
+  // one step = one tile per lane half.  ST: 0 / 1 (compile time).  In step 0 the six DMA rounds of the unit after next go
+  // out between the first products: the texture path takes 16 cycles per 1 KB round and all eight waves of the CU would
+  // otherwise queue there right after the barrier with the matrix pipe idle.
+  w4_f32x2 fP, hP;  // row-combined columns (4,5) of rows F / H: the next step's columns (0,1)
+  auto step = [&](const float* buf, float* dma_buf, auto ST) {
+    constexpr int st = decltype(ST)::value;
+    const float* xs = buf + lane + st * 256;            // + (row * 10 + cc) * 64
+    const float* gs = buf + W4_XF + lane + st * 256;    // + (row * 8 + cc) * 64
+    // ---- LDS reads of this step: input column pairs (0,1) [first step], (2,3), (4,5) and the gradient tile's column pairs
+    w4_f32x2 c1, c2, c3, c4, cA, cB, cC;
+    if (st == 0) {
+      c1 = ld2(xs + 640); c2 = ld2(xs + 2 * 640); c3 = ld2(xs + 3 * 640); c4 = ld2(xs + 4 * 640);
+      if (EDGE) { cA = ld2(xs + xa * 640); cB = ld2(xs + (xa + 2) * 640); cC = ld2(xs + (xa + 4) * 640); }
+    }
+    const w4_f32x2 q1 = ld2(xs + 128 + 640), q2 = ld2(xs + 128 + 2 * 640), q3 = ld2(xs + 128 + 3 * 640), q4 = ld2(xs + 128 + 4 * 640);
+    const w4_f32x2 p1 = ld2(xs + 256 + 640), p2 = ld2(xs + 256 + 2 * 640), p3 = ld2(xs + 256 + 3 * 640), p4 = ld2(xs + 256 + 4 * 640);
+    w4_f32x2 qA = q1, qB = q1, qC = q1, pA = p1, pB = p1, pC = p1;
     if (EDGE) {
-      const w4_f32x2 dA = ld2(xp + xa * 640), dB = ld2(xp + (xa + 2) * 640), dC = ld2(xp + (xa + 4) * 640);
-      f = __builtin_elementwise_fma(w4_f32x2{4.f, 4.f}, dA, __builtin_elementwise_fma(w4_f32x2{-5.f, -5.f}, dB, dC));
+      qA = ld2(xs + 128 + xa * 640); qB = ld2(xs + 128 + (xa + 2) * 640); qC = ld2(xs + 128 + (xa + 4) * 640);
+      pA = ld2(xs + 256 + xa * 640); pB = ld2(xs + 256 + (xa + 2) * 640); pC = ld2(xs + 256 + (xa + 4) * 640);
+    }
+    const w4_f32x2 ga0 = ld2(gs), ga1 = ld2(gs + 512), ga2 = ld2(gs + 2 * 512), ga3 = ld2(gs + 3 * 512);
+    const w4_f32x2 gb0 = ld2(gs + 128), gb1 = ld2(gs + 128 + 512), gb2 = ld2(gs + 128 + 2 * 512), gb3 = ld2(gs + 128 + 3 * 512);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- the previous step's products (+ the DMA rounds)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(uF[j], vF[j], acc[j], 0, 0, 0);
+      if (st == 0) {
+        issue_one(dma_buf, j);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) acc[6 + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(uH[j], vH[j], acc[6 + j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- input: column pass (rows F and H of B^T d)
+    auto xcol = [&](w4_f32x2 d1, w4_f32x2 d2, w4_f32x2 d3, w4_f32x2 d4, w4_f32x2 dA, w4_f32x2 dB, w4_f32x2 dC, w4_f32x2& f,
+                    w4_f32x2& h) {
+      const w4_f32x2 p = __builtin_elementwise_fma(w4_f32x2{al, al}, d2, d4), q = __builtin_elementwise_fma(w4_f32x2{al, al}, d1, d3);
+      h = __builtin_elementwise_fma(w4_f32x2{gH, gH}, q, p);
+      if (EDGE) f = __builtin_elementwise_fma(w4_f32x2{4.f, 4.f}, dA, __builtin_elementwise_fma(w4_f32x2{-5.f, -5.f}, dB, dC));
+      else f = __builtin_elementwise_fma(w4_f32x2{gF, gF}, q, p);
+    };
+    w4_f32x2 fR, hR, fQ, hQ;
+    if (st == 0) xcol(c1, c2, c3, c4, cA, cB, cC, fR, hR);
+    else { fR = fP; hR = hP; }
+    xcol(q1, q2, q3, q4, qA, qB, qC, fQ, hQ);
+    xcol(p1, p2, p3, p4, pA, pB, pC, fP, hP);
+    // ---- input: row passes.  v0 = 4 t0 - 5 t2 + t4, v5 = 4 t1 - 5 t3 + t5;  a = t4 - 4 t2, b = t3 - 4 t1: v1, v2 = a +- b;
+    //      c = t4 - t2, d = t3 - t1: v3, v4 = c +- 2 d
+    {
+      const w4_f32x2 v05 = __builtin_elementwise_fma(w4_f32x2{4.f, 4.f}, fR, __builtin_elementwise_fma(w4_f32x2{-5.f, -5.f}, fQ, fP));
+      const w4_f32x2 ac = __builtin_elementwise_fma(w4_f32x2{-4.f, -1.f}, fQ.xx, fP.xx);
+      const w4_f32x2 bd = __builtin_elementwise_fma(w4_f32x2{-4.f, -1.f}, fR.yy, fQ.yy);
+      const w4_f32x2 v13 = __builtin_elementwise_fma(w4_f32x2{1.f, 2.f}, bd, ac);
+      const w4_f32x2 v24 = __builtin_elementwise_fma(w4_f32x2{-1.f, -2.f}, bd, ac);
+      vF[0] = v05.x; vF[5] = v05.y; vF[1] = v13.x; vF[3] = v13.y; vF[2] = v24.x; vF[4] = v24.y;
+    }
+    if (!HI) {
+      const float a = fmaf(-4.f, hQ.x, hP.x), bq = fmaf(-4.f, hR.y, hQ.y);
+      const w4_f32x2 v12 = __builtin_elementwise_fma(w4_f32x2{1.f, -1.f}, w4_f32x2{bq, bq}, w4_f32x2{a, a});
+      vH[0] = fmaf(4.f, hR.x, fmaf(-5.f, hQ.x, hP.x));
+      vH[1] = v12.x; vH[2] = v12.y;
     } else {
-      f = __builtin_elementwise_fma(w4_f32x2{gF, gF}, q, p);
+      const float cc = hP.x - hQ.x, dd = hQ.y - hR.y;
+      const w4_f32x2 v34 = __builtin_elementwise_fma(w4_f32x2{2.f, -2.f}, w4_f32x2{dd, dd}, w4_f32x2{cc, cc});
+      vH[0] = v34.x; vH[1] = v34.y;
+      vH[2] = fmaf(4.f, hR.y, fmaf(-5.f, hQ.y, hP.y));
+    }
+    // ---- gradient: column pass (rows F, H of G'' dy) for the tile's two column pairs, then the row passes
+    auto gcol = [&](w4_f32x2 g0, w4_f32x2 g1, w4_f32x2 g2, w4_f32x2 g3, w4_f32x2& rf, w4_f32x2& rh) {
+      const w4_f32x2 e = __builtin_elementwise_fma(w4_f32x2{be, be}, g2, g0), o = __builtin_elementwise_fma(w4_f32x2{be, be}, g3, g1);
+      rh = __builtin_elementwise_fma(w4_f32x2{dH, dH}, o, e);
+      rf = EDGE ? (glast ? g3 : g0) : __builtin_elementwise_fma(w4_f32x2{dF, dF}, o, e);
+    };
+    w4_f32x2 rFa, rFb, rHa, rHb;
+    gcol(ga0, ga1, ga2, ga3, rFa, rHa);
+    gcol(gb0, gb1, gb2, gb3, rFb, rHb);
+    if (want_b) {  // bias gradient: wave w sums gradient row w (every wave holds the four raw rows)
+      const w4_f32x2 mine = WV == 0 ? ga0 + gb0 : WV == 1 ? ga1 + gb1 : WV == 2 ? ga2 + gb2 : ga3 + gb3;
+      bsum2 += mine;
+    }
+    {
+      const w4_f32x2 eo1 = rFa + rFb, eo2 = __builtin_elementwise_fma(w4_f32x2{4.f, 4.f}, rFb, rFa);
+      const w4_f32x2 u12 = __builtin_elementwise_fma(w4_f32x2{1.f, -1.f}, eo1.yy, eo1.xx);
+      const w4_f32x2 u34 = __builtin_elementwise_fma(w4_f32x2{2.f, -2.f}, eo2.yy, eo2.xx);
+      uF[0] = rFa.x; uF[1] = u12.x; uF[2] = u12.y; uF[3] = u34.x; uF[4] = u34.y; uF[5] = rFb.y;
+    }
+    if (!HI) {
+      const w4_f32x2 eo1 = rHa + rHb;
+      const w4_f32x2 u12 = __builtin_elementwise_fma(w4_f32x2{1.f, -1.f}, eo1.yy, eo1.xx);
+      uH[0] = rHa.x; uH[1] = u12.x; uH[2] = u12.y;
+    } else {
+      const w4_f32x2 eo2 = __builtin_elementwise_fma(w4_f32x2{4.f, 4.f}, rHb, rHa);
+      const w4_f32x2 u34 = __builtin_elementwise_fma(w4_f32x2{2.f, -2.f}, eo2.yy, eo2.xx);
+      uH[0] = u34.x; uH[1] = u34.y; uH[2] = rHb.y;
     }
   };
-  auto compute = [&](const float* buf) {
-    const float* xb = buf + lane;            // + (row * 10 + cc) * 64
-    const float* gb = buf + W4_XF + lane;    // + (row * 8 + cc) * 64
-    w4_f32x2 fR, fQ, fP, hR, hQ, hP;            // row-combined columns (0,1), (2,3), (4,5) of rows F / H
-    xcol2(xb, fP, hP);                       // columns 0, 1 of the first patch enter as the "carried" pair
-#pragma unroll 1
-    for (int st = 0; st < 2; ++st) {
-      const float* xs = xb + st * 256;
-      const float* gs = gb + st * 256;
-      // ---- input: column pass for the new patch columns (the walk keeps columns 4, 5 as the next tile's 0, 1)
-      fR = fP; hR = hP;
-      xcol2(xs + 2 * 64, fQ, hQ);
-      xcol2(xs + 4 * 64, fP, hP);
-      // ---- input: row passes.  v0 = 4 t0 - 5 t2 + t4, v5 = 4 t1 - 5 t3 + t5;  a = t4 - 4 t2, b = t3 - 4 t1: v1, v2 = a +- b;
-      //      c = t4 - t2, d = t3 - t1: v3, v4 = c +- 2 d
-      float vF[6], vH[3];
-      {
-        const w4_f32x2 v05 = __builtin_elementwise_fma(w4_f32x2{4.f, 4.f}, fR, __builtin_elementwise_fma(w4_f32x2{-5.f, -5.f}, fQ, fP));
-        const w4_f32x2 ac = __builtin_elementwise_fma(w4_f32x2{-4.f, -1.f}, fQ.xx, fP.xx);
-        const w4_f32x2 bd = __builtin_elementwise_fma(w4_f32x2{-4.f, -1.f}, fR.yy, fQ.yy);
-        const w4_f32x2 v13 = __builtin_elementwise_fma(w4_f32x2{1.f, 2.f}, bd, ac);
-        const w4_f32x2 v24 = __builtin_elementwise_fma(w4_f32x2{-1.f, -2.f}, bd, ac);
-        vF[0] = v05.x; vF[5] = v05.y; vF[1] = v13.x; vF[3] = v13.y; vF[2] = v24.x; vF[4] = v24.y;
-      }
-      if (!HI) {
-        const float a = fmaf(-4.f, hQ.x, hP.x), bq = fmaf(-4.f, hR.y, hQ.y);
-        const w4_f32x2 v12 = __builtin_elementwise_fma(w4_f32x2{1.f, -1.f}, w4_f32x2{bq, bq}, w4_f32x2{a, a});
-        vH[0] = fmaf(4.f, hR.x, fmaf(-5.f, hQ.x, hP.x));
-        vH[1] = v12.x; vH[2] = v12.y;
-      } else {
-        const float cc = hP.x - hQ.x, dd = hQ.y - hR.y;
-        const w4_f32x2 v34 = __builtin_elementwise_fma(w4_f32x2{2.f, -2.f}, w4_f32x2{dd, dd}, w4_f32x2{cc, cc});
-        vH[0] = v34.x; vH[1] = v34.y;
-        vH[2] = fmaf(4.f, hR.y, fmaf(-5.f, hQ.y, hP.y));
-      }
-      // ---- gradient: column pass (rows F, H of G'' dy) for the tile's two column pairs, then the row passes
-      w4_f32x2 rFa, rFb, rHa, rHb;
+  auto compute = [&](const float* buf, float* dma_buf) {
+    issue_prep();
+    step(buf, dma_buf, std::integral_constant<int, 0>{});
+    step(buf, dma_buf, std::integral_constant<int, 1>{});
+  };
+  auto mac = [&]() {
 #pragma unroll
-      for (int cp = 0; cp < 2; ++cp) {
-        const float* gp = gs + cp * 128;
-        const w4_f32x2 g0 = ld2(gp), g1 = ld2(gp + 512), g2 = ld2(gp + 2 * 512), g3 = ld2(gp + 3 * 512);
-        const w4_f32x2 e = __builtin_elementwise_fma(w4_f32x2{be, be}, g2, g0), o = __builtin_elementwise_fma(w4_f32x2{be, be}, g3, g1);
-        const w4_f32x2 rh = __builtin_elementwise_fma(w4_f32x2{dH, dH}, o, e);
-        const w4_f32x2 rf = EDGE ? (glast ? g3 : g0) : __builtin_elementwise_fma(w4_f32x2{dF, dF}, o, e);
-        if (cp == 0) { rFa = rf; rHa = rh; } else { rFb = rf; rHb = rh; }
-        if (EDGE && !HI) {
-          if (want_b) { const w4_f32x2 t = (g0 + g1) + (g2 + g3); bsum += t.x + t.y; }
-        }
-      }
-      float uF[6], uH[3];
-      {
-        const w4_f32x2 eo1 = rFa + rFb, eo2 = __builtin_elementwise_fma(w4_f32x2{4.f, 4.f}, rFb, rFa);
-        const w4_f32x2 u12 = __builtin_elementwise_fma(w4_f32x2{1.f, -1.f}, eo1.yy, eo1.xx);
-        const w4_f32x2 u34 = __builtin_elementwise_fma(w4_f32x2{2.f, -2.f}, eo2.yy, eo2.xx);
-        uF[0] = rFa.x; uF[1] = u12.x; uF[2] = u12.y; uF[3] = u34.x; uF[4] = u34.y; uF[5] = rFb.y;
-      }
-      if (!HI) {
-        const w4_f32x2 eo1 = rHa + rHb;
-        const w4_f32x2 u12 = __builtin_elementwise_fma(w4_f32x2{1.f, -1.f}, eo1.yy, eo1.xx);
-        uH[0] = rHa.x; uH[1] = u12.x; uH[2] = u12.y;
-      } else {
-        const w4_f32x2 eo2 = __builtin_elementwise_fma(w4_f32x2{4.f, 4.f}, rHb, rHa);
-        const w4_f32x2 u34 = __builtin_elementwise_fma(w4_f32x2{2.f, -2.f}, eo2.yy, eo2.xx);
-        uH[0] = u34.x; uH[1] = u34.y; uH[2] = rHb.y;
-      }
+    for (int j = 0; j < 6; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(uF[j], vF[j], acc[j], 0, 0, 0);
 #pragma unroll
-      for (int j = 0; j < 6; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(uF[j], vF[j], acc[j], 0, 0, 0);
-#pragma unroll
-      for (int j = 0; j < 3; ++j) acc[6 + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(uH[j], vH[j], acc[6 + j], 0, 0, 0);
-    }
+    for (int j = 0; j < 3; ++j) acc[6 + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(uH[j], vH[j], acc[6 + j], 0, 0, 0);
   };
 
   // units run in pairs (buffer A, buffer B); a unit index past the split's end loads zeros (no contribution), which keeps
   // the loop a single straight-line body — the accumulators stay in place
+  // three unit buffers: while unit u is read, unit u + 1 has landed or is landing and the rounds of unit u + 2 go out
+  // (a DMA round needs ~2000 cycles from issue to LDS under load; with two buffers every barrier waited for it)
   W4_TL(0);
   if (u_lo < u_hi) {
-    issue(u_lo, u_hi, ldsA);
-    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
+    issue_prep();
+#pragma unroll
+    for (int i = 0; i < 6; ++i) issue_one(ldsA, i);
+    issue_prep();
+#pragma unroll
+    for (int i = 0; i < 6; ++i) issue_one(ldsB, i);
+    __builtin_amdgcn_s_waitcnt(0x0f76);  // vmcnt(6): the first unit is in
     __syncthreads();
     W4_TL(1);
-    for (int u = u_lo; u < u_hi; u += 2) {
-      issue(u + 1, u_hi, ldsB);
+    for (int u = u_lo; u < u_hi; u += 3) {
       W4_TLU(0);
-      compute(ldsA);
+      compute(ldsA, ldsC);
       W4_TLU(1);
-      __builtin_amdgcn_s_waitcnt(0x0f70);
+      __builtin_amdgcn_s_waitcnt(0x0f76);
       __syncthreads();
       W4_TLU(2);
-      issue(u + 2, u_hi, ldsA);
+      if (u + 1 < u_hi) compute(ldsB, ldsA);
       W4_TLU(3);
-      compute(ldsB);
+      __builtin_amdgcn_s_waitcnt(0x0f76);
+      __syncthreads();
       W4_TLU(4);
-      __builtin_amdgcn_s_waitcnt(0x0f70);
+      if (u + 2 < u_hi) compute(ldsC, ldsB);
+      __builtin_amdgcn_s_waitcnt(0x0f76);
       __syncthreads();
       W4_TLU(5);
     }
+    __builtin_amdgcn_s_waitcnt(0x0f70);  // the zero rounds of the units past the end: the exchange reuses the buffers
+    __syncthreads();
   }
+  mac();  // the last step's products
   W4_TL(62);
 
   // ---- inverse transform.  C[b][j] = A'^T[b][j] s_j:  b = 0: (1/4, -1/6, -1/6, 1/24, 1/24, 0)
@@ -865,13 +950,14 @@ __device__ __forceinline__ void wgrad_w4_body(const WgradMultiArgs& args, const 
     }
   }
 
-  if (d.db && kt == 0) {
-    if (wave == 0) {
-      bsum += __shfl_xor(bsum, 32, 64);
-      if (lh == 0) bred[l31] = bsum;
-    }
+  if (want_b) {
+    float bsum = bsum2.x + bsum2.y;
+    bsum += __shfl_xor(bsum, 32, 64);
+    if (lh == 0) bred[WV * 32 + l31] = bsum;
     __syncthreads();
-    if (tid < 32) args.bpart[((int64_t)(args.btile_start[di] + ntile) * args.nsplit + s) * 32 + tid] = bred[tid];
+    if (tid < 32)
+      args.bpart[((int64_t)(args.btile_start[di] + ntile) * args.nsplit + s) * 32 + tid] =
+          (bred[tid] + bred[32 + tid]) + (bred[64 + tid] + bred[96 + tid]);
   }
   W4_TL(63);
 }
@@ -879,7 +965,8 @@ __device__ __forceinline__ void wgrad_w4_body(const WgradMultiArgs& args, const 
 __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_wino4_kernel(const WgradMultiArgs args) {
   __shared__ __attribute__((aligned(1024))) float ldsA[W4_BUF];
   __shared__ __attribute__((aligned(1024))) float ldsB[W4_BUF];
-  __shared__ float bred[32];
+  __shared__ __attribute__((aligned(1024))) float ldsC[W4_BUF];
+  __shared__ float bred[128];
   int pair = blockIdx.x, s = blockIdx.y;
   if (args.xcd) {  // XCD-pinned order, see conv3x3_wgrad_multi_kernel
     const int P = args.pair_start[MAXD];
@@ -905,10 +992,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_wino4_kernel(const Wgrad
   const int ntile = local / nkt, kt = local - ntile * nkt;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // wave 0: edge rows (0, 1 lo), 1: inner (2, 1 hi), 2: inner (3, 4 lo), 3: edge (5, 4 hi)
-  if (wave == 0) wgrad_w4_body<true, false>(args, d, di, pair, s, ntile, kt, ldsA, ldsB, bred);
-  else if (wave == 1) wgrad_w4_body<false, true>(args, d, di, pair, s, ntile, kt, ldsA, ldsB, bred);
-  else if (wave == 2) wgrad_w4_body<false, false>(args, d, di, pair, s, ntile, kt, ldsA, ldsB, bred);
-  else wgrad_w4_body<true, true>(args, d, di, pair, s, ntile, kt, ldsA, ldsB, bred);
+  if (wave == 0) wgrad_w4_body<true, false>(args, d, di, pair, s, ntile, kt, ldsA, ldsB, ldsC, bred);
+  else if (wave == 1) wgrad_w4_body<false, true>(args, d, di, pair, s, ntile, kt, ldsA, ldsB, ldsC, bred);
+  else if (wave == 2) wgrad_w4_body<false, false>(args, d, di, pair, s, ntile, kt, ldsA, ldsB, ldsC, bred);
+  else wgrad_w4_body<true, true>(args, d, di, pair, s, ntile, kt, ldsA, ldsB, ldsC, bred);
 }
 
 // ---------------------------------------------------------------------------------------------
