@@ -587,7 +587,13 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_wino_reduce_kernel(const Wg
 //     row-combined columns 4, 5 of a lane's first patch are columns 0, 1 of its second; lane = channel, and both raw
 //     tiles are stored [row][column-in-half][half][32 channels] so a ds_read_b32 of the wave touches 64 consecutive
 //     floats (6 x 10 x 2 input pixels x 32 cin — columns 8, 9 twice —, 4 x 8 x 2 gradient pixels x 32 cout; buffer-load
-//     DMA, two 24 KB buffers, one barrier per unit);
+//     DMA, THREE 24 KB buffers, one barrier per unit);
+//   * schedule of a step (one tile per lane half): the step's ds_reads, then the 9 products of the PREVIOUS step (the
+//     reads land under them), then the packed-fp32 transforms.  On this SIMD the fp32 MFMA passes and the vector
+//     instructions of both resident waves share one issue stream (experiments/ub: time = sum), so what counts is the
+//     vector instruction total: ~45 per 9 products.  The six DMA rounds of the unit after next are issued between the
+//     first products of a unit's first step (the texture path takes 16 cycles per round; issued in a block after the
+//     barrier, the eight waves of the CU queued there with the matrix pipe idle).
 //   * the inverse transform runs IN the kernel: each wave contracts its positions with C along j, the 8 row parts cross
 //     LDS once per output column b, and the workgroup writes a plain 9-tap partial — 36 KB instead of the 64 KB of
 //     16-position partials, summed over the splits by conv3x3_wgrad_reduce_kernel (fixed order: deterministic).
@@ -698,7 +704,7 @@ __device__ __forceinline__ void wgrad_w4_body(const WgradMultiArgs& args, const 
       ixx = 0;
       if (++iyy == units_y) { iyy = 0; ++ib; }
     }
-    if (inval == 0) {
+    if (inval == 0) {  // no granule leaves the image
 #pragma unroll
       for (int i = 0; i < 4; ++i) dvo[i] = xvo[i];
       dvo[4] = gvo[0];
