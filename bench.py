@@ -52,9 +52,10 @@ ALGO_MB_PER_PATCH = {"esrgan": 2852.8}
 ALIASES = {"paired_l1": "bench_esrgan", "otf_gan": "bench_esrgan_otf_gan", "swinir_percep": "bench_swinir_medium"}
 
 CLASS_NAMES = [
-    "packed-weight 3x3 conv, forward launches (conv3x3_wino_kernel | conv3x3_glds_kernel)",
-    "packed-weight 3x3 conv, backward-data launches (conv3x3_wino_kernel | conv3x3_glds_kernel)",
-    "3x3 weight gradient (conv3x3_wgrad_wino_kernel | conv3x3_wgrad_multi_kernel)", "weight-gradient split reduce",
+    "packed-weight 3x3 conv, forward launches (conv3x3_wino4_kernel | conv3x3_wino_kernel | conv3x3_glds_kernel)",
+    "packed-weight 3x3 conv, backward-data launches (conv3x3_wino4_kernel | conv3x3_wino_kernel | conv3x3_glds_kernel)",
+    "3x3 weight gradient (conv3x3_wgrad_wino4_kernel | conv3x3_wgrad_wino_kernel | conv3x3_wgrad_multi_kernel)",
+    "weight-gradient split reduce",
     "staged + thin conv kernels (forward)", "staged + thin conv kernels (backward-data)",
     "gemm NT (nn.Linear forward)", "gemm NN (nn.Linear backward-data)", "gemm TN (nn.Linear backward-weight)",
     "window attention forward", "window attention backward",
@@ -385,7 +386,7 @@ def main() -> None:
         allex = sum(ex[i] for i in COMPUTE_CLASSES)
         dom_algo = max(range(3), key=lambda a: algo[3 * dom + a])
         sym = ({0: "conv3x3_glds_kernel", 1: "conv3x3_wino_kernel", 2: "conv3x3_wino4_kernel"}[dom_algo] if dom in (0, 1)
-               else {0: "conv3x3_wgrad_multi_kernel", 1: "conv3x3_wgrad_wino_kernel", 2: "conv3x3_wgrad_wino_kernel"}[dom_algo] if dom == 2
+               else {0: "conv3x3_wgrad_multi_kernel", 1: "conv3x3_wgrad_wino_kernel", 2: "conv3x3_wgrad_wino4_kernel"}[dom_algo] if dom == 2
                else CLASS_SYMBOL[dom])
         tr = pmc_traffic(cfg_name, sym) if not (args.batch or args.arch) else None
         sq = sq_counters(cfg_name, sym) if not (args.batch or args.arch) else None
