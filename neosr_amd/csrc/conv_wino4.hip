@@ -165,6 +165,32 @@ void conv3x3_wino4_kernel(const ConvArgs args) {
     const int sy = d.ups ? (gy >> 1) : gy, sx = d.ups ? (gx >> 1) : gx;
     return ok ? ((sy * Win + sx) * d.in_cs + q4) * 4 : 0x7ffffff0;
   };
+  // ---- U image of this wave's 32-cout block: [chunk][pos 36][kp 2][cout block 2][k quad 4][cout 16][4] floats
+  const int nblk = N64 ? 2 * (int)blockIdx.y + sel : (int)blockIdx.y;
+  const bool blk_ok = nblk * 32 < d.N;   // (N64, N % 64 == 32: the upper half of the last workgroup has no channels)
+  const auto ru = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(d.w_wino4) + (int64_t)(blk_ok ? nblk : 0) * nchunks * QU_CHUNK, 0, blk_ok ? nchunks * QU_CHUNK * 4 : 0,
+      0x00020000);
+  const int u_lane = lane * 16;
+  typedef decltype(__builtin_amdgcn_raw_buffer_load_b128(ru, 0, 0, 0)) u32x4_t;
+  auto load_u3 = [&](int c, int kp, int j0, f32x4 (&u)[3][2]) {   // positions (ti, j0 .. j0 + 2), k-parity kp of chunk c
+    const int u_wave = ((ti * 6) * 4 + kp * 2) * 1024;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(ru, u_lane + nb * 1024, c * (QU_CHUNK * 4) + u_wave + (j0 + j) * 4096, 0);
+        u[j][nb] = __builtin_bit_cast(f32x4, v);
+      }
+  };
+
+  // chunk 0's first U half is requested HERE, before anything that waits for the table rows: the address path (16 cycles
+  // per 1 KB instruction, one per CU) is idle while the tables travel, and after the first barrier the transform and the
+  // first MFMAs find their weights in registers (requested behind the barrier they cost the launch ~0.4 us; requested
+  // between the DMA pieces and the barrier they queued ahead of the late waves' pieces)
+  f32x4 ulo[3][2], uhi[3][2], vlo[3], vhi[3];
+  load_u3(0, N64 ? 0 : sel, 0, ulo);
+  __builtin_amdgcn_sched_barrier(0);
   int in_off[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -201,25 +227,6 @@ void conv3x3_wino4_kernel(const ConvArgs args) {
   const float gm = three ? 4.f : (ti == 1 ? 1.f : ti == 2 ? -1.f : ti == 3 ? 2.f : -2.f);
   // LDS float offsets of (row q_row(ti, k), column 0 / column 4) of this lane's patch; columns c & 3 are +64 floats each
   const int pa[4][2] = {{pa_lo[0], pa_lo[1]}, {pa_lo[2], pa_lo[3]}, {pa_hi[0], pa_hi[1]}, {pa_hi[2], pa_hi[3]}};
-
-  // ---- U image of this wave's 32-cout block: [chunk][pos 36][kp 2][cout block 2][k quad 4][cout 16][4] floats
-  const int nblk = N64 ? 2 * (int)blockIdx.y + sel : (int)blockIdx.y;
-  const bool blk_ok = nblk * 32 < d.N;   // (N64, N % 64 == 32: the upper half of the last workgroup has no channels)
-  const auto ru = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(d.w_wino4) + (int64_t)(blk_ok ? nblk : 0) * nchunks * QU_CHUNK, 0, blk_ok ? nchunks * QU_CHUNK * 4 : 0,
-      0x00020000);
-  const int u_lane = lane * 16;
-  typedef decltype(__builtin_amdgcn_raw_buffer_load_b128(ru, 0, 0, 0)) u32x4_t;
-  auto load_u3 = [&](int c, int kp, int j0, f32x4 (&u)[3][2]) {   // positions (ti, j0 .. j0 + 2), k-parity kp of chunk c
-    const int u_wave = ((ti * 6) * 4 + kp * 2) * 1024;
-#pragma unroll
-    for (int j = 0; j < 3; ++j)
-#pragma unroll
-      for (int nb = 0; nb < 2; ++nb) {
-        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(ru, u_lane + nb * 1024, c * (QU_CHUNK * 4) + u_wave + (j0 + j) * 4096, 0);
-        u[j][nb] = __builtin_bit_cast(f32x4, v);
-      }
-  };
 
   f32x4 acc[6][2];
 #pragma unroll
@@ -270,7 +277,6 @@ void conv3x3_wino4_kernel(const ConvArgs args) {
     vhi[2] = fma4(p4, t[1], fma4(m5, t[3], t[5]));
   };
 
-  f32x4 ulo[3][2], uhi[3][2], vlo[3], vhi[3];
   TL_MARK(56);
   issue(0, ldsA);
   TL_MARK(57);
@@ -278,9 +284,6 @@ void conv3x3_wino4_kernel(const ConvArgs args) {
   TL_MARK(58);
   __syncthreads();
   TL_MARK(1);
-  // (the first U loads leave only now: in front of the barrier they would queue ahead of the late waves' DMA pieces in
-  // the CU's one address path — 16 cycles per 1 KB instruction —; they land under the first transform)
-  load_u3(0, N64 ? 0 : sel, 0, ulo);
   for (int c = 0; c < nchunks; ++c) {
     const float* rb = (c & 1) ? ldsB : ldsA;
     if (c > 0) mac3(3, vhi, uhi);  // positions (ti, 3..5) of the previous (sub-)chunk
