@@ -133,6 +133,17 @@ int neosr_set_wino4_n64(int mode);
 /* Weight gradient of the 32-channel-tile path: 1 (default; env NEOSR_AMD_WGRAD4) = the F(4x4-tile) Winograd form when
  * neosr_get_winograd() == 2, 0 = the F(2x2) form.  Returns the previous setting. */
 int neosr_set_wgrad4(int on);
+/* The RRDB trunk (neosr/archs/esrgan_arch.py:82-142 and its backward-data pass) as ONE launch per RRDB and direction
+ * (conv_wino4_chain.hip: fifteen F(4x4,3x3) layers, one persistent workgroup per 16 x 16-pixel tile, tile-to-tile hand-off
+ * through flag words) instead of one launch per convolution: 1 (default; env NEOSR_AMD_CHAIN) = wherever the trunk takes
+ * the F(4x4,3x3) kernel, the batch has at most one tile per CU and neosr_set_wino4_n64 is not 0; 0 = never.  Same
+ * arithmetic per layer: bit-identical to the per-convolution launches of the same workgroup shapes.  Returns the previous
+ * setting.  neosr_conv_chain_status: 0 while no flag wait ever ran into its spin bound on this device (it synchronises;
+ * a non-zero value means a chain launch did not get all its workgroups resident and its results are invalid).
+ * neosr_set_conv_chain_sync(0) skips the flag waits (timing experiments only: results are then racy); default 1. */
+int neosr_set_conv_chain(int on);
+int neosr_set_conv_chain_sync(int mode);
+int neosr_conv_chain_status(void);
 int64_t neosr_conv3x3_pack_wino4_bytes(int32_t N, int32_t K);
 int neosr_conv3x3_pack_wino4(const float* w, int32_t w_cout, int32_t w_cin, int32_t mode, float* dst, void* stream);
 /* Both images of MANY weight tensors in ceil(n / 24) launches per image kind (the per-layer calls above cost one launch

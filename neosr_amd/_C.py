@@ -257,6 +257,9 @@ SIGNATURES: dict[str, tuple] = {
     "neosr_get_winograd": (C.c_int, []),
     "neosr_set_wino4_n64": (C.c_int, [C.c_int]),
     "neosr_set_wgrad4": (C.c_int, [C.c_int]),
+    "neosr_set_conv_chain": (C.c_int, [C.c_int]),
+    "neosr_set_conv_chain_sync": (C.c_int, [C.c_int]),
+    "neosr_conv_chain_status": (C.c_int, []),
     "neosr_conv3x3_pack_wino_bytes": (_i64, [_i32, _i32]),
     "neosr_conv3x3_pack_wino": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp]),
     "neosr_conv3x3_pack_wino4_bytes": (_i64, [_i32, _i32]),

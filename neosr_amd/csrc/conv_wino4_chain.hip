@@ -1,0 +1,565 @@
+// conv_wino4_chain.hip — a CHAIN of Winograd F(4x4,3x3) convolution layers in ONE launch (gfx950, fp32 MFMA).
+//
+// The RDB trunk of RRDBNet (neosr/archs/esrgan_arch.py:82-142: five 3x3 convolutions per residual dense block, each
+// reading the concatenation of the block input and every earlier convolution's output) and its gather-form backward-data
+// pass are sequences of DEPENDENT launches of conv3x3_wino4_kernel with one 16 x 16-pixel tile per CU at B = 16.  Per
+// launch that kernel pays ~3 us of stream boundary, ~1.6 us of prologue (first DMA + weight round trip) and ~1 us of store
+// drain against 8-17 us of matrix work.  This kernel runs a whole table of such layers (nets.hip: the fifteen
+// convolutions of one RRDB) with the SAME arithmetic per layer (same transforms, same MFMA order: bit-identical
+// results), one persistent workgroup per pixel tile:
+//   * a layer's outputs are written through to memory (sc1 stores); every storing wave drains them, the workgroup
+//     publishes "layer l done" in its tile's flag word (relaxed agent-scope store), and a consumer reads activations only
+//     by sc1 `buffer_load ... lds` (L1 bypassed, MI355X_MICROARCH.md / cdna_hip_programming.md Guideline 16, form R1);
+//   * inside a dense block only the NEWEST 32-channel slice of a layer's input was written by the previous layer; it is
+//     the LAST chunk of the reduction.  The chunks in front of it are older than a whole layer, so the wait for the 3 x 3
+//     neighbour tiles' flags sits two chunks ahead of the first dependent DMA (the poll load is issued at the start of
+//     that iteration by wave 0 and looked at behind its MFMAs) and costs nothing when the neighbours keep pace; chunk 0
+//     of the next layer is requested during the last chunk of the current one into a THIRD raw buffer, so the next
+//     layer's prologue is hidden behind the current layer's tail;
+//   * only a layer whose whole input is new (conv1 of the next dense block; `dep` = 0) waits in the open: drain ->
+//     publish -> poll -> first DMA, about what the stream boundary it replaces costs;
+//   * every spin is bounded (status word, see W4ChainArgs); the host launches at most one workgroup per CU and only
+//     when the device has that many CUs, and zeroes the flag words in front of every pass.
+// LDS: two exchange / raw objects of 54 KB as in conv3x3_wino4_kernel plus one 45 KB raw buffer for chunk 0 = 153 KB.
+#include <cstring>
+#include <type_traits>
+#include <vector>
+#include <map>
+#include <mutex>
+#include <stdlib.h>
+#include "conv_wino4.h"
+#include "conv_wino4_chain.h"
+#include "prof.h"
+
+using namespace neosr_conv;
+
+namespace {
+
+typedef __attribute__((address_space(1))) unsigned gu32;
+constexpr int AUX_SC1 = 16;  // cache-policy bit of buffer loads / stores: sc1 (write-through store, L1-bypassing load)
+constexpr unsigned SPIN_LIMIT = 1u << 21;
+
+__global__ __attribute__((amdgpu_flat_work_group_size(768, 768), amdgpu_waves_per_eu(3, 3)))
+void conv3x3_wino4_chain_kernel(const W4ChainArgs args) {
+  __shared__ __attribute__((aligned(1024))) float ldsA[QBUF];
+  __shared__ __attribute__((aligned(1024))) float ldsB[QBUF];
+  __shared__ __attribute__((aligned(1024))) float ldsC[QSLOTS * 32];  // chunk 0 of every layer
+  const int tid_k = threadIdx.x;
+  const int tid = tid_k;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ti = wave >> 1, sel = wave & 1;   // transform row; channel parity (N64 layers: cout half)
+  const int prio = wave >= 8 ? 2 : (wave >= 4 ? 1 : 0);  // waves w, w + 4, w + 8 share a SIMD: three static priorities
+
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  const i32x4 gtab = *reinterpret_cast<const i32x4*>(g_qt.gran[tid]);
+
+  int bid = xcd_tile(blockIdx.x, gridDim.x, args.xcd);
+  int tx, ty, b;
+  if (args.tx_shift >= 0 && args.ty_shift >= 0) {
+    tx = bid & (args.tiles_x - 1);
+    ty = (bid >> args.tx_shift) & (args.tiles_y - 1);
+    b = bid >> (args.tx_shift + args.ty_shift);
+  } else {
+    tx = bid % args.tiles_x;
+    const int r = bid / args.tiles_x;
+    ty = r % args.tiles_y;
+    b = r / args.tiles_y;
+  }
+  const int x0 = tx * QT, y0 = ty * QT;
+  const int H = args.H, W = args.W, in_cs = args.in_cs;
+
+  // ---- DMA granules of this thread (the same for every layer: one geometry, one channel stride per chain)
+  int in_off[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int e = gtab[r];
+    const int y = e & 0xff, x = (e >> 8) & 0xff;
+    const int gy = y0 + y - 1, gx = x0 + x - 1;
+    const int q4 = (e >> 14) & 0x3fc;
+    const bool ok = (e >> 24) && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+    in_off[r] = ok ? ((gy * W + gx) * in_cs + q4) * 4 : 0x7ffffff0;
+  }
+  auto make_rin = [&](const float* in, int K) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in) + (int64_t)b * H * W * in_cs, 0,
+                                             ((H * W - 1) * in_cs + K) * 4, 0x00020000);
+  };
+  typedef decltype(make_rin(nullptr, 0)) rsrc_t;
+  auto issue = [&](rsrc_t rin, int c, float* buf) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (r == 3 && wave >= 9) break;  // granules 2304 .. 2879: waves 0-8
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_void)(buf + (r * 12 + wave) * 256), 16, in_off[r], c * 128, 0, AUX_SC1);
+    }
+  };
+
+  // ---- flag words: own tile, and (wave 0, lanes 0-8) the 3 x 3 neighbourhood; lane 9 watches the status word
+  const int my_flag = (b * args.tiles_y + ty) * args.tiles_x + tx;
+  int nb_flag = -1;
+  if (lane < 9) {
+    const int ny = ty + lane / 3 - 1, nx = tx + lane % 3 - 1;
+    if ((unsigned)ny < (unsigned)args.tiles_y && (unsigned)nx < (unsigned)args.tiles_x)
+      nb_flag = (b * args.tiles_y + ny) * args.tiles_x + nx;
+  }
+  const auto rflag = __builtin_amdgcn_make_buffer_rsrc(args.flags, 0, 0x7ffffff0, 0x00020000);
+  const auto rstat = __builtin_amdgcn_make_buffer_rsrc(args.status, 0, 4, 0x00020000);
+  auto poll_load = [&]() -> unsigned {  // (out-of-range offsets read 0)
+    unsigned v = __builtin_amdgcn_raw_buffer_load_b32(rflag, nb_flag >= 0 ? nb_flag * 4 : 0x7ffffff0, 0, AUX_SC1);
+    const unsigned s = __builtin_amdgcn_raw_buffer_load_b32(rstat, lane == 9 ? 0 : 0x7ffffff0, 0, AUX_SC1);
+    return lane == 9 ? s : v;
+  };
+  // every neighbour has finished `need` layers (or the chain was aborted by a timeout somewhere)
+  auto poll_ok = [&](unsigned v, unsigned need) -> bool {
+    const bool ok = lane >= 9 || nb_flag < 0 || v >= need;
+    const bool ab = lane == 9 && v != 0;
+    return __builtin_amdgcn_ballot_w64(!ok) == 0 || __builtin_amdgcn_ballot_w64(ab) != 0;
+  };
+  auto poll_wait = [&](unsigned v, unsigned need) {
+    if (!args.sync) return;
+    unsigned spins = 0;
+    while (!poll_ok(v, need)) {
+      __builtin_amdgcn_s_sleep(4);
+      v = poll_load();
+      if (++spins > SPIN_LIMIT) {
+        if (lane == 0) __hip_atomic_store((gu32*)args.status, 1u + need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+    }
+  };
+
+  // the layer table through the CONSTANT address space: uniform loads from it are scalar loads whatever the kernel has
+  // stored in between (from a plain global pointer hipcc takes a vector load behind the first store of the loop — every
+  // buffer resource built from it would then be "divergent" and each buffer instruction a waterfall loop)
+  typedef const __attribute__((address_space(4))) W4Layer* ctab_t;
+  const ctab_t tab = (ctab_t)(uintptr_t)args.layers;
+  const int nl = args.nlayers;
+  bool c0_issued = false;   // chunk 0 of the layer about to start was requested by the previous layer
+
+  auto layer = [&](auto n64tag, const int l) {
+    constexpr bool N64 = decltype(n64tag)::value;
+    W4Layer L;
+#define NEOSR_LF(f) L.f = tab[l].f
+    NEOSR_LF(in); NEOSR_LF(u); NEOSR_LF(bias); NEOSR_LF(res1); NEOSR_LF(res2); NEOSR_LF(out_mask); NEOSR_LF(out);
+    NEOSR_LF(K); NEOSR_LF(N); NEOSR_LF(out_cs); NEOSR_LF(res1_cs); NEOSR_LF(res1_nch); NEOSR_LF(res2_cs); NEOSR_LF(res2_nch);
+    NEOSR_LF(out_mask_cs); NEOSR_LF(act); NEOSR_LF(dep); NEOSR_LF(slope); NEOSR_LF(alpha); NEOSR_LF(alpha2); NEOSR_LF(out_mask_slope);
+#undef NEOSR_LF
+    const int K = L.K, nchunks = K >> 5;
+    if (prio == 2) __builtin_amdgcn_s_setprio(2);
+    else if (prio == 1) __builtin_amdgcn_s_setprio(1);
+
+    // (opaque copy of the thread id: everything derived from it below is recomputed per layer — hoisted out of the layer
+    // loop for both wave mappings it would occupy ~60 registers across the whole chain)
+    int tid = tid_k;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63;
+    const int t16 = lane & 15, kq = lane >> 4;
+    const int prow = N64 ? (wave & ~1) : wave;   // N64: the k-parity 0 row; parity 1 = the same offsets with bit 4 flipped
+    const i32x4 pa_lo = *reinterpret_cast<const i32x4*>(g_qt.pa[prow][lane]);
+    const i32x4 pa_hi = *reinterpret_cast<const i32x4*>(g_qt.pa[prow][lane] + 4);
+
+    // ---- U image of this wave's 32-cout block: [chunk][pos 36][kp 2][cout block 2][k quad 4][cout 16][4] floats
+    const int nblk = N64 ? sel : 0;
+    const bool blk_ok = nblk * 32 < L.N;
+    const auto ru = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(L.u) + (int64_t)(blk_ok ? nblk : 0) * nchunks * QU_CHUNK, 0, blk_ok ? nchunks * QU_CHUNK * 4 : 0,
+        0x00020000);
+    const int u_lane = lane * 16;
+    typedef decltype(__builtin_amdgcn_raw_buffer_load_b128(ru, 0, 0, 0)) u32x4_t;
+    auto load_u3 = [&](int c, int kp, int j0, f32x4 (&u)[3][2]) {
+      const int u_wave = ((ti * 6) * 4 + kp * 2) * 1024;
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+          const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(ru, u_lane + nb * 1024, c * (QU_CHUNK * 4) + u_wave + (j0 + j) * 4096, 0);
+          u[j][nb] = __builtin_bit_cast(f32x4, v);
+        }
+    };
+    f32x4 ulo[3][2], uhi[3][2], vlo[3], vhi[3];
+    load_u3(0, N64 ? 0 : sel, 0, ulo);
+    __builtin_amdgcn_sched_barrier(0);
+
+    const rsrc_t rin = make_rin(L.in, K);
+    // the layer's input holds channels written by the previous layer of THIS launch from chunk `dep` on (-1: none)
+    const int dep = l > 0 ? (L.dep == 1 ? 0 : L.dep) : -1;
+    if (l == 0 || (dep != 0 && !c0_issued)) issue(rin, 0, ldsC);   // (else: requested by the previous layer, or after the poll)
+    // previous layer's stores drained (every storing wave), chunk 0 landed, then publish
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (l > 0 && tid == 0) __hip_atomic_store((gu32*)args.flags + my_flag, (unsigned)l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (dep == 0) {  // the whole input is new: wait in the open
+      if (wave == 0) poll_wait(poll_load(), (unsigned)l);
+      __syncthreads();
+      issue(rin, 0, ldsC);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    const int pollc = dep >= 2 ? dep - 2 : -1;
+
+    const bool three = ti == 0 || ti == 5;
+    const float ap = three ? -5.f : (ti <= 2 ? -4.f : -1.f);
+    const float aq = ap;
+    const float gm = three ? 4.f : (ti == 1 ? 1.f : ti == 2 ? -1.f : ti == 3 ? 2.f : -2.f);
+    const int pa[4][2] = {{pa_lo[0], pa_lo[1]}, {pa_lo[2], pa_lo[3]}, {pa_hi[0], pa_hi[1]}, {pa_hi[2], pa_hi[3]}};
+
+    f32x4 acc[6][2];
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) acc[j][nb] = splat(0.f);
+
+    auto mac3 = [&](int j0, const f32x4 (&v)[3], const f32x4 (&u)[3][2]) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb)
+            acc[j0 + j][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[j][nb][e], v[j][e], acc[j0 + j][nb], 0, 0, 0);
+    };
+    auto transform = [&](const float* rb, int xr, f32x4 (&vlo)[3], f32x4 (&vhi)[3]) {
+      f32x4 t[6];
+      const f32x4 ap4 = splat(ap), aq4 = splat(aq), gm4 = splat(gm);
+      if (three) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+          const int o = (c & 3) * 64;
+          const f32x4 da = ld4f(rb + (pa[0][c >> 2] ^ xr) + o), db = ld4f(rb + (pa[1][c >> 2] ^ xr) + o);
+          const f32x4 dc = ld4f(rb + (pa[3][c >> 2] ^ xr) + o);
+          t[c] = fma4(gm4, da, fma4(ap4, db, dc));
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+          const int o = (c & 3) * 64;
+          const f32x4 d1 = ld4f(rb + (pa[0][c >> 2] ^ xr) + o), d2 = ld4f(rb + (pa[1][c >> 2] ^ xr) + o);
+          const f32x4 d3 = ld4f(rb + (pa[2][c >> 2] ^ xr) + o), d4 = ld4f(rb + (pa[3][c >> 2] ^ xr) + o);
+          t[c] = fma4(gm4, fma4(aq4, d1, d3), fma4(ap4, d2, d4));
+        }
+      }
+      const f32x4 m4 = splat(-4.f), m5 = splat(-5.f), p4 = splat(4.f), p2 = splat(2.f), m2 = splat(-2.f);
+      const f32x4 a = fma4(m4, t[2], t[4]), bq = fma4(m4, t[1], t[3]);
+      const f32x4 cc = t[4] - t[2], dd = t[3] - t[1];
+      vlo[0] = fma4(p4, t[0], fma4(m5, t[2], t[4]));
+      vlo[1] = a + bq;
+      vlo[2] = a - bq;
+      vhi[0] = fma4(p2, dd, cc);
+      vhi[1] = fma4(m2, dd, cc);
+      vhi[2] = fma4(p4, t[1], fma4(m5, t[3], t[5]));
+    };
+
+    // the next layer's chunk 0 may be requested during this layer's last chunk when it is older than this layer's output
+    bool next_c0 = false;
+    rsrc_t rin_next = rin;
+    if (l + 1 < nl) {
+      const int dn = tab[l + 1].dep;
+      next_c0 = dn != 0 && dn != 1;
+      rin_next = make_rin(tab[l + 1].in, tab[l + 1].K);
+    }
+
+    for (int c = 0; c < nchunks; ++c) {
+      const float* rb = c == 0 ? ldsC : ((c & 1) ? ldsA : ldsB);
+      unsigned fv = 0;
+      if (wave == 0 && c == pollc) fv = poll_load();
+      if (c > 0) mac3(3, vhi, uhi);  // positions (ti, 3..5) of the previous (sub-)chunk
+      __builtin_amdgcn_sched_barrier(0);
+      if (c + 1 < nchunks) issue(rin, c + 1, (c & 1) ? ldsB : ldsA);
+      else if (next_c0) issue(rin_next, 0, ldsC);
+      __builtin_amdgcn_sched_barrier(0);
+      transform(rb, 0, vlo, vhi);
+      __builtin_amdgcn_sched_barrier(0);
+      load_u3(c, N64 ? 0 : sel, 3, uhi);
+      __builtin_amdgcn_sched_barrier(0);
+      mac3(0, vlo, ulo);
+      __builtin_amdgcn_sched_barrier(0);
+      if (N64) {  // second k-parity of the same raw chunk, no barrier in between
+        load_u3(c, 1, 0, ulo);
+        __builtin_amdgcn_sched_barrier(0);
+        mac3(3, vhi, uhi);
+        __builtin_amdgcn_sched_barrier(0);
+        transform(rb, 16, vlo, vhi);
+        __builtin_amdgcn_sched_barrier(0);
+        load_u3(c, 1, 3, uhi);
+        __builtin_amdgcn_sched_barrier(0);
+        mac3(0, vlo, ulo);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (wave == 0 && c == pollc) poll_wait(fv, (unsigned)l);
+      if (c + 1 < nchunks) {
+        load_u3(c + 1, N64 ? 0 : sel, 0, ulo);
+        if (N64) __builtin_amdgcn_s_waitcnt(0x4f78);  // vmcnt(24): chunk c + 1 has landed
+        else __builtin_amdgcn_s_waitcnt(0x0f7c);      // vmcnt(12)
+      }
+      __syncthreads();
+    }
+    c0_issued = next_c0;
+    mac3(3, vhi, uhi);
+    __builtin_amdgcn_s_setprio(0);
+
+    // ---- epilogue (waves 4-11), as in conv3x3_wino4_kernel; stores are written through (sc1)
+    const bool fin = wave >= 4;
+    const int cq = N64 ? (tid & 15) << 2 : (tid & 7) << 2;
+    const int eb = N64 ? (tid >> 4) & 3 : (tid >> 3) & 3;
+    const int et0 = N64 ? ((tid - 256) >> 6) & 7 : ((tid - 256) >> 5) & 15;
+    const int chq = cq;
+    const bool ch_ok = fin && chq < L.N;
+    f32x4 bias = splat(0.f);
+    if (fin && L.bias) bias = ld4f(L.bias + (ch_ok ? chq : 0));
+    float s_uni = 1.f;
+    if (L.act == ACT_LRELU) s_uni = L.slope;
+    else if (L.act == ACT_RELU) s_uni = 0.f;
+    typedef decltype(__builtin_amdgcn_raw_buffer_load_b128(ru, 0, 0, 0)) raw4_t;
+    const auto r_out = __builtin_amdgcn_make_buffer_rsrc(L.out, 0, 0x7ffffff0, 0x00020000);
+    struct Epi {
+      int o_out[4];
+      f32x4 e1[4], e2[4], mk[4];
+    };
+    auto epi_load = [&](int et, Epi& E) {
+      const int ey = y0 + 4 * (et >> 2), ex = x0 + 4 * (et & 3) + eb;
+      const int pix0 = (b * H + ey) * W + ex;
+      const bool col_ok = ch_ok && ex < W;
+      bool okr[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) okr[a] = col_ok && ey + a < H;
+      auto offs = [&](int cs, bool ok_ch, int (&o)[4]) {
+        const int base = (pix0 * cs + chq) * 4, step = W * cs * 4;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) o[a] = (okr[a] && ok_ch) ? base + a * step : 0x7ffffff8;
+      };
+      auto load4 = [&](const float* p, const int (&o)[4], f32x4 (&v)[4]) {
+        const auto rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, 0x7ffffff0, 0x00020000);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) v[a] = __builtin_bit_cast(f32x4, (raw4_t)__builtin_amdgcn_raw_buffer_load_b128(rr, o[a], 0, 0));
+      };
+      offs(L.out_cs, true, E.o_out);
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        E.e1[a] = E.e2[a] = splat(0.f);
+        E.mk[a] = splat(1.f);
+      }
+      int o[4];
+      if (L.res1) {
+        offs(L.res1_cs, chq < L.res1_nch, o);
+        load4(L.res1, o, E.e1);
+      }
+      if (L.res2) {
+        offs(L.res2_cs, chq < L.res2_nch, o);
+        load4(L.res2, o, E.e2);
+      }
+      if (L.out_mask) {
+        offs(L.out_mask_cs, true, o);
+        load4(L.out_mask, o, E.mk);
+      }
+    };
+    Epi E0;
+    if (fin) epi_load(et0, E0);
+
+    constexpr int ES = N64 ? 68 : QES;
+    {
+      float* ex_img = N64 ? (ti >= 3 ? ldsB : ldsA) : (sel ? ldsB : ldsA);
+      const int er = N64 ? (ti >= 3 ? ti - 3 : ti) : ti;
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        const f32x4 s1 = acc[1][nb] + acc[2][nb], d1 = acc[1][nb] - acc[2][nb];
+        const f32x4 s2 = acc[3][nb] + acc[4][nb], d2 = acc[3][nb] - acc[4][nb];
+        const f32x4 x0v = (acc[0][nb] + s1) + s2;
+        const f32x4 x1v = fma4(splat(2.f), d2, d1);
+        const f32x4 x2v = fma4(splat(4.f), s2, s1);
+        const f32x4 x3v = fma4(splat(8.f), d2, d1) + acc[5][nb];
+        float* p = ex_img + ((er * 4) * 16 + t16) * ES + (N64 ? 32 * sel : 0) + 16 * nb + 4 * kq;
+        *reinterpret_cast<f32x4*>(p) = x0v;
+        *reinterpret_cast<f32x4*>(p + 16 * ES) = x1v;
+        *reinterpret_cast<f32x4*>(p + 32 * ES) = x2v;
+        *reinterpret_cast<f32x4*>(p + 48 * ES) = x3v;
+      }
+    }
+    __syncthreads();
+    if (!fin) return;
+
+    auto epi_finish = [&](int et, Epi& E) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        asm volatile("" : "+v"(E.mk[a]));
+        asm volatile("" : "+v"(E.e1[a]), "+v"(E.e2[a]));
+      }
+      f32x4 xi[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        if (N64) {
+          xi[i] = ld4f((i >= 3 ? ldsB : ldsA) + (((i >= 3 ? i - 3 : i) * 4 + eb) * 16 + et) * ES + cq);
+        } else {
+          const int o = ((i * 4 + eb) * 16 + et) * ES + cq;
+          xi[i] = ld4f(ldsA + o) + ld4f(ldsB + o);
+        }
+      }
+      f32x4 y[4];
+      {
+        const f32x4 s1 = xi[1] + xi[2], d1 = xi[1] - xi[2], s2 = xi[3] + xi[4], d2 = xi[3] - xi[4];
+        y[0] = (xi[0] + s1) + s2;
+        y[1] = fma4(splat(2.f), d2, d1);
+        y[2] = fma4(splat(4.f), s2, s1);
+        y[3] = fma4(splat(8.f), d2, d1) + xi[5];
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float t = y[a][e] + bias[e];
+          t = t > 0.f ? t : t * s_uni;
+          t = t * L.alpha + E.e1[a][e];
+          t = t * L.alpha2 + E.e2[a][e];
+          t += 0.f;   // (the `accumulate` term of the one-layer kernel: x + 0 keeps -0 -> +0 identical)
+          o[e] = E.mk[a][e] > 0.f ? t : t * L.out_mask_slope;
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(raw4_t, o), r_out, E.o_out[a], 0, AUX_SC1);
+      }
+    };
+    epi_finish(et0, E0);
+    if (N64) {
+      Epi E1;
+      epi_load(et0 + 8, E1);
+      epi_finish(et0 + 8, E1);
+    }
+  };
+
+  for (int l = 0; l < nl; ++l) {
+    const int n64 = tab[l].n64;
+    if (n64) layer(std::true_type{}, l);
+    else layer(std::false_type{}, l);
+  }
+}
+
+// ---- host side -------------------------------------------------------------------------------------------------
+struct TableShadow {
+  std::vector<W4Layer> host;
+};
+std::mutex g_mu;
+std::map<const void*, TableShadow> g_shadow;   // device table -> what it holds
+int g_chain_on = -1;                            // -1: read NEOSR_AMD_CHAIN on first use (default on)
+int g_chain_sync = 1;                           // debug: 0 = flag waits skipped (timing only, racy)
+
+}  // namespace
+
+extern "C" int neosr_set_conv_chain(int on) {
+  const int prev = g_chain_on < 0 ? 1 : g_chain_on;
+  g_chain_on = on ? 1 : 0;
+  return prev;
+}
+extern "C" int neosr_set_conv_chain_sync(int mode) {
+  const int prev = g_chain_sync;
+  g_chain_sync = mode;
+  return prev;
+}
+
+bool neosr_conv::chain_enabled() {
+  if (g_chain_on < 0) {
+    const char* e = getenv("NEOSR_AMD_CHAIN");
+    g_chain_on = (e && e[0] == '0') ? 0 : 1;
+  }
+  return g_chain_on == 1 && wino_mode() == 2;
+}
+
+namespace {
+// one sticky status word per device (zeroed once): a flag wait that ran into its spin bound leaves 1 + its epoch here
+unsigned* status_word() {
+  static std::map<int, unsigned*> words;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto it = words.find(dev);
+  if (it != words.end()) return it->second;
+  unsigned* p = nullptr;
+  if (hipMalloc((void**)&p, 256) != hipSuccess || hipMemset(p, 0, 256) != hipSuccess) return nullptr;
+  words[dev] = p;
+  return p;
+}
+}  // namespace
+
+// 0: no chain launch on this device ever gave up a flag wait; else 1 + the epoch the first one waited for.  Synchronises.
+extern "C" int neosr_conv_chain_status(void) {
+  unsigned* p = status_word();
+  unsigned v = 0;
+  if (!p || hipMemcpy(&v, p, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return (int)v;
+}
+
+// Returns 0 on success, 1 on error (message set), -1 when the layers do not qualify (caller launches them one by one).
+int neosr_conv::launch_wino4_chain(const neosr_conv_desc* d, const int* dep, int n, void* table_dev, unsigned* flags,
+                                   void* stream) {
+  if (n < 1 || !chain_enabled()) return -1;
+  const neosr_conv_desc& f = d[0];
+  const int tiles_x = ceil_div(f.W, QT), tiles_y = ceil_div(f.H, QT);
+  const int64_t tiles = (int64_t)tiles_x * tiles_y * f.B;
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return -1;
+    n_cu = p.multiProcessorCount;
+  }
+  if (tiles > n_cu) return -1;   // one resident workgroup per tile, one workgroup per CU (153 KB of LDS)
+  for (int i = 0; i < n; ++i)
+    if (d[i].N > 32 && wino4_n64_mode() == 0) return -1;   // 64 output channels need the 64-channel wave mapping here
+  auto small = [&](const void* p, int cs) { return !p || (int64_t)f.B * f.H * f.W * cs * 4 < (int64_t(1) << 31); };
+  std::vector<W4Layer> tab(n);
+  for (int i = 0; i < n; ++i) {
+    const neosr_conv_desc& c = d[i];
+    if (c.B != f.B || c.H != f.H || c.W != f.W || c.in_cs != f.in_cs) return -1;
+    if (!c.w_wino4 || (uintptr_t)c.w_wino4 % 16 || c.ups || c.s2d_c || c.in_mask || c.in_prelu || c.accumulate ||
+        c.act == NEOSR_ACT_PRELU || c.K % 32 || c.K < 64 || c.N > 64 || c.N % 4 || c.in_cs % 4 || c.out_cs % 4 ||
+        (uintptr_t)c.in % 16 || (uintptr_t)c.out % 16 || (uintptr_t)c.bias % 16 || (uintptr_t)c.res1 % 16 ||
+        (uintptr_t)c.res2 % 16 || (uintptr_t)c.out_mask % 16 || c.res1_cs % 4 || c.res2_cs % 4 || c.out_mask_cs % 4 ||
+        c.res1_nch % 4 || c.res2_nch % 4)
+      return -1;
+    if (!small(c.in, c.in_cs) || !small(c.out, c.out_cs) || !small(c.res1, c.res1_cs) || !small(c.res2, c.res2_cs) ||
+        !small(c.out_mask, c.out_mask_cs))
+      return -1;
+    W4Layer& L = tab[i];
+    memset(&L, 0, sizeof(L));
+    L.in = c.in; L.u = c.w_wino4; L.bias = c.bias; L.res1 = c.res1; L.res2 = c.res2; L.out_mask = c.out_mask; L.out = c.out;
+    L.K = c.K; L.N = c.N; L.out_cs = c.out_cs; L.res1_cs = c.res1_cs; L.res1_nch = c.res1_nch; L.res2_cs = c.res2_cs;
+    L.res2_nch = c.res2_nch; L.out_mask_cs = c.out_mask_cs; L.act = c.act; L.n64 = c.N > 32 ? 1 : 0;
+    L.dep = i == 0 ? -1 : dep[i];
+    L.slope = c.slope; L.alpha = c.alpha; L.alpha2 = c.alpha2; L.out_mask_slope = c.out_mask_slope;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    TableShadow& sh = g_shadow[table_dev];
+    if (sh.host.size() != tab.size() || memcmp(sh.host.data(), tab.data(), tab.size() * sizeof(W4Layer)) != 0) {
+      // (pageable source: the copy is staged before the call returns, `tab` may die)
+      NEOSR_HIP(hipMemcpyAsync(table_dev, tab.data(), tab.size() * sizeof(W4Layer), hipMemcpyHostToDevice, st));
+      sh.host = tab;
+    }
+  }
+  W4ChainArgs a;
+  memset(&a, 0, sizeof(a));
+  a.layers = (const W4Layer*)table_dev;
+  a.nlayers = n;
+  a.flags = flags;
+  a.status = status_word();
+  NEOSR_CHECK(a.status, "conv chain: no status word");
+  a.B = f.B; a.H = f.H; a.W = f.W; a.in_cs = f.in_cs;
+  a.tiles_x = tiles_x; a.tiles_y = tiles_y;
+  auto lg2 = [](int v) { int s = 0; while ((1 << s) < v) ++s; return (1 << s) == v ? s : -1; };
+  a.tx_shift = lg2(tiles_x);
+  a.ty_shift = lg2(tiles_y);
+  a.xcd = xcd_enabled() ? 1 : 0;
+  a.sync = g_chain_sync;
+  if (neosr_prof_on()) {
+    double fl = 0, by = 0;
+    const double px = (double)f.B * f.H * f.W;
+    for (int i = 0; i < n; ++i) {
+      fl += 2.0 * px * d[i].K * d[i].N * 9.0;
+      by += 4.0 * (px * d[i].K + px * d[i].N + 9.0 * d[i].K * d[i].N);
+    }
+    neosr_prof_begin(f.mode == NEOSR_CONV_FWD ? NEOSR_PROF_CONV_FWD : NEOSR_PROF_CONV_DGRAD, stream, fl, by);
+    neosr_prof_algo(2);
+    neosr_prof_layers(n);
+  }
+  hipLaunchKernelGGL(conv3x3_wino4_chain_kernel, dim3((unsigned)tiles), dim3(768), 0, st, a);
+  if (neosr_prof_on()) neosr_prof_end(stream);
+  NEOSR_LAUNCH_CHECK();
+  return 0;
+}

@@ -8,6 +8,7 @@
 // backward.
 #include "common.h"
 #include "conv_pack.h"
+#include "conv_wino4_chain.h"
 namespace neosr_conv {
 int wino_mode();                  // conv_wino.hip: 0 direct, 1 F(2x2,3x3), 2 F(4x4,3x3)
 extern int g_wino4_concurrency;   // conv_wino4.hip: launch chains running side by side (fill estimate of the F(4x4) kernel)
@@ -105,6 +106,10 @@ struct RrdbLayout {
   // the trunk launches can still reach the direct-to-LDS kernel (Winograd switched off, or buffers of 2 GB and more that
   // the F(4x4) kernel's 32-bit offsets refuse): only then are the direct images worth packing
   bool direct_trunk;
+  // conv3x3_wino4_chain_kernel (conv_wino4_chain.hip): one launch per RRDB and direction; per launch a layer table of
+  // fifteen records and one flag word per 16 x 16-pixel tile, plus one status word for the whole net
+  float *chain_tab_f, *chain_tab_d, *chain_flags;
+  int64_t chain_tab_floats, chain_flag_words;
   int64_t total;
 };
 
@@ -221,6 +226,14 @@ RrdbLayout rrdb_layout(const neosr_rrdbnet_cfg& c, void* ws) {
     L.w4_trunk = neosr_conv::wino_mode() == 2 &&
                  (int64_t)c.B * ((c.H + 15) / 16) * ((c.W + 15) / 16) * ((G + 31) / 32) >= NEOSR_WINO4_MIN_WGS;
     L.direct_trunk = neosr_conv::wino_mode() == 0 || (int64_t)c.B * c.H * c.W * L.CC * 4 >= (int64_t(1) << 31);
+  }
+  {
+    const int64_t tiles = (int64_t)c.B * ((c.H + 15) / 16) * ((c.W + 15) / 16);
+    L.chain_tab_floats = 15 * (int64_t)sizeof(neosr_conv::W4Layer) / 4;
+    L.chain_flag_words = (tiles + 63) & ~(int64_t)63;
+    L.chain_tab_f = b.take(L.NB * L.chain_tab_floats);
+    L.chain_tab_d = b.take(L.NB * L.chain_tab_floats);
+    L.chain_flags = b.take(2 * L.NB * L.chain_flag_words);
   }
   L.total = ((b.off + 255) & ~(int64_t)255);
   return L;
@@ -403,51 +416,78 @@ extern "C" int neosr_rrdbnet_forward(const neosr_rrdbnet_cfg* c, const float* co
     RUN(neosr_conv3x3(&d, st));
   }
   RUN(rrdb_pack_fwd(L, P, st));
-  // trunk: the two halves of the batch are independent launch chains (see Aux)
-  Aux* ax = B >= 2 ? aux_get(0) : nullptr;
+  // trunk.  One descriptor per (RRDB n, RDB r, conv k) over the samples [b0, b0 + nb)
+  auto trunk_desc = [&](int n, int r, int k, int b0, int nb) {
+    const float* pk = L.wpack_f + (int64_t)(3 * n + r) * L.pf_total;
+    const float* wk = L.wwino_f + (int64_t)(3 * n + r) * L.wf_total;
+    const float* wk4 = L.wwino4_f + (int64_t)(3 * n + r) * L.w4f_total;
+    const int64_t po = (int64_t)b0 * H * W;  // pixel offset of these samples
+    float* A = L.act[act_idx(L, 3 * n + r)] + po * CC;
+    neosr_conv_desc d = conv_base(nb, H, W);
+    d.in = A; d.in_cs = CC; d.K = F + k * G;
+    d.w = P[p_rdb(n, r, k)]; d.bias = P[p_rdb(n, r, k) + 1]; d.w_cin = F + k * G;
+    d.w_pack = pk + L.pf_off[k];
+    d.w_wino = L.w4_trunk ? nullptr : wk + L.wf_off[k];   // (only the image kind that was packed is offered)
+    d.w_wino4 = L.w4_trunk ? wk4 + L.w4f_off[k] : nullptr;
+    if (k < 4) {
+      d.w_cout = G;
+      d.out = A + F + k * G; d.out_cs = CC; d.N = G;
+      d.act = NEOSR_ACT_LRELU; d.slope = 0.2f;
+    } else {
+      d.w_cout = F;
+      const bool last = (n == L.NB - 1 && r == 2);
+      d.out = last ? L.trunk + po * F : L.act[act_idx(L, 3 * n + r + 1)] + po * CC;
+      d.out_cs = last ? F : CC;
+      d.N = F;
+      d.alpha = 0.2f; d.res1 = A; d.res1_cs = CC; d.res1_nch = F;
+      if (r == 2) {
+        d.alpha2 = 0.2f; d.res2 = L.act[act_idx(L, 3 * n)] + po * CC; d.res2_cs = CC; d.res2_nch = F;
+      }
+    }
+    return d;
+  };
+  // (a) every RRDB as ONE launch of the chain kernel (conv_wino4_chain.hip): conv k of an RDB depends on the previous
+  // layer only through the newest slice of the concat buffer = the chunk that starts at channel F + (k - 1) G; conv1
+  // reads the previous RDB's output: everything is new (dep 0)
+  bool chained = false;
+  if (L.w4_trunk && neosr_conv::chain_enabled()) {
+    NEOSR_HIP(hipMemsetAsync(L.chain_flags, 0, (size_t)L.NB * L.chain_flag_words * 4, (hipStream_t)st));
+    for (int n = 0; n < L.NB; ++n) {
+      neosr_conv_desc dd[15];
+      int dep[15];
+      for (int r = 0; r < 3; ++r)
+        for (int k = 0; k < 5; ++k) {
+          dd[r * 5 + k] = trunk_desc(n, r, k, 0, B);
+          dep[r * 5 + k] = k == 0 ? 0 : (F + (k - 1) * G) / 32;
+        }
+      const int rc = neosr_conv::launch_wino4_chain(dd, dep, 15, L.chain_tab_f + n * L.chain_tab_floats,
+                                                    (unsigned*)L.chain_flags + n * L.chain_flag_words, st);
+      if (rc > 0) return rc;
+      if (rc < 0) {
+        NEOSR_CHECK(n == 0, "rrdbnet_forward: the chain kernel refused RRDB %d after taking RRDB 0", n);
+        break;
+      }
+      chained = true;
+    }
+  }
+  // (b) one launch per conv: the two halves of the batch are independent launch chains (see Aux)
+  Aux* ax = (!chained && B >= 2) ? aux_get(0) : nullptr;
   const int nhalf = ax ? (g_num_streams < B ? g_num_streams : B) : 1;  // number of launch chains
   if (ax) {
     NEOSR_HIP(hipEventRecord(ax->fork, (hipStream_t)st));
     for (int h = 1; h < nhalf; ++h) NEOSR_HIP(hipStreamWaitEvent(ax->sc[h], ax->fork, 0));
   }
-  {
+  if (!chained) {
   ChainHint hint(nhalf);
   for (int n = 0; n < L.NB; ++n) {
     for (int r = 0; r < 3; ++r) {
-      const float* pk = L.wpack_f + (int64_t)(3 * n + r) * L.pf_total;
-      const float* wk = L.wwino_f + (int64_t)(3 * n + r) * L.wf_total;
-      const float* wk4 = L.wwino4_f + (int64_t)(3 * n + r) * L.w4f_total;
       for (int h = 0; h < nhalf; ++h) {
         const int b0 = (int)((int64_t)B * h / nhalf), nb = (int)((int64_t)B * (h + 1) / nhalf) - b0;
         void* sh = h ? (void*)ax->sc[h] : st;
-        const int64_t po = (int64_t)b0 * H * W;  // pixel offset of this chain's samples
-        float* A = L.act[act_idx(L, 3 * n + r)] + po * CC;
-        for (int k = 0; k < 4; ++k) {
-          neosr_conv_desc d = conv_base(nb, H, W);
-          d.in = A; d.in_cs = CC; d.K = F + k * G;
-          d.w = P[p_rdb(n, r, k)]; d.bias = P[p_rdb(n, r, k) + 1]; d.w_cout = G; d.w_cin = F + k * G;
-          d.w_pack = pk + L.pf_off[k];
-          d.w_wino = L.w4_trunk ? nullptr : wk + L.wf_off[k];   // (only the image kind that was packed is offered)
-          d.w_wino4 = L.w4_trunk ? wk4 + L.w4f_off[k] : nullptr;
-          d.out = A + F + k * G; d.out_cs = CC; d.N = G;
-          d.act = NEOSR_ACT_LRELU; d.slope = 0.2f;
+        for (int k = 0; k < 5; ++k) {
+          const neosr_conv_desc d = trunk_desc(n, r, k, b0, nb);
           RUN(neosr_conv3x3(&d, sh));
         }
-        neosr_conv_desc d = conv_base(nb, H, W);
-        d.in = A; d.in_cs = CC; d.K = CC;
-        d.w = P[p_rdb(n, r, 4)]; d.bias = P[p_rdb(n, r, 4) + 1]; d.w_cout = F; d.w_cin = CC;
-        d.w_pack = pk + L.pf_off[4];
-        d.w_wino = L.w4_trunk ? nullptr : wk + L.wf_off[4];
-        d.w_wino4 = L.w4_trunk ? wk4 + L.w4f_off[4] : nullptr;
-        const bool last = (n == L.NB - 1 && r == 2);
-        d.out = last ? L.trunk + po * F : L.act[act_idx(L, 3 * n + r + 1)] + po * CC;
-        d.out_cs = last ? F : CC;
-        d.N = F;
-        d.alpha = 0.2f; d.res1 = A; d.res1_cs = CC; d.res1_nch = F;
-        if (r == 2) {
-          d.alpha2 = 0.2f; d.res2 = L.act[act_idx(L, 3 * n)] + po * CC; d.res2_cs = CC; d.res2_nch = F;
-        }
-        RUN(neosr_conv3x3(&d, sh));
       }
     }
   }
@@ -617,7 +657,89 @@ int rrdb_backward_impl(const neosr_rrdbnet_cfg* c, const float* const* P, float*
   // of four gradient buffers bounds how far the chains may run ahead: RDB t+3 overwrites the g5 slot of
   // the buffer RDB t's weight gradient reads.
   const int NR = 3 * L.NB;
-  Aux* ax = B >= 2 ? aux_get((MAX_CHAINS + 1) * NR) : nullptr;
+  // data-gradient descriptor of (RRDB n, RDB r, slice j) over the samples [b0, b0 + nb); gbi = ring slot of the RDB's buffer
+  auto dgrad_desc = [&](int n, int r, int j, int gbi, const float* dOut, int b0, int nb) {
+    const float* pk = L.wpack_d + (int64_t)(3 * n + r) * L.pd_total;
+    const float* wk = L.wwino_d + (int64_t)(3 * n + r) * L.wd_total;
+    const float* wk4 = L.wwino4_d + (int64_t)(3 * n + r) * L.w4d_total;
+    const int64_t po = (int64_t)b0 * H * W * CC;
+    const float* A = L.act[3 * n + r] + po;
+    float* GB = L.gb[gbi] + po;
+    float* NG = L.gb[(gbi + 1) & 3] + po;
+    neosr_conv_desc d = conv_base(nb, H, W);
+    d.mode = NEOSR_CONV_DGRAD;
+    d.in = GB; d.in_cs = CC;
+    d.w_pack = pk + L.pd_off[j];
+    d.w_wino = L.w4_trunk ? nullptr : wk + L.wd_off[j];
+    d.w_wino4 = L.w4_trunk ? wk4 + L.w4d_off[j] : nullptr;
+    if (j >= 1) {  // g_j = lrelu'(x_j) * sum over conv5..conv(j+1)
+      d.K = F + (4 - j) * G;
+      d.out = GB + g_off(F, G, j); d.out_cs = CC; d.N = G;
+      d.out_mask = A + F + (j - 1) * G; d.out_mask_cs = CC; d.out_mask_slope = 0.2f;
+    } else {       // gradient wrt the RDB input -> g5 slot of the next RDB's buffer
+      d.K = CC;
+      d.out = NG; d.out_cs = CC; d.N = F;
+      d.alpha = 0.2f; d.res1 = GB; d.res1_cs = CC; d.res1_nch = F;
+      if (r == 2) d.alpha2 = 0.2f;
+      if (r == 0) { d.res2 = dOut + po; d.res2_cs = CC; d.res2_nch = F; }
+    }
+    return d;
+  };
+  auto wgrad_rdb = [&](int n, int r, int gbi, void* sw_) -> int {  // all five weight gradients of this RDB in one launch
+    neosr_wgrad_desc wd[5];
+    for (int m = 1; m <= 5; ++m) {
+      neosr_wgrad_desc w = wgrad_base(B, H, W);
+      w.in = L.act[3 * n + r]; w.in_cs = CC; w.K = F + (m - 1) * G;
+      w.g = L.gb[gbi] + g_off(F, G, m); w.g_cs = CC; w.N = m == 5 ? F : G;
+      w.scale = (r == 2) ? 0.04f : 0.2f;
+      w.dw = Gp[p_rdb(n, r, m - 1)]; w.db = Gp[p_rdb(n, r, m - 1) + 1];
+      wd[m - 1] = w;
+    }
+    return neosr_conv3x3_wgrad_multi(wd, 5, L.wg_ws, sw_);
+  };
+  int gbi = 0, t = 0;
+  const float* dOut = nullptr;  // gradient wrt the output of the current RRDB (g5 slot of its last RDB)
+  float* prev = nullptr;
+  // (a) the fifteen data-gradient convolutions of an RRDB as ONE launch of the chain kernel (conv_wino4_chain.hip),
+  // its three weight-gradient launches behind it on the same stream (a chain workgroup and a weight-gradient workgroup
+  // do not fit one CU together, so a second stream could only interleave them workgroup by workgroup).  Slice j of an
+  // RDB's gradient buffer is produced from the prefix in front of it: the newest slice is the last chunk again, and
+  // g4 of the next RDB reads the g5 slot the previous layer wrote (dep 0).
+  bool chained = false;
+  if (L.w4_trunk && neosr_conv::chain_enabled()) {
+    unsigned* flags = (unsigned*)L.chain_flags + (int64_t)L.NB * L.chain_flag_words;
+    NEOSR_HIP(hipMemsetAsync(flags, 0, (size_t)L.NB * L.chain_flag_words * 4, (hipStream_t)st));
+    for (int n = L.NB - 1; n >= 0; --n) {
+      neosr_conv_desc dd[15];
+      int dep[15];
+      const int g0 = gbi;
+      dOut = L.gb[g0];
+      for (int r = 2, i = 0; r >= 0; --r)
+        for (int j = 4; j >= 0; --j, ++i) {
+          dd[i] = dgrad_desc(n, r, j, (g0 + (2 - r)) & 3, dOut, 0, B);
+          dep[i] = j == 4 ? 0 : (F + (j == 0 ? 3 : 3 - j) * G) / 32;
+        }
+      const int rc = neosr_conv::launch_wino4_chain(dd, dep, 15, L.chain_tab_d + n * L.chain_tab_floats,
+                                                    flags + n * L.chain_flag_words, st);
+      if (rc > 0) return rc;
+      if (rc < 0) {
+        NEOSR_CHECK(n == L.NB - 1, "rrdbnet_backward: the chain kernel refused RRDB %d after taking the last one", n);
+        break;
+      }
+      chained = true;
+      for (int r = 2; r >= 0; --r) RUN(wgrad_rdb(n, r, (g0 + (2 - r)) & 3, st));
+      for (int i = 0; i < n_marks; ++i)
+        if (mark_block[i] == n) NEOSR_HIP(hipEventRecord((hipEvent_t)mark_event[i], (hipStream_t)st));
+      gbi = (g0 + 3) & 3;
+      prev = L.gb[gbi];
+    }
+  }
+  // (b) one launch per convolution.
+  // Two launch chains again (see Aux) for the data gradients; the weight gradients (one full-batch
+  // launch per RDB, independent of the chain that follows) run on a third stream behind them.  The ring
+  // of four gradient buffers bounds how far the chains may run ahead: RDB t+3 overwrites the g5 slot of
+  // the buffer RDB t's weight gradient reads.
+  Aux* ax = (!chained && B >= 2) ? aux_get((MAX_CHAINS + 1) * NR) : nullptr;
   const int nhalf = ax ? (g_num_streams < B ? g_num_streams : B) : 1;  // number of launch chains
   void* sw = ax ? (void*)ax->s3 : st;  // weight-gradient stream
   if (ax) {
@@ -625,47 +747,17 @@ int rrdb_backward_impl(const neosr_rrdbnet_cfg* c, const float* const* P, float*
     for (int h = 1; h < nhalf; ++h) NEOSR_HIP(hipStreamWaitEvent(ax->sc[h], ax->fork, 0));
     NEOSR_HIP(hipStreamWaitEvent(ax->s3, ax->fork, 0));
   }
-  int gbi = 0, t = 0;
-  const float* dOut = nullptr;  // gradient wrt the output of the current RRDB (g5 slot of its last RDB)
-  float* prev = nullptr;
-  {
+  if (!chained) {
   ChainHint hint(nhalf);
   for (int n = L.NB - 1; n >= 0; --n) {
     for (int r = 2; r >= 0; --r, ++t) {
       if (r == 2) dOut = L.gb[gbi];
-      const float* pk = L.wpack_d + (int64_t)(3 * n + r) * L.pd_total;
-      const float* wk = L.wwino_d + (int64_t)(3 * n + r) * L.wd_total;
-      const float* wk4 = L.wwino4_d + (int64_t)(3 * n + r) * L.w4d_total;
       for (int h = 0; h < nhalf; ++h) {
         const int b0 = (int)((int64_t)B * h / nhalf), nb = (int)((int64_t)B * (h + 1) / nhalf) - b0;
         void* sh = h ? (void*)ax->sc[h] : st;
-        const int64_t po = (int64_t)b0 * H * W * CC;
-        const float* A = L.act[3 * n + r] + po;
-        float* GB = L.gb[gbi] + po;
-        float* NG = L.gb[(gbi + 1) & 3] + po;
-        for (int j = 4; j >= 1; --j) {  // g_j = lrelu'(x_j) * sum over conv5..conv(j+1)
-          neosr_conv_desc d = conv_base(nb, H, W);
-          d.mode = NEOSR_CONV_DGRAD;
-          d.in = GB; d.in_cs = CC; d.K = F + (4 - j) * G;
-          d.w_pack = pk + L.pd_off[j];
-          d.w_wino = L.w4_trunk ? nullptr : wk + L.wd_off[j];
-          d.w_wino4 = L.w4_trunk ? wk4 + L.w4d_off[j] : nullptr;
-          d.out = GB + g_off(F, G, j); d.out_cs = CC; d.N = G;
-          d.out_mask = A + F + (j - 1) * G; d.out_mask_cs = CC; d.out_mask_slope = 0.2f;
-          RUN(neosr_conv3x3(&d, sh));
-        }
-        {  // gradient wrt the RDB input -> g5 slot of the next RDB's buffer
-          if (ax && t >= 3) NEOSR_HIP(hipStreamWaitEvent((hipStream_t)sh, ax->ev[MAX_CHAINS * NR + t - 3], 0));
-          neosr_conv_desc d = conv_base(nb, H, W);
-          d.mode = NEOSR_CONV_DGRAD;
-          d.in = GB; d.in_cs = CC; d.K = CC;
-          d.w_pack = pk + L.pd_off[0];
-          d.w_wino = L.w4_trunk ? nullptr : wk + L.wd_off[0];
-          d.w_wino4 = L.w4_trunk ? wk4 + L.w4d_off[0] : nullptr;
-          d.out = NG; d.out_cs = CC; d.N = F;
-          d.alpha = 0.2f; d.res1 = GB; d.res1_cs = CC; d.res1_nch = F;
-          if (r == 2) d.alpha2 = 0.2f;
-          if (r == 0) { d.res2 = dOut + po; d.res2_cs = CC; d.res2_nch = F; }
+        for (int j = 4; j >= 0; --j) {
+          if (j == 0 && ax && t >= 3) NEOSR_HIP(hipStreamWaitEvent((hipStream_t)sh, ax->ev[MAX_CHAINS * NR + t - 3], 0));
+          const neosr_conv_desc d = dgrad_desc(n, r, j, gbi, dOut, b0, nb);
           RUN(neosr_conv3x3(&d, sh));
         }
         if (ax) {
@@ -673,17 +765,7 @@ int rrdb_backward_impl(const neosr_rrdbnet_cfg* c, const float* const* P, float*
           NEOSR_HIP(hipStreamWaitEvent(ax->s3, ax->ev[h * NR + t], 0));
         }
       }
-      neosr_wgrad_desc wd[5];
-      for (int m = 1; m <= 5; ++m) {
-        neosr_wgrad_desc w = wgrad_base(B, H, W);
-        w.in = L.act[3 * n + r]; w.in_cs = CC; w.K = F + (m - 1) * G;
-        w.g = L.gb[gbi] + g_off(F, G, m); w.g_cs = CC; w.N = m == 5 ? F : G;
-        w.scale = (r == 2) ? 0.04f : 0.2f;
-        w.dw = Gp[p_rdb(n, r, m - 1)]; w.db = Gp[p_rdb(n, r, m - 1) + 1];
-        wd[m - 1] = w;
-      }
-      // all five weight gradients of this RDB in one launch
-      RUN(neosr_conv3x3_wgrad_multi(wd, 5, L.wg_ws, sw));
+      RUN(wgrad_rdb(n, r, gbi, sw));
       if (ax) NEOSR_HIP(hipEventRecord(ax->ev[MAX_CHAINS * NR + t], ax->s3));
       // gradient marks: the weight gradients of RRDB n and of everything behind it in the parameter order
       // (RRDBs n+1.., conv_body .. conv_last, which ran on `st` before the fork) are enqueued on `sw` -> the

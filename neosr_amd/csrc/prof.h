@@ -17,4 +17,5 @@ enum : int {
 bool neosr_prof_on();
 void neosr_prof_begin(int cls, void* stream, double flops, double bytes);
 void neosr_prof_algo(int algo);  // the launch just begun: 1 = Winograd F(2x2,3x3), 2 = F(4x4,3x3) (executed FLOPs)
+void neosr_prof_layers(int n);  // the launch just begun runs n layers (conv3x3_wino4_chain_kernel)
 void neosr_prof_end(void* stream);

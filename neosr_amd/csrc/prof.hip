@@ -53,6 +53,11 @@ void neosr_prof_algo(int algo) {
   g_algo[g_last_cls][algo] += 1;
 }
 
+// the launch just begun is a chain of n layers: they count as n launches of the class (per-layer averages stay comparable)
+void neosr_prof_layers(int n) {
+  if (n > 1) g_launch[g_last_cls] += n - 1, g_algo[g_last_cls][2] += n - 1;
+}
+
 void neosr_prof_end(void* stream) { hipEventRecord(g_recs.back().b, (hipStream_t)stream); }
 
 extern "C" int neosr_prof_enable(int on) {
