@@ -55,6 +55,7 @@ __device__ __forceinline__ int xcd_tile(int bid, int ntiles, int on) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
 }
 
+unsigned long long* debug_timeline();  // neosr_debug_set_timeline (NEOSR_TIMELINE builds)
 bool xcd_enabled();  // NEOSR_AMD_XCD=0 / neosr_set_xcd_aware(0) restores dispatch order (A/B measurements)
 
 

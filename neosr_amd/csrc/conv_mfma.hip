@@ -357,7 +357,9 @@ extern "C" int neosr_set_xcd_aware(int on) {
   return prev;
 }
 
-// debug hook (NEOSR_TIMELINE builds only record anything): device buffer of 4*64 uint64
+unsigned long long* neosr_conv::debug_timeline() { return g_timeline; }
+
+// debug hook (NEOSR_TIMELINE builds only record anything): device buffer of 4*64 uint64 (chain kernel: 12*128)
 extern "C" int neosr_debug_set_timeline(void* dev_buf) {
   g_timeline = (unsigned long long*)dev_buf;
   return 0;

@@ -31,6 +31,7 @@ struct W4ChainArgs {
   int32_t B, H, W, in_cs;
   int32_t tiles_x, tiles_y, tx_shift, ty_shift, xcd;
   int32_t sync;       // 0: flag waits skipped (timing experiments only: results are then racy)
+  unsigned long long* timeline;  // debug only (NEOSR_TIMELINE builds): [wave 12][layer 16][mark 8] clocks of workgroup 0
 };
 
 bool chain_enabled();  // NEOSR_AMD_CHAIN=0 / neosr_set_conv_chain(0): one launch per layer

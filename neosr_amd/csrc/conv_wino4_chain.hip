@@ -39,6 +39,16 @@ typedef __attribute__((address_space(1))) unsigned gu32;
 constexpr int AUX_SC1 = 16;  // cache-policy bit of buffer loads / stores: sc1 (write-through store, L1-bypassing load)
 constexpr unsigned SPIN_LIMIT = 1u << 21;
 
+#ifdef NEOSR_TIMELINE
+#define CTL_MARK(l, m)                                                                            \
+  do {                                                                                            \
+    if (args.timeline && blockIdx.x == 0 && (threadIdx.x & 63) == 0 && (l) < 16)                  \
+      args.timeline[((threadIdx.x >> 6) * 16 + (l)) * 8 + (m)] = clock64();                       \
+  } while (0)
+#else
+#define CTL_MARK(l, m) do {} while (0)
+#endif
+
 __global__ __attribute__((amdgpu_flat_work_group_size(768, 768), amdgpu_waves_per_eu(3, 3)))
 void conv3x3_wino4_chain_kernel(const W4ChainArgs args) {
   __shared__ __attribute__((aligned(1024))) float ldsA[QBUF];
@@ -176,6 +186,7 @@ void conv3x3_wino4_chain_kernel(const W4ChainArgs args) {
         }
     };
     f32x4 ulo[3][2], uhi[3][2], vlo[3], vhi[3];
+    CTL_MARK(l, 0);
     load_u3(0, N64 ? 0 : sel, 0, ulo);
     __builtin_amdgcn_sched_barrier(0);
 
@@ -185,7 +196,9 @@ void conv3x3_wino4_chain_kernel(const W4ChainArgs args) {
     if (l == 0 || (dep != 0 && !c0_issued)) issue(rin, 0, ldsC);   // (else: requested by the previous layer, or after the poll)
     // previous layer's stores drained (every storing wave), chunk 0 landed, then publish
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    CTL_MARK(l, 1);
     __syncthreads();
+    CTL_MARK(l, 2);
     if (l > 0 && tid == 0) __hip_atomic_store((gu32*)args.flags + my_flag, (unsigned)l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (dep == 0) {  // the whole input is new: wait in the open
       if (wave == 0) poll_wait(poll_load(), (unsigned)l);
@@ -195,6 +208,7 @@ void conv3x3_wino4_chain_kernel(const W4ChainArgs args) {
       __syncthreads();
     }
     const int pollc = dep >= 2 ? dep - 2 : -1;
+    CTL_MARK(l, 3);
 
     const bool three = ti == 0 || ti == 5;
     const float ap = three ? -5.f : (ti <= 2 ? -4.f : -1.f);
@@ -293,6 +307,7 @@ void conv3x3_wino4_chain_kernel(const W4ChainArgs args) {
       __syncthreads();
     }
     c0_issued = next_c0;
+    CTL_MARK(l, 4);
     mac3(3, vhi, uhi);
     __builtin_amdgcn_s_setprio(0);
 
@@ -373,7 +388,9 @@ void conv3x3_wino4_chain_kernel(const W4ChainArgs args) {
         *reinterpret_cast<f32x4*>(p + 48 * ES) = x3v;
       }
     }
+    CTL_MARK(l, 5);
     __syncthreads();
+    CTL_MARK(l, 6);
     if (!fin) return;
 
     auto epi_finish = [&](int et, Epi& E) {
@@ -421,6 +438,7 @@ void conv3x3_wino4_chain_kernel(const W4ChainArgs args) {
       epi_load(et0 + 8, E1);
       epi_finish(et0 + 8, E1);
     }
+    CTL_MARK(l, 7);
   };
 
   for (int l = 0; l < nl; ++l) {
@@ -547,6 +565,7 @@ int neosr_conv::launch_wino4_chain(const neosr_conv_desc* d, const int* dep, int
   a.ty_shift = lg2(tiles_y);
   a.xcd = xcd_enabled() ? 1 : 0;
   a.sync = g_chain_sync;
+  a.timeline = debug_timeline();
   if (neosr_prof_on()) {
     double fl = 0, by = 0;
     const double px = (double)f.B * f.H * f.W;

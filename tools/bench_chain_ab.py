@@ -1,7 +1,8 @@
 """A/B on one box: esrgan B=16 training step with the trunk as chain launches vs per-convolution launches."""
 import json, sys, time
 import torch
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from neosr_amd import _C
 from neosr_amd.archs import build_network
 
