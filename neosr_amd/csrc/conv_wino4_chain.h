@@ -23,8 +23,10 @@ struct W4Layer {  // device-side record of one layer, 128 bytes (read with scala
 };
 static_assert(sizeof(W4Layer) == 128, "W4Layer is read as two 64-byte scalar loads");
 
+constexpr int W4_MAX_LAYERS = 15;   // (15 x 128 bytes + the header below stay under the 4 KB kernel-argument segment)
+
 struct W4ChainArgs {
-  const W4Layer* layers;
+  W4Layer layers[W4_MAX_LAYERS];   // the layer table travels in the kernel arguments: constant address space, no upload
   unsigned* flags;    // one word per pixel tile: layers finished by the tile's workgroup; zeroed before the launch
   unsigned* status;   // [0] != 0: a flag wait ran into its spin bound (value = 1 + the epoch it waited for); sticky
   int32_t nlayers;
@@ -34,10 +36,11 @@ struct W4ChainArgs {
   unsigned long long* timeline;  // debug only (NEOSR_TIMELINE builds): [wave 12][layer 16][mark 8] clocks of workgroup 0
 };
 
+int chain_max_tiles();  // pixel tiles (= workgroups) one chain launch may have: the CU count of the device
 bool chain_enabled();  // NEOSR_AMD_CHAIN=0 / neosr_set_conv_chain(0): one launch per layer
 // `dep[i]`: see W4Layer::dep (dep[0] is ignored: layer 0 only reads what earlier launches wrote).  All layers share B, H,
-// W and the input channel stride.  Returns 0 = launched, 1 = error (neosr_last_error), -1 = the table does not qualify
+// W and the input channel stride; n <= W4_MAX_LAYERS.  Returns 0 = launched, 1 = error (neosr_last_error), -1 = the table does not qualify
 // (geometry, options, more tiles than CUs, chain switched off): the caller launches the layers one by one.
-int launch_wino4_chain(const neosr_conv_desc* d, const int* dep, int n, void* table_dev, unsigned* flags, void* stream);
+int launch_wino4_chain(const neosr_conv_desc* d, const int* dep, int n, unsigned* flags, void* stream);
 
 }  // namespace neosr_conv

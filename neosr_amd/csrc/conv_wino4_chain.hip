@@ -137,18 +137,16 @@ void conv3x3_wino4_chain_kernel(const W4ChainArgs args) {
     }
   };
 
-  // the layer table through the CONSTANT address space: uniform loads from it are scalar loads whatever the kernel has
-  // stored in between (from a plain global pointer hipcc takes a vector load behind the first store of the loop — every
-  // buffer resource built from it would then be "divergent" and each buffer instruction a waterfall loop)
-  typedef const __attribute__((address_space(4))) W4Layer* ctab_t;
-  const ctab_t tab = (ctab_t)(uintptr_t)args.layers;
+  // (the layer table is part of the kernel arguments: uniform reads of args.layers[l] are scalar loads from the
+  // kernel-argument segment whatever the kernel has stored in between; only direct member reads — taking the array's
+  // address makes hipcc copy all of it to scratch)
   const int nl = args.nlayers;
   bool c0_issued = false;   // chunk 0 of the layer about to start was requested by the previous layer
 
   auto layer = [&](auto n64tag, const int l) {
     constexpr bool N64 = decltype(n64tag)::value;
     W4Layer L;
-#define NEOSR_LF(f) L.f = tab[l].f
+#define NEOSR_LF(f) L.f = args.layers[l].f
     NEOSR_LF(in); NEOSR_LF(u); NEOSR_LF(bias); NEOSR_LF(res1); NEOSR_LF(res2); NEOSR_LF(out_mask); NEOSR_LF(out);
     NEOSR_LF(K); NEOSR_LF(N); NEOSR_LF(out_cs); NEOSR_LF(res1_cs); NEOSR_LF(res1_nch); NEOSR_LF(res2_cs); NEOSR_LF(res2_nch);
     NEOSR_LF(out_mask_cs); NEOSR_LF(act); NEOSR_LF(dep); NEOSR_LF(slope); NEOSR_LF(alpha); NEOSR_LF(alpha2); NEOSR_LF(out_mask_slope);
@@ -266,9 +264,9 @@ void conv3x3_wino4_chain_kernel(const W4ChainArgs args) {
     bool next_c0 = false;
     rsrc_t rin_next = rin;
     if (l + 1 < nl) {
-      const int dn = tab[l + 1].dep;
+      const int dn = args.layers[l + 1].dep;
       next_c0 = dn != 0 && dn != 1;
-      rin_next = make_rin(tab[l + 1].in, tab[l + 1].K);
+      rin_next = make_rin(args.layers[l + 1].in, args.layers[l + 1].K);
     }
 
     for (int c = 0; c < nchunks; ++c) {
@@ -442,18 +440,14 @@ void conv3x3_wino4_chain_kernel(const W4ChainArgs args) {
   };
 
   for (int l = 0; l < nl; ++l) {
-    const int n64 = tab[l].n64;
+    const int n64 = args.layers[l].n64;
     if (n64) layer(std::true_type{}, l);
     else layer(std::false_type{}, l);
   }
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------
-struct TableShadow {
-  std::vector<W4Layer> host;
-};
 std::mutex g_mu;
-std::map<const void*, TableShadow> g_shadow;   // device table -> what it holds
 int g_chain_on = -1;                            // -1: read NEOSR_AMD_CHAIN on first use (default on)
 int g_chain_sync = 1;                           // debug: 0 = flag waits skipped (timing only, racy)
 
@@ -502,25 +496,32 @@ extern "C" int neosr_conv_chain_status(void) {
   return (int)v;
 }
 
-// Returns 0 on success, 1 on error (message set), -1 when the layers do not qualify (caller launches them one by one).
-int neosr_conv::launch_wino4_chain(const neosr_conv_desc* d, const int* dep, int n, void* table_dev, unsigned* flags,
-                                   void* stream) {
-  if (n < 1 || !chain_enabled()) return -1;
-  const neosr_conv_desc& f = d[0];
-  const int tiles_x = ceil_div(f.W, QT), tiles_y = ceil_div(f.H, QT);
-  const int64_t tiles = (int64_t)tiles_x * tiles_y * f.B;
+// Workgroups of a chain launch that are certainly co-resident: one per CU of the current device (MI355X: 256 when no
+// device is visible, e.g. while sizing a workspace on a build host).
+int neosr_conv::chain_max_tiles() {
   static int n_cu = 0;
   if (!n_cu) {
     int dev = 0;
     hipDeviceProp_t p;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return -1;
-    n_cu = p.multiProcessorCount;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 256;
+    n_cu = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
   }
-  if (tiles > n_cu) return -1;   // one resident workgroup per tile, one workgroup per CU (153 KB of LDS)
+  return n_cu;
+}
+
+// Returns 0 on success, 1 on error (message set), -1 when the layers do not qualify (caller launches them one by one).
+int neosr_conv::launch_wino4_chain(const neosr_conv_desc* d, const int* dep, int n, unsigned* flags, void* stream) {
+  if (n < 1 || n > W4_MAX_LAYERS || !chain_enabled()) return -1;
+  const neosr_conv_desc& f = d[0];
+  const int tiles_x = ceil_div(f.W, QT), tiles_y = ceil_div(f.H, QT);
+  const int64_t tiles = (int64_t)tiles_x * tiles_y * f.B;
+  if (tiles > chain_max_tiles()) return -1;   // one resident workgroup per tile, one workgroup per CU (153 KB of LDS)
   for (int i = 0; i < n; ++i)
     if (d[i].N > 32 && wino4_n64_mode() == 0) return -1;   // 64 output channels need the 64-channel wave mapping here
   auto small = [&](const void* p, int cs) { return !p || (int64_t)f.B * f.H * f.W * cs * 4 < (int64_t(1) << 31); };
-  std::vector<W4Layer> tab(n);
+  W4ChainArgs a;
+  memset(&a, 0, sizeof(a));
+  W4Layer* tab = a.layers;
   for (int i = 0; i < n; ++i) {
     const neosr_conv_desc& c = d[i];
     if (c.B != f.B || c.H != f.H || c.W != f.W || c.in_cs != f.in_cs) return -1;
@@ -542,18 +543,6 @@ int neosr_conv::launch_wino4_chain(const neosr_conv_desc* d, const int* dep, int
     L.slope = c.slope; L.alpha = c.alpha; L.alpha2 = c.alpha2; L.out_mask_slope = c.out_mask_slope;
   }
   hipStream_t st = (hipStream_t)stream;
-  {
-    std::lock_guard<std::mutex> lk(g_mu);
-    TableShadow& sh = g_shadow[table_dev];
-    if (sh.host.size() != tab.size() || memcmp(sh.host.data(), tab.data(), tab.size() * sizeof(W4Layer)) != 0) {
-      // (pageable source: the copy is staged before the call returns, `tab` may die)
-      NEOSR_HIP(hipMemcpyAsync(table_dev, tab.data(), tab.size() * sizeof(W4Layer), hipMemcpyHostToDevice, st));
-      sh.host = tab;
-    }
-  }
-  W4ChainArgs a;
-  memset(&a, 0, sizeof(a));
-  a.layers = (const W4Layer*)table_dev;
   a.nlayers = n;
   a.flags = flags;
   a.status = status_word();

@@ -106,10 +106,12 @@ struct RrdbLayout {
   // the trunk launches can still reach the direct-to-LDS kernel (Winograd switched off, or buffers of 2 GB and more that
   // the F(4x4) kernel's 32-bit offsets refuse): only then are the direct images worth packing
   bool direct_trunk;
-  // conv3x3_wino4_chain_kernel (conv_wino4_chain.hip): one launch per RRDB and direction; per launch a layer table of
-  // fifteen records and one flag word per 16 x 16-pixel tile, plus one status word for the whole net
-  float *chain_tab_f, *chain_tab_d, *chain_flags;
-  int64_t chain_tab_floats, chain_flag_words;
+  // conv3x3_wino4_chain_kernel (conv_wino4_chain.hip): one launch per RRDB and direction (the fifteen layer records travel
+  // in the kernel arguments); per launch one flag word per 16 x 16-pixel tile
+  // A batch with more tiles than CUs runs as `chain_groups` launches over consecutive groups of `chain_gb` samples.
+  float* chain_flags;
+  int64_t chain_flag_words;
+  int chain_groups, chain_gb;
   int64_t total;
 };
 
@@ -228,12 +230,13 @@ RrdbLayout rrdb_layout(const neosr_rrdbnet_cfg& c, void* ws) {
     L.direct_trunk = neosr_conv::wino_mode() == 0 || (int64_t)c.B * c.H * c.W * L.CC * 4 >= (int64_t(1) << 31);
   }
   {
-    const int64_t tiles = (int64_t)c.B * ((c.H + 15) / 16) * ((c.W + 15) / 16);
-    L.chain_tab_floats = 15 * (int64_t)sizeof(neosr_conv::W4Layer) / 4;
-    L.chain_flag_words = (tiles + 63) & ~(int64_t)63;
-    L.chain_tab_f = b.take(L.NB * L.chain_tab_floats);
-    L.chain_tab_d = b.take(L.NB * L.chain_tab_floats);
-    L.chain_flags = b.take(2 * L.NB * L.chain_flag_words);
+    const int64_t tps = (int64_t)((c.H + 15) / 16) * ((c.W + 15) / 16);   // tiles per sample
+    const int64_t cap = neosr_conv::chain_max_tiles();
+    L.chain_gb = tps <= cap ? (int)(cap / tps < c.B ? cap / tps : c.B) : 0;  // samples per launch (0: a sample alone is too big)
+    L.chain_groups = L.chain_gb ? (c.B + L.chain_gb - 1) / L.chain_gb : 0;
+    L.chain_flag_words = (tps * (L.chain_gb ? L.chain_gb : 1) + 63) & ~(int64_t)63;
+    const int ng = L.chain_groups ? L.chain_groups : 1;
+    L.chain_flags = b.take(2 * L.NB * ng * L.chain_flag_words);
   }
   L.total = ((b.off + 255) & ~(int64_t)255);
   return L;
@@ -450,25 +453,27 @@ extern "C" int neosr_rrdbnet_forward(const neosr_rrdbnet_cfg* c, const float* co
   // layer only through the newest slice of the concat buffer = the chunk that starts at channel F + (k - 1) G; conv1
   // reads the previous RDB's output: everything is new (dep 0)
   bool chained = false;
-  if (L.w4_trunk && neosr_conv::chain_enabled()) {
-    NEOSR_HIP(hipMemsetAsync(L.chain_flags, 0, (size_t)L.NB * L.chain_flag_words * 4, (hipStream_t)st));
-    for (int n = 0; n < L.NB; ++n) {
-      neosr_conv_desc dd[15];
-      int dep[15];
-      for (int r = 0; r < 3; ++r)
-        for (int k = 0; k < 5; ++k) {
-          dd[r * 5 + k] = trunk_desc(n, r, k, 0, B);
-          dep[r * 5 + k] = k == 0 ? 0 : (F + (k - 1) * G) / 32;
+  if (L.w4_trunk && L.chain_groups && neosr_conv::chain_enabled()) {
+    const int ng = L.chain_groups;
+    NEOSR_HIP(hipMemsetAsync(L.chain_flags, 0, (size_t)L.NB * ng * L.chain_flag_words * 4, (hipStream_t)st));
+    for (int n = 0; n < L.NB && (n == 0 || chained); ++n)
+      for (int gi = 0; gi < ng; ++gi) {
+        const int b0 = gi * L.chain_gb, nb = B - b0 < L.chain_gb ? B - b0 : L.chain_gb;
+        neosr_conv_desc dd[15];
+        int dep[15];
+        for (int r = 0; r < 3; ++r)
+          for (int k = 0; k < 5; ++k) {
+            dd[r * 5 + k] = trunk_desc(n, r, k, b0, nb);
+            dep[r * 5 + k] = k == 0 ? 0 : (F + (k - 1) * G) / 32;
+          }
+        const int rc = neosr_conv::launch_wino4_chain(dd, dep, 15, (unsigned*)L.chain_flags + (n * ng + gi) * L.chain_flag_words, st);
+        if (rc > 0) return rc;
+        if (rc < 0) {
+          NEOSR_CHECK(n == 0 && gi == 0, "rrdbnet_forward: the chain kernel refused RRDB %d after taking RRDB 0", n);
+          break;
         }
-      const int rc = neosr_conv::launch_wino4_chain(dd, dep, 15, L.chain_tab_f + n * L.chain_tab_floats,
-                                                    (unsigned*)L.chain_flags + n * L.chain_flag_words, st);
-      if (rc > 0) return rc;
-      if (rc < 0) {
-        NEOSR_CHECK(n == 0, "rrdbnet_forward: the chain kernel refused RRDB %d after taking RRDB 0", n);
-        break;
+        chained = true;
       }
-      chained = true;
-    }
   }
   // (b) one launch per conv: the two halves of the batch are independent launch chains (see Aux)
   Aux* ax = (!chained && B >= 2) ? aux_get(0) : nullptr;
@@ -706,26 +711,28 @@ int rrdb_backward_impl(const neosr_rrdbnet_cfg* c, const float* const* P, float*
   // RDB's gradient buffer is produced from the prefix in front of it: the newest slice is the last chunk again, and
   // g4 of the next RDB reads the g5 slot the previous layer wrote (dep 0).
   bool chained = false;
-  if (L.w4_trunk && neosr_conv::chain_enabled()) {
-    unsigned* flags = (unsigned*)L.chain_flags + (int64_t)L.NB * L.chain_flag_words;
-    NEOSR_HIP(hipMemsetAsync(flags, 0, (size_t)L.NB * L.chain_flag_words * 4, (hipStream_t)st));
+  if (L.w4_trunk && L.chain_groups && neosr_conv::chain_enabled()) {
+    const int ng = L.chain_groups;
+    unsigned* flags = (unsigned*)L.chain_flags + (int64_t)L.NB * ng * L.chain_flag_words;
+    NEOSR_HIP(hipMemsetAsync(flags, 0, (size_t)L.NB * ng * L.chain_flag_words * 4, (hipStream_t)st));
     for (int n = L.NB - 1; n >= 0; --n) {
-      neosr_conv_desc dd[15];
-      int dep[15];
       const int g0 = gbi;
       dOut = L.gb[g0];
-      for (int r = 2, i = 0; r >= 0; --r)
-        for (int j = 4; j >= 0; --j, ++i) {
-          dd[i] = dgrad_desc(n, r, j, (g0 + (2 - r)) & 3, dOut, 0, B);
-          dep[i] = j == 4 ? 0 : (F + (j == 0 ? 3 : 3 - j) * G) / 32;
-        }
-      const int rc = neosr_conv::launch_wino4_chain(dd, dep, 15, L.chain_tab_d + n * L.chain_tab_floats,
-                                                    flags + n * L.chain_flag_words, st);
-      if (rc > 0) return rc;
-      if (rc < 0) {
-        NEOSR_CHECK(n == L.NB - 1, "rrdbnet_backward: the chain kernel refused RRDB %d after taking the last one", n);
-        break;
+      int rc = 0;
+      for (int gi = 0; gi < ng && rc == 0; ++gi) {
+        const int b0 = gi * L.chain_gb, nb = B - b0 < L.chain_gb ? B - b0 : L.chain_gb;
+        neosr_conv_desc dd[15];
+        int dep[15];
+        for (int r = 2, i = 0; r >= 0; --r)
+          for (int j = 4; j >= 0; --j, ++i) {
+            dd[i] = dgrad_desc(n, r, j, (g0 + (2 - r)) & 3, dOut, b0, nb);
+            dep[i] = j == 4 ? 0 : (F + (j == 0 ? 3 : 3 - j) * G) / 32;
+          }
+        rc = neosr_conv::launch_wino4_chain(dd, dep, 15, flags + (n * ng + gi) * L.chain_flag_words, st);
+        if (rc < 0) NEOSR_CHECK(n == L.NB - 1 && gi == 0, "rrdbnet_backward: the chain kernel refused RRDB %d after taking the last one", n);
       }
+      if (rc > 0) return rc;
+      if (rc < 0) break;
       chained = true;
       for (int r = 2; r >= 0; --r) RUN(wgrad_rdb(n, r, (g0 + (2 - r)) & 3, st));
       for (int i = 0; i < n_marks; ++i)

@@ -38,7 +38,7 @@ def _fwd_bwd(net, x, gy):
     return y.detach().clone(), [p.grad.detach().clone() for p in net.parameters()]
 
 
-@pytest.mark.parametrize("batch,hw,blocks", [(16, 64, 3), (4, 64, 2), (3, 48, 2), (5, 80, 1)])
+@pytest.mark.parametrize("batch,hw,blocks", [(16, 64, 3), (4, 64, 2), (3, 48, 2), (5, 80, 1), (20, 64, 1)])
 def test_chain_is_bit_identical_to_per_layer_launches(lib, batch, hw, blocks):
     net = _net(blocks)
     g = torch.Generator().manual_seed(batch * 100 + hw)
