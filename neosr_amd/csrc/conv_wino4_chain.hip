@@ -49,6 +49,18 @@ constexpr unsigned SPIN_LIMIT = 1u << 21;
 #define CTL_MARK(l, m) do {} while (0)
 #endif
 
+typedef int w4c_i32x4 __attribute__((ext_vector_type(4)));
+// 16-byte write-through (sc1) buffer store as inline assembly: hipcc's wait-count pass does not see it.  vmcnt counts loads
+// and stores together and they complete out of order with each other, so behind a store it knows about the pass can only
+// wait for "everything" at the next use of ANY loaded register — in a 64-channel layer the second unit's epilogue
+// operands would wait for the first unit's write-through stores to drain (~2.7k cycles).  Hidden, its counted waits stay
+// exact for loads (pending stores only make the hardware count larger: a wait can last longer than needed, never
+// shorter); the one place that needs the stores themselves complete — the barrier in front of the flag — says
+// s_waitcnt vmcnt(0) explicitly.  (s_nop: the store reads four data registers; the next instruction may overwrite them.)
+__device__ __forceinline__ void store16_sc1(f32x4 v, w4c_i32x4 rsrc, int voff) {
+  asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen sc1\n\ts_nop 1" : : "v"(v), "v"(voff), "s"(rsrc) : "memory");
+}
+
 __global__ __attribute__((amdgpu_flat_work_group_size(768, 768), amdgpu_waves_per_eu(3, 3)))
 void conv3x3_wino4_chain_kernel(const W4ChainArgs args) {
   __shared__ __attribute__((aligned(1024))) float ldsA[QBUF];
@@ -322,7 +334,9 @@ void conv3x3_wino4_chain_kernel(const W4ChainArgs args) {
     if (L.act == ACT_LRELU) s_uni = L.slope;
     else if (L.act == ACT_RELU) s_uni = 0.f;
     typedef decltype(__builtin_amdgcn_raw_buffer_load_b128(ru, 0, 0, 0)) raw4_t;
-    const auto r_out = __builtin_amdgcn_make_buffer_rsrc(L.out, 0, 0x7ffffff0, 0x00020000);
+    // (readfirstlane: the asm's "s" operand must be a scalar register tuple even where hipcc keeps the pointer in a VGPR)
+    const w4c_i32x4 r_out = {__builtin_amdgcn_readfirstlane((int)(uintptr_t)L.out),
+                             __builtin_amdgcn_readfirstlane((int)(((uintptr_t)L.out >> 32) & 0xffff)), 0x7ffffff0, 0x00020000};
     struct Epi {
       int o_out[4];
       f32x4 e1[4], e2[4], mk[4];
@@ -427,14 +441,16 @@ void conv3x3_wino4_chain_kernel(const W4ChainArgs args) {
           t += 0.f;   // (the `accumulate` term of the one-layer kernel: x + 0 keeps -0 -> +0 identical)
           o[e] = E.mk[a][e] > 0.f ? t : t * L.out_mask_slope;
         }
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(raw4_t, o), r_out, E.o_out[a], 0, AUX_SC1);
+        store16_sc1(o, r_out, E.o_out[a]);
       }
     };
-    epi_finish(et0, E0);
-    if (N64) {
+    if (N64) {  // second unit: its operands are requested before the first unit's arithmetic and stores
       Epi E1;
       epi_load(et0 + 8, E1);
+      epi_finish(et0, E0);
       epi_finish(et0 + 8, E1);
+    } else {
+      epi_finish(et0, E0);
     }
     CTL_MARK(l, 7);
   };
