@@ -52,8 +52,8 @@ ALGO_MB_PER_PATCH = {"esrgan": 2852.8}
 ALIASES = {"paired_l1": "bench_esrgan", "otf_gan": "bench_esrgan_otf_gan", "swinir_percep": "bench_swinir_medium"}
 
 CLASS_NAMES = [
-    "packed-weight 3x3 conv, forward launches (conv3x3_wino4_kernel | conv3x3_wino_kernel | conv3x3_glds_kernel)",
-    "packed-weight 3x3 conv, backward-data launches (conv3x3_wino4_kernel | conv3x3_wino_kernel | conv3x3_glds_kernel)",
+    "packed-weight 3x3 conv, forward layers (conv3x3_wino4_chain_kernel | conv3x3_wino4_kernel | conv3x3_wino_kernel | conv3x3_glds_kernel)",
+    "packed-weight 3x3 conv, backward-data layers (conv3x3_wino4_chain_kernel | conv3x3_wino4_kernel | conv3x3_wino_kernel | conv3x3_glds_kernel)",
     "3x3 weight gradient (conv3x3_wgrad_wino4_kernel | conv3x3_wgrad_wino_kernel | conv3x3_wgrad_multi_kernel)",
     "weight-gradient split reduce",
     "staged + thin conv kernels (forward)", "staged + thin conv kernels (backward-data)",
@@ -361,10 +361,15 @@ def main() -> None:
         nc = lib.neosr_prof_num_classes()
         ms, ln, fl, by = (C.c_double * nc)(), (C.c_longlong * nc)(), (C.c_double * nc)(), (C.c_double * nc)()
         ex, algo = (C.c_double * nc)(), (C.c_longlong * (3 * nc))()
+        ch_l, ch_n = (C.c_longlong * nc)(), (C.c_longlong * nc)()
+        _C.check(lib.neosr_prof_collect_chain(ch_l, ch_n), "neosr_prof_collect_chain")
         _C.check(lib.neosr_prof_collect_exec(ex, algo), "neosr_prof_collect_exec")
         _C.check(lib.neosr_prof_collect(ms, ln, fl, by), "neosr_prof_collect")
         lib.neosr_prof_enable(0)
         lib.neosr_set_num_streams(prev_streams)
+        chain_status = lib.neosr_conv_chain_status()
+        if chain_status != 0:
+            raise RuntimeError(f"chain kernel: a flag wait ran into its bound (status {chain_status}); results invalid")
         ALGO = ("direct", "winograd F(2x2,3x3): 16 of the direct form's 36 multiplications",
                 "winograd F(4x4,3x3): 36 of the direct form's 144 multiplications")
         kern = {}
@@ -378,6 +383,9 @@ def main() -> None:
                                         "executed_tflops": tf(ex[i]), "direct_equiv_tflops": tf(fl[i]),
                                         "launches_by_algorithm": {ALGO[a].split(":")[0]: int(algo[3 * i + a]) for a in range(3) if algo[3 * i + a]},
                                         "algo_GBps": round(by[i] / (ms[i] * 1e6), 1) if ms[i] > 0 and by[i] else None}
+                if ch_l[i]:  # layers that ran inside chain launches count as one "launch" each above
+                    kern[CLASS_NAMES[i]].update({"chain_launches": int(ch_l[i]), "chain_layers": int(ch_n[i]),
+                                                 "kernel_launches": int(ln[i] - ch_n[i] + ch_l[i])})
         dom = max(COMPUTE_CLASSES, key=lambda i: ms[i])
         ach = ex[dom] / (ms[dom] * 1e9) if ms[dom] > 0 else 0.0           # executed TFLOP/s: the hardware fraction
         ach_direct = fl[dom] / (ms[dom] * 1e9) if ms[dom] > 0 else 0.0    # direct-form equivalent
@@ -385,7 +393,9 @@ def main() -> None:
         allfl = sum(fl[i] for i in COMPUTE_CLASSES)
         allex = sum(ex[i] for i in COMPUTE_CLASSES)
         dom_algo = max(range(3), key=lambda a: algo[3 * dom + a])
-        sym = ({0: "conv3x3_glds_kernel", 1: "conv3x3_wino_kernel", 2: "conv3x3_wino4_kernel"}[dom_algo] if dom in (0, 1)
+        chain_dom = dom in (0, 1) and 2 * ch_n[dom] > ln[dom]   # most layers of the class ran inside chain launches
+        sym = ("conv3x3_wino4_chain_kernel" if chain_dom
+               else {0: "conv3x3_glds_kernel", 1: "conv3x3_wino_kernel", 2: "conv3x3_wino4_kernel"}[dom_algo] if dom in (0, 1)
                else {0: "conv3x3_wgrad_multi_kernel", 1: "conv3x3_wgrad_wino_kernel", 2: "conv3x3_wgrad_wino4_kernel"}[dom_algo] if dom == 2
                else CLASS_SYMBOL[dom])
         tr = pmc_traffic(cfg_name, sym) if not (args.batch or args.arch) else None
@@ -407,8 +417,13 @@ def main() -> None:
                                 "issue / latency (no committed SQ-counter summary for this kernel)"),
                     "sq_counters": sq,
                     "traffic": tr["bytes_per_launch"] if tr else None, "traffic_detail": tr,
-                    "algo_bytes_per_launch": round(by[dom] / max(1, ln[dom])),
+                    # per KERNEL launch, like `traffic` (a chain launch moves the bytes of its 15 layers)
+                    "algo_bytes_per_launch": round(by[dom] / max(1, ln[dom] - ch_n[dom] + ch_l[dom])),
                     "avg_launch_us": round(1e3 * ms[dom] / max(1, ln[dom]), 2),
+                    # (a chain launch runs 15 layers; `avg_launch_us` above is per LAYER, so that it stays comparable with the
+                    # one-layer kernels; the class's mean KERNEL duration — what rocprofv3 lists — is this)
+                    "avg_kernel_launch_us": round(1e3 * ms[dom] / max(1, ln[dom] - ch_n[dom] + ch_l[dom]), 2),
+                    "layers_per_chain_launch": round(ch_n[dom] / ch_l[dom], 2) if ch_l[dom] else None,
                     "all_mfma_kernels_executed_tflops": round(allex / (allms * 1e9), 2) if allms > 0 else None,
                     "all_mfma_kernels_direct_equiv_tflops": round(allfl / (allms * 1e9), 2) if allms > 0 else None,
                     "mfma_kernel_share_of_profiled_step": round(allms / nprof / (step_s * 1e3), 4),

@@ -713,6 +713,9 @@ int neosr_prof_collect(double* ms, long long* launches, double* flops, double* b
  * by_algo[3 c + a]: launches in the direct (a = 0) / F(2x2,3x3) (1) / F(4x4,3x3) (2) form.  Call before
  * neosr_prof_collect. */
 int neosr_prof_collect_exec(double* executed, long long* by_algo);
+/* chain_launches[c] / chain_layers[c]: launches of the chain kernel (neosr_set_conv_chain) in class c and the layers they
+ * ran; every layer counts as one launch in neosr_prof_collect's launches[c].  Call before neosr_prof_collect. */
+int neosr_prof_collect_chain(long long* chain_launches, long long* chain_layers);
 
 /* whole-network plans ------------------------------------------------------------------------ */
 /*

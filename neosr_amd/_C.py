@@ -364,6 +364,7 @@ SIGNATURES: dict[str, tuple] = {
         [C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double), C.POINTER(C.c_double)],
     ),
     "neosr_prof_collect_exec": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
+    "neosr_prof_collect_chain": (C.c_int, [C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "neosr_rrdbnet_workspace_bytes": (_i64, [C.POINTER(RRDBNetCfg)]),
     "neosr_rrdbnet_num_params": (_i32, [C.POINTER(RRDBNetCfg)]),
     "neosr_rrdbnet_forward": (C.c_int, [C.POINTER(RRDBNetCfg), c_void_pp, _vp, _vp, _vp, _vp]),

@@ -54,8 +54,11 @@ void neosr_prof_algo(int algo) {
 }
 
 // the launch just begun is a chain of n layers: they count as n launches of the class (per-layer averages stay comparable)
+long long g_chain_launch[NEOSR_PROF_NCLASS], g_chain_layers[NEOSR_PROF_NCLASS];
 void neosr_prof_layers(int n) {
   if (n > 1) g_launch[g_last_cls] += n - 1, g_algo[g_last_cls][2] += n - 1;
+  g_chain_launch[g_last_cls] += 1;
+  g_chain_layers[g_last_cls] += n;
 }
 
 void neosr_prof_end(void* stream) { hipEventRecord(g_recs.back().b, (hipStream_t)stream); }
@@ -66,6 +69,7 @@ extern "C" int neosr_prof_enable(int on) {
     for (int i = 0; i < NEOSR_PROF_NCLASS; ++i) {
       g_flops[i] = 0; g_bytes[i] = 0; g_launch[i] = 0; g_exec[i] = 0;
       g_algo[i][0] = g_algo[i][1] = g_algo[i][2] = 0;
+      g_chain_launch[i] = g_chain_layers[i] = 0;
     }
   }
   return 0;
@@ -91,6 +95,17 @@ extern "C" int neosr_prof_collect(double* ms, long long* launches, double* flops
 // executed[c] = FLOPs of the multiplications the class's launches really ran (flops[c] of neosr_prof_collect counts the
 // DIRECT form, SURVEY §8d's algorithmic figure); by_algo[3 c + a] = launches in the direct / F(2x2,3x3) / F(4x4,3x3) form.
 // Call before neosr_prof_collect (which recycles the events, not these sums).
+// chain_launches[c] / chain_layers[c]: launches of conv3x3_wino4_chain_kernel in class c and the layers they ran (each layer
+// counts as one launch in neosr_prof_collect's launches[c], so that per-layer averages stay comparable with the
+// one-layer kernels; kernel launches = launches[c] - chain_layers[c] + chain_launches[c]).  Call before neosr_prof_collect.
+extern "C" int neosr_prof_collect_chain(long long* chain_launches, long long* chain_layers) {
+  for (int i = 0; i < NEOSR_PROF_NCLASS; ++i) {
+    chain_launches[i] = g_chain_launch[i];
+    chain_layers[i] = g_chain_layers[i];
+  }
+  return 0;
+}
+
 extern "C" int neosr_prof_collect_exec(double* executed, long long* by_algo) {
   for (int i = 0; i < NEOSR_PROF_NCLASS; ++i) {
     executed[i] = g_exec[i];
