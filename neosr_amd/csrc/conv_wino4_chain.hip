@@ -37,7 +37,11 @@ namespace {
 
 typedef __attribute__((address_space(1))) unsigned gu32;
 constexpr int AUX_SC1 = 16;  // cache-policy bit of buffer loads / stores: sc1 (write-through store, L1-bypassing load)
-constexpr unsigned SPIN_LIMIT = 1u << 21;
+// Bound of a flag wait, in polls (~1-2.5 us each once the back-off has grown: well over a minute).  A wait this long means a
+// workgroup of the launch never became resident (the device has fewer free CUs than tiles for good); legitimate waits are
+// microseconds, or — when another kernel holds CUs for a while, e.g. an RCCL collective that itself waits for a peer
+// rank during warm-up — as long as that kernel runs.
+constexpr unsigned SPIN_LIMIT = 1u << 25;
 
 #ifdef NEOSR_TIMELINE
 #define CTL_MARK(l, m)                                                                            \
@@ -140,7 +144,8 @@ void conv3x3_wino4_chain_kernel(const W4ChainArgs args) {
     if (!args.sync) return;
     unsigned spins = 0;
     while (!poll_ok(v, need)) {
-      __builtin_amdgcn_s_sleep(4);
+      if (spins < 64) __builtin_amdgcn_s_sleep(4);   // back off: a long wait should not load the memory system
+      else __builtin_amdgcn_s_sleep(64);
       v = poll_load();
       if (++spins > SPIN_LIMIT) {
         if (lane == 0) __hip_atomic_store((gu32*)args.status, 1u + need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
