@@ -6,7 +6,7 @@
 
 namespace neosr_conv {
 
-struct W4Layer {  // device-side record of one layer, 128 bytes (read with scalar loads)
+struct W4Layer {  // device-side record of one layer, 128 bytes
   const float* in;        // (B, H, W, in_cs): the first K channels are reduced
   const float* u;         // Winograd F(4x4,3x3) weight image (neosr_conv3x3_pack_wino4)
   const float* bias;
@@ -21,7 +21,7 @@ struct W4Layer {  // device-side record of one layer, 128 bytes (read with scala
   float slope, alpha, alpha2, out_mask_slope;
   int32_t pad1[2];
 };
-static_assert(sizeof(W4Layer) == 128, "W4Layer is read as two 64-byte scalar loads");
+static_assert(sizeof(W4Layer) == 128, "W4Layer: 32 dwords (the kernel reads it as eight 16-byte LDS reads)");
 
 constexpr int W4_MAX_LAYERS = 15;   // (15 x 128 bytes + the header below stay under the 4 KB kernel-argument segment)
 
@@ -33,7 +33,7 @@ struct W4ChainArgs {
   int32_t B, H, W, in_cs;
   int32_t tiles_x, tiles_y, tx_shift, ty_shift, xcd;
   int32_t sync;       // 0: flag waits skipped (timing experiments only: results are then racy)
-  unsigned long long* timeline;  // debug only (NEOSR_TIMELINE builds): [wave 12][layer 16][mark 8] clocks of workgroup 0
+  unsigned long long* timeline;  // debug only (NEOSR_TIMELINE builds): [wave 12][layer 16][mark 16] clocks of workgroup 0
 };
 
 int chain_max_tiles();  // pixel tiles (= workgroups) one chain launch may have: the CU count of the device

@@ -21,6 +21,7 @@
 //   * every spin is bounded (status word, see W4ChainArgs); the host launches at most one workgroup per CU and only
 //     when the device has that many CUs, and zeroes the flag words in front of every pass.
 // LDS: two exchange / raw objects of 54 KB as in conv3x3_wino4_kernel plus one 45 KB raw buffer for chunk 0 = 153 KB.
+#include <cstddef>
 #include <cstring>
 #include <type_traits>
 #include <vector>
@@ -47,7 +48,7 @@ constexpr unsigned SPIN_LIMIT = 1u << 25;
 #define CTL_MARK(l, m)                                                                            \
   do {                                                                                            \
     if (args.timeline && blockIdx.x == 0 && (threadIdx.x & 63) == 0 && (l) < 16)                  \
-      args.timeline[((threadIdx.x >> 6) * 16 + (l)) * 8 + (m)] = clock64();                       \
+      args.timeline[((threadIdx.x >> 6) * 16 + (l)) * 16 + (m)] = clock64();                       \
   } while (0)
 #else
 #define CTL_MARK(l, m) do {} while (0)
@@ -70,6 +71,11 @@ void conv3x3_wino4_chain_kernel(const W4ChainArgs args) {
   __shared__ __attribute__((aligned(1024))) float ldsA[QBUF];
   __shared__ __attribute__((aligned(1024))) float ldsB[QBUF];
   __shared__ __attribute__((aligned(1024))) float ldsC[QSLOTS * 32];  // chunk 0 of every layer
+  // The layer table, copied once from the kernel-argument segment: a record read from there costs a scalar-load round
+  // trip of ~1.3 us (the segment is not served from a warm cache), two of them in a row per layer (the wave-mapping flag,
+  // then the record) on the epilogue waves' path to the layer barrier.  From LDS a record is a few broadcast reads of one
+  // uniform address + v_readfirstlane per field.
+  __shared__ __attribute__((aligned(16))) int tabL[W4_MAX_LAYERS * 32];
   const int tid_k = threadIdx.x;
   const int tid = tid_k;
   const int lane = tid & 63;
@@ -79,6 +85,16 @@ void conv3x3_wino4_chain_kernel(const W4ChainArgs args) {
 
   typedef int i32x4 __attribute__((ext_vector_type(4)));
   const i32x4 gtab = *reinterpret_cast<const i32x4*>(g_qt.gran[tid]);
+  {
+    static_assert(offsetof(W4ChainArgs, layers) == 0, "the table is read as the first bytes of the kernel arguments");
+    static_assert(offsetof(W4Layer, out) == 48 && offsetof(W4Layer, K) == 56 && offsetof(W4Layer, act) == 88 &&
+                      offsetof(W4Layer, n64) == 92 && offsetof(W4Layer, dep) == 96 && offsetof(W4Layer, slope) == 104 &&
+                      offsetof(W4Layer, out_mask_slope) == 116,
+                  "dword indices of the record reader below");
+    typedef const __attribute__((address_space(4))) int* kptr_t;
+    const kptr_t ka = (kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+    if (tid < W4_MAX_LAYERS * 32) tabL[tid] = ka[tid];
+  }
 
   int bid = xcd_tile(blockIdx.x, gridDim.x, args.xcd);
   int tx, ty, b;
@@ -158,17 +174,28 @@ void conv3x3_wino4_chain_kernel(const W4ChainArgs args) {
   // kernel-argument segment whatever the kernel has stored in between; only direct member reads — taking the array's
   // address makes hipcc copy all of it to scratch)
   const int nl = args.nlayers;
+  uintptr_t nx_u = 0;      // first fields of the NEXT layer's record (see the layer start)
+  int nx_K = 0, nx_N = 0, nx_n64 = 0;
+  auto read_next = [&](int ln) {
+    const int* rec = tabL + ln * 32;
+    nx_u = (uintptr_t)(unsigned)__builtin_amdgcn_readfirstlane(rec[2]) | ((uintptr_t)(unsigned)__builtin_amdgcn_readfirstlane(rec[3]) << 32);
+    nx_K = __builtin_amdgcn_readfirstlane(rec[14]);
+    nx_N = __builtin_amdgcn_readfirstlane(rec[15]);
+    nx_n64 = __builtin_amdgcn_readfirstlane(rec[23]);
+  };
   bool c0_issued = false;   // chunk 0 of the layer about to start was requested by the previous layer
 
   auto layer = [&](auto n64tag, const int l) {
     constexpr bool N64 = decltype(n64tag)::value;
+    CTL_MARK(l, 8);
+    // weights pointer, K and N of this layer travel in scalar registers from the previous layer's tail (nx_*): the first
+    // weight / table loads below leave before anything waits.  hipcc puts s_waitcnt vmcnt(0) in front of ANY LDS read
+    // while an LDS-DMA is in flight (it cannot tell the raw buffers from tabL), which for the epilogue waves means
+    // "until my output stores have drained" — with the loads already under way the two latencies overlap instead of adding.
     W4Layer L;
-#define NEOSR_LF(f) L.f = args.layers[l].f
-    NEOSR_LF(in); NEOSR_LF(u); NEOSR_LF(bias); NEOSR_LF(res1); NEOSR_LF(res2); NEOSR_LF(out_mask); NEOSR_LF(out);
-    NEOSR_LF(K); NEOSR_LF(N); NEOSR_LF(out_cs); NEOSR_LF(res1_cs); NEOSR_LF(res1_nch); NEOSR_LF(res2_cs); NEOSR_LF(res2_nch);
-    NEOSR_LF(out_mask_cs); NEOSR_LF(act); NEOSR_LF(dep); NEOSR_LF(slope); NEOSR_LF(alpha); NEOSR_LF(alpha2); NEOSR_LF(out_mask_slope);
-#undef NEOSR_LF
+    L.u = (const float*)nx_u; L.K = nx_K; L.N = nx_N;
     const int K = L.K, nchunks = K >> 5;
+    CTL_MARK(l, 9);
     if (prio == 2) __builtin_amdgcn_s_setprio(2);
     else if (prio == 1) __builtin_amdgcn_s_setprio(1);
 
@@ -203,6 +230,18 @@ void conv3x3_wino4_chain_kernel(const W4ChainArgs args) {
     f32x4 ulo[3][2], uhi[3][2], vlo[3], vhi[3];
     CTL_MARK(l, 0);
     load_u3(0, N64 ? 0 : sel, 0, ulo);
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      const int* rec = tabL + l * 32;
+      auto w = [&](int k) { return __builtin_amdgcn_readfirstlane(rec[k]); };
+      auto ptr = [&](int k) { return (uintptr_t)(unsigned)w(k) | ((uintptr_t)(unsigned)w(k + 1) << 32); };
+      L.in = (const float*)ptr(0); L.bias = (const float*)ptr(4); L.res1 = (const float*)ptr(6);
+      L.res2 = (const float*)ptr(8); L.out_mask = (const float*)ptr(10); L.out = (float*)ptr(12);
+      L.out_cs = w(16); L.res1_cs = w(17); L.res1_nch = w(18); L.res2_cs = w(19); L.res2_nch = w(20);
+      L.out_mask_cs = w(21); L.act = w(22); L.dep = w(24);
+      L.slope = __int_as_float(w(26)); L.alpha = __int_as_float(w(27)); L.alpha2 = __int_as_float(w(28));
+      L.out_mask_slope = __int_as_float(w(29));
+    }
     __builtin_amdgcn_sched_barrier(0);
 
     const rsrc_t rin = make_rin(L.in, K);
@@ -281,9 +320,12 @@ void conv3x3_wino4_chain_kernel(const W4ChainArgs args) {
     bool next_c0 = false;
     rsrc_t rin_next = rin;
     if (l + 1 < nl) {
-      const int dn = args.layers[l + 1].dep;
+      const int* nx = tabL + (l + 1) * 32;
+      const int dn = __builtin_amdgcn_readfirstlane(nx[24]);
       next_c0 = dn != 0 && dn != 1;
-      rin_next = make_rin(args.layers[l + 1].in, args.layers[l + 1].K);
+      const uintptr_t nin = (uintptr_t)(unsigned)__builtin_amdgcn_readfirstlane(nx[0]) |
+                            ((uintptr_t)(unsigned)__builtin_amdgcn_readfirstlane(nx[1]) << 32);
+      rin_next = make_rin((const float*)nin, __builtin_amdgcn_readfirstlane(nx[14]));
     }
 
     for (int c = 0; c < nchunks; ++c) {
@@ -324,6 +366,7 @@ void conv3x3_wino4_chain_kernel(const W4ChainArgs args) {
     c0_issued = next_c0;
     CTL_MARK(l, 4);
     mac3(3, vhi, uhi);
+    read_next(l + 1 < nl ? l + 1 : l);
     __builtin_amdgcn_s_setprio(0);
 
     // ---- epilogue (waves 4-11), as in conv3x3_wino4_kernel; stores are written through (sc1)
@@ -460,9 +503,10 @@ void conv3x3_wino4_chain_kernel(const W4ChainArgs args) {
     CTL_MARK(l, 7);
   };
 
+  __syncthreads();   // tabL
+  read_next(0);
   for (int l = 0; l < nl; ++l) {
-    const int n64 = args.layers[l].n64;
-    if (n64) layer(std::true_type{}, l);
+    if (nx_n64) layer(std::true_type{}, l);
     else layer(std::false_type{}, l);
   }
 }

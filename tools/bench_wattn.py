@@ -30,6 +30,6 @@ for shift in (0, 4):
     t = timeit(lambda: tr.window_attention(qkv.detach(), tab.detach(), heads, 8, shift, 30 ** -0.5))
     o = tr.window_attention(qkv, tab, heads, 8, shift, 30 ** -0.5)
     go = torch.randn_like(o)
-    tb = timeit(lambda: torch.autograd.grad(o, (qkv, tab), go, retain_graph=True))
+    tb = timeit(lambda: torch.autograd.grad(o, (qkv,), go, retain_graph=True))
     fl = 4.0 * M * 64 * C
     print(f"wattn shift {shift}: fwd {t:7.1f} us ({fl / t / 1e6:5.1f} TF)  bwd {tb:7.1f} us ({2.5 * fl / tb / 1e6:5.1f} TF)")

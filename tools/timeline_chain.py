@@ -17,19 +17,19 @@ for _ in range(3):
     with torch.no_grad():
         net(x)
 torch.cuda.synchronize()
-tl = torch.zeros(12 * 16 * 8, dtype=torch.int64, device="cuda")
+tl = torch.zeros(12 * 16 * 16, dtype=torch.int64, device="cuda")
 lib.neosr_debug_set_timeline(tl.data_ptr())
 with torch.no_grad():
     net(x)
 torch.cuda.synchronize()
 lib.neosr_debug_set_timeline(None)
-t = tl.cpu().view(12, 16, 8)
+t = tl.cpu().view(12, 16, 16)
 base = int(t[:, 0, 0].min())
-names = ["start", "drained", "bar1", "loop", "loopend", "exch", "exbar", "stored"]
+names = ["start", "drained", "bar1", "loop", "loopend", "exch", "exbar", "stored", "entry", "rec"]
 for l in range(15):
     print(f"-- layer {l} (conv{l % 5 + 1})")
     for w in (0, 1, 4, 5, 8, 11):
-        r = t[w, l]
+        r = t[w, l][:10]
         vals = [int(v) - base if int(v) else None for v in r]
         print(f"   wave{w:2d}: " + " ".join(f"{n}@{v}" for n, v in zip(names, vals)))
 # summary: per layer, max over waves of each mark, as deltas
