@@ -423,7 +423,9 @@ extern "C" int neosr_conv3x3(const neosr_conv_desc* dp, void* stream) {
     const double px = (double)d.B * d.H * d.W;
     // algorithmic traffic: read |x| + |W|, write |y| (fp32)
     neosr_prof_begin((d.mode == NEOSR_CONV_FWD ? NEOSR_PROF_CONV_FWD : NEOSR_PROF_CONV_DGRAD) + (use_pack ? 0 : 4), stream,
-                     2.0 * px * d.K * d.N * 9.0,
+                     // (a 4x4 / stride-2 layer run as a 3x3 over the space-to-depth tensor multiplies 16 of its 36 (tap,
+                     // sub-pixel) blocks: the other 20 are structurally zero and skipped)
+                     2.0 * px * d.K * d.N * (d.s2d_c > 0 ? 4.0 : 9.0),
                      4.0 * (px / (d.ups ? 4.0 : 1.0) * d.K + px * d.N + 9.0 * d.K * d.N));
     neosr_prof_algo(use_wino4 ? 2 : use_wino ? 1 : 0);
   }

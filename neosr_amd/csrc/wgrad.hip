@@ -1378,7 +1378,7 @@ extern "C" int neosr_conv3x3_wgrad_multi(const neosr_wgrad_desc* ds, int32_t n, 
     double fl = 0, by = 0;
     const double px = (double)a.B * a.H * a.W;
     for (int i = 0; i < n; ++i) {
-      fl += 2.0 * px * ds[i].K * ds[i].N * 9.0;
+      fl += 2.0 * px * ds[i].K * ds[i].N * (ds[i].s2d_c > 0 ? 4.0 : 9.0);   // (space-to-depth layers: 4 live taps per sub-pixel)
       by += 4.0 * (px * ds[i].N + px / (a.ups ? 4.0 : 1.0) * ds[i].K + 9.0 * ds[i].K * ds[i].N);
     }
     neosr_prof_begin(NEOSR_PROF_CONV_WGRAD, stream, fl, by);
