@@ -142,6 +142,10 @@ int neosr_set_wgrad4(int on);
  * a non-zero value means a chain launch did not get all its workgroups resident and its results are invalid).
  * neosr_set_conv_chain_sync(0) skips the flag waits (timing experiments only: results are then racy); default 1. */
 int neosr_set_conv_chain(int on);
+/* Behind a chain launch the fifteen weight gradients of an RRDB run as ONE neosr_conv3x3_wgrad_multi launch (1, default;
+ * env NEOSR_AMD_WGRAD_RRDB) or as one launch per RDB (0): another split of the pixel range, i.e. another summation
+ * order (~1e-7 relative).  Returns the previous setting. */
+int neosr_set_wgrad_rrdb(int on);
 int neosr_set_conv_chain_sync(int mode);
 int neosr_conv_chain_status(void);
 int64_t neosr_conv3x3_pack_wino4_bytes(int32_t N, int32_t K);
@@ -188,10 +192,10 @@ typedef struct neosr_wgrad_desc {
 int64_t neosr_conv3x3_wgrad_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t K, int32_t N);
 int neosr_conv3x3_wgrad(const neosr_wgrad_desc* d, void* stream);
 /* Up to NEOSR_WGRAD_MAX convolutions that share (B, H, W, ups) in ONE launch — e.g. the five
- * convs of a Residual Dense Block (esrgan_arch.py:109-116) — so every workgroup gets a long
+ * convs of a Residual Dense Block (esrgan_arch.py:109-116), or the fifteen of an RRDB — so every workgroup gets a long
  * pixel strip and the chip is filled by a single resident round.  `workspace` (shared) must
  * hold neosr_conv3x3_wgrad_multi_workspace_bytes(); the per-descriptor workspace field is unused. */
-#define NEOSR_WGRAD_MAX 8
+#define NEOSR_WGRAD_MAX 16
 int64_t neosr_conv3x3_wgrad_multi_workspace_bytes(const neosr_wgrad_desc* descs, int32_t n);
 int neosr_conv3x3_wgrad_multi(const neosr_wgrad_desc* descs, int32_t n, float* workspace,
                               void* stream);

@@ -258,6 +258,7 @@ SIGNATURES: dict[str, tuple] = {
     "neosr_set_wino4_n64": (C.c_int, [C.c_int]),
     "neosr_set_wgrad4": (C.c_int, [C.c_int]),
     "neosr_set_conv_chain": (C.c_int, [C.c_int]),
+    "neosr_set_wgrad_rrdb": (C.c_int, [C.c_int]),
     "neosr_set_conv_chain_sync": (C.c_int, [C.c_int]),
     "neosr_conv_chain_status": (C.c_int, []),
     "neosr_conv3x3_pack_wino_bytes": (_i64, [_i32, _i32]),

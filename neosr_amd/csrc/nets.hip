@@ -164,6 +164,10 @@ RrdbLayout rrdb_layout(const neosr_rrdbnet_cfg& c, void* ws) {
         wd[k].N = (k < 4) ? G : F;
       }
       w = max64(w, neosr_conv3x3_wgrad_multi_workspace_bytes(wd, 5));
+      // ... and the fifteen of one RRDB (behind a chain launch, see rrdb_backward_impl)
+      neosr_wgrad_desc wd3[15];
+      for (int k = 0; k < 15; ++k) wd3[k] = wd[k % 5];
+      w = max64(w, neosr_conv3x3_wgrad_multi_workspace_bytes(wd3, 15));
     }
     w = max64(w, neosr_conv3x3_wgrad_workspace_bytes(B, H, W, F, F));
     w = max64(w, neosr_conv3x3_wgrad_workspace_bytes(B, 2 * H, 2 * W, F, F));
@@ -275,6 +279,7 @@ struct Aux {
   hipEvent_t fork = nullptr, join[MAX_CHAINS] = {nullptr, nullptr, nullptr, nullptr};
   std::vector<hipEvent_t> ev;
 };
+int g_wgrad_rrdb = -1;   // -1: read NEOSR_AMD_WGRAD_RRDB on first use (default on), see neosr_set_wgrad_rrdb
 int g_num_streams = -1;  // -1: read NEOSR_AMD_STREAMS on first use (default 2)
 
 Aux* aux_get(int nev) {
@@ -690,18 +695,24 @@ int rrdb_backward_impl(const neosr_rrdbnet_cfg* c, const float* const* P, float*
     }
     return d;
   };
+  auto wgrad_desc_of = [&](int n, int r, int gbi, int m) {
+    neosr_wgrad_desc w = wgrad_base(B, H, W);
+    w.in = L.act[3 * n + r]; w.in_cs = CC; w.K = F + (m - 1) * G;
+    w.g = L.gb[gbi] + g_off(F, G, m); w.g_cs = CC; w.N = m == 5 ? F : G;
+    w.scale = (r == 2) ? 0.04f : 0.2f;
+    w.dw = Gp[p_rdb(n, r, m - 1)]; w.db = Gp[p_rdb(n, r, m - 1) + 1];
+    return w;
+  };
   auto wgrad_rdb = [&](int n, int r, int gbi, void* sw_) -> int {  // all five weight gradients of this RDB in one launch
     neosr_wgrad_desc wd[5];
-    for (int m = 1; m <= 5; ++m) {
-      neosr_wgrad_desc w = wgrad_base(B, H, W);
-      w.in = L.act[3 * n + r]; w.in_cs = CC; w.K = F + (m - 1) * G;
-      w.g = L.gb[gbi] + g_off(F, G, m); w.g_cs = CC; w.N = m == 5 ? F : G;
-      w.scale = (r == 2) ? 0.04f : 0.2f;
-      w.dw = Gp[p_rdb(n, r, m - 1)]; w.db = Gp[p_rdb(n, r, m - 1) + 1];
-      wd[m - 1] = w;
-    }
+    for (int m = 1; m <= 5; ++m) wd[m - 1] = wgrad_desc_of(n, r, gbi, m);
     return neosr_conv3x3_wgrad_multi(wd, 5, L.wg_ws, sw_);
   };
+  if (g_wgrad_rrdb < 0) {
+    const char* e = getenv("NEOSR_AMD_WGRAD_RRDB");
+    g_wgrad_rrdb = (e && e[0] == '0') ? 0 : 1;
+  }
+  const bool wgrad15 = g_wgrad_rrdb == 1;
   int gbi = 0, t = 0;
   const float* dOut = nullptr;  // gradient wrt the output of the current RRDB (g5 slot of its last RDB)
   float* prev = nullptr;
@@ -734,7 +745,14 @@ int rrdb_backward_impl(const neosr_rrdbnet_cfg* c, const float* const* P, float*
       if (rc > 0) return rc;
       if (rc < 0) break;
       chained = true;
-      for (int r = 2; r >= 0; --r) RUN(wgrad_rdb(n, r, (g0 + (2 - r)) & 3, st));
+      if (wgrad15) {  // the fifteen weight gradients of the RRDB in one launch
+        neosr_wgrad_desc wd[15];
+        for (int r = 2, i = 0; r >= 0; --r)
+          for (int m = 1; m <= 5; ++m, ++i) wd[i] = wgrad_desc_of(n, r, (g0 + (2 - r)) & 3, m);
+        RUN(neosr_conv3x3_wgrad_multi(wd, 15, L.wg_ws, st));
+      } else {
+        for (int r = 2; r >= 0; --r) RUN(wgrad_rdb(n, r, (g0 + (2 - r)) & 3, st));
+      }
       for (int i = 0; i < n_marks; ++i)
         if (mark_block[i] == n) NEOSR_HIP(hipEventRecord((hipEvent_t)mark_event[i], (hipStream_t)st));
       gbi = (g0 + 3) & 3;
@@ -976,6 +994,15 @@ extern "C" int neosr_compact_backward(const neosr_compact_cfg* c, const float* c
 
 // 1 = the RRDB trunk runs on the caller's stream only, n = 2 (default) .. 4 = the batch is cut into n groups of samples
 // that run as independent launch chains.  Returns the previous setting.  Env NEOSR_AMD_STREAMS=n selects it at start-up.
+// Behind a chain launch (neosr_set_conv_chain) the fifteen weight gradients of an RRDB run as ONE launch (1, default) or
+// as one launch per RDB (0).  Same products, another split of the pixel range: results differ by summation order
+// (~1e-7 relative).  Returns the previous setting.
+extern "C" int neosr_set_wgrad_rrdb(int on) {
+  const int prev = g_wgrad_rrdb < 0 ? 1 : g_wgrad_rrdb;
+  g_wgrad_rrdb = on ? 1 : 0;
+  return prev;
+}
+
 extern "C" int neosr_set_num_streams(int n) {
   aux_get(0);  // resolve the default
   const int prev = g_num_streams;

@@ -45,6 +45,7 @@ def test_chain_is_bit_identical_to_per_layer_launches(lib, batch, hw, blocks):
     x = torch.rand(batch, 3, hw, hw, generator=g).to(DEV)
     gy = (torch.randn(batch, 3, 4 * hw, 4 * hw, generator=g) * 1e-3).to(DEV)
     prev_n64 = lib.neosr_set_wino4_n64(1)   # both paths: 64-channel workgroups for the 64-channel layers
+    prev_wg = lib.neosr_set_wgrad_rrdb(0)   # weight gradients: one launch per RDB on both paths (same pixel splits)
     prev = lib.neosr_set_conv_chain(0)
     try:
         y0, g0 = _fwd_bwd(net, x, gy)
@@ -54,9 +55,19 @@ def test_chain_is_bit_identical_to_per_layer_launches(lib, batch, hw, blocks):
             assert torch.equal(y0, y1), (rep, rel_err(y1, y0))
             bad = [i for i, (a, b) in enumerate(zip(g0, g1)) if not torch.equal(a, b)]
             assert not bad, (rep, bad[:8], max(rel_err(g1[i], g0[i]) for i in bad))
+        # the default: the fifteen weight gradients of an RRDB in one launch = another split of the pixel range, i.e.
+        # the same sums in another order; run-to-run identical
+        lib.neosr_set_wgrad_rrdb(1)
+        y2, g2 = _fwd_bwd(net, x, gy)
+        y3, g3 = _fwd_bwd(net, x, gy)
+        assert torch.equal(y0, y2) and torch.equal(y2, y3)
+        assert all(torch.equal(a, b) for a, b in zip(g2, g3))
+        worst = max(rel_err(a, b) for a, b in zip(g2, g0))
+        assert worst < 5e-6, worst
         assert lib.neosr_conv_chain_status() == 0
     finally:
         lib.neosr_set_conv_chain(prev)
+        lib.neosr_set_wgrad_rrdb(prev_wg)
         lib.neosr_set_wino4_n64(prev_n64)
 
 
@@ -68,6 +79,7 @@ def test_chain_full_size_repeated(lib):
     x = torch.rand(16, 3, 64, 64, generator=g).to(DEV)
     gy = (torch.randn(16, 3, 256, 256, generator=g) * 1e-3).to(DEV)
     prev = lib.neosr_set_conv_chain(0)
+    prev_wg = lib.neosr_set_wgrad_rrdb(0)
     try:
         y0, g0 = _fwd_bwd(net, x, gy)
         lib.neosr_set_conv_chain(1)
@@ -78,6 +90,7 @@ def test_chain_full_size_repeated(lib):
         assert lib.neosr_conv_chain_status() == 0
     finally:
         lib.neosr_set_conv_chain(prev)
+        lib.neosr_set_wgrad_rrdb(prev_wg)
 
 
 def test_chain_inference_ring(lib):
