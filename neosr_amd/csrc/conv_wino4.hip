@@ -32,6 +32,8 @@
 // F(2x2): ~5e-6 of the output scale against the float64 convolution (tests: <= 1e-4 at kernel level; north_star allows
 // 1e-3).  neosr_set_winograd(1) keeps F(2x2,3x3) for every launch, neosr_set_winograd(0) the direct kernel.
 #include <cstring>
+#include <mutex>
+#include <string>
 #include <vector>
 #include <stdlib.h>
 #include "conv_wino4.h"
@@ -411,8 +413,7 @@ void conv3x3_wino4_kernel(const ConvArgs args) {
 // U = G g G^T of every (cin, cout) pair of an image, in float64, rounded once:
 //   dst[nblk][chunk 32 k][pos = i * 6 + j][kp 2][cout block 2][k quad 4][cout 16][4]
 // one thread per (n-block, chunk, k quad 0..7, n 0..31) loads the 4 x 9 taps of its four channels and writes 36 granules.
-__global__ __launch_bounds__(256) void conv_pack_wino4_kernel(const neosr_pack::Batch batch) {
-  const neosr_pack::Image& im = batch.im[blockIdx.y];
+__device__ __forceinline__ void pack_wino4_image(const neosr_pack::Image& im) {
   const int nch = (im.K + 31) >> 5, nblk = (im.N + 31) >> 5;
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (t >= nblk * nch * 256) return;
@@ -466,6 +467,16 @@ __global__ __launch_bounds__(256) void conv_pack_wino4_kernel(const neosr_pack::
     }
 }
 
+__global__ __launch_bounds__(256) void conv_pack_wino4_kernel(const neosr_pack::Batch batch) {
+  pack_wino4_image(batch.im[blockIdx.y]);
+}
+
+// the same over a table of images in device memory (any number of images in one launch)
+__global__ __launch_bounds__(256) void conv_pack_wino4_table_kernel(const neosr_pack::Image* __restrict__ tab) {
+  const neosr_pack::Image im = tab[blockIdx.y];
+  pack_wino4_image(im);
+}
+
 }  // namespace
 
 // launch chains of the caller that run side by side (nets.hip: the two half-batch chains of the RRDB trunk): the fill
@@ -504,8 +515,71 @@ void neosr_conv::launch_wino4(const ConvArgs& a, hipStream_t st) {
   }
 }
 
+namespace {
+// Image tables of big sets (the 2 x 345 images of an RRDBNet) live in library-owned device memory, keyed by their bytes: the
+// descriptors only change when the caller's buffers move, so a steady-state step uploads nothing and packs a whole set in
+// ONE launch instead of ceil(n / 24).  (Library-owned: a table inside a caller's workspace could be handed to another
+// tensor by the caller's allocator while a host-side "unchanged" check still holds.)
+struct PackTable {
+  std::string bytes;
+  neosr_pack::Image* dev = nullptr;
+  int dev_id = 0;
+  uint64_t stamp = 0;
+};
+std::vector<PackTable> g_tables;
+uint64_t g_table_clock = 0;
+std::mutex g_table_mu;
+constexpr size_t MAX_TABLES = 16;
+
+const neosr_pack::Image* device_table(const neosr_pack::Image* images, int n, hipStream_t st) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  const size_t nbytes = (size_t)n * sizeof(neosr_pack::Image);
+  std::lock_guard<std::mutex> lk(g_table_mu);
+  for (PackTable& t : g_tables)
+    if (t.dev_id == dev && t.bytes.size() == nbytes && memcmp(t.bytes.data(), images, nbytes) == 0) {
+      t.stamp = ++g_table_clock;
+      return t.dev;
+    }
+  PackTable* slot = nullptr;
+  if (g_tables.size() < MAX_TABLES) {
+    g_tables.emplace_back();
+    slot = &g_tables.back();
+  } else {  // recycle the least recently used entry (its launches are ordered before this one only on the same stream:
+            // wait for the device before the buffer is reused)
+    slot = &g_tables[0];
+    for (PackTable& t : g_tables)
+      if (t.stamp < slot->stamp) slot = &t;
+    if (hipDeviceSynchronize() != hipSuccess) return nullptr;
+    if (slot->dev) (void)hipFree(slot->dev);
+    slot->dev = nullptr;
+  }
+  if (hipMalloc((void**)&slot->dev, nbytes) != hipSuccess) { slot->dev = nullptr; slot->bytes.clear(); return nullptr; }
+  slot->bytes.assign((const char*)images, nbytes);
+  slot->dev_id = dev;
+  slot->stamp = ++g_table_clock;
+  // (from slot->bytes, which lives as long as the entry: the copy may be asynchronous)
+  if (hipMemcpyAsync(slot->dev, slot->bytes.data(), nbytes, hipMemcpyHostToDevice, st) != hipSuccess) return nullptr;
+  return slot->dev;
+}
+}  // namespace
+
 int neosr_pack::launch_wino4(const Image* images, int n, void* stream) {
   NEOSR_CHECK(images && n > 0, "conv pack (winograd 4x4): bad arguments");
+  static const bool use_table = [] { const char* e = getenv("NEOSR_AMD_PACK_TABLE"); return !(e && e[0] == '0'); }();
+  if (use_table && n > BATCH && n <= 65535) {
+    if (const Image* tab = device_table(images, n, (hipStream_t)stream)) {
+      int64_t thr = 0;
+      for (int i = 0; i < n; ++i) {
+        const int64_t g = wino4_image_floats(images[i].N, images[i].K) / 144;  // one thread per 36 granules
+        thr = g > thr ? g : thr;
+      }
+      dim3 grid((unsigned)((thr + 255) / 256), n);
+      hipLaunchKernelGGL(conv_pack_wino4_table_kernel, grid, dim3(256), 0, (hipStream_t)stream, tab);
+      NEOSR_LAUNCH_CHECK();
+      return 0;
+    }
+  }
   for (int i0 = 0; i0 < n; i0 += BATCH) {
     const int cnt = n - i0 < BATCH ? n - i0 : BATCH;
     Batch bt;
