@@ -347,6 +347,12 @@ int neosr_blur_kernels(const double* params, int32_t n, float* out, void* stream
  * the 16 taps scattered into a (N, 4C, 3, 3) weight, so it runs on neosr_conv3x3[_wgrad]. */
 int neosr_space_to_depth2(const float* in, float* out, int32_t B, int32_t Hlo, int32_t Wlo,
                           int32_t C, int32_t inverse, void* stream);
+/* Backward of neosr_space_to_depth2 fused with the two passes that follow it in the U-Net discriminator's backward
+ * (unet_arch.py:36-60: x0 / x1 / x2 feed a 4x4 / stride-2 convolution AND a skip addition): out (B, 2Hlo, 2Wlo, C) =
+ * (depth_to_space(g) + skip) * (y > 0 ? 1 : slope); skip and y optional (NULL: no addend / no mask).  Same expressions as
+ * the separate passes (autograd's sum, then neosr_leaky_relu's derivative form): bit-identical. */
+int neosr_depth_to_space2_fused(const float* g, const float* skip, const float* y, float slope, float* out,
+                                int32_t B, int32_t Hlo, int32_t Wlo, int32_t C, void* stream);
 /* F.interpolate(scale_factor=2, mode="bilinear", align_corners=False) (unet_arch.py:45,51,57);
  * backward=1: its adjoint in gather form (in = grad (B,2H,2W,C), out = (B,H,W,C)). */
 int neosr_bilinear_up2(const float* in, float* out, int32_t B, int32_t H, int32_t W, int32_t C,

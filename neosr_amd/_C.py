@@ -304,6 +304,7 @@ SIGNATURES: dict[str, tuple] = {
     "neosr_normal_sample": (C.c_int, [_vp, _i64, C.c_uint64, C.c_uint64, _vp]),
     "neosr_blur_kernels": (C.c_int, [_vp, _i32, _vp, _vp]),
     "neosr_space_to_depth2": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "neosr_depth_to_space2_fused": (C.c_int, [_vp, _vp, _vp, C.c_float, _vp, _i32, _i32, _i32, _i32, _vp]),
     "neosr_bilinear_up2": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "neosr_maxpool2": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "neosr_add": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),

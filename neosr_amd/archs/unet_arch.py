@@ -18,6 +18,9 @@ from neosr_amd.hip import layers as L
 from neosr_amd.utils.registry import ARCH_REGISTRY
 
 
+_FUSED_SKIP = __import__("os").environ.get("NEOSR_AMD_UNET_FUSED_SKIP", "1") != "0"   # A/B switch (bit-identical results)
+
+
 @ARCH_REGISTRY.register()
 class unet(nn.Module):
     def __init__(self, num_in_ch: int = 3, num_feat: int = 64, skip_connection: bool = True) -> None:
@@ -44,9 +47,16 @@ class unet(nn.Module):
         lr = L.ACT_LRELU
         t = L.ToNHWC.apply(x, (self.num_in_ch + 3) // 4 * 4)
         x0 = L.conv3x3(t, self.conv0.weight, self.conv0.bias, lr, 0.2)
-        x1 = L.conv4x4s2(x0, self._w(self.conv1), None, lr, 0.2)
-        x2 = L.conv4x4s2(x1, self._w(self.conv2), None, lr, 0.2)
-        x3 = L.conv4x4s2(x2, self._w(self.conv3), None, lr, 0.2)
+        if self.skip_connection and _FUSED_SKIP:
+            # x0 / x1 / x2 feed a strided convolution and a skip addition, nothing else: the depth-to-space of the
+            # convolution's input gradient, the skip gradient and the LeakyReLU derivative are ONE backward pass
+            x1, x0 = L.conv4x4s2_skip(x0, 0.2, self._w(self.conv1), None, lr, 0.2)
+            x2, x1 = L.conv4x4s2_skip(x1, 0.2, self._w(self.conv2), None, lr, 0.2)
+            x3, x2 = L.conv4x4s2_skip(x2, 0.2, self._w(self.conv3), None, lr, 0.2)
+        else:
+            x1 = L.conv4x4s2(x0, self._w(self.conv1), None, lr, 0.2)
+            x2 = L.conv4x4s2(x1, self._w(self.conv2), None, lr, 0.2)
+            x3 = L.conv4x4s2(x2, self._w(self.conv3), None, lr, 0.2)
         x3 = L.BilinearUp2.apply(x3)
         x4 = L.conv3x3(x3, self._w(self.conv4), None, lr, 0.2)
         if self.skip_connection:

@@ -453,16 +453,16 @@ __device__ __forceinline__ void pack_wino4_image(const neosr_pack::Image& im) {
     for (int a = 0; a < 3; ++a)
 #pragma unroll
       for (int j = 0; j < 6; ++j)
-        cg[e][a][j] = G0[j] * (double)g[e][a * 3] + G1[j] * (double)g[e][a * 3 + 1] + G2[j] * (double)g[e][a * 3 + 2];
+        cg[e][a][j] = fma(G2[j], (double)g[e][a * 3 + 2], fma(G1[j], (double)g[e][a * 3 + 1], G0[j] * (double)g[e][a * 3]));
 #pragma unroll
   for (int i = 0; i < 6; ++i)
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
       float4 v;
-      v.x = (float)(G0[i] * cg[0][0][j] + G1[i] * cg[0][1][j] + G2[i] * cg[0][2][j]);
-      v.y = (float)(G0[i] * cg[1][0][j] + G1[i] * cg[1][1][j] + G2[i] * cg[1][2][j]);
-      v.z = (float)(G0[i] * cg[2][0][j] + G1[i] * cg[2][1][j] + G2[i] * cg[2][2][j]);
-      v.w = (float)(G0[i] * cg[3][0][j] + G1[i] * cg[3][1][j] + G2[i] * cg[3][2][j]);
+      v.x = (float)fma(G2[i], cg[0][2][j], fma(G1[i], cg[0][1][j], G0[i] * cg[0][0][j]));
+      v.y = (float)fma(G2[i], cg[1][2][j], fma(G1[i], cg[1][1][j], G0[i] * cg[1][0][j]));
+      v.z = (float)fma(G2[i], cg[2][2][j], fma(G1[i], cg[2][1][j], G0[i] * cg[2][0][j]));
+      v.w = (float)fma(G2[i], cg[3][2][j], fma(G1[i], cg[3][1][j], G0[i] * cg[3][0][j]));
       *reinterpret_cast<float4*>(dst + (i * 6 + j) * 1024) = v;
     }
 }

@@ -60,6 +60,37 @@ __global__ __launch_bounds__(256) void s2d_kernel(const float* __restrict__ in, 
   }
 }
 
+// depth-to-space of a gradient fused with what follows it in the U-Net's backward pass (unet_arch.py:36-60: x0 / x1 / x2
+// feed a 4x4 / stride-2 convolution AND a skip addition): out = (d2s(g) + skip) * (y > 0 ? 1 : slope) — the sum autograd
+// would form in a pass of its own and the LeakyReLU derivative of the producing layer, in the pass that re-lays the
+// gradient out anyway.  Same expressions as the separate passes: bit-identical.
+template <int V>
+__global__ __launch_bounds__(256) void d2s_fused_kernel(const float* __restrict__ g, const float* __restrict__ skip,
+                                                        const float* __restrict__ y, float slope, float* __restrict__ out,
+                                                        int B, int H2, int W2, int C) {
+  const int Cv = C / V;
+  const int64_t total = (int64_t)B * H2 * W2 * 4 * Cv;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int c = (int)(e % Cv) * V;
+    int64_t t = e / Cv;
+    const int q = (int)(t & 3);
+    t >>= 2;
+    const int X = (int)(t % W2);
+    t /= W2;
+    const int Y = (int)(t % H2);
+    const int b = (int)(t / H2);
+    const int64_t hi = (((int64_t)b * 2 * H2 + 2 * Y + (q >> 1)) * 2 * W2 + 2 * X + (q & 1)) * C + c;
+    const int64_t lo = e * V;
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      float v = g[lo + k];
+      if (skip) v = skip[hi + k] + v;
+      if (y) v = y[hi + k] > 0.f ? v : v * slope;
+      out[hi + k] = v;
+    }
+  }
+}
+
 // ------------------------------------------------------------------ bilinear x2, align_corners=False
 // src = (dst + 0.5) / 2 - 0.5 clamped at 0: taps {i0, i1} with weights {1-l, l}
 __device__ __forceinline__ void bil_tap(int o, int n_in, int& i0, int& i1, float& l) {
@@ -500,6 +531,21 @@ extern "C" int neosr_space_to_depth2(const float* in, float* out, int32_t B, int
   else
     hipLaunchKernelGGL(s2d_kernel<1>, dim3(grid_for((int64_t)B * Hlo * Wlo * 4 * C)), dim3(256), 0, ST, in, out,
                        B, Hlo, Wlo, C, inverse);
+  NEOSR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int neosr_depth_to_space2_fused(const float* g, const float* skip, const float* y, float slope, float* out,
+                                           int32_t B, int32_t Hlo, int32_t Wlo, int32_t C, void* stream) {
+  NEOSR_CHECK(g && out && B > 0 && Hlo > 0 && Wlo > 0 && C > 0, "depth_to_space2_fused: bad args");
+  const bool v4 = C % 4 == 0 && (uintptr_t)g % 16 == 0 && (uintptr_t)out % 16 == 0 && (uintptr_t)skip % 16 == 0 &&
+                  (uintptr_t)y % 16 == 0;
+  if (v4)
+    hipLaunchKernelGGL(d2s_fused_kernel<4>, dim3(grid_for((int64_t)B * Hlo * Wlo * C)), dim3(256), 0, ST, g, skip, y, slope,
+                       out, B, Hlo, Wlo, C);
+  else
+    hipLaunchKernelGGL(d2s_fused_kernel<1>, dim3(grid_for((int64_t)B * Hlo * Wlo * 4 * C)), dim3(256), 0, ST, g, skip, y,
+                       slope, out, B, Hlo, Wlo, C);
   NEOSR_LAUNCH_CHECK();
   return 0;
 }

@@ -293,6 +293,45 @@ class SpaceToDepth2(torch.autograd.Function):
         return out
 
 
+class SpaceToDepth2Skip(torch.autograd.Function):
+    """(space_to_depth(x), x) for a LeakyReLU(slope) layer output x whose ONLY consumers are a 4x4 / stride-2 convolution
+    (through the first output) and a skip addition (through the second) — the U-Net's x0 / x1 / x2.  backward: the
+    depth-to-space of the convolution's input gradient, the skip gradient autograd would add in a pass of its own and the
+    LeakyReLU derivative the producing layer would apply in another, in ONE pass (neosr_depth_to_space2_fused); the
+    result is tagged so that the producer skips its own mask (see Conv3x3.backward).  Bit-identical to the separate
+    passes."""
+
+    @staticmethod
+    def forward(ctx, x, slope):
+        lib = _C.load()
+        x = _C.require_device(x, "x").contiguous()
+        B, H, W, C_ = x.shape
+        if H % 2 or W % 2:
+            raise _C.NeosrAmdError("4x4/s2 conv needs even H, W")
+        out = torch.empty(B, H // 2, W // 2, 4 * C_, device=x.device, dtype=torch.float32)
+        _C.check(lib.neosr_space_to_depth2(x.data_ptr(), out.data_ptr(), B, H // 2, W // 2, C_, 0, _st()),
+                 "neosr_space_to_depth2")
+        ctx.save_for_backward(x)
+        ctx.slope = float(slope)
+        return out, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g, gskip):
+        (x,) = ctx.saved_tensors
+        lib = _C.load()
+        B, H, W, C_ = x.shape
+        if g is None:
+            g = torch.zeros(B, H // 2, W // 2, 4 * C_, device=x.device, dtype=torch.float32)
+        g = g.contiguous()
+        gskip = None if gskip is None else gskip.contiguous()
+        out = torch.empty_like(x)
+        _C.check(lib.neosr_depth_to_space2_fused(g.data_ptr(), None if gskip is None else gskip.data_ptr(), x.data_ptr(),
+                                                 ctx.slope, out.data_ptr(), B, H // 2, W // 2, C_, _st()),
+                 "neosr_depth_to_space2_fused")
+        out._neosr_act_masked = (x.data_ptr(), out._version)
+        return out, None
+
+
 _S2D_INDEX: dict[tuple, torch.Tensor] = {}
 
 
@@ -342,6 +381,13 @@ class _Expand4x4s2(torch.autograd.Function):
 def conv4x4s2(x, w, b=None, act=ACT_NONE, slope=0.0):
     """nn.Conv2d(C, N, 4, 2, 1) on channels-last x, as space-to-depth + the MFMA 3x3 kernel."""
     return conv3x3(SpaceToDepth2.apply(x), expand_4x4s2_weight(w), b, act, slope, s2d_c=x.shape[3])
+
+
+def conv4x4s2_skip(x, x_slope, w, b=None, act=ACT_NONE, slope=0.0):
+    """conv4x4s2(x, ...) for a LeakyReLU(x_slope) output x that also feeds a skip addition: returns (y, x') with x' to be
+    used by the skip INSTEAD of x (see SpaceToDepth2Skip: x must have no other consumer)."""
+    t, xs = SpaceToDepth2Skip.apply(x, x_slope)
+    return conv3x3(t, expand_4x4s2_weight(w), b, act, slope, s2d_c=x.shape[3]), xs
 
 
 # --------------------------------------------------------------------------------------------

@@ -179,3 +179,35 @@ def test_perceptual_loss_other_criteria_vs_oracle(prims, criterion):
     ref.backward()
     assert abs(v.item() - float(ref)) < 1e-4 * float(ref)
     assert rel_err(x.grad, xr.grad) < 1e-3
+
+
+def test_unet_fused_skip_backward_is_bit_identical(monkeypatch):
+    """x0 / x1 / x2 of the U-Net: depth-to-space + skip gradient + LeakyReLU derivative in one backward pass
+    (layers.SpaceToDepth2Skip, neosr_depth_to_space2_fused) against the separate passes (autograd's sum, then the
+    producer's neosr_leaky_relu pass): the same expressions, so every gradient must agree bit for bit."""
+    from neosr_amd.archs import build_network
+    from neosr_amd.hip import layers as L
+
+    torch.manual_seed(3)
+    d = build_network({"type": "unet", "num_in_ch": 3, "num_feat": 16}).to(DEV).train()
+    x = torch.rand(2, 3, 64, 48, device=DEV, generator=None)
+    r = torch.randn(2, 1, 64, 48, device=DEV)
+
+    def run():
+        d.zero_grad(set_to_none=True)
+        for m in d.modules():   # same power-iteration state for both runs
+            if hasattr(m, "weight_u"):
+                m.weight_u.data.copy_(state[id(m)][0])
+                m.weight_v.data.copy_(state[id(m)][1])
+        xi = x.clone().requires_grad_(True)
+        y = d(xi)
+        (y * r).sum().backward()
+        return y.detach().clone(), xi.grad.clone(), [p.grad.clone() for p in d.parameters()]
+
+    state = {id(m): (m.weight_u.data.clone(), m.weight_v.data.clone()) for m in d.modules() if hasattr(m, "weight_u")}
+    y1, gx1, g1 = run()
+    monkeypatch.setattr(L, "conv4x4s2_skip", lambda x, xs, w, b=None, act=L.ACT_NONE, slope=0.0: (L.conv4x4s2(x, w, b, act, slope), x))
+    y0, gx0, g0 = run()
+    assert torch.equal(y0, y1)
+    assert torch.equal(gx0, gx1)
+    assert all(torch.equal(a, b) for a, b in zip(g0, g1))
