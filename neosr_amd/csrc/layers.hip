@@ -81,12 +81,23 @@ __global__ __launch_bounds__(256) void d2s_fused_kernel(const float* __restrict_
     const int b = (int)(t / H2);
     const int64_t hi = (((int64_t)b * 2 * H2 + 2 * Y + (q >> 1)) * 2 * W2 + 2 * X + (q & 1)) * C + c;
     const int64_t lo = e * V;
-#pragma unroll
-    for (int k = 0; k < V; ++k) {
-      float v = g[lo + k];
-      if (skip) v = skip[hi + k] + v;
-      if (y) v = y[hi + k] > 0.f ? v : v * slope;
-      out[hi + k] = v;
+    if (V == 4) {
+      float4 v = *reinterpret_cast<const float4*>(g + lo);
+      if (skip) {
+        const float4 a = *reinterpret_cast<const float4*>(skip + hi);
+        v.x = a.x + v.x; v.y = a.y + v.y; v.z = a.z + v.z; v.w = a.w + v.w;
+      }
+      if (y) {
+        const float4 m = *reinterpret_cast<const float4*>(y + hi);
+        v.x = m.x > 0.f ? v.x : v.x * slope; v.y = m.y > 0.f ? v.y : v.y * slope;
+        v.z = m.z > 0.f ? v.z : v.z * slope; v.w = m.w > 0.f ? v.w : v.w * slope;
+      }
+      *reinterpret_cast<float4*>(out + hi) = v;
+    } else {
+      float v = g[lo];
+      if (skip) v = skip[hi] + v;
+      if (y) v = y[hi] > 0.f ? v : v * slope;
+      out[hi] = v;
     }
   }
 }
