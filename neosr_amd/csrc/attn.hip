@@ -333,12 +333,7 @@ __global__ __launch_bounds__(256) void window_attention_fwd_kernel(const neosr_w
 
 __global__ __launch_bounds__(256) void window_attention_bwd_kernel(const neosr_wattn_desc d) {
   __shared__ float Qs[NTOK * QS], Ks[NTOK * QS], Vs[NTOK * QS], Gs[NTOK * QS];
-#ifdef EXP_ALIAS
-  __shared__ float P[NTOK * PS];
-  float* dS = P;   // timing experiment only (wrong results): 52 KB of LDS -> three workgroups per CU
-#else
   __shared__ float P[NTOK * PS], dS[NTOK * PS];
-#endif
   __shared__ float lse_s[NTOK], delta_s[NTOK];
   __shared__ Tables T;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
@@ -405,11 +400,7 @@ __global__ __launch_bounds__(256) void window_attention_bwd_kernel(const neosr_w
     __syncthreads();
   }
   // relative-position-bias gradient of this (window, head): bin sums in a fixed order
-#ifdef EXP_NOBIAS
-  if (false) {
-#else
   if (tid < NB) {
-#endif
     // all 64 query positions, straight-line: the pairs that leave the window read element 0 and add 0, so the LDS
     // reads are independent (a loop over the valid range is a chain of dependent read + add latencies); same
     // summation order (yi, then xi)
