@@ -18,6 +18,7 @@
 // neosr/archs/compact_arch.py:76-79 (see include/neosr_amd.h).
 #include <cstring>
 #include "conv_common.h"
+#include "conv_wino4_chain.h"
 #include "prof.h"
 #include <stdlib.h>
 
@@ -437,7 +438,9 @@ extern "C" int neosr_conv3x3(const neosr_conv_desc* dp, void* stream) {
   const bool thin_n = plain_in && d.N <= 4 && d.K >= 8 && (d.K % 4 == 0) && al_mk && !d.res1 && !d.res2 &&
                       !d.accumulate && !d.out_mask && d.act != NEOSR_ACT_PRELU;
   if (use_wino4) {
-    launch_wino4(a, st);
+    const int rc = neosr_conv::launch_wino4_strips(d, stream);
+    if (rc > 0) return rc;
+    if (rc < 0) launch_wino4(a, st);
   } else if (use_wino) {
     launch_wino(a, st);
   } else if (use_pack) {

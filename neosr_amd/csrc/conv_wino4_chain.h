@@ -33,14 +33,17 @@ struct W4ChainArgs {
   int32_t B, H, W, in_cs;
   int32_t tiles_x, tiles_y, tx_shift, ty_shift, xcd;
   int32_t sync;       // 0: flag waits skipped (timing experiments only: results are then racy)
+  int32_t indep;      // 1: the layers are independent of each other (sample strips of one convolution): no drain, no flags
   unsigned long long* timeline;  // debug only (NEOSR_TIMELINE builds): [wave 12][layer 16][mark 16] clocks of workgroup 0
 };
 
 int chain_max_tiles();  // pixel tiles (= workgroups) one chain launch may have: the CU count of the device
 bool chain_enabled();  // NEOSR_AMD_CHAIN=0 / neosr_set_conv_chain(0): one launch per layer
-// `dep[i]`: see W4Layer::dep (dep[0] is ignored: layer 0 only reads what earlier launches wrote).  All layers share B, H,
+// `dep[i]`: see W4Layer::dep; dep == nullptr: independent layers, `flags` may be nullptr (dep[0] is ignored: layer 0 only reads what earlier launches wrote).  All layers share B, H,
 // W and the input channel stride; n <= W4_MAX_LAYERS.  Returns 0 = launched, 1 = error (neosr_last_error), -1 = the table does not qualify
 // (geometry, options, more tiles than CUs, chain switched off): the caller launches the layers one by one.
-int launch_wino4_chain(const neosr_conv_desc* d, const int* dep, int n, unsigned* flags, void* stream);
+int launch_wino4_chain(const neosr_conv_desc* d, const int* dep, int n, unsigned* flags, void* stream, bool profile = true);
+// one convolution with more pixel tiles than CUs as chain launches over strips of samples (dep == nullptr form of the above)
+int launch_wino4_strips(const neosr_conv_desc& d, void* stream);
 
 }  // namespace neosr_conv

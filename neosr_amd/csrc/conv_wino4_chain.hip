@@ -248,12 +248,16 @@ void conv3x3_wino4_chain_kernel(const W4ChainArgs args) {
     // the layer's input holds channels written by the previous layer of THIS launch from chunk `dep` on (-1: none)
     const int dep = l > 0 ? (L.dep == 1 ? 0 : L.dep) : -1;
     if (l == 0 || (dep != 0 && !c0_issued)) issue(rin, 0, ldsC);   // (else: requested by the previous layer, or after the poll)
-    // previous layer's stores drained (every storing wave), chunk 0 landed, then publish
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // previous layer's stores drained (every storing wave), chunk 0 landed, then publish.  A table of INDEPENDENT layers
+    // (args.indep: sample strips of one convolution) has nobody to tell: no drain, no flag — chunk 0 was requested during
+    // the previous layer's last iteration, every wave's pieces had landed before it left that layer's last MFMAs (their
+    // weights were loaded behind the request; the wait for them is vmcnt(0)) and its exchange barrier made them visible.
+    if (!args.indep || l == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     CTL_MARK(l, 1);
     __syncthreads();
     CTL_MARK(l, 2);
-    if (l > 0 && tid == 0) __hip_atomic_store((gu32*)args.flags + my_flag, (unsigned)l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!args.indep && l > 0 && tid == 0)
+      __hip_atomic_store((gu32*)args.flags + my_flag, (unsigned)l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (dep == 0) {  // the whole input is new: wait in the open
       if (wave == 0) poll_wait(poll_load(), (unsigned)l);
       __syncthreads();
@@ -547,7 +551,7 @@ unsigned* status_word() {
   auto it = words.find(dev);
   if (it != words.end()) return it->second;
   unsigned* p = nullptr;
-  if (hipMalloc((void**)&p, 256) != hipSuccess || hipMemset(p, 0, 256) != hipSuccess) return nullptr;
+  if (hipMalloc((void**)&p, 4096) != hipSuccess || hipMemset(p, 0, 4096) != hipSuccess) return nullptr;
   words[dev] = p;
   return p;
 }
@@ -575,7 +579,8 @@ int neosr_conv::chain_max_tiles() {
 }
 
 // Returns 0 on success, 1 on error (message set), -1 when the layers do not qualify (caller launches them one by one).
-int neosr_conv::launch_wino4_chain(const neosr_conv_desc* d, const int* dep, int n, unsigned* flags, void* stream) {
+int neosr_conv::launch_wino4_chain(const neosr_conv_desc* d, const int* dep, int n, unsigned* flags, void* stream,
+                                   bool profile) {
   if (n < 1 || n > W4_MAX_LAYERS || !chain_enabled()) return -1;
   const neosr_conv_desc& f = d[0];
   const int tiles_x = ceil_div(f.W, QT), tiles_y = ceil_div(f.H, QT);
@@ -604,14 +609,15 @@ int neosr_conv::launch_wino4_chain(const neosr_conv_desc* d, const int* dep, int
     L.in = c.in; L.u = c.w_wino4; L.bias = c.bias; L.res1 = c.res1; L.res2 = c.res2; L.out_mask = c.out_mask; L.out = c.out;
     L.K = c.K; L.N = c.N; L.out_cs = c.out_cs; L.res1_cs = c.res1_cs; L.res1_nch = c.res1_nch; L.res2_cs = c.res2_cs;
     L.res2_nch = c.res2_nch; L.out_mask_cs = c.out_mask_cs; L.act = c.act; L.n64 = c.N > 32 ? 1 : 0;
-    L.dep = i == 0 ? -1 : dep[i];
+    L.dep = (i == 0 || !dep) ? -1 : dep[i];
     L.slope = c.slope; L.alpha = c.alpha; L.alpha2 = c.alpha2; L.out_mask_slope = c.out_mask_slope;
   }
   hipStream_t st = (hipStream_t)stream;
   a.nlayers = n;
-  a.flags = flags;
   a.status = status_word();
   NEOSR_CHECK(a.status, "conv chain: no status word");
+  a.indep = dep ? 0 : 1;   // no dependency array: independent layers (no flags are read or written)
+  a.flags = flags ? flags : a.status + 64;
   a.B = f.B; a.H = f.H; a.W = f.W; a.in_cs = f.in_cs;
   a.tiles_x = tiles_x; a.tiles_y = tiles_y;
   auto lg2 = [](int v) { int s = 0; while ((1 << s) < v) ++s; return (1 << s) == v ? s : -1; };
@@ -620,7 +626,7 @@ int neosr_conv::launch_wino4_chain(const neosr_conv_desc* d, const int* dep, int
   a.xcd = xcd_enabled() ? 1 : 0;
   a.sync = g_chain_sync;
   a.timeline = debug_timeline();
-  if (neosr_prof_on()) {
+  if (profile && neosr_prof_on()) {
     double fl = 0, by = 0;
     const double px = (double)f.B * f.H * f.W;
     for (int i = 0; i < n; ++i) {
@@ -632,7 +638,47 @@ int neosr_conv::launch_wino4_chain(const neosr_conv_desc* d, const int* dep, int
     neosr_prof_layers(n);
   }
   hipLaunchKernelGGL(conv3x3_wino4_chain_kernel, dim3((unsigned)tiles), dim3(768), 0, st, a);
-  if (neosr_prof_on()) neosr_prof_end(stream);
+  if (profile && neosr_prof_on()) neosr_prof_end(stream);
   NEOSR_LAUNCH_CHECK();
+  return 0;
+}
+
+// One big convolution (more pixel tiles than CUs) as chain launches over STRIPS of samples: layer i of a launch is the same
+// convolution on the next group of samples, so a persistent workgroup walks through up to 15 tiles and the request for
+// the next tile's first chunk runs under the current tile's last one (a fresh workgroup per tile pays its prologue and
+// its dispatch in the open: ~5k of ~40k cycles at K = 64).  Same kernel arithmetic: bit-identical to launch_wino4 with the
+// same workgroup shape.  Returns 0 = done, 1 = error, -1 = not applicable.
+int neosr_conv::launch_wino4_strips(const neosr_conv_desc& d, void* stream) {
+  static const bool on = [] { const char* e = getenv("NEOSR_AMD_CONV_STRIPS"); return !(e && e[0] == '0'); }();
+  if (!on || !chain_enabled()) return -1;
+  const int tps = ceil_div(d.W, QT) * ceil_div(d.H, QT);
+  const int cap = chain_max_tiles();
+  if (d.ups || d.accumulate || d.N > 64 || d.K % 32 || d.K < 64 || tps > cap || (int64_t)tps * d.B < 2 * cap) return -1;
+  if (d.N > 32 && wino4_n64_mode() == 0) return -1;
+  const int gs = cap / tps;                 // samples per layer
+  if (gs < 1 || d.B % gs) return -1;
+  const int nlay = d.B / gs;
+  auto off = [&](const float* p, int cs, int s) { return p ? p + (int64_t)s * gs * d.H * d.W * cs : nullptr; };
+  for (int l0 = 0; l0 < nlay; l0 += W4_MAX_LAYERS) {
+    const int n = nlay - l0 < W4_MAX_LAYERS ? nlay - l0 : W4_MAX_LAYERS;
+    neosr_conv_desc dd[W4_MAX_LAYERS];
+    for (int i = 0; i < n; ++i) {
+      neosr_conv_desc& c = dd[i];
+      c = d;
+      c.B = gs;
+      const int s = l0 + i;
+      c.in = off(d.in, d.in_cs, s);
+      c.out = const_cast<float*>(off(d.out, d.out_cs, s));
+      c.res1 = off(d.res1, d.res1_cs, s);
+      c.res2 = off(d.res2, d.res2_cs, s);
+      c.out_mask = off(d.out_mask, d.out_mask_cs, s);
+    }
+    const int rc = launch_wino4_chain(dd, nullptr, n, nullptr, stream, false);
+    if (rc != 0) {
+      if (rc < 0 && l0 == 0) return -1;
+      if (rc < 0) neosr_set_error("conv strips: the chain kernel refused a later launch");
+      return 1;
+    }
+  }
   return 0;
 }

@@ -109,3 +109,39 @@ def test_chain_inference_ring(lib):
     finally:
         lib.neosr_set_conv_chain(prev)
         lib.neosr_set_wino4_n64(prev_n64)
+
+
+@pytest.mark.parametrize("B,H,W,K,N,opts", [
+    (8, 128, 128, 64, 64, "plain"),
+    (8, 128, 128, 128, 32, "lrelu_res"),
+    (32, 64, 64, 64, 64, "mask"),
+    (4, 256, 256, 64, 64, "dgrad"),
+])
+def test_sample_strips_of_one_convolution_are_bit_identical(lib, B, H, W, K, N, opts):
+    """A convolution with at least twice as many pixel tiles as CUs runs as chain launches over strips of samples
+    (conv_wino4_chain.hip, launch_wino4_strips: independent layers, no flags); the same launch through the one-layer kernel
+    (neosr_set_conv_chain(0)) must give the same bits."""
+    from neosr_amd.hip import ops
+
+    g = torch.Generator().manual_seed(B + H + K + N)
+    x = torch.randn(B, H, W, K + 8, generator=g).to(DEV)
+    mode = ops.CONV_DGRAD if opts == "dgrad" else ops.CONV_FWD
+    w = (torch.randn(N, K, 3, 3, generator=g) * 0.05).to(DEV) if mode == ops.CONV_FWD else (torch.randn(K, N, 3, 3, generator=g) * 0.05).to(DEV)
+    kw = dict(mode=mode, k_in=K, w_pack=ops.conv3x3_pack_weights(w, mode), w_wino4=ops.conv3x3_pack_wino4(w, mode))
+    if opts == "lrelu_res":
+        kw.update(bias=torch.randn(N, generator=g).to(DEV), act=ops.ACT_LRELU, slope=0.2, alpha=0.2,
+                  res1=torch.randn(B, H, W, N, generator=g).to(DEV))
+    if opts == "mask":
+        kw.update(out_mask=torch.randn(B, H, W, N, generator=g).to(DEV), out_mask_slope=0.2)
+    prev_n64 = lib.neosr_set_wino4_n64(1)
+    prev = lib.neosr_set_conv_chain(0)
+    try:
+        y0 = ops.conv3x3(x, w, **kw).clone()
+        lib.neosr_set_conv_chain(1)
+        for _ in range(3):
+            y1 = ops.conv3x3(x, w, **kw)
+            assert torch.equal(y0, y1), rel_err(y1, y0)
+        assert lib.neosr_conv_chain_status() == 0
+    finally:
+        lib.neosr_set_conv_chain(prev)
+        lib.neosr_set_wino4_n64(prev_n64)
