@@ -367,9 +367,6 @@ def main() -> None:
         _C.check(lib.neosr_prof_collect(ms, ln, fl, by), "neosr_prof_collect")
         lib.neosr_prof_enable(0)
         lib.neosr_set_num_streams(prev_streams)
-        chain_status = lib.neosr_conv_chain_status()
-        if chain_status != 0:
-            raise RuntimeError(f"chain kernel: a flag wait ran into its bound (status {chain_status}); results invalid")
         ALGO = ("direct", "winograd F(2x2,3x3): 16 of the direct form's 36 multiplications",
                 "winograd F(4x4,3x3): 36 of the direct form's 144 multiplications")
         kern = {}
@@ -440,10 +437,15 @@ def main() -> None:
         if ms[0] + ms[1] > 0:  # forward + backward-data launches of ONE symbol: comparable with its rocprofv3 row
             roofline["packed_conv_kernel_avg_us"] = round(1e3 * (ms[0] + ms[1]) / max(1, ln[0] + ln[1]), 2)
 
+    # a chain launch that never got all its workgroups resident leaves a sticky status (results invalid): looked at on every
+    # rank, but only raised behind the barrier so that no rank is left waiting for one that stopped
+    chain_status = _C.load().neosr_conv_chain_status()
     if world > 1:
         dist.barrier()
         if rank != 0:
             dist.destroy_process_group()
+    if chain_status != 0:
+        raise RuntimeError(f"chain kernel: a flag wait ran into its bound (status {chain_status}); results invalid")
     if rank != 0:
         return
     patches = world * B * args.steps
