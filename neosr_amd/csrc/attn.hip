@@ -211,6 +211,21 @@ __device__ __forceinline__ void load_tile(const Tables& T, const float* src, int
                                           float mul, float* dst) {
   const int n = threadIdx.x >> 2, part = threadIdx.x & 3;  // 64 tokens x 4 column groups of 8
   const float* row = src + (int64_t)T.tok[n] * ld + col0;
+  if (((ld | col0 | hd) & 1) == 0 && (reinterpret_cast<uintptr_t>(src) & 7) == 0) {
+    // even row stride, head offset and head size: the slice is 8-byte aligned -> four 8-byte loads instead of eight 4-byte ones
+    float2 v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = part * 8 + 2 * e;
+      v[e] = c < hd ? *reinterpret_cast<const float2*>(row + c) : make_float2(0.f, 0.f);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      dst[n * QS + part * 8 + 2 * e] = v[e].x * mul;
+      dst[n * QS + part * 8 + 2 * e + 1] = v[e].y * mul;
+    }
+    return;
+  }
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const int c = part * 8 + e;
@@ -354,11 +369,22 @@ __global__ __launch_bounds__(256) void window_attention_bwd_kernel(const neosr_w
     const int n = tid >> 2, part = tid & 3;
     const int64_t row = (int64_t)T.tok[n] * d.C + w.head * hd;
     float gv[8], ov[8];
+    if (((d.C | hd) & 1) == 0 && ((reinterpret_cast<uintptr_t>(d.dout) | reinterpret_cast<uintptr_t>(d.out)) & 7) == 0) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int c = part * 8 + e;
-      gv[e] = c < hd ? d.dout[row + c] : 0.f;
-      ov[e] = c < hd ? d.out[row + c] : 0.f;
+      for (int e = 0; e < 4; ++e) {  // 8-byte loads (see load_tile)
+        const int c = part * 8 + 2 * e;
+        const float2 a = c < hd ? *reinterpret_cast<const float2*>(d.dout + row + c) : make_float2(0.f, 0.f);
+        const float2 b = c < hd ? *reinterpret_cast<const float2*>(d.out + row + c) : make_float2(0.f, 0.f);
+        gv[2 * e] = a.x; gv[2 * e + 1] = a.y;
+        ov[2 * e] = b.x; ov[2 * e + 1] = b.y;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int c = part * 8 + e;
+        gv[e] = c < hd ? d.dout[row + c] : 0.f;
+        ov[e] = c < hd ? d.out[row + c] : 0.f;
+      }
     }
     float s = 0.f;
 #pragma unroll
