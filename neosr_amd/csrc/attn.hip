@@ -346,9 +346,15 @@ __global__ __launch_bounds__(256) void window_attention_fwd_kernel(const neosr_w
   }
 }
 
+// HAVE_O (the forward output is at hand, as in training): ONE 64 x 64 score buffer — P, then dS in place — instead of two:
+// 52 KB of LDS, three workgroups per CU instead of two (-9 % on its own).  The products that read P (dV) run between P and
+// the in-place dS; dQ and dK behind it are then one 32-MFMA product per wave pair (before: dV + dQ on two waves, dK on two).
+template <bool HAVE_O>
 __global__ __launch_bounds__(256) void window_attention_bwd_kernel(const neosr_wattn_desc d) {
   __shared__ float Qs[NTOK * QS], Ks[NTOK * QS], Vs[NTOK * QS], Gs[NTOK * QS];
-  __shared__ float P[NTOK * PS], dS[NTOK * PS];
+  __shared__ float P[NTOK * PS];
+  __shared__ float dS2[HAVE_O ? 1 : NTOK * PS];
+  float* dS = HAVE_O ? P : dS2;
   __shared__ float lse_s[NTOK], delta_s[NTOK];
   __shared__ Tables T;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
@@ -361,7 +367,7 @@ __global__ __launch_bounds__(256) void window_attention_bwd_kernel(const neosr_w
   load_tile(T, d.qkv, ld, w.head * hd, hd, d.scale, Qs);
   load_tile(T, d.qkv, ld, d.C + w.head * hd, hd, 1.f, Ks);
   load_tile(T, d.qkv, ld, 2 * d.C + w.head * hd, hd, 1.f, Vs);
-  const bool have_o = d.out != nullptr;
+  constexpr bool have_o = HAVE_O;
   if (have_o) {
     // delta[i] = sum_j P dP = sum_d dO[i][d] O[i][d]: with the forward output at hand the row sums come from two
     // 30-float rows instead of two 64 x 64 LDS tiles, and dS is finished in the score tile's registers.  The O row is
@@ -399,16 +405,35 @@ __global__ __launch_bounds__(256) void window_attention_bwd_kernel(const neosr_w
     load_tile(T, d.dout, d.C, w.head * hd, hd, 1.f, Gs);
   }
   __syncthreads();
+  float* g = d.dqkv + w.head * hd + l31;
   {
     const int ti = wave >> 1, tj = wave & 1;
     const f32x16 s = tile_abt(Qs, QS, Ks, QS, ti, tj, kq, l31, lh);
     scores_to_lds(T, s, ti, tj, l31, lh, lse_s, P);                   // P = softmax (recomputed)
     const f32x16 dp = tile_abt(Gs, QS, Vs, QS, ti, tj, kq, l31, lh);  // dP = dO V^T
     const int i0 = 32 * ti + 4 * lh, j = 32 * tj + l31;
+    if (HAVE_O) {
+      __syncthreads();   // P complete
+      if (wave >= 2) {   // dV[j][d] = sum_i P[i][j] dO[i][d]
+        const f32x16 dv = tile_atb(P, PS, Gs, QS, wave - 2, 0, l31, lh);
+        if (l31 < hd) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int i = i0 + (r & 3) + 8 * (r >> 2);
-      dS[i * PS + j] = have_o ? P[i * PS + j] * (dp[r] - delta_s[i]) : dp[r];
+          for (int r = 0; r < 16; ++r)
+            g[(int64_t)T.tok[32 * (wave - 2) + (r & 3) + 8 * (r >> 2) + 4 * lh] * ld + 2 * d.C] = dv[r];
+        }
+      }
+      __syncthreads();   // P has been read: dS over it, every lane on the elements it wrote
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = i0 + (r & 3) + 8 * (r >> 2);
+        dS[i * PS + j] = P[i * PS + j] * (dp[r] - delta_s[i]);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = i0 + (r & 3) + 8 * (r >> 2);
+        dS[i * PS + j] = dp[r];
+      }
     }
   }
   __syncthreads();
@@ -446,17 +471,16 @@ __global__ __launch_bounds__(256) void window_attention_bwd_kernel(const neosr_w
     }
     d.workspace[((int64_t)(bid / d.heads) * NB + tid) * d.heads + w.head] = s;
   }
-  float* g = d.dqkv + w.head * hd + l31;
   if (wave < 2) {
-    // dV[j][d] = sum_i P[i][j] dO[i][d]
-    const f32x16 dv = tile_atb(P, PS, Gs, QS, wave, 0, l31, lh);
     // dQ[i][d] = scale * sum_j dS[i][j] K[j][d]
     const f32x16 dq = tile_ab(dS, PS, Ks, QS, wave, 0, l31, lh);
+    f32x16 dv;
+    if (!HAVE_O) dv = tile_atb(P, PS, Gs, QS, wave, 0, l31, lh);   // dV[j][d] = sum_i P[i][j] dO[i][d]
     if (l31 < hd) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int64_t t = (int64_t)T.tok[32 * wave + (r & 3) + 8 * (r >> 2) + 4 * lh] * ld;
-        g[t + 2 * d.C] = dv[r];
+        if (!HAVE_O) g[t + 2 * d.C] = dv[r];
         g[t] = dq[r] * d.scale;
       }
     }
@@ -606,7 +630,8 @@ extern "C" int neosr_window_attention_bwd(const neosr_wattn_desc* d, void* strea
     static const bool rowpass = getenv("NEOSR_WATTN_ROWPASS") != nullptr;  // A/B: delta from the score tiles, not from O
     neosr_wattn_desc dd = *d;
     if (rowpass) dd.out = nullptr;
-    hipLaunchKernelGGL(window_attention_bwd_kernel, dim3(nbw * d->heads), dim3(256), 0, (hipStream_t)stream, dd);
+    if (dd.out) hipLaunchKernelGGL(window_attention_bwd_kernel<true>, dim3(nbw * d->heads), dim3(256), 0, (hipStream_t)stream, dd);
+    else hipLaunchKernelGGL(window_attention_bwd_kernel<false>, dim3(nbw * d->heads), dim3(256), 0, (hipStream_t)stream, dd);
   }
   if (prof) neosr_prof_end(stream);
   NEOSR_LAUNCH_CHECK();
