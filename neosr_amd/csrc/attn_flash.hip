@@ -122,6 +122,18 @@ constexpr int KEY_NONE = -2147483647 - 1;
 __device__ __forceinline__ void load_row8(const float* src, int tok, int ld, int col0, int hd, int part,
                                           float (&v)[8]) {
   const float* row = src + (int64_t)(tok < 0 ? 0 : tok) * ld + col0;
+  if (((ld | col0 | hd) & 1) == 0 && (reinterpret_cast<uintptr_t>(src) & 7) == 0) {
+    // even row stride, head offset and head size (30-float head slices of a 180-channel row): 8-byte aligned -> four
+    // 8-byte loads instead of eight 4-byte ones (the 8x8-window kernel gained 10 % from the same change)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = part * 8 + 2 * e;
+      const float2 t = (tok >= 0 && c < hd) ? *reinterpret_cast<const float2*>(row + c) : make_float2(0.f, 0.f);
+      v[2 * e] = t.x;
+      v[2 * e + 1] = t.y;
+    }
+    return;
+  }
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const int c = part * 8 + e;
