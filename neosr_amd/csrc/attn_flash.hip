@@ -519,6 +519,15 @@ __global__ __launch_bounds__(256) void flash_wattn_bwd_dkv_kernel(const neosr_fa
     store_row8(S.Vs, n, part, vr, 1.f);
   }
   f32x16 acc = zero16();  // waves 0,1: dV rows 32 wave..; waves 2,3: dK rows 32 (wave-2)..
+  // the next query block's q / dO rows travel in registers while the current block is consumed (every thread works out
+  // its own row's pixel: no table, no barrier in front of the loads) — as the dQ kernel does with its key blocks
+  float qn[8], gn[8];
+  {
+    int tok, reg;
+    query_geom<WS>(d, w, n, tok, reg);
+    load_row8(d.qkv, tok, ld, w.head * hd, hd, part, qn);
+    load_row8(d.dout, tok, d.C, w.head * hd, hd, part, gn);
+  }
   for (int qb = 0; qb < G::NQB; ++qb) {
     __syncthreads();  // previous products finished with Qs / Gs / P / dS
     w.qb = qb;
@@ -530,15 +539,15 @@ __global__ __launch_bounds__(256) void flash_wattn_bwd_dkv_kernel(const neosr_fa
       S.lse[tid] = d.lse[(wh * G::NQB + qb) * QB + tid];
       S.dsum[tid] = d.workspace[ws.dsum + (wh * G::NQB + qb) * QB + tid];
     }
+    store_row8(S.Qs, n, part, qn, d.scale);
+    store_row8(S.Gs, n, part, gn, 1.f);
     __syncthreads();
-    {
-      float q[8], g[8];
-      load_row8(d.qkv, S.qtok[n], ld, w.head * hd, hd, part, q);
-      load_row8(d.dout, S.qtok[n], d.C, w.head * hd, hd, part, g);
-      store_row8(S.Qs, n, part, q, d.scale);
-      store_row8(S.Gs, n, part, g, 1.f);
+    if (qb + 1 < G::NQB) {
+      int tok, reg;
+      query_geom<WS>(d, w, (qb + 1) * QB + n, tok, reg);
+      load_row8(d.qkv, tok, ld, w.head * hd, hd, part, qn);
+      load_row8(d.dout, tok, d.C, w.head * hd, hd, part, gn);
     }
-    __syncthreads();
     recompute_p_ds<G::NBINS, G::SELF>(S, kq, wave, l31, lh);
     if (wave < 2)
       acc = mm_atb(acc, S.P, PS, S.Gs, QS, wave, 0, l31, lh);       // dV[j][d] += sum_i P[i][j] dO[i][d]
