@@ -181,6 +181,16 @@ __device__ __forceinline__ f32x16 mm_ab(f32x16 acc, const float* A, int sa, cons
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * ks], bp[2 * ks * sb], acc, 0, 0, 0);
   return acc;
 }
+// the same over the 32 reduction indices k0 .. k0 + 31 only
+__device__ __forceinline__ f32x16 mm_ab_half(f32x16 acc, const float* A, int sa, const float* B, int sb, int ti, int tj,
+                                             int l31, int lh, int k0) {
+  const float* ap = A + (32 * ti + l31) * sa + k0 + lh;
+  const float* bp = B + (k0 + lh) * sb + 32 * tj + l31;
+#pragma unroll 16
+  for (int ks = 0; ks < QB / 4; ++ks)
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * ks], bp[2 * ks * sb], acc, 0, 0, 0);
+  return acc;
+}
 // D[i][j] += sum_k A[k][i] B[k][j], k < 64
 __device__ __forceinline__ f32x16 mm_atb(f32x16 acc, const float* A, int sa, const float* B, int sb, int ti,
                                          int tj, int l31, int lh) {
@@ -474,19 +484,27 @@ __global__ __launch_bounds__(256, KS > WS ? 2 : 1) void flash_wattn_bwd_dq_kerne
       for (int c = 0; c < 16; ++c)
         if (kb * QB + part * 16 + c < G::NK) o[c] = gr[c];
     }
-    if (wave < 2) dq = mm_ab(dq, S.dS, PS, S.Ks, QS, wave, 0, l31, lh);
+    // dQ[i][d] += sum_j dS[i][j] K[j][d]: all four waves — wave (tile = wave & 1, key half = wave >> 1) takes 32 of the
+    // block's 64 keys (before: the two tiles on waves 0, 1 while waves 2, 3 idled); the halves meet once, at the end
+    dq = mm_ab_half(dq, S.dS, PS, S.Ks, QS, wave & 1, 0, l31, lh, 32 * (wave >> 1));
   }
+  __syncthreads();   // last block's products have read P / dS
   if (G::SELF) {  // partial bins of (window, query block): row (bw index, qb) of a [rows][bin][head] matrix
-    __syncthreads();
     float* row = d.workspace + ws.ds_full +
                  ((int64_t)(bid / (d.heads * G::NQB)) * G::NQB + w.qb) * G::NBINS * d.heads + w.head;
     for (int k = tid; k < G::NBINS; k += 256) row[(int64_t)k * d.heads] = S.bins[k];
   }
+  if (wave >= 2) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) S.P[(wave - 2) * 1024 + r * 64 + lane] = dq[r];
+  }
+  __syncthreads();
   if (wave < 2 && l31 < hd) {
     float* g = d.dqkv + w.head * hd + l31;
 #pragma unroll
     for (int r = 0; r < 16; ++r)
-      g[(int64_t)S.qtok[32 * wave + (r & 3) + 8 * (r >> 2) + 4 * lh] * ld] = dq[r] * d.scale;
+      g[(int64_t)S.qtok[32 * wave + (r & 3) + 8 * (r >> 2) + 4 * lh] * ld] =
+          (dq[r] + S.P[wave * 1024 + r * 64 + lane]) * d.scale;
   }
 }
 
