@@ -33,10 +33,12 @@ for K, N in [(180, 60), (60, 180), (180, 180)]:
     fl = 2.0 * B * H * W * K * N * 9
     t1 = timeit(lambda: ops.conv3x3(x, w, bias, out=out, w_pack=pack))
     t2 = timeit(lambda: ops.conv3x3(x, w, bias, out=out, w_pack=pack, w_wino=wino))
+    w4 = ops.conv3x3_pack_wino4(w)
+    t5 = timeit(lambda: ops.conv3x3(x, w, bias, out=out, w_pack=pack, w_wino=wino, w_wino4=w4))
     g = torch.randn(B, H, W, N, device=dev)
     gx = torch.empty(B, H, W, K, device=dev)
     pd, wd = ops.conv3x3_pack_weights(w, ops.CONV_DGRAD), ops.conv3x3_pack_wino(w, ops.CONV_DGRAD)
     t3 = timeit(lambda: ops.conv3x3(g, w, None, mode=ops.CONV_DGRAD, out=gx, w_pack=pd, w_wino=wd))
     t4 = timeit(lambda: ops.conv3x3_wgrad(x, g, N, K))
-    print(f"B={B} K={K:3d} N={N:3d}: fwd glds {t1:6.1f} us {fl / t1 / 1e6:6.1f} TF | fwd wino {t2:6.1f} us {fl / t2 / 1e6:6.1f} | "
+    print(f"B={B} K={K:3d} N={N:3d}: fwd glds {t1:6.1f} us {fl / t1 / 1e6:6.1f} TF | fwd wino {t2:6.1f} us {fl / t2 / 1e6:6.1f} | fwd wino4 {t5:6.1f} us | "
           f"dgrad wino {t3:6.1f} us {fl / t3 / 1e6:6.1f} | wgrad {t4:6.1f} us {fl / t4 / 1e6:6.1f} TF-eq")
