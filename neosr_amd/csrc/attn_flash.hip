@@ -354,7 +354,8 @@ __host__ __device__ inline BwdWs bwd_ws(const neosr_fattn_desc& d) {
 
 // shared by both backward kernels: P = exp(S - lse), dP = dO V^T, dS = P (dP - D) for the current
 // (query block in Qs/Gs, key block in Ks/Vs); leaves P and dS tiles in LDS
-template <int NBINS, bool SELF>
+// NEED_P = false (the dQ kernel only consumes dS): the P tile is not written
+template <int NBINS, bool SELF, bool NEED_P = true>
 __device__ __forceinline__ void recompute_p_ds(SharedBwd& S, int kq, int wave, int l31, int lh) {
   {
     const int ti = wave >> 1, tj = wave & 1;
@@ -376,7 +377,7 @@ __device__ __forceinline__ void recompute_p_ds(SharedBwd& S, int kq, int wave, i
       // dS = P (dP - D) with D = rowsum(dO . O) already in LDS: finished in the tile's own registers (a separate row
       // pass over the two LDS tiles cost 32 reads + 16 writes per thread and one more barrier per key block)
       const float p = none ? 0.f : __expf(v - S.lse[i]);
-      S.P[i * PS + j] = p;
+      if (NEED_P) S.P[i * PS + j] = p;
       S.dS[i * PS + j] = p * (dp[r] - S.dsum[i]);
     }
   }
@@ -442,7 +443,7 @@ __global__ __launch_bounds__(256, KS > WS ? 2 : 1) void flash_wattn_bwd_dq_kerne
       load_row8(d.qkv, ktok, ld, d.C + w.head * hd, hd, part, kr);
       load_row8(d.qkv, ktok, ld, 2 * d.C + w.head * hd, hd, part, vr);
     }
-    recompute_p_ds<G::NBINS, G::SELF>(S, kq, wave, l31, lh);
+    recompute_p_ds<G::NBINS, G::SELF, false>(S, kq, wave, l31, lh);
     if (G::SELF) {
       // bias gradient of this 64-query x 64-key tile, owner-computes: the tile is RQ x RQ window rows of WS (4 x 4 rows of
       // 16, or the whole 8 x 8 window), so it touches (2 RQ - 1) x (2 WS - 1) bins (dy = yi - yj, dx = xi - xj) and thread
