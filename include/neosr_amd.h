@@ -139,7 +139,8 @@ int neosr_set_wgrad4(int on);
  * the F(4x4,3x3) kernel, the batch has at most one tile per CU and neosr_set_wino4_n64 is not 0; 0 = never.  Same
  * arithmetic per layer: bit-identical to the per-convolution launches of the same workgroup shapes.  Returns the previous
  * setting.  neosr_conv_chain_status: 0 while no flag wait ever ran into its spin bound on this device (it synchronises;
- * a non-zero value means a chain launch did not get all its workgroups resident and its results are invalid).
+ * a non-zero value means a chain launch did not get all its workgroups resident: its
+ * results are invalid, and from this read on the library uses one launch per convolution in this process).
  * neosr_set_conv_chain_sync(0) skips the flag waits (timing experiments only: results are then racy); default 1. */
 int neosr_set_conv_chain(int on);
 /* Behind a chain launch the fifteen weight gradients of an RRDB run as ONE neosr_conv3x3_wgrad_multi launch (1, default;

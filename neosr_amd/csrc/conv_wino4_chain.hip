@@ -519,6 +519,7 @@ void conv3x3_wino4_chain_kernel(const W4ChainArgs args) {
 std::mutex g_mu;
 int g_chain_on = -1;                            // -1: read NEOSR_AMD_CHAIN on first use (default on)
 int g_chain_sync = 1;                           // debug: 0 = flag waits skipped (timing only, racy)
+bool g_chain_tripped = false;                   // neosr_conv_chain_status() has seen an aborted launch: no more chain launches
 
 }  // namespace
 
@@ -538,7 +539,7 @@ bool neosr_conv::chain_enabled() {
     const char* e = getenv("NEOSR_AMD_CHAIN");
     g_chain_on = (e && e[0] == '0') ? 0 : 1;
   }
-  return g_chain_on == 1 && wino_mode() == 2;
+  return g_chain_on == 1 && !g_chain_tripped && wino_mode() == 2;
 }
 
 namespace {
@@ -558,10 +559,17 @@ unsigned* status_word() {
 }  // namespace
 
 // 0: no chain launch on this device ever gave up a flag wait; else 1 + the epoch the first one waited for.  Synchronises.
+// Once a wait has given up, the sticky word ends every later wait of every launch at once (poll_ok), so the damaged
+// launches finish quickly — on unfinished neighbour data: their results are garbage.  Nothing may consume them: the
+// models read this word whenever they read their loss scalars (models/base.py: get_current_log raises), and once this
+// function has seen a non-zero word the library stops using chain launches in this process (one launch per convolution
+// from then on).  (Leaving the kernel early instead — an abort word every wave looks at once per layer — was measured at
+// -4 % on the headline step, 645 -> 620 LR-patches/s, for a path that only runs after a failure; not kept.)
 extern "C" int neosr_conv_chain_status(void) {
   unsigned* p = status_word();
   unsigned v = 0;
   if (!p || hipMemcpy(&v, p, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  if (v) g_chain_tripped = true;
   return (int)v;
 }
 

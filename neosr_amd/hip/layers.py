@@ -207,6 +207,7 @@ class Conv3x3(torch.autograd.Function):
                         w_pack=packed_weights(w, ops.CONV_FWD), s2d_c=s2d_c, **wino)
         ctx.s2d_c = s2d_c
         ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
+        ctx.leaves = (w, b)
         ctx.act, ctx.slope, ctx.has_bias, ctx.ups, ctx.has_res = act, slope, b is not None, ups, res is not None
         if act != ACT_NONE and res is not None:
             raise _C.NeosrAmdError("Conv3x3: activation + residual cannot be differentiated from the output")
@@ -260,8 +261,14 @@ class Conv3x3(torch.autograd.Function):
                 pad = torch.zeros(*x.shape[:3], x.shape[3] - gx.shape[3], device=g.device)
                 gx = torch.cat((gx, pad), 3)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            # data-parallel runs: straight into the parameters' slices of the exchange arena (transformer.GRAD_SLOT)
+            from neosr_amd.hip import transformer as _tr
+
+            wl, bl = ctx.leaves
+            dw = _tr.GRAD_SLOT(wl) if _tr.GRAD_SLOT is not None else None
+            db = _tr.GRAD_SLOT(bl) if _tr.GRAD_SLOT is not None and ctx.has_bias and bl is not None else None
             gw, gb = ops.conv3x3_wgrad(x, g, w.shape[0], w.shape[1], g_mask=y, mask_slope=slope,
-                                       want_bias=ctx.has_bias, ups=ctx.ups, s2d_c=ctx.s2d_c)
+                                       want_bias=ctx.has_bias, ups=ctx.ups, s2d_c=ctx.s2d_c, dw=dw, db=db)
         return gx, gw, gb, None, None, None, (g if ctx.has_res else None), None, None
 
 

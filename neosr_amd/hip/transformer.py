@@ -8,6 +8,7 @@ torch is used for allocation and the autograd graph only; every FLOP runs in lib
 
 from __future__ import annotations
 
+import contextlib
 import os
 
 import torch
@@ -74,10 +75,36 @@ def row_scale(x2d, scale, rows_per_scale):
     return out
 
 
-def _wgrad_pair(like, n_out: int, k_in: int, want_bias: bool):
+# Set by the model on data-parallel runs (GradSync.grad_slot): where the first gradient contribution of a parameter may
+# be written directly — its slice of the gradient arena the all-reduce and the optimizer work on — instead of a fresh
+# tensor that has to be packed later.  None / returning None: allocate as usual.
+GRAD_SLOT = None
+
+
+def _pair_slots(first, second, n_first: int, n_second: int):
+    """arena slices of two parameters whose gradients one kernel writes back to back (weight | bias, gamma | beta), as
+    one flat (n_first + n_second) view — or None when they are not adjacent slots"""
+    if GRAD_SLOT is None or first is None:
+        return None
+    a = GRAD_SLOT(first)
+    if a is None or not a.is_contiguous() or a.numel() != n_first:
+        return None
+    if second is None:
+        return a.view(-1)
+    b = GRAD_SLOT(second)
+    if b is None or b.numel() != n_second or b.data_ptr() != a.data_ptr() + 4 * n_first:
+        return None
+    flat = torch.empty(0, device=a.device, dtype=torch.float32)
+    flat.set_(a.untyped_storage(), a.storage_offset(), (n_first + n_second,), (1,))
+    return flat
+
+
+def _wgrad_pair(like, n_out: int, k_in: int, want_bias: bool, wl=None, bl=None):
     """(dW (n_out, k_in), db (n_out)) in one buffer, db right behind dW: the TN GEMM then finishes both with a
-    single split-K reduction pass"""
-    buf = _new((n_out * k_in + (n_out if want_bias else 0),), like)
+    single split-K reduction pass.  `wl` / `bl`: the leaves the gradients are for (GRAD_SLOT)."""
+    buf = _pair_slots(wl, bl if want_bias else None, n_out * k_in, n_out)
+    if buf is None:
+        buf = _new((n_out * k_in + (n_out if want_bias else 0),), like)
     return buf[: n_out * k_in].view(n_out, k_in), (buf[n_out * k_in:] if want_bias else None)
 
 
@@ -89,7 +116,13 @@ def _wgrad_pair(like, n_out: int, k_in: int, want_bias: bool):
 # unfinished sum.  Only leaf tensors are deferred (a non-leaf weight needs its gradient inside the graph).
 _DEFERRED: list = []
 _DEFERRED_BYTES = 0
-DEFER_REDUCTIONS = os.environ.get("NEOSR_AMD_DEFER_REDUCE", "1") != "0"
+# OPT-IN (ADVICE r2 / VERDICT r3): a deferred gradient bypasses autograd (the Function returns None and `.grad` is
+# written by the flush), so `torch.autograd.grad(loss, params)` in user code would see None.  The queue is therefore
+# only used inside `deferred_reductions()` — which the models put around their own `backward()` calls
+# (models/image.py) — or process-wide with NEOSR_AMD_DEFER_REDUCE=1; NEOSR_AMD_DEFER_REDUCE=0 switches it off everywhere.
+_DEFER_ENV = os.environ.get("NEOSR_AMD_DEFER_REDUCE")
+DEFER_REDUCTIONS = _DEFER_ENV == "1"
+_DEFER_SCOPE = 0
 # A queued job pins the WHOLE workspace its partials live in (a view keeps the storage alive: ~100 MB per HAB of hat_l at
 # B = 4, the split-K slabs of every Linear) until it is flushed, so the queue is bounded: it is flushed from inside the
 # backward pass once it holds DEFER_MAX_JOBS jobs (the launch batch of `neosr_colsum_many`) or DEFER_MAX_BYTES of pinned
@@ -101,6 +134,20 @@ DEFER_MAX_BYTES = 1 << 30
 GRADS_READY = None
 
 
+@contextlib.contextmanager
+def deferred_reductions(on: bool = True):
+    """Scope in which parameter-gradient reductions may be batched at the end of `backward()` (see above)."""
+    global _DEFER_SCOPE
+    if not on or _DEFER_ENV == "0":
+        yield
+        return
+    _DEFER_SCOPE += 1
+    try:
+        yield
+    finally:
+        _DEFER_SCOPE -= 1
+
+
 def _task_id() -> int:
     fn = getattr(torch._C, "_current_graph_task_id", None)  # noqa: SLF001
     return fn() if fn is not None else -1
@@ -108,7 +155,7 @@ def _task_id() -> int:
 
 def _can_defer(*params) -> bool:
     # (not under hipGraph capture: the captured backward must contain its reductions)
-    return (DEFER_REDUCTIONS and all(p is not None and p.is_leaf and p.requires_grad for p in params)
+    return ((DEFER_REDUCTIONS or _DEFER_SCOPE > 0) and all(p is not None and p.is_leaf and p.requires_grad for p in params)
             and not torch.cuda.is_current_stream_capturing())
 
 
@@ -201,8 +248,8 @@ class Linear(torch.autograd.Function):
             gx = gemm(_C.GEMM_NN, g2, w, M, K, N, row_scale=rs, rows_per_scale=rps).view(*g.shape[:-1], K)
         want_b = has_b and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            gw, gb = _wgrad_pair(g2, N, K, want_b)  # bias gradient rides in the weight-gradient GEMM
             wl, bl = ctx.leaves
+            gw, gb = _wgrad_pair(g2, N, K, want_b, wl, bl)  # bias gradient rides in the weight-gradient GEMM
             if _can_defer(wl, *((bl,) if want_b else ())):
                 gemm(_C.GEMM_TN, g2, x2, N, K, M, out=gw, colsum_a=gb, row_scale=rs, rows_per_scale=rps,
                      defer_to=[(wl, gw)] + ([(bl, gb)] if want_b else []))
@@ -246,9 +293,9 @@ class Mlp(torch.autograd.Function):
         x2, w1, w2, pre, h, rs = ctx.saved_tensors
         M, K, Hd, N, rps, has_res = ctx.meta
         g2 = _as2d(g)
-        gw2, gb2 = _wgrad_pair(g2, N, Hd, True)  # bias gradients ride in the weight-gradient GEMMs
-        gw1, gb1 = _wgrad_pair(g2, Hd, K, True)
         l1, lb1, l2, lb2 = ctx.leaves
+        gw2, gb2 = _wgrad_pair(g2, N, Hd, True, l2, lb2)  # bias gradients ride in the weight-gradient GEMMs
+        gw1, gb1 = _wgrad_pair(g2, Hd, K, True, l1, lb1)
         # (split reductions of both weight gradients queued for the batched pass at the end of backward when all four
         # parameters are leaves)
         defer = _can_defer(l1, lb1, l2, lb2) and all(ctx.needs_input_grad[1:5])
@@ -331,7 +378,9 @@ class ResidualLayerNorm(torch.autograd.Function):
         g2 = _as2d(g)
         gs2 = None if gs is None else _as2d(gs)
         dx = torch.empty_like(x2)
-        dgb = _new((2 * C_,), x2)  # dgamma | dbeta adjacent: one reduction launch
+        dgb = _pair_slots(ctx.gamma_leaf, ctx.beta_leaf, C_, C_)
+        if dgb is None:
+            dgb = _new((2 * C_,), x2)  # dgamma | dbeta adjacent: one reduction launch
         dg, db = dgb[:C_], dgb[C_:]
         ws = _new(((2 * 1024 + 512) * C_,), x2)
         if _can_defer(ctx.gamma_leaf, ctx.beta_leaf):
@@ -527,6 +576,8 @@ class ChannelGate(torch.autograd.Function):
     """out = res + alpha * y * sigmoid(W2 relu(W1 mean_hw(y) + b1) + b2): ChannelAttention
     (hat_arch.py:15-37) fused with HAB's `+ conv_x * conv_scale` (:347).  y, res: (B, H, W, C)."""
 
+    trace = None   # tests: a list collects (pooled, w1, b1) of every forward (the bottleneck's ReLU inputs follow from them)
+
     @staticmethod
     def forward(ctx, y, w1, b1, w2, b2, res, alpha):
         lib = _C.load()
@@ -541,6 +592,8 @@ class ChannelGate(torch.autograd.Function):
         _C.check(lib.neosr_channel_attention_fwd(pooled.data_ptr(), w1c.data_ptr(), b1.data_ptr(), w2c.data_ptr(),
                                                  b2.data_ptr(), hidden.data_ptr(), attn.data_ptr(), B, C_, Cs, _st()),
                  "neosr_channel_attention_fwd")
+        if ChannelGate.trace is not None:
+            ChannelGate.trace.append((pooled, w1c, b1))
         out = torch.empty_like(y)
         r = None if res is None else res.contiguous()
         _C.check(lib.neosr_scale_channels_add(y.data_ptr(), attn.data_ptr(), _p(r), out.data_ptr(), B, rows, C_, alpha,

@@ -25,7 +25,7 @@ import torch
 import torch.distributed as dist
 from torch import nn
 
-from neosr_amd import optimizers
+from neosr_amd import _C, optimizers
 from neosr_amd.hip.nets import flatten_parameters_
 from neosr_amd.utils.dist_util import master_only
 from neosr_amd.utils.misc import get_root_logger, tc
@@ -130,6 +130,17 @@ class base:
             host = vals.detach().float().cpu().tolist()
             self.log_dict = OrderedDict(zip(keys, host))
             self._log_dev = None
+            # The chain launches of the RRDB trunk need all their workgroups resident at once; one that never got them
+            # (another process or a long collective holding CUs) gives up after its spin bound, finishes on
+            # unfinished neighbour data and leaves a sticky status word.  The device was just synchronised by the read above, so looking
+            # at the word costs one 4-byte copy: raise instead of training on from garbage.  Reading a
+            # non-zero word also makes the library drop chain launches for the rest of the process.
+            st = _C.load().neosr_conv_chain_status() if vals.is_cuda else 0
+            if st > 0:
+                msg = (f"conv chain launch aborted (status {st}): a chain launch did not get all its workgroups resident; "
+                       "the iterations since the last log read are invalid.  Chain launches are now off in this process "
+                       "(NEOSR_AMD_CHAIN=0 avoids them from the start when the GPU is shared).")
+                raise _C.NeosrAmdError(msg)
             tot = self.log_dict.get("l_g_total")
             if tot is not None and tot != tot:
                 msg = (f"{tc.red}NaN found, aborting training. Make sure you're using a proper "
@@ -158,8 +169,8 @@ class base:
         if not torch.cuda.is_available():
             msg = "neosr_amd models need a HIP device (no CPU fallback on the product path)"
             raise RuntimeError(msg)
-        net = net.to(self.device)
-        flatten_parameters_(net)
+        flatten_parameters_(net, self.device)   # host gather + ONE transfer; the parameters become device views
+        net = net.to(self.device)               # (moves what is left: the buffers)
         if self.opt["dist"]:
             # DDP's constructor broadcasts rank 0's parameters AND buffers (base.py:140-146): ranks seed with
             # manual_seed + rank, so without this the spectral-norm weight_u / weight_v start different per rank

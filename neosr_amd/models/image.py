@@ -31,6 +31,7 @@ from neosr_amd import _C, optimizers
 from neosr_amd.archs import build_network
 from neosr_amd.data.augmentations import apply_augment, resize_aa
 from neosr_amd.data.draws import LiveDraws
+from neosr_amd.hip import transformer as _tr
 from neosr_amd.hip.nets import arena_layout, flat_grad_of, flatten_parameters_, pack_grads
 from neosr_amd.losses import build_loss
 from neosr_amd.losses.consistency_loss import _Clamp
@@ -170,10 +171,9 @@ class image(base):
             self.net_g._neosr_grad_sync = self._sync_g  # noqa: SLF001
             if not getattr(self.net_g, "plan_sends_grad_buckets", False) and os.environ.get("NEOSR_AMD_DDP_HOOKS", "1") != "0":
                 # layer-composed generator (SwinIR, HAT, compact): DDP-style buckets driven by gradient hooks
-                from neosr_amd.hip import transformer as _tr
-
                 self._sync_g.attach(list(self.net_g.parameters()))
                 _tr.GRADS_READY = self._sync_g.grads_ready
+                _tr.GRAD_SLOT = self._sync_g.grad_slot   # large gradients are written straight into the exchange arena
             if self.net_d is not None:
                 self._sync_d = GradSync()
 
@@ -369,7 +369,8 @@ class image(base):
         l_g_total = l_g_total / self.accum_iters
         if self._sync_g is not None:
             self._sync_g.arm_backward()   # hook-driven buckets leave from inside this backward (no-op for the RRDB plan)
-        l_g_total.backward()
+        with _tr.deferred_reductions():   # parameter-gradient column sums batched at the end of the pass (opt-in)
+            l_g_total.backward()
         if step_now:
             self._sync_grads(self.sam_optimizer_g if self._sam_now else self.optimizer_g, self._sync_g)
 
@@ -389,8 +390,9 @@ class image(base):
                 loss_dict["l_d_fake"] = l_d_fake
                 loss_dict["out_d_fake"] = self.cri_gan.last_mean
                 loss_dict["l_d_total"] = (l_d_real + l_d_fake) / 2
-                l_d_real.backward()
-                l_d_fake.backward()
+                with _tr.deferred_reductions():
+                    l_d_real.backward()
+                    l_d_fake.backward()
             if step_now:
                 self._sync_grads(self.optimizer_d, self._sync_d)
 
@@ -398,8 +400,6 @@ class image(base):
         return l_g_total
 
     def optimize_parameters(self, current_iter: int) -> None:
-        from neosr_amd.hip import transformer as _tr
-
         _tr.reset_deferred()  # (reductions queued by a backward pass that raised)
         self.n_accumulated += 1
         if self.n_accumulated >= self.accum_iters:

@@ -12,10 +12,15 @@ DDP's many small ones.  The 1/world_size is folded into the fused optimizer kern
 Networks whose gradients arrive tensor by tensor (SwinIR, HAT, compact generators: layer-composed) get DDP's own
 mechanism, rebuilt around the flat arena (`attach`): the parameter arena is cut into a few contiguous buckets;
 post-accumulate hooks (and the deferred-reduction flush of hip/transformer.py, which writes `.grad` outside autograd)
-count the parameters of a bucket that have their gradient; the moment a bucket is complete its gradients are packed into
-the persistent gradient arena by ONE `cat`, the parameters' `.grad` are re-pointed at the arena, an event is recorded and
-the communication stream all-reduces that slice — while backward is still working on the earlier layers.  What is not
-complete when backward returns (unused parameters) goes with `start()`.  The discriminator (two backward passes per
+count the parameters of a bucket that have their gradient.  The producers of the large gradients (Linear / Mlp weight +
+bias, LayerNorm affine, 3x3 convolution weight + bias) ask `grad_slot()` for the parameter's slice of the persistent
+gradient arena and write their result THERE, so a complete bucket is normally already in place; stragglers (small
+tensors produced by other ops, accumulated gradients) are moved by one multi-tensor copy and `.grad` is re-pointed at the
+arena.  Buckets leave in ONE order on every rank — highest arena offset first, i.e. backward order; a complete bucket is
+held back until its predecessors have been sent — so ranks whose parameters became ready in different orders (or not at
+all: a data-dependent branch) still issue identical collectives.  An event is recorded and the communication
+stream all-reduces the slice while backward is still working on the earlier layers.  What is not complete when backward
+returns (unused parameters: zeros) goes from `end_backward()`, in the same order.  The discriminator (two backward passes per
 step) and accumulating / SAM steps are reduced after backward, but still asynchronously: `start()` only enqueues,
 `finish()` is called right before that network's optimizer step, so the exchange of G overlaps the whole discriminator
 phase and the exchange of D overlaps the generator's optimizer step.
@@ -53,7 +58,10 @@ class GradSync:
         self._bucket_range: list[tuple[int, int]] = []
         self._pending: list[int] = []
         self._sent: list[bool] = []
+        self._next = -1                               # next bucket to leave (descending)
         self._seen: set[int] = set()
+        self._taken: set[int] = set()
+        self._slot_of: dict[int, torch.Tensor] = {}   # id(param) -> its view of the gradient arena
         self._live = False                            # a hook-driven exchange is in progress for this backward
         self.in_backward_buckets = 0                  # buckets issued from inside the last backward (tests / bench)
 
@@ -129,10 +137,12 @@ class GradSync:
         self.finish()
         if self._arena is None or self._arena.device != self._params[0].device:
             self._arena = torch.zeros(self._total, device=self._params[0].device, dtype=torch.float32)
+            self._slot_of = {id(p): self._arena[o : o + p.numel()].view_as(p) for p, o in zip(self._params, self._offs)}
         self._flat, self._lo, self.buckets = self._arena, self._total, []
         self._pending = [sum(1 for i in idx if self._params[i].requires_grad) for idx in self._bucket_params]
         self._sent = [False] * len(self._bucket_params)
-        self._seen = set()
+        self._next = len(self._bucket_params) - 1
+        self._seen, self._taken = set(), set()
         self._live, self.in_backward_buckets = True, 0
         self.armed = True
 
@@ -149,28 +159,46 @@ class GradSync:
                 continue
             self._seen.add(id(p))
             self._pending[b] -= 1
-            if self._pending[b] == 0 and not self._sent[b]:
+        self._send_in_order(False)
+
+    def grad_slot(self, p) -> torch.Tensor | None:
+        """Where the FIRST gradient contribution of `p` in this backward may be written directly: its view of the gradient
+        arena (shape of `p`), or None (no hook-driven exchange in progress, `p` not ours, or `p` already has a gradient —
+        a second contribution accumulates through autograd as usual)."""
+        if not self._live or p.grad is not None or id(p) in self._seen or id(p) in self._taken:
+            return None
+        slot = self._slot_of.get(id(p))
+        if slot is not None:
+            self._taken.add(id(p))   # handed out once per backward: a second producer of the same parameter gets None
+        return slot
+
+    def _send_in_order(self, force: bool) -> None:
+        while self._next >= 0 and (force or self._pending[self._next] == 0):
+            b = self._next
+            self._next -= 1
+            if not self._sent[b]:
                 self._send_bucket(b)
-                self.in_backward_buckets += 1
+                if not force:
+                    self.in_backward_buckets += 1
 
     def _send_bucket(self, b: int) -> None:
         lo, hi = self._bucket_range[b]
-        idx = self._bucket_params[b]
-        parts, pos = [], lo
-        for i in idx:
-            p = self._params[i]
-            off = self._offs[i]
-            if off > pos:
-                parts.append(self._arena.new_zeros(off - pos))
-            g = p.grad
-            parts.append(g.reshape(-1) if g is not None else self._arena.new_zeros(p.numel()))
-            pos = off + p.numel()
-        if hi > pos:
-            parts.append(self._arena.new_zeros(hi - pos))
-        torch.cat(parts, out=self._arena[lo:hi])
-        for i in idx:  # the optimizer and the all-reduce see ONE buffer: no second copy
-            p = self._params[i]
-            p.grad = self._arena[self._offs[i] : self._offs[i] + p.numel()].view_as(p)
+        dst, src = [], []
+        with torch.no_grad():
+            for i in self._bucket_params[b]:
+                p = self._params[i]
+                slot = self._slot_of[id(p)]
+                g = p.grad
+                if g is None:            # unused in this backward: its slice may hold an earlier step's gradient
+                    slot.zero_()
+                elif g.data_ptr() != slot.data_ptr() or not g.is_contiguous():
+                    dst.append(slot)
+                    src.append(g)
+            if dst:
+                torch._foreach_copy_(dst, src)  # noqa: SLF001  (one multi-tensor launch for the stragglers)
+            for i in self._bucket_params[b]:  # the optimizer and the all-reduce see ONE buffer: no second copy
+                p = self._params[i]
+                p.grad = self._slot_of[id(p)]
         self._sent[b] = True
         event = None
         if self.comm is not None and self._arena.is_cuda:
@@ -183,9 +211,7 @@ class GradSync:
         exchange was hook-driven (then `start()` has nothing left to do)."""
         if not self._live:
             return False
-        for b in range(len(self._bucket_params)):
-            if not self._sent[b]:
-                self._send_bucket(b)
+        self._send_in_order(True)
         self._live, self._lo = False, 0
         return True
 

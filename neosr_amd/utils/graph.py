@@ -24,7 +24,9 @@ def graph_train_forward(net: torch.nn.Module, sample: torch.Tensor) -> None:
     from neosr_amd.hip import transformer
 
     layers.FORCE_REPACK_IN_CAPTURE = True
-    defer, transformer.DEFER_REDUCTIONS = transformer.DEFER_REDUCTIONS, False  # warm-up uses autograd.grad on the parameters
+    # (warm-up and capture use autograd.grad on the parameters: reductions must not be deferred — they are not, outside a
+    # `deferred_reductions()` scope, unless NEOSR_AMD_DEFER_REDUCE=1 forces them process-wide)
+    defer, transformer.DEFER_REDUCTIONS = transformer.DEFER_REDUCTIONS, False
     try:
         torch.cuda.make_graphed_callables(net, (sample,))
     finally:

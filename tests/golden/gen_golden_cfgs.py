@@ -208,22 +208,40 @@ def gen_hat_l() -> None:
             for p in net.parameters():
                 p.add_(torch.randn(p.shape, generator=sgen) * 0.02)
         x = torch.rand(1, 3, 64, 64, generator=sgen).requires_grad_(True)
+        # Two kinds of derivative jumps.  A (Leaky)ReLU over a feature MAP: one element near zero moves one element of
+        # the gradients (2e-7 as in gen_golden_swinir.py).  The ReLU of a channel-attention bottleneck (input 1 x 1:
+        # 6 hidden units per CAB, 72 CABs) gates a whole 180-channel map: a unit within rounding of zero on the
+        # other side changes every gradient upstream by percents, so the draw must keep all 432 of them well away
+        # from zero (1e-3 against values of ~0.13; fp32 summation-order noise there is ~1e-6).
         closest = [float("inf")]
-        hooks = [m.register_forward_pre_hook(lambda _m, a: closest.__setitem__(0, min(closest[0], float(a[0].abs().min()))))
-                 for m in net.modules() if isinstance(m, (torch.nn.LeakyReLU, torch.nn.ReLU))]
+        ca_pre = []
+
+        def hook(_m, a):
+            v = a[0]
+            if v.shape[-2:] == (1, 1):
+                ca_pre.append(v.detach().flatten().clone())
+            else:
+                closest[0] = min(closest[0], float(v.abs().min()))
+
+        hooks = [m.register_forward_pre_hook(hook) for m in net.modules()
+                 if isinstance(m, (torch.nn.LeakyReLU, torch.nn.ReLU))]
         net.train()
         y = net(x)
         for h in hooks:
             h.remove()
-        print(f"hat_l: seed {seed} closest LeakyReLU / ReLU input to zero {closest[0]:.2e}")
-        if closest[0] > 2e-7:  # see gen_golden_swinir.py: the derivative jumps at 0
+        ca_pre = torch.cat(ca_pre)
+        ca_min = float(ca_pre.abs().min())
+        print(f"hat_l: seed {seed} closest LeakyReLU / ReLU map input to zero {closest[0]:.2e}, "
+              f"closest channel-attention ReLU input {ca_min:.2e} of {ca_pre.numel()}")
+        if closest[0] > 2e-7 and ca_min > 1e-3:
             break
     else:
         raise RuntimeError("no well-conditioned draw found")
     r = torch.randn(y.shape, generator=sgen)
     (y * r).sum().backward()
     A = {"seed": np.int64(seed), "x": x.detach().numpy(), "r": r.numpy(), "y": y.detach().numpy(),
-         "gx": x.grad.numpy().copy()}
+         "gx": x.grad.numpy().copy(),
+         "ca/pre": ca_pre.numpy()}   # ReLU inputs of the 72 channel-attention bottlenecks, in forward order
     keys, s, a = checksums(dict(net.named_parameters()))
     A["p/keys"], A["p/sum"], A["p/abs"] = keys, s, a
     grads = {k: v.grad for k, v in net.named_parameters()}

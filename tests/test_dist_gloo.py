@@ -104,6 +104,74 @@ def _worker(rank: int, world: int, port: int, q) -> None:
     dist.destroy_process_group()
 
 
+def _worker_unused(rank: int, world: int, port: int, q) -> None:
+    """Hook-driven buckets when a parameter gets NO gradient on some ranks only (a data-dependent branch): every rank must
+    still issue the same collectives in the same order (descending arena offset; a complete bucket waits for its
+    predecessors), the unused slice contributes zeros — also when the arena still holds last step's gradient there."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from neosr_amd.hip.nets import flat_grad_of
+    from neosr_amd.utils.dist_util import init_dist
+    from neosr_amd.utils.grad_sync import GradSync
+
+    init_dist("pytorch", backend="gloo")
+    torch.manual_seed(11)
+    L = [torch.nn.Linear(16, 16) for _ in range(4)]
+    params = [p for m in L for p in m.parameters()]
+    g = torch.Generator().manual_seed(77)
+    X = torch.randn(world, 3, 16, generator=g)
+
+    def fwd(x, skip):
+        h = L[0](x)
+        if not skip:
+            h = h + L[1](h)      # the branch
+        return L[3](L[2](h))
+
+    gs = GradSync(device="cpu")
+    gs.attach(params, n_buckets=4)
+    ok = len(gs._bucket_range) == 4
+    for step in range(2):
+        skip = (rank + step) % 2 == 1           # odd ranks skip the branch in step 0, even ranks in step 1
+        for p in params:
+            p.grad = None
+        gs.armed = True
+        gs.arm_backward()
+        fwd(X[rank], skip).square().sum().backward()
+        inside = gs.in_backward_buckets
+        ok = ok and gs.end_backward()
+        gs.finish()
+        # same collectives, same order, on every rank (highest offset first)
+        ok = ok and gs.buckets == sorted(gs._bucket_range, reverse=True)
+        # ranks that skipped the branch could only send the buckets in front of it from inside backward
+        ok = ok and (inside == 2 if skip else inside == 4)
+        ref = [torch.zeros_like(p) for p in params]
+        for r in range(world):
+            grads = torch.autograd.grad(fwd(X[r], (r + step) % 2 == 1).square().sum(), params, allow_unused=True)
+            for a, gr in zip(ref, grads):
+                if gr is not None:
+                    a += gr
+        flat = flat_grad_of(params)
+        ok = ok and flat is not None
+        ok = ok and all(torch.allclose(p.grad, a, rtol=1e-5, atol=1e-6) for p, a in zip(params, ref))
+    q.put((rank, bool(ok), float(flat.sum())))
+    dist.destroy_process_group()
+
+
+def test_hook_buckets_world4_unused_parameters_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_unused, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res), res
+    assert len({r[2] for r in res}) == 1      # bit-identical sums on all four ranks
+
+
 def test_flat_allreduce_world2_gloo():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

@@ -163,6 +163,32 @@ def test_deferred_parameter_gradient_reductions_equal_immediate_ones(monkeypatch
             assert u is not None and torch.equal(u, v)
 
 
+def test_deferred_reductions_are_opt_in():
+    """Outside `deferred_reductions()` (the scope models/image.py puts around its own backward calls) nothing bypasses
+    autograd: `torch.autograd.grad` returns every parameter gradient, equal bit for bit to what the scoped, deferred
+    pass leaves in `.grad` (VERDICT r3 / ADVICE r2)."""
+    from neosr_amd.hip import transformer as tr
+
+    if tr._DEFER_ENV is not None:
+        pytest.skip("NEOSR_AMD_DEFER_REDUCE set")
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(2, 2048, 180, generator=g).to(DEV)
+    P = [t.to(DEV).requires_grad_(True) for t in (torch.randn(180, generator=g), torch.randn(180, generator=g),
+                                                  torch.randn(360, 180, generator=g) * .05, torch.randn(360, generator=g))]
+
+    def loss():
+        _sc, n = tr.residual_layer_norm(x, P[0], P[1])
+        return tr.linear(n, P[2], P[3]).square().sum()
+
+    grads = torch.autograd.grad(loss(), P)
+    assert all(gr is not None for gr in grads) and not tr._DEFERRED
+    with tr.deferred_reductions():
+        loss().backward()
+    assert not tr._DEFERRED
+    for p, gr in zip(P, grads):
+        assert torch.equal(p.grad, gr)
+
+
 def test_gemm_random_shapes_all_modes_and_epilogues():
     """Seeded sweep over odd shapes: every GEMM kernel (128- and 64-row NT tiles with trimmed last chunk / skipped column
     tile / LDS bias / prefetched residual, staged NN, register-fed and staged TN) and every epilogue against float64."""

@@ -20,7 +20,14 @@ for mode in (2,):
     keys = [str(k) for k in fix["p/keys"]]
     net = net.cuda().train()
     x = T(fix["x"]).cuda().requires_grad_(True)
+    from neosr_amd.hip.transformer import ChannelGate
+    ChannelGate.trace = []
     y = net(x)
+    tr, ChannelGate.trace = ChannelGate.trace, None
+    pre = torch.cat([(p.detach().double().cpu() @ w.detach().double().cpu().reshape(w.shape[0], -1).T + b.detach().double().cpu()).flatten() for p, w, b in tr]).numpy()
+    if "ca/pre" in fix:
+        d = np.abs(pre - fix["ca/pre"])
+        print(f"   channel-attention ReLU inputs: max |ours - reference| {d.max():.2e} (unit {d.argmax()}), reference min |input| {np.abs(fix['ca/pre']).min():.2e}")
     y.backward(T(fix["r"]).cuda())
     P = dict(net.named_parameters())
     l2 = np.array([float(P[k].grad.double().norm()) for k in keys])
