@@ -523,6 +523,11 @@ typedef struct neosr_fattn_desc {
 int64_t neosr_flash_window_attention_workspace_bytes(const neosr_fattn_desc* d);
 int neosr_flash_window_attention_fwd(const neosr_fattn_desc* d, void* stream);
 int neosr_flash_window_attention_bwd(const neosr_fattn_desc* d, void* stream);
+/* Backward of the self-attention form (ks == ws): 1 (default; env NEOSR_AMD_FATTN_FUSED) = ONE pass per (window, head)
+ * — every score tile is formed once and feeds dQ, dK and dV (5 products per tile) —, 0 = the two recompute passes
+ * (dQ per query block, dK / dV per key block: 7 products) the overlapping form always takes.  Same accumulation order:
+ * bit-identical results.  Returns the previous setting. */
+int neosr_set_fattn_fused(int on);
 /* MSELoss / HuberLoss with reduction = "mean" (neosr/losses/basic_loss.py:57-127: F.mse_loss,
  * F.huber_loss(delta)): loss = loss_weight * mean(term(pred - target)); workspace >= 1024 floats;
  * bwd: grad_pred = grad_out[0] * loss_weight / n * term'(pred - target). */
@@ -791,6 +796,54 @@ int neosr_compact_forward(const neosr_compact_cfg* cfg, const float* const* para
 int neosr_compact_backward(const neosr_compact_cfg* cfg, const float* const* params,
                            float* const* grads, const float* gy, float* gx, void* workspace,
                            void* stream);
+
+/*
+ * One transformer block of the SwinIR / HAT generators as ONE call per direction (csrc/blocks.hip):
+ *   attn = 0: SwinTransformerBlock (neosr/archs/swinir_arch.py:231-392) — norm1, qkv, neosr_window_attention (ws = 8),
+ *             proj + DropPath + shortcut, norm2, fc1 + GELU, fc2 + DropPath + shortcut;
+ *   attn = 1, ks = 1.5 ws: OCAB (neosr/archs/hat_arch.py:393-515), the same chain around the overlapping cross-attention;
+ *   attn = 1, ks = ws, cab_mid > 0: HAB (neosr/archs/hat_arch.py:218-350) — the chain around the (shifted-)window
+ *             self-attention plus `conv_scale * CAB(norm1(x))` (conv3x3 -> GELU -> conv3x3 -> channel attention,
+ *             hat_arch.py:15-52) added in front of norm2.
+ * Replaces the ~40 ATen dispatches per block and direction of the reference (and the 6-9 / 12-20 per-op calls of this
+ * library's Python fronts) — the plans enqueue the same kernels with the same descriptors, bit-identical results.
+ * x, out, dout, dx: (B, H, W, C) channels-last = the (B, H W, C) token matrix.  `save` (neosr_tblock_save_floats floats,
+ * written by forward, read by backward) keeps the activations; `workspace` (neosr_tblock_bwd_workspace_floats) holds
+ * the temporaries of backward.  drop_scale / drop_scale2: per-sample DropPath scales (B floats: 0 or 1 / keep_prob) or NULL.
+ * Parameters in canonical torch layouts.  HAB only: the four packed images of the two CAB convolutions the conv
+ * kernels would be given (c0 / c2, forward and backward-data: w_pack always, exactly one of w_wino / w_wino4 as
+ * neosr_conv3x3 would pick for the geometry).
+ */
+typedef struct neosr_tblock_desc {
+  int32_t B, H, W, C, heads, ws, ks, shift, hidden;
+  int32_t attn;              /* 0: neosr_window_attention; 1: neosr_flash_window_attention */
+  int32_t cab_mid, cab_sq;   /* HAB: channels of the CAB's first conv / of the squeeze bottleneck; 0, 0: no CAB */
+  float scale, eps1, eps2, conv_scale;
+  const float *n1_w, *n1_b, *rpb, *qkv_w, *qkv_b, *proj_w, *proj_b, *n2_w, *n2_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
+  const float *c0_w, *c0_b, *c2_w, *c2_b, *ca1_w, *ca1_b, *ca2_w, *ca2_b;   /* CAB (HAB only) */
+  const float *c0_pack_f, *c0_wino_f, *c0_wino4_f, *c0_pack_d, *c0_wino_d, *c0_wino4_d;
+  const float *c2_pack_f, *c2_wino_f, *c2_wino4_f, *c2_pack_d, *c2_wino_d, *c2_wino4_d;
+  const float* drop_scale;    /* DropPath scales of the attention branch (proj) ... */
+  const float* drop_scale2;   /* ... and of the MLP branch: two independent draws in the reference (swinir_arch.py:387,390) */
+} neosr_tblock_desc;
+/* Gradient targets of backward.  Each (weight, bias) and (gamma, beta) pair must be contiguous — as they are in a
+ * buffer laid out like the block's slice of the network's flat parameter arena (named_parameters order, tensor starts
+ * rounded up to 4 floats): one fixed-order column-sum job then finishes both tensors of a pair. */
+typedef struct neosr_tblock_grads {
+  float *n1_w, *n1_b, *rpb, *qkv_w, *qkv_b, *proj_w, *proj_b, *n2_w, *n2_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
+  float *c0_w, *c0_b, *c2_w, *c2_b, *ca1_w, *ca1_b, *ca2_w, *ca2_b;
+} neosr_tblock_grads;
+int64_t neosr_tblock_save_floats(const neosr_tblock_desc* d);
+int64_t neosr_tblock_bwd_workspace_floats(const neosr_tblock_desc* d);
+int neosr_tblock_forward(const neosr_tblock_desc* d, const float* x, float* out, float* save, void* stream);
+int neosr_tblock_backward(const neosr_tblock_desc* d, const float* x, const float* dout, const float* save, float* dx,
+                          const neosr_tblock_grads* grads, float* workspace, void* stream);
+/* Backward runs the block's weight gradients (4 split-K GEMMs, the 2 CAB convolutions' gradients) on a library-owned
+ * side stream, forked / joined with events inside the call, beside the dependent data-gradient chain on the caller's
+ * stream: 2 (env NEOSR_AMD_BLOCK_STREAMS=2) = on, 1 (default) = everything on the caller's stream — measured neutral on
+ * swinir_medium and 4 % slower on the host-bound hat_l config (14 event calls per block).  A scheduling choice:
+ * bit-identical results.  Returns the previous setting. */
+int neosr_set_tblock_streams(int n);
 
 #ifdef __cplusplus
 }

@@ -230,6 +230,30 @@ class FattnDesc(C.Structure):
     )
 
 
+TBLOCK_PARAMS = ("n1_w", "n1_b", "rpb", "qkv_w", "qkv_b", "proj_w", "proj_b", "n2_w", "n2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b")
+TBLOCK_CAB_PARAMS = ("c0_w", "c0_b", "c2_w", "c2_b", "ca1_w", "ca1_b", "ca2_w", "ca2_b")
+TBLOCK_IMAGES = tuple(f"{c}_{k}_{m}" for c in ("c0", "c2") for m in ("f", "d") for k in ("pack", "wino", "wino4"))
+
+
+class TBlockDesc(C.Structure):
+    """neosr_tblock_desc"""
+
+    _fields_ = (
+        [(n, C.c_int32) for n in ("B", "H", "W", "C", "heads", "ws", "ks", "shift", "hidden", "attn", "cab_mid", "cab_sq")]
+        + [(n, C.c_float) for n in ("scale", "eps1", "eps2", "conv_scale")]
+        + [(n, C.c_void_p) for n in TBLOCK_PARAMS + TBLOCK_CAB_PARAMS]
+        + [(n, C.c_void_p) for n in ("c0_pack_f", "c0_wino_f", "c0_wino4_f", "c0_pack_d", "c0_wino_d", "c0_wino4_d",
+                                     "c2_pack_f", "c2_wino_f", "c2_wino4_f", "c2_pack_d", "c2_wino_d", "c2_wino4_d")]
+        + [("drop_scale", C.c_void_p), ("drop_scale2", C.c_void_p)]
+    )
+
+
+class TBlockGrads(C.Structure):
+    """neosr_tblock_grads"""
+
+    _fields_ = [(n, C.c_void_p) for n in TBLOCK_PARAMS + TBLOCK_CAB_PARAMS]
+
+
 class MsssimDesc(C.Structure):
     """neosr_msssim_desc"""
 
@@ -352,6 +376,12 @@ SIGNATURES: dict[str, tuple] = {
     "neosr_flash_window_attention_workspace_bytes": (_i64, [C.POINTER(FattnDesc)]),
     "neosr_flash_window_attention_fwd": (C.c_int, [C.POINTER(FattnDesc), _vp]),
     "neosr_flash_window_attention_bwd": (C.c_int, [C.POINTER(FattnDesc), _vp]),
+    "neosr_set_fattn_fused": (C.c_int, [C.c_int]),
+    "neosr_tblock_save_floats": (_i64, [C.POINTER(TBlockDesc)]),
+    "neosr_tblock_bwd_workspace_floats": (_i64, [C.POINTER(TBlockDesc)]),
+    "neosr_tblock_forward": (C.c_int, [C.POINTER(TBlockDesc), _vp, _vp, _vp, _vp]),
+    "neosr_tblock_backward": (C.c_int, [C.POINTER(TBlockDesc), _vp, _vp, _vp, _vp, C.POINTER(TBlockGrads), _vp, _vp]),
+    "neosr_set_tblock_streams": (C.c_int, [C.c_int]),
     "neosr_pixel_shuffle_nhwc": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "neosr_affine": (C.c_int, [_vp, _vp, _i64, _f32, _f32, _vp]),
     "neosr_row_scale": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _vp]),

@@ -101,9 +101,40 @@ class HAB(nn.Module):
         self.norm2 = nn.LayerNorm(dim)
         self.mlp = Mlp(dim, int(dim * mlp_ratio))
 
+    def _plan_images(self, b: int, h: int, w: int) -> dict:
+        """packed weight images of the two CAB convolutions, forward and backward-data, as `L.Conv3x3` would pick them"""
+        out = {}
+        for tag, conv in (("c0", self.conv_block.cab[0]), ("c2", self.conv_block.cab[2])):
+            wt = conv.weight
+            for m, mode, n_out in (("f", L.ops.CONV_FWD, wt.shape[0]), ("d", L.ops.CONV_DGRAD, wt.shape[1])):
+                out[f"{tag}_pack_{m}"] = L.packed_weights(wt, mode)
+                for k, v in L.wino_images(wt, mode, b, h, w, n_out).items():
+                    out[f"{tag}_{k[2:]}_{m}"] = v
+        return out
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:  # (B, H, W, C)
         b, h, w, _ = x.shape
         a = self.attn
+        if T.BLOCK_PLANS and a.qkv.bias is not None:   # the whole block as one library call per direction (csrc/blocks.hip)
+            meta = getattr(self, "_plan_meta", None)
+            cab, ca = self.conv_block.cab, self.conv_block.cab[3].attention
+            if meta is None:
+                meta = self._plan_meta = {
+                    "names": _C.TBLOCK_PARAMS[:7] + _C.TBLOCK_CAB_PARAMS + _C.TBLOCK_PARAMS[7:],
+                    "ints": {"heads": self.num_heads, "ws": self.window_size, "ks": self.window_size,
+                             "shift": self.shift_size, "hidden": self.mlp.fc1.out_features, "attn": 1,
+                             "cab_mid": cab[0].weight.shape[0], "cab_sq": ca[1].weight.shape[0]},
+                    "floats": {"scale": float(a.scale), "eps1": self.norm1.eps, "eps2": self.norm2.eps,
+                               "conv_scale": float(self.conv_scale)},
+                    "images": self._plan_images}
+            m = self.mlp
+            params = (self.norm1.weight, self.norm1.bias, a.relative_position_bias_table, a.qkv.weight, a.qkv.bias,
+                      a.proj.weight, a.proj.bias, cab[0].weight, cab[0].bias, cab[2].weight, cab[2].bias,
+                      ca[1].weight, ca[1].bias, ca[3].weight, ca[3].bias, self.norm2.weight, self.norm2.bias,
+                      m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias)
+            rs = drop_scale(self.drop_prob, self.training, b, x.device)    # two sites, two draws (hat_arch.py:343,349)
+            rs2 = drop_scale(self.drop_prob, self.training, b, x.device)
+            return T.tblock(x, rs, rs2, meta, params)
         x, y = T.residual_layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)  # (shortcut, norm)
         qkv = T.linear(y, a.qkv.weight, a.qkv.bias)
         at = T.flash_window_attention(qkv, a.relative_position_bias_table, self.num_heads, self.window_size,
@@ -132,6 +163,19 @@ class OCAB(nn.Module):
         self.mlp = Mlp(dim, int(dim * mlp_ratio))
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if T.BLOCK_PLANS and self.qkv.bias is not None:   # one library call per direction (csrc/blocks.hip)
+            meta = getattr(self, "_plan_meta", None)
+            if meta is None:
+                meta = self._plan_meta = {
+                    "names": ("rpb", "n1_w", "n1_b") + _C.TBLOCK_PARAMS[3:],   # named_parameters(): the table comes first
+                    "ints": {"heads": self.num_heads, "ws": self.window_size, "ks": self.overlap_win_size, "shift": 0,
+                             "hidden": self.mlp.fc1.out_features, "attn": 1},
+                    "floats": {"scale": float(self.scale), "eps1": self.norm1.eps, "eps2": self.norm2.eps}}
+            m = self.mlp
+            params = (self.relative_position_bias_table, self.norm1.weight, self.norm1.bias, self.qkv.weight,
+                      self.qkv.bias, self.proj.weight, self.proj.bias, self.norm2.weight, self.norm2.bias,
+                      m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias)
+            return T.tblock(x, None, None, meta, params)
         x, y = T.residual_layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)  # (shortcut, norm)
         qkv = T.linear(y, self.qkv.weight, self.qkv.bias)
         at = T.flash_window_attention(qkv, self.relative_position_bias_table, self.num_heads, self.overlap_win_size, 0,

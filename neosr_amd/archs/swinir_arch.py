@@ -86,9 +86,26 @@ class SwinTransformerBlock(nn.Module):
         mask = _shift_mask(*input_resolution, self.window_size, self.shift_size) if self.shift_size > 0 else None
         self.register_buffer("attn_mask", mask)
 
+    def _plan_params(self):
+        a, m = self.attn, self.mlp
+        return (self.norm1.weight, self.norm1.bias, a.relative_position_bias_table, a.qkv.weight, a.qkv.bias,
+                a.proj.weight, a.proj.bias, self.norm2.weight, self.norm2.bias, m.fc1.weight, m.fc1.bias,
+                m.fc2.weight, m.fc2.bias)
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:  # x: (B, H, W, C) channels-last tokens
         b, h, w, _ = x.shape
         a = self.attn
+        if T.BLOCK_PLANS and a.qkv.bias is not None:   # the whole block as one library call per direction (csrc/blocks.hip)
+            meta = getattr(self, "_plan_meta", None)
+            if meta is None:
+                meta = self._plan_meta = {
+                    "names": _C.TBLOCK_PARAMS,
+                    "ints": {"heads": self.num_heads, "ws": self.window_size, "ks": self.window_size,
+                             "shift": self.shift_size, "hidden": self.mlp.fc1.out_features, "attn": 0},
+                    "floats": {"scale": float(a.scale), "eps1": self.norm1.eps, "eps2": self.norm2.eps}}
+            rs = drop_scale(self.drop_prob, self.training, b, x.device)    # two sites, two draws (swinir_arch.py:387,390)
+            rs2 = drop_scale(self.drop_prob, self.training, b, x.device)
+            return T.tblock(x, rs, rs2, meta, self._plan_params())
         x, y = T.residual_layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)  # (shortcut, norm)
         qkv = T.linear(y, a.qkv.weight, a.qkv.bias)
         y = T.window_attention(qkv, a.relative_position_bias_table, self.num_heads, self.window_size,

@@ -17,6 +17,8 @@
 // dK, dV (written in place for HAB; into an unfolded buffer + a fixed-order fold for OCAB, where up to
 // four windows overlap on a pixel); (C) bias gradient = column sums over windows, then a fixed-order
 // gather per table row.  No float atomics anywhere.
+#include <cstdlib>
+
 #include "common.h"
 #include "../../include/neosr_amd.h"
 #include "prof.h"
@@ -589,6 +591,149 @@ __global__ __launch_bounds__(256) void flash_wattn_bwd_dkv_kernel(const neosr_fa
   }
 }
 
+
+// (A+B) self-attention form, ONE pass: one workgroup per (window, head) walks the query blocks (outer) and key blocks
+// (inner); every 64 x 64 tile's S = Q K^T, dP = dO V^T, P and dS are formed ONCE and feed all three gradients — dQ of the
+// query block (one accumulator, as in kernel (A)), dV += P^T dO and dK += dS^T Q of the key block (NKB accumulators per
+// wave, resident across the outer loop: waves 0, 1 hold dV, waves 2, 3 dK).  5 products per tile instead of the 7 of the
+// two recompute passes (A) + (B), half the Q / K / V / dO tile loads, half the exponentials; no rowsum(dO . O) round trip
+// through the workspace.  Every output accumulates its tiles in the order the two-pass kernels use (dQ over key blocks,
+// dK / dV over query blocks; bias bins per query block, written as the same [window, query block] partial rows):
+// bit-identical results (tests/test_hip_hat.py).  LDS as kernel (A): two workgroups per CU.
+template <int WS, int KS>
+__global__ __launch_bounds__(256, 2) void flash_wattn_bwd_fused_kernel(const neosr_fattn_desc d, const BwdWs ws) {
+  using G = Geo<WS, KS>;
+  static_assert(G::SELF, "the overlapping form folds dK / dV over windows: two-pass kernels");
+  __shared__ SharedBwd S;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const int bid = xcd_bid();            // (b, window, head)
+  Win w = decode(d, bid, 1);
+  const int hd = d.C / d.heads, ld = 3 * d.C, kq = (hd + 1) & ~1;
+  const int n = tid >> 2, part = tid & 3;
+  for (int k = tid; k < G::NBINS; k += 256) S.tab[k] = d.rpb_table[k * d.heads + w.head];
+  f32x16 dkv[G::NKB];   // waves 0, 1: dV rows 32 wave..; waves 2, 3: dK rows 32 (wave - 2)..  of key block kb
+#pragma unroll
+  for (int kb = 0; kb < G::NKB; ++kb) dkv[kb] = zero16();
+  for (int qb = 0; qb < G::NQB; ++qb) {
+    w.qb = qb;
+    __syncthreads();   // the previous query block's epilogue has read S.P / S.qtok
+    if (tid < QB) {
+      int tok, reg;
+      query_geom<WS>(d, w, qb * QB + tid, tok, reg);
+      S.qtok[tid] = tok;
+      S.qpk[tid] = query_term<WS, KS>(qb * QB + tid) * 16 + reg;
+      S.lse[tid] = d.lse[((int64_t)bid * G::NQB + qb) * QB + tid];
+    }
+    for (int k = tid; k < G::NBINS; k += 256) S.bins[k] = 0.f;
+    __syncthreads();
+    {
+      float q[8], g[8], o[8];
+      const int tok = S.qtok[n];
+      load_row8(d.qkv, tok, ld, w.head * hd, hd, part, q);
+      load_row8(d.dout, tok, d.C, w.head * hd, hd, part, g);
+      load_row8(d.out, tok, d.C, w.head * hd, hd, part, o);
+      store_row8(S.Qs, n, part, q, d.scale);
+      store_row8(S.Gs, n, part, g, 1.f);
+      float ds = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ds += g[e] * o[e];
+      ds += __shfl_xor(ds, 1, 64);
+      ds += __shfl_xor(ds, 2, 64);
+      if (part == 0) S.dsum[n] = ds;
+    }
+    float kr[8], vr[8];
+    int ktok, kreg, kterm;
+    bool kex;
+    key_geom<WS, KS>(d, w, n, ktok, kreg, kterm, kex);
+    load_row8(d.qkv, ktok, ld, d.C + w.head * hd, hd, part, kr);
+    load_row8(d.qkv, ktok, ld, 2 * d.C + w.head * hd, hd, part, vr);
+    f32x16 dq = zero16();
+    // (the loop stays rolled — unrolled, its four copies of the bias-bin walk spilled 29 VGPRs at the 256 a wave may hold
+    // with two workgroups per CU; only the accumulation into the key block's own registers is spelled out per block)
+#pragma unroll 1
+    for (int kb = 0; kb < G::NKB; ++kb) {
+      __syncthreads();
+      store_row8(S.Ks, n, part, kr, 1.f);
+      store_row8(S.Vs, n, part, vr, 1.f);
+      if (part == 0) S.kpk[n] = kex ? kterm * 16 + kreg : KEY_NONE;
+      __syncthreads();
+      if (kb + 1 < G::NKB) {
+        key_geom<WS, KS>(d, w, (kb + 1) * QB + n, ktok, kreg, kterm, kex);
+        load_row8(d.qkv, ktok, ld, d.C + w.head * hd, hd, part, kr);
+        load_row8(d.qkv, ktok, ld, 2 * d.C + w.head * hd, hd, part, vr);
+      }
+      recompute_p_ds<G::NBINS, G::SELF, true>(S, kq, wave, l31, lh);
+      {  // bias gradient of the tile (see kernel (A))
+        constexpr int RQ = QB / WS, NB1 = 2 * WS - 1;
+        static_assert((2 * RQ - 1) * NB1 <= 256, "one bin of the tile per thread");
+        if (tid < (2 * RQ - 1) * NB1) {
+          const int dyi = tid / NB1, dx = tid % NB1 - (WS - 1);
+          const int xi0 = dx > 0 ? dx : 0, xj0 = dx < 0 ? -dx : 0, len = WS - (dx < 0 ? -dx : dx);
+          float s = 0.f;
+#pragma unroll
+          for (int a = 0; a < RQ; ++a) {
+            const int b = a - (dyi - (RQ - 1));
+            const bool oky = b >= 0 && b < RQ;
+            const int bc = b < 0 ? 0 : (b >= RQ ? RQ - 1 : b);
+            const float* base = S.dS + (a * WS + xi0) * PS + bc * WS + xj0;
+            float sa = 0.f;
+#pragma unroll
+            for (int t = 0; t < WS; ++t) {
+              const float v = base[t * (PS + 1)];
+              sa += t < len ? v : 0.f;
+            }
+            s += oky ? sa : 0.f;
+          }
+          const int dy = RQ * (qb - kb) - (RQ - 1) + dyi;
+          if (dy > -WS && dy < WS) S.bins[(dy + WS - 1) * NB1 + dx + WS - 1] += s;
+        }
+      }
+      {
+        // waves 0, 1: dV[j][d] += sum_i P[i][j] dO[i][d];  waves 2, 3: dK[j][d] += sum_i dS[i][j] (scale q)[i][d]
+        const float* A = wave < 2 ? S.P : S.dS;
+        const float* Bm = wave < 2 ? S.Gs : S.Qs;
+        const int ti = wave & 1;
+#pragma unroll
+        for (int c = 0; c < G::NKB; ++c)
+          if (kb == c) dkv[c] = mm_atb(dkv[c], A, PS, Bm, QS, ti, 0, l31, lh);
+      }
+      dq = mm_ab_half(dq, S.dS, PS, S.Ks, QS, wave & 1, 0, l31, lh, 32 * (wave >> 1));
+    }
+    __syncthreads();   // the last block's products have read P / dS
+    {  // partial bins of (window, query block): row (bw index, qb) of a [rows][bin][head] matrix
+      float* row = d.workspace + ws.ds_full + ((int64_t)(bid / d.heads) * G::NQB + qb) * G::NBINS * d.heads + w.head;
+      for (int k = tid; k < G::NBINS; k += 256) row[(int64_t)k * d.heads] = S.bins[k];
+    }
+    if (wave >= 2) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) S.P[(wave - 2) * 1024 + r * 64 + lane] = dq[r];
+    }
+    __syncthreads();
+    if (wave < 2 && l31 < hd) {
+      float* g = d.dqkv + w.head * hd + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        g[(int64_t)S.qtok[32 * wave + (r & 3) + 8 * (r >> 2) + 4 * lh] * ld] =
+            (dq[r] + S.P[wave * 1024 + r * 64 + lane]) * d.scale;
+    }
+  }
+  // dK / dV of every key block
+  if (l31 < hd) {
+    const int which = wave < 2 ? 2 : 1;  // v : k
+    const int jt = wave & 1;
+#pragma unroll
+    for (int kb = 0; kb < G::NKB; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = kb * QB + 32 * jt + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        int tok, reg;
+        query_geom<WS>(d, w, j, tok, reg);   // (self-attention: key j is query token j)
+        d.dqkv[(int64_t)tok * ld + which * d.C + w.head * hd + l31] = dkv[kb][r];
+      }
+    }
+  }
+}
+
 // OCAB: nn.Unfold's adjoint — every pixel sums the k / v gradients of the (up to 4) overlapping
 // windows that contain it, in (Wy, Wx) order
 template <int WS, int KS>
@@ -653,6 +798,15 @@ __global__ __launch_bounds__(256) void rpb_bins_kernel(const float* __restrict__
   if (lane == 0) dtab[e] = accumulate ? dtab[e] + s : s;
 }
 
+int g_fattn_fused = -1;   // -1: read NEOSR_AMD_FATTN_FUSED on first use (default on)
+bool fattn_fused_on() {
+  if (g_fattn_fused < 0) {
+    const char* e = getenv("NEOSR_AMD_FATTN_FUSED");
+    g_fattn_fused = (e && e[0] == '0') ? 0 : 1;
+  }
+  return g_fattn_fused == 1;
+}
+
 template <int WS, int KS>
 int launch_bwd(const neosr_fattn_desc& d, hipStream_t st) {
   using G = Geo<WS, KS>;
@@ -661,9 +815,20 @@ int launch_bwd(const neosr_fattn_desc& d, hipStream_t st) {
   const bool prof = neosr_prof_on();
   const double tok = (double)d.B * d.H * d.W;  // dP, dV, dQ, dK over KS*KS keys per query (recompute not counted)
   if (prof) neosr_prof_begin(NEOSR_PROF_ATTN_BWD, (void*)st, 8.0 * KS * KS * tok * d.C, 4.0 * tok * 8 * d.C);
-  hipLaunchKernelGGL((flash_wattn_bwd_dq_kernel<WS, KS>), dim3(bw * d.heads * G::NQB), dim3(256), 0, st, d, ws);
-  NEOSR_LAUNCH_CHECK();
-  hipLaunchKernelGGL((flash_wattn_bwd_dkv_kernel<WS, KS>), dim3(bw * d.heads * G::NKB), dim3(256), 0, st, d, ws);
+  // self-attention: the one-pass kernel (NEOSR_AMD_FATTN_FUSED=0 keeps the two recompute passes: same bits)
+  if constexpr (G::SELF) {
+    if (fattn_fused_on()) {
+      hipLaunchKernelGGL((flash_wattn_bwd_fused_kernel<WS, KS>), dim3(bw * d.heads), dim3(256), 0, st, d, ws);
+    } else {
+      hipLaunchKernelGGL((flash_wattn_bwd_dq_kernel<WS, KS>), dim3(bw * d.heads * G::NQB), dim3(256), 0, st, d, ws);
+      NEOSR_LAUNCH_CHECK();
+      hipLaunchKernelGGL((flash_wattn_bwd_dkv_kernel<WS, KS>), dim3(bw * d.heads * G::NKB), dim3(256), 0, st, d, ws);
+    }
+  } else {
+    hipLaunchKernelGGL((flash_wattn_bwd_dq_kernel<WS, KS>), dim3(bw * d.heads * G::NQB), dim3(256), 0, st, d, ws);
+    NEOSR_LAUNCH_CHECK();
+    hipLaunchKernelGGL((flash_wattn_bwd_dkv_kernel<WS, KS>), dim3(bw * d.heads * G::NKB), dim3(256), 0, st, d, ws);
+  }
   if (prof) neosr_prof_end((void*)st);
   NEOSR_LAUNCH_CHECK();
   if (!G::SELF) {
@@ -731,6 +896,12 @@ extern "C" int neosr_flash_window_attention_fwd(const neosr_fattn_desc* d, void*
 extern "C" int64_t neosr_flash_window_attention_workspace_bytes(const neosr_fattn_desc* d) {
   if (!d || check(d) || d->B <= 0) return 0;
   return bwd_ws(*d).total * 4;
+}
+
+extern "C" int neosr_set_fattn_fused(int on) {
+  const int prev = fattn_fused_on() ? 1 : 0;
+  g_fattn_fused = on ? 1 : 0;
+  return prev;
 }
 
 extern "C" int neosr_flash_window_attention_bwd(const neosr_fattn_desc* d, void* stream) {

@@ -1,0 +1,491 @@
+// blocks.hip — host-side plans for ONE transformer block of the SwinIR / HAT generators: every kernel of the block's
+// forward (or backward) enqueued by a single C-ABI call, from a descriptor of plain pointers.
+//
+//   SwinIR  SwinTransformerBlock   neosr/archs/swinir_arch.py:231-392   norm1 -> qkv -> (shifted-)window attention ->
+//           proj + DropPath + shortcut -> norm2 -> fc1 -> GELU -> fc2 + DropPath + shortcut
+//   HAT     OCAB                   neosr/archs/hat_arch.py:393-515      the same chain with the overlapping cross-attention
+//   HAT     HAB                    neosr/archs/hat_arch.py:218-350      the same chain + the CAB branch on norm1's output
+//                                                                       (conv3x3 -> GELU -> conv3x3 -> channel attention,
+//                                                                       scaled by conv_scale) added in front of norm2
+// The reference dispatches ~40 ATen ops per block and direction; rounds 1-3 composed the block from Python, one
+// autograd.Function + one ctypes call per fused op (6-9 forward, 12-20 backward launches per block, ~6 000 host dispatches
+// per hat_l step: host enqueue 83 of 102 ms).  Here a block is TWO calls per step.  The plans call the library's own entry
+// points (neosr_layernorm_*, neosr_gemm, neosr_*window_attention_*, neosr_conv3x3*, neosr_colsum_many) with exactly the
+// descriptors the Python fronts (hip/transformer.py, hip/layers.py) build, in the same order: bit-identical results.
+// No allocation, no synchronisation: activations kept for backward live in a caller-owned `save` buffer, temporaries of
+// the backward pass in a caller-owned workspace (sizes from the *_floats functions).
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
+#include "common.h"
+#include "../../include/neosr_amd.h"
+
+namespace {
+
+struct Carve {
+  float* base;
+  int64_t off = 0;
+  explicit Carve(float* b) : base(b) {}
+  float* take(int64_t n) {
+    float* p = base ? base + off : nullptr;
+    off += (n + 63) & ~(int64_t)63;   // 256-byte granules: every piece satisfies the kernels' 16-byte alignment
+    return p;
+  }
+};
+
+struct SaveLayout {   // activations the backward pass reads again
+  float *stats1, *y1, *qkv, *lse, *att, *x2, *stats2, *y2, *pre, *h;
+  float *u0, *t0, *t1, *pooled, *gate, *hidden, *x3, *bcs;   // CAB (HAB only)
+  int64_t total;
+};
+
+int64_t tokens(const neosr_tblock_desc& d) { return (int64_t)d.B * d.H * d.W; }
+
+SaveLayout save_layout(const neosr_tblock_desc& d, float* base) {
+  Carve c(base);
+  SaveLayout s;
+  memset(&s, 0, sizeof(s));
+  const int64_t M = tokens(d);
+  s.stats1 = c.take(2 * M);
+  s.y1 = c.take(M * d.C);
+  s.qkv = c.take(M * 3 * d.C);
+  s.lse = c.take(M * d.heads);
+  s.att = c.take(M * d.C);
+  s.x2 = c.take(M * d.C);
+  if (d.cab_mid > 0) {
+    s.u0 = c.take(M * d.cab_mid);
+    s.t0 = c.take(M * d.cab_mid);
+    s.t1 = c.take(M * d.C);
+    s.pooled = c.take((int64_t)d.B * d.C);
+    s.gate = c.take((int64_t)d.B * d.C);
+    s.hidden = c.take((int64_t)d.B * d.cab_sq);
+    s.x3 = c.take(M * d.C);
+    s.bcs = c.take((int64_t)d.B * 32 * d.C);   // scratch of the forward pooling pass
+  }
+  s.stats2 = c.take(2 * M);
+  s.y2 = c.take(M * d.C);
+  s.pre = c.take(M * d.hidden);
+  s.h = c.take(M * d.hidden);
+  s.total = c.off;
+  return s;
+}
+
+int check(const neosr_tblock_desc* d) {
+  NEOSR_CHECK(d, "tblock: null descriptor");
+  NEOSR_CHECK(d->B > 0 && d->H > 0 && d->W > 0 && d->C > 0 && d->heads > 0 && d->ws > 0 && d->hidden > 0 &&
+                  d->C % d->heads == 0 && d->C % 4 == 0 && d->hidden % 4 == 0,
+              "tblock: bad geometry");
+  NEOSR_CHECK(d->attn == 0 || d->attn == 1, "tblock: attn must be 0 (window attention) or 1 (flash window attention)");
+  NEOSR_CHECK(d->n1_w && d->n1_b && d->rpb && d->qkv_w && d->proj_w && d->n2_w && d->n2_b && d->fc1_w && d->fc1_b &&
+                  d->fc2_w && d->fc2_b,
+              "tblock: missing parameter");
+  NEOSR_CHECK(d->cab_mid == 0 || (d->cab_mid > 0 && d->cab_sq > 0 && d->c0_w && d->c0_b && d->c2_w && d->c2_b &&
+                                  d->ca1_w && d->ca1_b && d->ca2_w && d->ca2_b),
+              "tblock: missing CAB parameter");
+  return 0;
+}
+
+neosr_gemm_desc gemm_desc(int mode, const float* A, const float* B, float* C, int M, int N, int K) {
+  neosr_gemm_desc g;
+  memset(&g, 0, sizeof(g));
+  g.A = A; g.B = B; g.C = C;
+  g.M = M; g.N = N; g.K = K;
+  g.lda = mode != NEOSR_GEMM_TN ? K : M;
+  g.ldb = mode == NEOSR_GEMM_NT ? K : N;
+  g.ldc = N; g.ldres = N; g.ldaux = N;
+  g.mode = mode;
+  return g;
+}
+
+// plain 3x3 convolution launch as hip/ops.py:conv3x3 describes it (forward / backward-data of a CAB convolution)
+int conv_launch(const neosr_tblock_desc& d, int mode, const float* in, int in_cs, const float* w, int w_cout, int w_cin,
+                const float* bias, float* out, const float* res1, const float* pack, const float* wino, const float* wino4,
+                void* stream) {
+  neosr_conv_desc c;
+  memset(&c, 0, sizeof(c));
+  c.in = in; c.in_cs = in_cs; c.w = w; c.bias = bias; c.out = out;
+  c.B = d.B; c.H = d.H; c.W = d.W;
+  c.K = mode == NEOSR_CONV_FWD ? w_cin : w_cout;
+  c.N = mode == NEOSR_CONV_FWD ? w_cout : w_cin;
+  c.out_cs = c.N;
+  c.w_cout = w_cout; c.w_cin = w_cin;
+  c.mode = mode;
+  c.mask_slope = 1.f; c.alpha = 1.f; c.alpha2 = 1.f; c.out_mask_slope = 1.f;
+  if (res1) { c.res1 = res1; c.res1_cs = c.N; c.res1_nch = c.N; }
+  c.w_pack = pack; c.w_wino = wino; c.w_wino4 = wino4;
+  return neosr_conv3x3(&c, stream);
+}
+
+int wgrad_launch(const neosr_tblock_desc& d, const float* in, int K, const float* g, int N, float* dw, float* db, float* ws,
+                 void* stream) {
+  neosr_wgrad_desc w;
+  memset(&w, 0, sizeof(w));
+  w.in = in; w.in_cs = K; w.g = g; w.g_cs = N; w.dw = dw; w.db = db; w.workspace = ws;
+  w.B = d.B; w.H = d.H; w.W = d.W; w.K = K; w.N = N;
+  w.mask_slope = 1.f; w.scale = 1.f;
+  return neosr_conv3x3_wgrad(&w, stream);
+}
+
+#define TB_RUN(expr)            \
+  do {                          \
+    if (int rc__ = (expr)) return rc__; \
+  } while (0)
+
+// attention forward / backward with the block's geometry
+int attn_fwd(const neosr_tblock_desc& d, const SaveLayout& s, void* stream) {
+  if (d.attn == 0) {
+    neosr_wattn_desc a;
+    memset(&a, 0, sizeof(a));
+    a.qkv = s.qkv; a.rpb_table = d.rpb; a.out = s.att; a.lse = s.lse;
+    a.B = d.B; a.H = d.H; a.W = d.W; a.C = d.C; a.heads = d.heads; a.ws = d.ws; a.shift = d.shift; a.scale = d.scale;
+    return neosr_window_attention_fwd(&a, stream);
+  }
+  neosr_fattn_desc a;
+  memset(&a, 0, sizeof(a));
+  a.qkv = s.qkv; a.rpb_table = d.rpb; a.out = s.att; a.lse = s.lse;
+  a.B = d.B; a.H = d.H; a.W = d.W; a.C = d.C; a.heads = d.heads; a.ws = d.ws; a.ks = d.ks; a.shift = d.shift; a.scale = d.scale;
+  return neosr_flash_window_attention_fwd(&a, stream);
+}
+
+neosr_fattn_desc fattn_bwd_desc(const neosr_tblock_desc& d) {
+  neosr_fattn_desc a;
+  memset(&a, 0, sizeof(a));
+  a.B = d.B; a.H = d.H; a.W = d.W; a.C = d.C; a.heads = d.heads; a.ws = d.ws; a.ks = d.ks; a.shift = d.shift; a.scale = d.scale;
+  return a;
+}
+
+// temporaries of the backward pass
+struct BwdLayout {
+  float *gpre, *gy2, *dx2, *gatt, *dqkv, *gy1;
+  float *tn_fc2, *tn_fc1, *tn_proj, *tn_qkv, *ln2, *ln1, *attn_ws, *many;
+  float *gx3, *gt1, *dattn, *dpooled, *gt0, *gu0, *gy1c, *bcs, *wg0, *wg2;   // CAB
+  int64_t tn_fc2_n, tn_fc1_n, tn_proj_n, tn_qkv_n, attn_n, many_n;
+  int64_t total;
+};
+
+int64_t tn_ws_floats(int M, int N, int K) {
+  neosr_gemm_desc g = gemm_desc(NEOSR_GEMM_TN, nullptr, nullptr, nullptr, M, N, K);
+  return neosr_gemm_workspace_bytes(&g) / 4;
+}
+
+constexpr int MAX_JOBS = 12;
+
+BwdLayout bwd_layout(const neosr_tblock_desc& d, float* base) {
+  Carve c(base);
+  BwdLayout b;
+  memset(&b, 0, sizeof(b));
+  const int64_t M = tokens(d);
+  const int C = d.C, Hd = d.hidden;
+  b.gpre = c.take(M * Hd);
+  b.gy2 = c.take(M * C);
+  b.dx2 = c.take(M * C);
+  b.gatt = c.take(M * C);
+  b.dqkv = c.take(M * 3 * C);
+  b.gy1 = c.take(M * C);
+  b.tn_fc2_n = tn_ws_floats(C, Hd, (int)M);
+  b.tn_fc1_n = tn_ws_floats(Hd, C, (int)M);
+  b.tn_proj_n = tn_ws_floats(C, C, (int)M);
+  b.tn_qkv_n = tn_ws_floats(3 * C, C, (int)M);
+  b.tn_fc2 = c.take(b.tn_fc2_n);
+  b.tn_fc1 = c.take(b.tn_fc1_n);
+  b.tn_proj = c.take(b.tn_proj_n);
+  b.tn_qkv = c.take(b.tn_qkv_n);
+  b.ln2 = c.take((int64_t)(2 * 1024 + 512) * C);
+  b.ln1 = c.take((int64_t)(2 * 1024 + 512) * C);
+  const int nW = (d.H / d.ws) * (d.W / d.ws);
+  if (d.attn == 0) {
+    b.attn_n = ((int64_t)d.B * nW + 256) * d.heads * (2 * d.ws - 1) * (2 * d.ws - 1);
+  } else {
+    neosr_fattn_desc a = fattn_bwd_desc(d);
+    a.qkv = d.qkv_w; a.rpb_table = d.rpb;   // (the size query validates the descriptor: any non-null pointers)
+    b.attn_n = neosr_flash_window_attention_workspace_bytes(&a) / 4;
+  }
+  b.attn_ws = c.take(b.attn_n);
+  // neosr_colsum_many: its workspace depends on the jobs' shapes only; upper bound over this block's jobs
+  {
+    neosr_colsum_item it[MAX_JOBS];
+    memset(it, 0, sizeof(it));
+    int n = 0;
+    auto job = [&](int rows, int64_t cols) { it[n].rows = rows; it[n].cols = (int)cols; it[n].ld = (int)cols; ++n; };
+    // (row counts are bounded by the split counts the kernels may return: 256 splits / 1024 LN partial rows / windows)
+    job(256, (int64_t)C * Hd + C);
+    job(256, (int64_t)Hd * C + Hd);
+    job(256, (int64_t)C * C + C);
+    job(256, (int64_t)3 * C * C + 3 * C);
+    job(1024, 2 * C);
+    job(1024, 2 * C);
+    job(d.B * nW * (d.attn ? (d.ws * d.ws / 64 > 0 ? d.ws * d.ws / 64 : 1) : 1), (int64_t)d.heads * (2 * d.ws - 1) * (2 * d.ws - 1));
+    b.many_n = 2 * neosr_colsum_many_workspace_floats(it, n) + 4096;
+  }
+  b.many = c.take(b.many_n);
+  if (d.cab_mid > 0) {
+    const int mid = d.cab_mid;
+    b.gt1 = c.take(M * C);
+    b.dattn = c.take((int64_t)d.B * C);
+    b.dpooled = c.take((int64_t)d.B * C);
+    b.gt0 = c.take(M * mid);
+    b.gu0 = c.take(M * mid);
+    b.gy1c = c.take(M * C);
+    b.bcs = c.take((int64_t)d.B * 32 * C);
+    b.wg2 = c.take(neosr_conv3x3_wgrad_workspace_bytes(d.B, d.H, d.W, mid, C) / 4 + 64);
+    b.wg0 = c.take(neosr_conv3x3_wgrad_workspace_bytes(d.B, d.H, d.W, C, mid) / 4 + 64);
+  }
+  b.total = c.off;
+  return b;
+}
+
+// Side stream of the backward plan.  The four weight-gradient GEMMs (and the two weight gradients of the CAB convolutions)
+// of a block feed nothing inside the block — only the optimizer reads them — while the data-gradient chain
+// (GEMM -> LayerNorm -> GEMM -> attention -> GEMM -> LayerNorm) is a sequence of DEPENDENT launches that each pay their
+// fill / first-load / drain in the open (~15 us of a 30 us launch at M = 16 384: DESIGN §7).  They run on a library-owned
+// stream, forked / joined with events inside the call (each waits for the event behind the kernel that produced its
+// operand; the caller's stream waits for the side stream before the block's batched column sums), so their workgroups
+// fill the CUs the chain leaves idle at every launch boundary.  Same kernels, same operands: bit-identical results.
+// OFF by default (NEOSR_AMD_BLOCK_STREAMS=2 / neosr_set_tblock_streams(2) turns it on): measured on MI355X in round 4,
+// swinir_medium (B = 8) 38.52 vs 38.54 ms per step (nothing), hat_l (B = 4, host enqueue 80 of 98 ms) 97.9 -> 101.9 ms —
+// the 14 event calls per block cost the host more than the overlap gives the device.
+struct Side {
+  int dev = -1;
+  hipStream_t s = nullptr;
+  hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+};
+enum { EV_FORK = 0, EV_GPRE, EV_DX2, EV_GT1, EV_GU0, EV_DQKV, EV_JOIN };
+int g_block_streams = -1;
+
+Side* side_get() {
+  static Side a;
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lk(mu);
+  if (g_block_streams < 0) {
+    const char* e = getenv("NEOSR_AMD_BLOCK_STREAMS");
+    g_block_streams = (e && atoi(e) == 2) ? 2 : 1;
+  }
+  if (g_block_streams < 2) return nullptr;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  if (a.s && a.dev != dev) a = Side();   // streams / events belong to the device they were created on
+  a.dev = dev;
+  if (!a.s) {
+    if (hipStreamCreateWithFlags(&a.s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    for (auto& e : a.ev)
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+  }
+  return &a;
+}
+
+}  // namespace
+
+extern "C" int neosr_set_tblock_streams(int n) {
+  const int prev = g_block_streams < 0 ? 1 : g_block_streams;
+  g_block_streams = n <= 1 ? 1 : 2;
+  return prev;
+}
+
+extern "C" int64_t neosr_tblock_save_floats(const neosr_tblock_desc* d) {
+  if (check(d)) return -1;
+  return save_layout(*d, nullptr).total;
+}
+
+extern "C" int64_t neosr_tblock_bwd_workspace_floats(const neosr_tblock_desc* d) {
+  if (check(d)) return -1;
+  return bwd_layout(*d, nullptr).total;
+}
+
+extern "C" int neosr_tblock_forward(const neosr_tblock_desc* dp, const float* x, float* out, float* save, void* stream) {
+  if (check(dp)) return 1;
+  const neosr_tblock_desc& d = *dp;
+  NEOSR_CHECK(x && out && save, "tblock forward: null buffer");
+  const SaveLayout s = save_layout(d, save);
+  const int64_t M64 = tokens(d);
+  NEOSR_CHECK(M64 * 3 * d.C < (int64_t(1) << 31), "tblock: token matrix too large for 32-bit GEMM extents");
+  const int M = (int)M64, C = d.C, Hd = d.hidden, rps = d.H * d.W;
+  // norm1 (the shortcut is x itself)
+  TB_RUN(neosr_layernorm_fwd(x, d.n1_w, d.n1_b, s.y1, s.stats1, M, C, d.eps1, stream));
+  // qkv
+  {
+    neosr_gemm_desc g = gemm_desc(NEOSR_GEMM_NT, s.y1, d.qkv_w, s.qkv, M, 3 * C, C);
+    g.bias = d.qkv_b;
+    TB_RUN(neosr_gemm(&g, stream));
+  }
+  TB_RUN(attn_fwd(d, s, stream));
+  // proj + DropPath + shortcut
+  {
+    neosr_gemm_desc g = gemm_desc(NEOSR_GEMM_NT, s.att, d.proj_w, s.x2, M, C, C);
+    g.bias = d.proj_b; g.res = x; g.row_scale = d.drop_scale; g.rows_per_scale = d.drop_scale ? rps : 0;
+    TB_RUN(neosr_gemm(&g, stream));
+  }
+  const float* xm = s.x2;
+  if (d.cab_mid > 0) {   // HAB: x3 = x2 + conv_scale * CAB(norm1(x))   (hat_arch.py:15-52, 347)
+    const int mid = d.cab_mid;
+    TB_RUN(conv_launch(d, NEOSR_CONV_FWD, s.y1, C, d.c0_w, mid, C, d.c0_b, s.u0, nullptr, d.c0_pack_f, d.c0_wino_f,
+                       d.c0_wino4_f, stream));
+    TB_RUN(neosr_gelu(s.u0, nullptr, s.t0, (int64_t)M * mid, stream));
+    TB_RUN(conv_launch(d, NEOSR_CONV_FWD, s.t0, mid, d.c2_w, C, mid, d.c2_b, s.t1, nullptr, d.c2_pack_f, d.c2_wino_f,
+                       d.c2_wino4_f, stream));
+    TB_RUN(neosr_batched_colsum(s.t1, nullptr, s.pooled, s.bcs, d.B, rps, C, 1.0f / rps, stream));
+    TB_RUN(neosr_channel_attention_fwd(s.pooled, d.ca1_w, d.ca1_b, d.ca2_w, d.ca2_b, s.hidden, s.gate, d.B, C, d.cab_sq,
+                                       stream));
+    TB_RUN(neosr_scale_channels_add(s.t1, s.gate, s.x2, s.x3, d.B, rps, C, d.conv_scale, stream));
+    xm = s.x3;
+  }
+  TB_RUN(neosr_layernorm_fwd(xm, d.n2_w, d.n2_b, s.y2, s.stats2, M, C, d.eps2, stream));
+  {
+    neosr_gemm_desc g = gemm_desc(NEOSR_GEMM_NT, s.y2, d.fc1_w, s.h, M, Hd, C);
+    g.bias = d.fc1_b; g.aux_out = s.pre; g.gelu = 1;
+    TB_RUN(neosr_gemm(&g, stream));
+  }
+  {
+    neosr_gemm_desc g = gemm_desc(NEOSR_GEMM_NT, s.h, d.fc2_w, out, M, C, Hd);
+    g.bias = d.fc2_b; g.res = xm; g.row_scale = d.drop_scale2; g.rows_per_scale = d.drop_scale2 ? rps : 0;
+    TB_RUN(neosr_gemm(&g, stream));
+  }
+  return 0;
+}
+
+// Backward.  `grads` points at the block's parameter gradients in ONE buffer laid out like the parameters in the
+// network's flat arena (named_parameters order, every tensor start rounded up to 4 floats): each (weight, bias) and
+// (gamma, beta) pair is then contiguous, which lets ONE fixed-order column-sum job finish both (neosr_gemm TN with
+// accumulate == 2, neosr_layernorm_bwd_res without targets).  All column sums of the block — four split-K weight
+// gradients, two LayerNorm affine gradients, the relative-position-bias bins — run as one neosr_colsum_many at the end.
+extern "C" int neosr_tblock_backward(const neosr_tblock_desc* dp, const float* x, const float* dout, const float* save,
+                                     float* dx, const neosr_tblock_grads* gp, float* workspace, void* stream) {
+  if (check(dp)) return 1;
+  const neosr_tblock_desc& d = *dp;
+  NEOSR_CHECK(x && dout && save && dx && gp && workspace, "tblock backward: null buffer");
+  const neosr_tblock_grads& G = *gp;
+  NEOSR_CHECK(G.n1_w && G.rpb && G.qkv_w && G.proj_w && G.n2_w && G.fc1_w && G.fc2_w, "tblock backward: missing gradient target");
+  const SaveLayout s = save_layout(d, const_cast<float*>(save));
+  const BwdLayout b = bwd_layout(d, workspace);
+  const int M = (int)tokens(d), C = d.C, Hd = d.hidden, rps = d.H * d.W;
+  const float* rs = d.drop_scale;      // attention branch
+  const int rsn = rs ? rps : 0;
+  const float* rs2 = d.drop_scale2;    // MLP branch
+  const int rsn2 = rs2 ? rps : 0;
+  NEOSR_CHECK(G.n1_b == G.n1_w + C && G.n2_b == G.n2_w + C && G.fc1_b == G.fc1_w + (int64_t)Hd * C &&
+                  G.fc2_b == G.fc2_w + (int64_t)C * Hd && G.proj_b == G.proj_w + (int64_t)C * C &&
+                  (!d.qkv_b || G.qkv_b == G.qkv_w + (int64_t)3 * C * C),
+              "tblock backward: (weight, bias) / (gamma, beta) gradient pairs must be contiguous");
+  Side* side = side_get();
+  void* sw = side ? (void*)side->s : stream;   // the stream of the weight gradients
+  // `after(e)`: the side stream continues behind what the caller's stream has enqueued so far
+  auto after = [&](int e) -> int {
+    if (!side) return 0;
+    NEOSR_HIP(hipEventRecord(side->ev[e], (hipStream_t)stream));
+    NEOSR_HIP(hipStreamWaitEvent(side->s, side->ev[e], 0));
+    return 0;
+  };
+  TB_RUN(after(EV_FORK));
+  neosr_colsum_item jobs[MAX_JOBS];
+  int nj = 0;
+  auto add_job = [&](const float* part, int rows, int64_t cols, float* out) {
+    jobs[nj].x = part; jobs[nj].out = out; jobs[nj].rows = rows; jobs[nj].cols = (int)cols; jobs[nj].ld = (int)cols;
+    jobs[nj].accumulate = 0;
+    ++nj;
+  };
+  // TN GEMM with its split reduction left for the batched pass
+  auto wgrad = [&](const float* dy, const float* xin, float* dw, float* db, int N, int K, float* ws, const float* rscale,
+                   int rscale_n) -> int {
+    neosr_gemm_desc g = gemm_desc(NEOSR_GEMM_TN, dy, xin, dw, N, K, M);
+    g.colsum_a = db; g.workspace = ws; g.accumulate = 2; g.row_scale = rscale; g.rows_per_scale = rscale_n;
+    const int rc = neosr_gemm(&g, sw);
+    if (rc >= 0) return rc ? rc : (neosr_set_error("tblock: TN gemm did not defer its reduction"), 1);
+    add_job(ws, -rc, (int64_t)N * K + (db ? N : 0), dw);
+    return 0;
+  };
+  const float* xm = d.cab_mid > 0 ? s.x3 : s.x2;   // input of norm2
+  NEOSR_CHECK(d.cab_mid == 0 || (G.c0_w && G.c0_b && G.c2_w && G.c2_b && G.ca1_w && G.ca1_b && G.ca2_w && G.ca2_b),
+              "tblock backward: missing CAB gradient target");
+  // ---- Mlp (hip/transformer.py: Mlp.backward)
+  TB_RUN(wgrad(dout, s.h, G.fc2_w, G.fc2_b, C, Hd, b.tn_fc2, rs2, rsn2));
+  {
+    neosr_gemm_desc g = gemm_desc(NEOSR_GEMM_NN, dout, d.fc2_w, b.gpre, M, Hd, C);   // (g W2) GELU'(pre)
+    g.aux_in = s.pre; g.row_scale = rs2; g.rows_per_scale = rsn2;
+    TB_RUN(neosr_gemm(&g, stream));
+  }
+  TB_RUN(after(EV_GPRE));
+  TB_RUN(wgrad(b.gpre, s.y2, G.fc1_w, G.fc1_b, Hd, C, b.tn_fc1, nullptr, 0));
+  {
+    neosr_gemm_desc g = gemm_desc(NEOSR_GEMM_NN, b.gpre, d.fc1_w, b.gy2, M, C, Hd);
+    TB_RUN(neosr_gemm(&g, stream));
+  }
+  // ---- norm2 with the shortcut gradient (= dout) summed in the same pass
+  {
+    const int rc = neosr_layernorm_bwd_res(b.gy2, xm, s.stats2, d.n2_w, dout, b.dx2, nullptr, nullptr, b.ln2, M, C, 0, stream);
+    if (rc >= 0) return rc ? rc : (neosr_set_error("tblock: layernorm did not defer its reduction"), 1);
+    add_job(b.ln2, -rc, 2 * C, G.n2_w);
+  }
+  TB_RUN(after(EV_DX2));
+  // ---- CAB branch (HAB): the gradient that reached x3 (b.dx2) also is the gradient of x2 (x3 = x2 + ...)
+  if (d.cab_mid > 0) {
+    const int mid = d.cab_mid;
+    // channel gate (hip/transformer.py: ChannelGate.backward)
+    TB_RUN(neosr_batched_colsum(b.dx2, s.t1, b.dattn, b.bcs, d.B, rps, C, d.conv_scale, stream));
+    TB_RUN(neosr_channel_attention_bwd(b.dattn, s.gate, s.hidden, s.pooled, d.ca1_w, d.ca2_w, b.dpooled, G.ca1_w, G.ca1_b,
+                                       G.ca2_w, G.ca2_b, d.B, C, d.cab_sq, stream));
+    TB_RUN(neosr_scale_channels_bwd(b.dx2, s.gate, b.dpooled, b.gt1, d.B, rps, C, d.conv_scale, stream));
+    // second convolution: weight + bias gradient (side stream), data gradient (hip/layers.py: Conv3x3.backward)
+    TB_RUN(after(EV_GT1));
+    TB_RUN(wgrad_launch(d, s.t0, mid, b.gt1, C, G.c2_w, G.c2_b, b.wg2, sw));
+    TB_RUN(conv_launch(d, NEOSR_CONV_DGRAD, b.gt1, C, d.c2_w, C, mid, nullptr, b.gt0, nullptr, d.c2_pack_d, d.c2_wino_d,
+                       d.c2_wino4_d, stream));
+    TB_RUN(neosr_gelu(s.u0, b.gt0, b.gu0, (int64_t)M * mid, stream));
+    // first convolution; its data gradient is one of the two contributions to norm1's output (the other comes from qkv,
+    // whose GEMM adds this one in its epilogue below: a + b in either order, as autograd's accumulation would)
+    TB_RUN(after(EV_GU0));
+    TB_RUN(wgrad_launch(d, s.y1, C, b.gu0, mid, G.c0_w, G.c0_b, b.wg0, sw));
+    TB_RUN(conv_launch(d, NEOSR_CONV_DGRAD, b.gu0, mid, d.c0_w, mid, C, nullptr, b.gy1c, nullptr, d.c0_pack_d, d.c0_wino_d,
+                       d.c0_wino4_d, stream));
+  }
+  // ---- proj (Linear.backward): data gradient with the DropPath scale in the epilogue, weight gradient with it on the rows
+  TB_RUN(wgrad(b.dx2, s.att, G.proj_w, G.proj_b, C, C, b.tn_proj, rs, rsn));
+  {
+    neosr_gemm_desc g = gemm_desc(NEOSR_GEMM_NN, b.dx2, d.proj_w, b.gatt, M, C, C);
+    g.row_scale = rs; g.rows_per_scale = rsn;
+    TB_RUN(neosr_gemm(&g, stream));
+  }
+  // ---- attention
+  {
+    const int bins = (d.attn == 0 || d.ks == d.ws) ? (2 * d.ws - 1) * (2 * d.ws - 1) : 0;
+    int rc;
+    const float* part = b.attn_ws;
+    if (d.attn == 0) {
+      neosr_wattn_desc a;
+      memset(&a, 0, sizeof(a));
+      a.qkv = s.qkv; a.rpb_table = d.rpb; a.out = s.att; a.lse = s.lse; a.dout = b.gatt; a.dqkv = b.dqkv;
+      a.d_rpb_table = G.rpb; a.workspace = b.attn_ws;
+      a.B = d.B; a.H = d.H; a.W = d.W; a.C = C; a.heads = d.heads; a.ws = d.ws; a.shift = d.shift; a.scale = d.scale;
+      a.accumulate_rpb = 2;
+      rc = neosr_window_attention_bwd(&a, stream);
+    } else {
+      neosr_fattn_desc a = fattn_bwd_desc(d);
+      a.qkv = s.qkv; a.rpb_table = d.rpb; a.out = s.att; a.lse = s.lse; a.dout = b.gatt; a.dqkv = b.dqkv;
+      a.d_rpb_table = G.rpb; a.workspace = b.attn_ws;
+      a.accumulate_rpb = d.ks == d.ws ? 2 : 0;   // (the overlapping form gathers its bins from a dense sum itself)
+      rc = neosr_flash_window_attention_bwd(&a, stream);
+      part = b.attn_ws + (int64_t)d.B * (d.H / d.ws) * (d.W / d.ws) * d.heads * d.ws * d.ws;
+    }
+    if (rc < 0) add_job(part, -rc, (int64_t)d.heads * bins, G.rpb);
+    else if (rc) return rc;
+  }
+  // ---- qkv
+  TB_RUN(after(EV_DQKV));
+  TB_RUN(wgrad(b.dqkv, s.y1, G.qkv_w, d.qkv_b ? G.qkv_b : nullptr, 3 * C, C, b.tn_qkv, nullptr, 0));
+  {
+    neosr_gemm_desc g = gemm_desc(NEOSR_GEMM_NN, b.dqkv, d.qkv_w, b.gy1, M, C, 3 * C);
+    if (d.cab_mid > 0) g.res = b.gy1c;
+    TB_RUN(neosr_gemm(&g, stream));
+  }
+  // ---- norm1 with the shortcut gradient (= what reached x2 = dx2)
+  {
+    const int rc = neosr_layernorm_bwd_res(b.gy1, x, s.stats1, d.n1_w, b.dx2, dx, nullptr, nullptr, b.ln1, M, C, 0, stream);
+    if (rc >= 0) return rc ? rc : (neosr_set_error("tblock: layernorm did not defer its reduction"), 1);
+    add_job(b.ln1, -rc, 2 * C, G.n1_w);
+  }
+  if (side) {   // join: the column sums below read the partials of both streams
+    NEOSR_HIP(hipEventRecord(side->ev[EV_JOIN], side->s));
+    NEOSR_HIP(hipStreamWaitEvent((hipStream_t)stream, side->ev[EV_JOIN], 0));
+  }
+  NEOSR_CHECK(neosr_colsum_many_workspace_floats(jobs, nj) <= b.many_n, "tblock backward: column-sum workspace too small");
+  return neosr_colsum_many(jobs, nj, b.many, stream);
+}

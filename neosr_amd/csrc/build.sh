@@ -8,7 +8,7 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
 OBJS=""
 PIDS=""
-for f in api prof conv_mfma conv_glds conv_wino conv_wino4 conv_wino4_chain conv_thin wgrad elementwise degrade layers gemm_mfma attn attn_wave attn_flash cab augment ssim color losses optim nets; do
+for f in api prof conv_mfma conv_glds conv_wino conv_wino4 conv_wino4_chain conv_thin wgrad elementwise degrade layers gemm_mfma attn attn_wave attn_flash cab augment ssim color losses optim nets blocks; do
   "$HIPCC" $FLAGS -c "$HERE/$f.hip" -o "$OUT/$f.o" "$@" &
   PIDS="$PIDS $!"
   OBJS="$OBJS $OUT/$f.o"

@@ -65,6 +65,9 @@ typedef int w4c_i32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store16_sc1(f32x4 v, w4c_i32x4 rsrc, int voff) {
   asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen sc1\n\ts_nop 1" : : "v"(v), "v"(voff), "s"(rsrc) : "memory");
 }
+// (Round 4 tried plain write-back stores for tiles whose 3 x 3 neighbourhood shares their XCD — all of them at B = 16,
+// where an XCD's band of tiles is two whole samples: 1.2 % SLOWER (632 vs 640 LR-patches/s) and WRONG — the chain tests
+// fail: the block -> XCD map is not a contract and a consumer on another L2 reads stale lines.  The stores stay sc1.)
 
 __global__ __attribute__((amdgpu_flat_work_group_size(768, 768), amdgpu_waves_per_eu(3, 3)))
 void conv3x3_wino4_chain_kernel(const W4ChainArgs args) {

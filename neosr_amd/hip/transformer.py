@@ -450,6 +450,110 @@ def window_attention(qkv, table, heads, ws, shift, scale):
     return WindowAttention.apply(qkv, table, heads, ws, shift, scale)
 
 
+# ------------------------------------------------------------------------------------------------
+# Whole transformer blocks on the C++ plans of csrc/blocks.hip: TWO library calls per block and step instead of one
+# autograd.Function + ctypes call per fused op.  NEOSR_AMD_BLOCK_PLANS=0 keeps the op-by-op composition (same kernels,
+# same descriptors: bit-identical; tests/test_hip_blocks.py).
+BLOCK_PLANS = os.environ.get("NEOSR_AMD_BLOCK_PLANS", "1") != "0"
+
+
+def _block_grad_buffer(params, like):
+    """One flat buffer for the gradients of a block's parameters, laid out like their slice of the network's parameter
+    arena (so every (weight, bias) / (gamma, beta) pair is contiguous) — the slice of the data-parallel exchange arena
+    itself when GradSync hands out slots (GRAD_SLOT) — and its per-parameter views."""
+    from neosr_amd.hip.nets import arena_layout
+
+    offs, total = arena_layout(params)
+    flat = None
+    if GRAD_SLOT is not None:
+        slots = [GRAD_SLOT(p) for p in params]
+        s0 = slots[0]
+        if all(s is not None for s in slots) and all(s.data_ptr() == s0.data_ptr() + 4 * o for s, o in zip(slots, offs)):
+            flat = torch.empty(0, device=s0.device, dtype=torch.float32)
+            flat.set_(s0.untyped_storage(), s0.storage_offset(), (total,), (1,))
+    if flat is None:
+        flat = _new((total,), like)
+    return flat, [flat[o : o + p.numel()].view(p.shape) for p, o in zip(params, offs)]
+
+
+class TBlock(torch.autograd.Function):
+    """SwinTransformerBlock (swinir_arch.py:231-392) / OCAB (hat_arch.py:393-515) / HAB (hat_arch.py:218-350) through
+    `neosr_tblock_forward` / `neosr_tblock_backward`.  `params`: the block's parameters in `named_parameters()` order
+    (= their order in the network's flat arena), `meta["names"]` the descriptor field of each (`_C.TBLOCK_PARAMS`,
+    `_C.TBLOCK_CAB_PARAMS`); `meta["images"]()` -> the packed weight images of the CAB convolutions (HAB only)."""
+
+    @staticmethod
+    def _desc(meta, x, params):
+        """the block's descriptor, cached on `meta` per (geometry, parameter addresses): ~40 ctypes field writes and 13-21
+        device / contiguity checks per call otherwise"""
+        B, H, W, C_ = x.shape
+        key = (B, H, W, C_) + tuple(p.data_ptr() for p in params)
+        hit = meta.get("_desc")
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        names = meta["names"]
+        if len(params) != len(names):
+            raise _C.NeosrAmdError(f"TBlock: expected {len(names)} parameter tensors, got {len(params)}")
+        d = _C.TBlockDesc(B=B, H=H, W=W, C=C_, **meta["ints"], **meta["floats"])
+        for n, p in zip(names, params):
+            _C.require_device(p, n)
+            if not p.is_contiguous():
+                raise _C.NeosrAmdError(f"TBlock: parameter {n} must be contiguous")
+            setattr(d, n, p.data_ptr())
+        nsave = _C.load().neosr_tblock_save_floats(d)
+        nws = _C.load().neosr_tblock_bwd_workspace_floats(d)
+        if nsave < 0 or nws < 0:
+            _C.check(1, "neosr_tblock_save_floats")
+        meta["_desc"] = (key, (d, nsave, nws))
+        return d, nsave, nws
+
+    @staticmethod
+    def forward(ctx, x, rs, rs2, meta, *params):
+        lib = _C.load()
+        x = _C.require_device(x, "x").contiguous()
+        d, nsave, nws = TBlock._desc(meta, x, params)
+        imgs = meta["images"](*x.shape[:3]) if "images" in meta else None
+        if imgs:
+            for n, t in imgs.items():
+                setattr(d, n, _p(t))
+        d.drop_scale, d.drop_scale2 = _p(rs), _p(rs2)
+        save = _new((nsave,), x)
+        out = torch.empty_like(x)
+        _C.check(lib.neosr_tblock_forward(d, x.data_ptr(), out.data_ptr(), save.data_ptr(), _st()), "neosr_tblock_forward")
+        if any(ctx.needs_input_grad):
+            # (the parameters are leaves the module keeps alive; like the whole-network plans, backward reads them as they
+            # are then — nothing may write them between forward and backward, which autograd would only have detected)
+            ctx.save_for_backward(x, rs, rs2, save)
+            ctx.meta, ctx.leaves, ctx.imgs = meta, params, imgs
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _C.load()
+        x, rs, rs2, save = ctx.saved_tensors
+        meta, params = ctx.meta, ctx.leaves
+        g = g.contiguous()
+        d, _nsave, nws = TBlock._desc(meta, x, params)
+        if ctx.imgs:
+            for n, t in ctx.imgs.items():
+                setattr(d, n, _p(t))
+        d.drop_scale, d.drop_scale2 = _p(rs), _p(rs2)
+        _flat, views = _block_grad_buffer(list(params), x)
+        G = _C.TBlockGrads()
+        for n, v in zip(meta["names"], views):
+            setattr(G, n, v.data_ptr())
+        ws = _new((nws,), x)
+        dx = torch.empty_like(x)
+        _C.check(lib.neosr_tblock_backward(d, x.data_ptr(), g.data_ptr(), save.data_ptr(), dx.data_ptr(), G,
+                                           ws.data_ptr(), _st()), "neosr_tblock_backward")
+        grads = [v if need else None for v, need in zip(views, ctx.needs_input_grad[4:])]
+        return (dx if ctx.needs_input_grad[0] else None), None, None, None, *grads
+
+
+def tblock(x, rs, rs2, meta, params):
+    return TBlock.apply(x, rs, rs2, meta, *params)
+
+
 class PixelShuffleNHWC(torch.autograd.Function):
     """nn.PixelShuffle(r) on channels-last tensors: (B,H,W,C*r*r) -> (B,H*r,W*r,C). Bit-exact."""
 

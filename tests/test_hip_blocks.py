@@ -1,0 +1,125 @@
+"""GPU: whole transformer blocks on the C++ plans of csrc/blocks.hip (`neosr_tblock_forward/backward`: one library call
+per block and direction) against the op-by-op composition of the same kernels from Python (rounds 1-3): outputs, input
+gradients and every parameter gradient must agree BIT FOR BIT — the plans build the same descriptors in the same order.
+References: neosr/archs/swinir_arch.py:231-392 (SwinTransformerBlock), neosr/archs/hat_arch.py:218-350 (HAB), :393-515
+(OCAB)."""
+
+from __future__ import annotations
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _run(net, x, gy, plans: bool, seed: int):
+    from neosr_amd.hip import transformer as tr
+
+    prev = tr.BLOCK_PLANS
+    tr.BLOCK_PLANS = plans
+    try:
+        if net.training and not getattr(net, "_warm", False):
+            # (the first train-mode forward of a network RECORDS its DropPath sites with one draw per site; every later one
+            # takes all sites from one batched draw — another use of the RNG stream: compare like with like)
+            net(x)
+            net._warm = True
+        torch.manual_seed(seed)   # DropPath draws
+        net.zero_grad(set_to_none=True)
+        xd = x.clone().requires_grad_(True)
+        y = net(xd)
+        y.backward(gy)
+        torch.cuda.synchronize()
+        return y.detach().clone(), xd.grad.clone(), {k: p.grad.clone() for k, p in net.named_parameters()}
+    finally:
+        tr.BLOCK_PLANS = prev
+
+
+def _same(a, b):
+    ya, gxa, ga = a
+    yb, gxb, gb = b
+    assert torch.equal(ya, yb)
+    assert torch.equal(gxa, gxb)
+    bad = [k for k in ga if not torch.equal(ga[k], gb[k])]
+    assert not bad, bad[:6]
+
+
+@pytest.mark.parametrize("train,drop", [(True, 0.1), (True, 0.0), (False, 0.1)])
+def test_swinir_block_plan_is_bit_identical_to_op_by_op(train, drop):
+    from neosr_amd.archs import swinir_arch as A
+
+    torch.manual_seed(3)
+    net = A.swinir_small(upscale=4, drop_path_rate=drop).to(DEV)
+    net.train(train)
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand(2, 3, 32, 48, generator=g).to(DEV)
+    gy = torch.randn(2, 3, 128, 192, generator=g).to(DEV)
+    _same(_run(net, x, gy, True, 11), _run(net, x, gy, False, 11))
+
+
+def test_swinir_block_plan_under_no_grad_and_twice():
+    """inference (no autograd graph) and a second training pass re-using the parameters: same bits again"""
+    from neosr_amd.archs import swinir_arch as A
+    from neosr_amd.hip import transformer as tr
+
+    torch.manual_seed(4)
+    net = A.swinir_small(upscale=4, drop_path_rate=0.0).to(DEV).eval()
+    x = torch.rand(1, 3, 24, 40, device=DEV)
+    outs = []
+    for plans in (True, False, True):
+        tr.BLOCK_PLANS = plans
+        with torch.no_grad():
+            outs.append(net(x))
+    tr.BLOCK_PLANS = True
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+@pytest.mark.parametrize("ws,res,drop,cr", [(16, 32, 0.1, 3), (8, 16, 0.0, 3), (16, 64, 0.0, 3), (16, 32, 0.1, 4)])
+def test_hat_block_plans_are_bit_identical_to_op_by_op(ws, res, drop, cr):
+    """HAB (CAB branch, both of its convolutions' gradients, the channel gate, shifted windows) and OCAB; compress_ratio 4
+    gives the CAB 6 inner channels (hat_s: 144 / 24) — not a multiple of 4, the convolutions take their generic kernels"""
+    from neosr_amd.archs.hat_arch import hat
+
+    torch.manual_seed(5)
+    net = hat(img_size=res, embed_dim=24, depths=(2, 2), num_heads=(2, 2), window_size=ws, compress_ratio=cr,
+              squeeze_factor=6, mlp_ratio=2, drop_path_rate=drop, upsampler="pixelshuffle", upscale=4).to(DEV).train()
+    g = torch.Generator().manual_seed(2)
+    x = torch.rand(2, 3, res, res, generator=g).to(DEV)
+    gy = torch.randn(2, 3, 4 * res, 4 * res, generator=g).to(DEV)
+    _same(_run(net, x, gy, True, 13), _run(net, x, gy, False, 13))
+
+
+def test_hat_l_block_plans_full_width():
+    """hat_l geometry (dim 180, 6 heads, windows of 16, CAB 180 -> 60 -> 180 with F(4x4) images) at B = 1, two groups"""
+    from neosr_amd.archs.hat_arch import hat
+
+    torch.manual_seed(6)
+    net = hat(img_size=64, embed_dim=180, depths=(2, 2), num_heads=(6, 6), window_size=16, compress_ratio=3,
+              squeeze_factor=30, mlp_ratio=2, drop_path_rate=0.0, upsampler="pixelshuffle", upscale=4).to(DEV).train()
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(1, 3, 64, 64, generator=g).to(DEV)
+    gy = torch.randn(1, 3, 256, 256, generator=g).to(DEV)
+    _same(_run(net, x, gy, True, 17), _run(net, x, gy, False, 17))
+
+
+def test_block_backward_side_stream_does_not_change_results():
+    """`neosr_set_tblock_streams`: weight gradients on the library's side stream (fork / join by events inside the call)
+    vs everything on the caller's stream — bit-identical, run after run (a missing event wait would show up here)"""
+    from neosr_amd import _C
+    from neosr_amd.archs.hat_arch import hat
+
+    lib = _C.load()
+    torch.manual_seed(8)
+    net = hat(img_size=32, embed_dim=60, depths=(2, 2), num_heads=(6, 6), window_size=16, compress_ratio=3,
+              squeeze_factor=30, mlp_ratio=2, drop_path_rate=0.0, upsampler="pixelshuffle", upscale=4).to(DEV).train()
+    g = torch.Generator().manual_seed(4)
+    x = torch.rand(4, 3, 32, 32, generator=g).to(DEV)
+    gy = torch.randn(4, 3, 128, 128, generator=g).to(DEV)
+    prev = lib.neosr_set_tblock_streams(1)
+    try:
+        ref = _run(net, x, gy, True, 19)
+        lib.neosr_set_tblock_streams(2)
+        for _ in range(4):
+            _same(_run(net, x, gy, True, 19), ref)
+    finally:
+        lib.neosr_set_tblock_streams(prev)

@@ -85,16 +85,21 @@ def test_hat_l_forward_backward_vs_reference_fixture():
     P = dict(net.named_parameters())
     assert keys == list(P)
     np.testing.assert_allclose(np.array([float(P[k].double().sum()) for k in keys]), fix["p/sum"], rtol=1e-6, atol=1e-5)
-    from neosr_amd.hip.transformer import ChannelGate
+    from neosr_amd.hip import transformer as tr
 
     net = net.to(DEV).train()
     x = T(fix["x"]).to(DEV).requires_grad_(True)
-    ChannelGate.trace = []
+    # the bottlenecks' inputs are visible where the blocks are composed op by op (`ChannelGate.trace`); the block plans
+    # (the default, used for the forward / backward comparison below) run the same kernels with the same descriptors
+    tr.ChannelGate.trace, plans, tr.BLOCK_PLANS = [], tr.BLOCK_PLANS, False
     try:
-        y = net(x)
-        trace = ChannelGate.trace
+        with torch.no_grad():
+            y_ops = net(x)
+        trace = tr.ChannelGate.trace
     finally:
-        ChannelGate.trace = None
+        tr.ChannelGate.trace, tr.BLOCK_PLANS = None, plans
+    y = net(x)
+    assert torch.equal(y, y_ops)
     assert rel_err(y, T(fix["y"])) < 1e-4
     # The 432 ReLU inputs of the channel-attention bottlenecks (hat_arch.py:15-37) are where a last-bit difference can
     # become a percent-level one: each gates a whole 180-channel map.  The fixture's draw keeps the reference's values

@@ -116,6 +116,33 @@ def test_flash_attention_bwd_is_deterministic():
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
+@pytest.mark.parametrize("B,H,W,C,heads,shift,ws", [(2, 32, 48, 180, 6, 8, 16), (1, 64, 64, 60, 6, 0, 16), (3, 16, 24, 24, 2, 4, 8)])
+def test_flash_self_attention_one_pass_backward_is_bit_identical_to_two_pass(B, H, W, C, heads, shift, ws):
+    """`neosr_set_fattn_fused`: the one-pass backward (S / dP / P / dS of a tile formed once, dQ + dK + dV from them) against
+    the two recompute passes it replaces — same accumulation orders, so dqkv and the bias-table gradient must be equal
+    bit for bit; the vs-oracle tests above run on the one-pass kernel (the default)."""
+    from neosr_amd import _C
+    from neosr_amd.hip import transformer as tr
+
+    lib = _C.load()
+    g = torch.Generator().manual_seed(B * H + C + shift)
+    qkv = torch.randn(B, H, W, 3 * C, generator=g).to(DEV)
+    table = (torch.randn((2 * ws - 1) ** 2, heads, generator=g) * 0.5).to(DEV)
+    r = torch.randn(B, H, W, C, generator=g).to(DEV)
+    outs = []
+    prev = lib.neosr_set_fattn_fused(1)
+    try:
+        for fused in (1, 0, 1):
+            lib.neosr_set_fattn_fused(fused)
+            a, t = qkv.clone().requires_grad_(True), table.clone().requires_grad_(True)
+            (tr.flash_window_attention(a, t, heads, ws, shift, (C // heads) ** -0.5, ws) * r).sum().backward()
+            outs.append((a.grad.clone(), t.grad.clone()))
+    finally:
+        lib.neosr_set_fattn_fused(prev)
+    for ga, gt in outs[1:]:
+        assert torch.equal(ga, outs[0][0]) and torch.equal(gt, outs[0][1])
+
+
 def _nhwc(t):
     return t.permute(0, 2, 3, 1).contiguous()
 
