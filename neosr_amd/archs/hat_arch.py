@@ -103,6 +103,15 @@ class HAB(nn.Module):
 
     def _plan_images(self, b: int, h: int, w: int) -> dict:
         """packed weight images of the two CAB convolutions, forward and backward-data, as `L.Conv3x3` would pick them"""
+        c0, c2 = self.conv_block.cab[0].weight, self.conv_block.cab[2].weight
+        # (valid while no weight changed: the fused optimizers bump `_C.WEIGHTS_EPOCH`, torch in-place writes `_version`;
+        # a stale key goes through `L.packed_weights`, which re-packs every stale image of the device in one call)
+        key = (_C.WEIGHTS_EPOCH, c0._version, c2._version, c0.data_ptr(), b, h, w)
+        hit = getattr(self, "_plan_imgs", None)
+        # (not while a hipGraph capture is pending / running: `L._packed` must see the request — its first one inside a
+        # capture re-packs every image as a node of the graph, utils/graph.py)
+        if hit is not None and hit[0] == key and not L.FORCE_REPACK_IN_CAPTURE and not torch.cuda.is_current_stream_capturing():
+            return hit[1]
         out = {}
         for tag, conv in (("c0", self.conv_block.cab[0]), ("c2", self.conv_block.cab[2])):
             wt = conv.weight
@@ -110,6 +119,7 @@ class HAB(nn.Module):
                 out[f"{tag}_pack_{m}"] = L.packed_weights(wt, mode)
                 for k, v in L.wino_images(wt, mode, b, h, w, n_out).items():
                     out[f"{tag}_{k[2:]}_{m}"] = v
+        self._plan_imgs = (key, out)
         return out
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:  # (B, H, W, C)

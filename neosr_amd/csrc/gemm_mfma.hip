@@ -475,6 +475,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds64_kernel(const GemmArgs a
   epilogue<0, float4[4], 1>(args, acc, m0, n0, 0, bias_s, resq, wm * 32, wn * 32);
 }
 
+
+// (Round 4 tried a whole-K-panel variant for the K = 180 Linears — a 32 x 64 tile whose six chunks are all requested at
+// once behind one wait and one barrier, four waves = 2 column tiles x 2 k-halves, two workgroups per CU — on the theory
+// that a 0.5 us chunk cannot hide the DMA it waits for: 52 TF against 78 at M = 32 768 (qkv), 50 against 69 at M = 16 384;
+// swinir_medium 38.4 -> 41.0 ms per step.  One accumulator chain per wave and two LDS reads per four MFMAs lose more than
+// the barriers cost; the chunked kernels above stay.)
+
 // TN GEMM fed from registers (weight gradients dW[m][n] = sum_t dY[t][m] X[t][n]): both operands are
 // contiguous along their OUTPUT index, so an MFMA fragment is a plain coalesced row load — lane (l31, lh) reads
 // 3 consecutive dY columns and 2 consecutive X columns of token 2s + lh (buffer_load_dwordx3 / dwordx2; a

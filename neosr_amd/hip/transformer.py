@@ -457,13 +457,20 @@ def window_attention(qkv, table, heads, ws, shift, scale):
 BLOCK_PLANS = os.environ.get("NEOSR_AMD_BLOCK_PLANS", "1") != "0"
 
 
-def _block_grad_buffer(params, like):
+def _block_grad_buffer(params, like, meta=None):
     """One flat buffer for the gradients of a block's parameters, laid out like their slice of the network's parameter
     arena (so every (weight, bias) / (gamma, beta) pair is contiguous) — the slice of the data-parallel exchange arena
-    itself when GradSync hands out slots (GRAD_SLOT) — and its per-parameter views."""
-    from neosr_amd.hip.nets import arena_layout
+    itself when GradSync hands out slots (GRAD_SLOT) — and its per-parameter views (one `as_strided` each; the layout is
+    cached on `meta`: it depends on the shapes only)."""
+    lay = meta.get("_layout") if meta is not None else None
+    if lay is None:
+        from neosr_amd.hip.nets import arena_layout
 
-    offs, total = arena_layout(params)
+        offs, total = arena_layout(params)
+        lay = (offs, total, [tuple(p.shape) for p in params], [p.stride() for p in params])
+        if meta is not None:
+            meta["_layout"] = lay
+    offs, total, shapes, strides = lay
     flat = None
     if GRAD_SLOT is not None:
         slots = [GRAD_SLOT(p) for p in params]
@@ -473,7 +480,8 @@ def _block_grad_buffer(params, like):
             flat.set_(s0.untyped_storage(), s0.storage_offset(), (total,), (1,))
     if flat is None:
         flat = _new((total,), like)
-    return flat, [flat[o : o + p.numel()].view(p.shape) for p, o in zip(params, offs)]
+    base = flat.storage_offset()
+    return flat, [flat.as_strided(sh, st, base + o) for sh, st, o in zip(shapes, strides, offs)]
 
 
 class TBlock(torch.autograd.Function):
@@ -538,10 +546,16 @@ class TBlock(torch.autograd.Function):
             for n, t in ctx.imgs.items():
                 setattr(d, n, _p(t))
         d.drop_scale, d.drop_scale2 = _p(rs), _p(rs2)
-        _flat, views = _block_grad_buffer(list(params), x)
-        G = _C.TBlockGrads()
-        for n, v in zip(meta["names"], views):
-            setattr(G, n, v.data_ptr())
+        flat, views = _block_grad_buffer(params, x, meta)
+        hit = meta.get("_G")   # (the allocator hands a step's buffers out at the same addresses: the struct is reused)
+        if hit is not None and hit[0] == flat.data_ptr():
+            G = hit[1]
+        else:
+            G = _C.TBlockGrads()
+            base = flat.data_ptr()
+            for n, o in zip(meta["names"], meta["_layout"][0]):
+                setattr(G, n, base + 4 * o)
+            meta["_G"] = (base, G)
         ws = _new((nws,), x)
         dx = torch.empty_like(x)
         _C.check(lib.neosr_tblock_backward(d, x.data_ptr(), g.data_ptr(), save.data_ptr(), dx.data_ptr(), G,
