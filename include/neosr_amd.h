@@ -97,6 +97,14 @@ typedef struct neosr_conv_desc {
                                neosr_set_winograd(2) (the default) launches that would take w_wino
                                take the F(4x4,3x3) kernel instead (36 multiplications per 4x4 output tile and channel
                                pair instead of 144 direct / 64 with F(2x2,3x3); same epilogue) */
+  /* F(4x4,3x3) kernel only (round 4: lets conv + PReLU chains — SRVGGNetCompact, compact_arch.py:49-85 — run as plain
+   * Winograd launches; a launch that sets them and does not qualify for that kernel is an error): */
+  const float* out_mask_slopes; /* optional per-n slope of the out_mask derivative (PReLU'), instead of out_mask_slope */
+  float* out2;                  /* optional second output (B, H, W, out2_cs): conv + bias BEFORE activation / residuals /
+                                   mask — the pre-activation a PReLU layer keeps for its backward pass (forward), the
+                                   unmasked gradient its slope gradient needs (backward-data) */
+  int32_t out2_cs;
+  int32_t reserved1;
 } neosr_conv_desc;
 
 int neosr_conv3x3(const neosr_conv_desc* d, void* stream);
@@ -233,6 +241,16 @@ int neosr_prelu_dslope(const float* dA, const float* z, float* dslope, float* wo
                        int64_t npix, int32_t C, int32_t da_cs, int32_t z_cs, int32_t accumulate,
                        void* stream);
 int64_t neosr_prelu_dslope_workspace_bytes(int64_t npix, int32_t C);
+/* The same for n (dA, z, dslope) triples of one geometry in two launches (the PReLU layers of SRVGGNetCompact,
+ * compact_arch.py:49-72, at the end of its backward pass); workspace >= n * neosr_prelu_dslope_workspace_bytes bytes.
+ * Same sums in the same order as n calls of neosr_prelu_dslope (accumulate = 0). */
+typedef struct neosr_dslope_item {
+  const float* dA;
+  const float* z;
+  float* dslope;
+} neosr_dslope_item;
+int neosr_prelu_dslope_many(const neosr_dslope_item* items, int32_t n, float* workspace, int64_t npix, int32_t C,
+                            int32_t da_cs, int32_t z_cs, void* stream);
 
 /* p[0..n) = v ; out[p,c] += alpha*in[p,c] over a channels-last slice (skip-connection grads:
  * esrgan_arch.py:205 `feat = feat + body_feat`). */

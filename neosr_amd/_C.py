@@ -61,6 +61,10 @@ class ConvDesc(C.Structure):
         ("reserved0", C.c_int32),
         ("w_wino", C.c_void_p),
         ("w_wino4", C.c_void_p),
+        ("out_mask_slopes", C.c_void_p),
+        ("out2", C.c_void_p),
+        ("out2_cs", C.c_int32),
+        ("reserved1", C.c_int32),
     ]
 
 
@@ -254,6 +258,12 @@ class TBlockGrads(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in TBLOCK_PARAMS + TBLOCK_CAB_PARAMS]
 
 
+class DslopeItem(C.Structure):
+    """neosr_dslope_item"""
+
+    _fields_ = [("dA", C.c_void_p), ("z", C.c_void_p), ("dslope", C.c_void_p)]
+
+
 class MsssimDesc(C.Structure):
     """neosr_msssim_desc"""
 
@@ -382,6 +392,7 @@ SIGNATURES: dict[str, tuple] = {
     "neosr_tblock_forward": (C.c_int, [C.POINTER(TBlockDesc), _vp, _vp, _vp, _vp]),
     "neosr_tblock_backward": (C.c_int, [C.POINTER(TBlockDesc), _vp, _vp, _vp, _vp, C.POINTER(TBlockGrads), _vp, _vp]),
     "neosr_set_tblock_streams": (C.c_int, [C.c_int]),
+    "neosr_prelu_dslope_many": (C.c_int, [C.POINTER(DslopeItem), _i32, _vp, _i64, _i32, _i32, _i32, _vp]),
     "neosr_pixel_shuffle_nhwc": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "neosr_affine": (C.c_int, [_vp, _vp, _i64, _f32, _f32, _vp]),
     "neosr_row_scale": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _vp]),

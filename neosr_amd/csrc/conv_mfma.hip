@@ -415,15 +415,22 @@ extern "C" int neosr_conv3x3(const neosr_conv_desc* dp, void* stream) {
   // (32-bit byte offsets in its epilogue: tensors of 2 GB and more stay with F(2x2,3x3); small launches too, if they can)
   const int64_t w4_wgs = (int64_t)d.B * ceil_div(d.H, 16) * ceil_div(d.W, 16) * ceil_div(d.N, 32);
   auto small = [&](const void* p, int cs) { return !p || (int64_t)d.B * d.H * d.W * cs * 4 < (int64_t(1) << 31); };
-  const bool use_wino4 = use_pack && d.w_wino4 && ((uintptr_t)d.w_wino4 % 16 == 0) && d.s2d_c == 0 &&
-                         d.act != NEOSR_ACT_PRELU && neosr_conv::wino_mode() == 2 &&
+  // (the F(4x4,3x3) kernel needs no direct image: a launch may come with w_wino4 alone; it also is the one kernel with a
+  // per-channel PReLU epilogue, per-channel out_mask slopes and the second output)
+  const bool pack_ok = al_in && al_ep && (d.K % 4 == 0) && (d.N % 4 == 0) && !d.in_mask && !d.in_prelu;
+  const bool use_wino4 = pack_ok && d.w_wino4 && ((uintptr_t)d.w_wino4 % 16 == 0) && d.s2d_c == 0 &&
+                         (d.act != NEOSR_ACT_PRELU || ((uintptr_t)d.prelu % 16 == 0 && d.prelu)) &&
+                         (uintptr_t)d.out_mask_slopes % 16 == 0 && (uintptr_t)d.out2 % 16 == 0 && d.out2_cs % 4 == 0 &&
+                         small(d.out2, d.out2_cs) && neosr_conv::wino_mode() == 2 &&
                          (w4_wgs >= NEOSR_WINO4_MIN_WGS || !use_wino) && small(d.out, d.out_cs) && small(d.res1, d.res1_cs) &&
                          small(d.res2, d.res2_cs) && small(d.out_mask, d.out_mask_cs) && small(d.in, d.in_cs);
+  NEOSR_CHECK(use_wino4 || (!d.out2 && !d.out_mask_slopes),
+              "conv3x3: out2 / out_mask_slopes need the F(4x4,3x3) kernel (w_wino4, winograd mode 2, aligned tensors)");
   const bool prof = neosr_prof_on();
   if (prof) {
     const double px = (double)d.B * d.H * d.W;
     // algorithmic traffic: read |x| + |W|, write |y| (fp32)
-    neosr_prof_begin((d.mode == NEOSR_CONV_FWD ? NEOSR_PROF_CONV_FWD : NEOSR_PROF_CONV_DGRAD) + (use_pack ? 0 : 4), stream,
+    neosr_prof_begin((d.mode == NEOSR_CONV_FWD ? NEOSR_PROF_CONV_FWD : NEOSR_PROF_CONV_DGRAD) + (use_pack || use_wino4 ? 0 : 4), stream,
                      // (a 4x4 / stride-2 layer run as a 3x3 over the space-to-depth tensor multiplies 16 of its 36 (tap,
                      // sub-pixel) blocks: the other 20 are structurally zero and skipped)
                      2.0 * px * d.K * d.N * (d.s2d_c > 0 ? 4.0 : 9.0),

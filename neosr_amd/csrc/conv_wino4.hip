@@ -280,8 +280,14 @@ void conv3x3_wino4_kernel(const ConvArgs args) {
   float s_uni = 1.f;
   if (d.act == ACT_LRELU) s_uni = d.slope;
   else if (d.act == ACT_RELU) s_uni = 0.f;
+  // per-channel slopes (PReLU in the epilogue, PReLU' behind out_mask): uniform branches, a launch without them pays two
+  // scalar tests
+  f32x4 s_vec = splat(s_uni), m_vec = splat(d.out_mask_slope);
+  if (fin && d.act == ACT_PRELU) s_vec = ld4f(d.prelu + (ch_ok ? chq : 0));
+  if (fin && d.out_mask_slopes) m_vec = ld4f(d.out_mask_slopes + (ch_ok ? chq : 0));
   typedef decltype(__builtin_amdgcn_raw_buffer_load_b128(ru, 0, 0, 0)) raw4_t;
   const auto r_out = __builtin_amdgcn_make_buffer_rsrc(d.out, 0, 0x7ffffff0, 0x00020000);
+  const auto r_out2 = __builtin_amdgcn_make_buffer_rsrc(d.out2 ? d.out2 : d.out, 0, 0x7ffffff0, 0x00020000);
   struct Epi {
     int o_out[4];
     f32x4 e1[4], e2[4], e0[4], mk[4];
@@ -385,17 +391,27 @@ void conv3x3_wino4_kernel(const ConvArgs args) {
       y[2] = fma4(splat(4.f), s2, s1);
       y[3] = fma4(splat(8.f), d2, d1) + xi[5];
     }
+    if (d.out2) {   // second output: conv + bias, before activation / residuals / mask (same pixels, its own channel stride)
+      const int ey = y0 + 4 * (et >> 2), ex = x0 + 4 * (et & 3) + eb;
+      const int base = (((b * H + ey) * W + ex) * d.out2_cs + chq) * 4, step = W * d.out2_cs * 4;
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const f32x4 raw = y[a] + bias;
+        const int o2 = (ch_ok && ex < W && ey + a < H) ? base + a * step : 0x7ffffff8;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(raw4_t, raw), r_out2, o2, 0, 0);
+      }
+    }
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
       f32x4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float t = y[a][e] + bias[e];
-        t = t > 0.f ? t : t * s_uni;
+        t = t > 0.f ? t : t * s_vec[e];
         t = t * d.alpha + E.e1[a][e];
         t = t * d.alpha2 + E.e2[a][e];
         t += E.e0[a][e];
-        o[e] = E.mk[a][e] > 0.f ? t : t * d.out_mask_slope;
+        o[e] = E.mk[a][e] > 0.f ? t : t * m_vec[e];
       }
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(raw4_t, o), r_out, E.o_out[a], 0, 0);
     }

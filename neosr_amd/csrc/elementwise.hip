@@ -1,6 +1,8 @@
 // elementwise.hip — HBM-bound layout, index, loss and optimizer kernels for gfx950.
 // All reductions are two-stage with a fixed summation order (no float atomics) so that results
 // are run-to-run deterministic.  Reference call sites: see include/neosr_amd.h.
+#include <cstring>
+
 #include "common.h"
 #include "../../include/neosr_amd.h"
 
@@ -439,6 +441,60 @@ static int prelu_blocks(int64_t npix) {
   return (int)b;
 }
 
+// the same two stages for MANY (dA, z, dslope) triples of one geometry in two launches: blockIdx.y = job, each job's
+// partial rows in its own slice of the workspace — same sums in the same order as neosr_prelu_dslope
+constexpr int DS_MAX = 32;
+struct DslopeBatch {
+  neosr_dslope_item it[DS_MAX];
+};
+__global__ __launch_bounds__(256) void prelu_dslope_many_stage1(const DslopeBatch bt, float* __restrict__ part, int64_t npix,
+                                                                int C, int da_cs, int z_cs, int pix_per_block, int nblk) {
+  __shared__ float sm[256];
+  const neosr_dslope_item& j = bt.it[blockIdx.y];
+  const float* __restrict__ dA = j.dA;
+  const float* __restrict__ z = j.z;
+  part += (int64_t)blockIdx.y * nblk * C;
+  const int cpad = C <= 64 ? 64 : (C <= 128 ? 128 : 256);
+  const int c = threadIdx.x % cpad, pl = threadIdx.x / cpad, npl = 256 / cpad;
+  const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
+  const int64_t p1 = p0 + pix_per_block < npix ? p0 + pix_per_block : npix;
+  float s = 0.f;
+  if (c < C)
+    for (int64_t p = p0 + pl; p < p1; p += npl) {
+      const float zz = z[p * z_cs + c];
+      s += dA[p * da_cs + c] * fminf(zz, 0.f);
+    }
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  if (pl == 0 && c < C) {
+    float tot = 0.f;
+    for (int k = 0; k < npl; ++k) tot += sm[k * cpad + c];
+    part[(int64_t)blockIdx.x * C + c] = tot;
+  }
+}
+__global__ __launch_bounds__(256) void prelu_dslope_many_stage2(const DslopeBatch bt, const float* __restrict__ part, int nblk,
+                                                                int C) {
+  __shared__ float red[4][64];
+  float* __restrict__ dslope = bt.it[blockIdx.y].dslope;
+  part += (int64_t)blockIdx.y * nblk * C;
+  const int o = threadIdx.x & 63, kl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + o;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < C) {
+    int k = kl;
+    for (; k + 12 < nblk; k += 16) {
+      s0 += part[(int64_t)k * C + c];
+      s1 += part[(int64_t)(k + 4) * C + c];
+      s2 += part[(int64_t)(k + 8) * C + c];
+      s3 += part[(int64_t)(k + 12) * C + c];
+    }
+    for (; k < nblk; k += 4) s0 += part[(int64_t)k * C + c];
+  }
+  red[kl][o] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (kl == 0 && c < C) dslope[c] = ((red[0][o] + red[1][o]) + red[2][o]) + red[3][o];
+}
+
 extern "C" int64_t neosr_prelu_dslope_workspace_bytes(int64_t npix, int32_t C) {
   return (int64_t)prelu_blocks(npix) * C * 4;
 }
@@ -455,6 +511,29 @@ extern "C" int neosr_prelu_dslope(const float* dA, const float* z, float* dslope
   NEOSR_LAUNCH_CHECK();
   hipLaunchKernelGGL(prelu_dslope_stage2, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream,
                      workspace, dslope, nblk, C, accumulate);
+  NEOSR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int neosr_prelu_dslope_many(const neosr_dslope_item* items, int32_t n, float* workspace, int64_t npix,
+                                       int32_t C, int32_t da_cs, int32_t z_cs, void* stream) {
+  NEOSR_CHECK(items && n > 0 && workspace && npix > 0 && C > 0 && C <= 256, "prelu_dslope_many: bad args (C<=256)");
+  const int nblk = prelu_blocks(npix);
+  const int ppb = (int)((npix + nblk - 1) / nblk);
+  for (int i0 = 0; i0 < n; i0 += DS_MAX) {
+    const int cnt = n - i0 < DS_MAX ? n - i0 : DS_MAX;
+    DslopeBatch bt;
+    memset(&bt, 0, sizeof(bt));
+    for (int i = 0; i < cnt; ++i) {
+      NEOSR_CHECK(items[i0 + i].dA && items[i0 + i].z && items[i0 + i].dslope, "prelu_dslope_many: null tensor");
+      bt.it[i] = items[i0 + i];
+    }
+    float* part = workspace + (int64_t)i0 * nblk * C;
+    hipLaunchKernelGGL(prelu_dslope_many_stage1, dim3(nblk, cnt), dim3(256), 0, (hipStream_t)stream, bt, part, npix, C,
+                       da_cs, z_cs, ppb, nblk);
+    hipLaunchKernelGGL(prelu_dslope_many_stage2, dim3((C + 63) / 64, cnt), dim3(256), 0, (hipStream_t)stream, bt, part,
+                       nblk, C);
+  }
   NEOSR_LAUNCH_CHECK();
   return 0;
 }

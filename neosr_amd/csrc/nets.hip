@@ -844,8 +844,29 @@ struct CompactLayout {
   float* zl;              // last conv output (Cout*r*r)
   float* slopes_const;    // constant slope vector for relu / leakyrelu
   float *g_zl, *dA[2], *wg_ws, *ps_ws;
+  // Winograd scheme (compact_w4): post-activation outputs a_i next to the pre-activations z_i, the masked gradients
+  // g_z_i of every layer (the body's weight gradients run as ONE launch at the end), F(4x4,3x3) images
+  int w4;
+  std::vector<float*> a, gz, dAall;
+  float* psm_ws;
+  float *img_f, *img_d;          // NC + 1 images each: convs 1..NC then the last conv
+  float* wgm_ws;                 // workspace of the body's multi weight-gradient launch
+  int64_t img_body, img_last_f, img_last_d;
   int64_t total;
 };
+
+// The conv + PReLU chain as plain F(4x4,3x3) launches (round 4).  Rounds 1-3 kept only the pre-activations z_i and applied
+// the PReLU (forward) / its derivative (backward) ON LOAD — which only the staged direct kernel can do: 16 + 16 launches of
+// 64 workgroups at 0.14 of the matrix peak and 17 masked weight-gradient launches per step.  Here the F(4x4,3x3) kernel's
+// epilogue writes a_i = PReLU(z_i) (per-channel slopes) AND z_i (second output), the backward-data epilogue writes
+// g_z_{i-1} = dA_{i-1} . PReLU'(z_{i-1}) AND dA_{i-1} (for the slope gradient), so every convolution and every weight
+// gradient of the body is a plain Winograd launch and the NC body weight gradients are one neosr_conv3x3_wgrad_multi
+// launch.  NEOSR_AMD_COMPACT_W4=0, a Winograd mode other than 2 or num_feat % 4 != 0 keep the on-load scheme.
+bool compact_w4(const neosr_compact_cfg& c) {
+  static const bool on = [] { const char* e = getenv("NEOSR_AMD_COMPACT_W4"); return !(e && e[0] == '0'); }();
+  return on && neosr_conv::wino_mode() == 2 && c.num_feat % 4 == 0 && c.num_conv >= 1 &&
+         (int64_t)c.B * c.H * c.W * c.num_feat * 4 < (int64_t(1) << 31);
+}
 
 CompactLayout compact_layout(const neosr_compact_cfg& c, void* ws) {
   CompactLayout L;
@@ -873,6 +894,35 @@ CompactLayout compact_layout(const neosr_compact_cfg& c, void* ws) {
     L.wg_ws = b.take(w / 4 + 64);
     L.ps_ws = b.take(neosr_prelu_dslope_workspace_bytes(L.np, L.F) / 4 + 64);
   }
+  L.w4 = compact_w4(c) ? 1 : 0;
+  if (L.w4) {
+    L.a.resize(c.training ? L.NC + 1 : 2);   // (inference: a ring of two)
+    for (auto& p : L.a) p = b.take(L.np * L.F);
+    L.img_body = neosr_pack::wino4_image_floats(L.F, L.F);
+    L.img_last_f = neosr_pack::wino4_image_floats(L.Clast, L.F);
+    L.img_last_d = neosr_pack::wino4_image_floats(L.F, L.Clast);
+    L.img_f = b.take(L.NC * L.img_body + L.img_last_f);
+    if (c.training) {
+      L.img_d = b.take(L.NC * L.img_body + L.img_last_d);
+      L.gz.resize(L.NC + 1);
+      for (int i = 0; i <= L.NC; ++i) L.gz[i] = b.take(L.np * L.F);
+      if (L.has_prelu) {   // unmasked gradients of every layer + partial rows: all slope gradients in one call at the end
+        L.dAall.resize(L.NC + 1);
+        for (int i = 0; i <= L.NC; ++i) L.dAall[i] = b.take(L.np * L.F);
+        L.psm_ws = b.take((int64_t)(L.NC + 1) * (neosr_prelu_dslope_workspace_bytes(L.np, L.F) / 4) + 64);
+      }
+      std::vector<neosr_wgrad_desc> wd(L.NC < NEOSR_WGRAD_MAX ? L.NC : NEOSR_WGRAD_MAX);
+      float* const dummy = (float*)16;   // (the size query validates the descriptors: any non-null, 16-byte aligned address)
+      for (auto& w : wd) {
+        w = wgrad_base(c.B, c.H, c.W);
+        w.K = L.F; w.N = L.F; w.in_cs = L.F; w.g_cs = L.F;
+        w.in = dummy; w.g = dummy; w.dw = dummy; w.db = dummy;
+      }
+      const int64_t wm = neosr_conv3x3_wgrad_multi_workspace_bytes(wd.data(), (int)wd.size());
+      L.wgm_ws = b.take((wm > 0 ? wm : 0) / 4 + 64);
+      if (wm <= 0) L.w4 = 0;   // (cannot size the body's weight-gradient launch: keep the on-load scheme)
+    }
+  }
   L.total = (b.off + 255) & ~(int64_t)255;
   return L;
 }
@@ -899,6 +949,142 @@ inline const float* cp_slope(const CompactLayout& L, const float* const* P, int 
   return L.has_prelu ? P[cp_w(L, i) + 2] : L.slopes_const;
 }
 
+
+// ---- Winograd scheme (see compact_w4)
+int compact_pack_w4(const CompactLayout& L, const float* const* P, int mode, void* st) {
+  std::vector<neosr_pack::Image> imgs(L.NC + 1);
+  memset(imgs.data(), 0, imgs.size() * sizeof(neosr_pack::Image));
+  float* base = mode == NEOSR_CONV_FWD ? L.img_f : L.img_d;
+  for (int i = 1; i <= L.NC; ++i) {
+    neosr_pack::Image& im = imgs[i - 1];
+    im.dst = base + (int64_t)(i - 1) * L.img_body;
+    im.N = L.F; im.K = L.F; im.mode = mode; im.nseg = 1;
+    im.seg[0].w = P[cp_w(L, i)]; im.seg[0].w_cin = L.F; im.seg[0].k_cnt = L.F;
+  }
+  neosr_pack::Image& il = imgs[L.NC];
+  il.dst = base + (int64_t)L.NC * L.img_body;
+  il.mode = mode; il.nseg = 1;
+  il.seg[0].w = P[cp_last(L)]; il.seg[0].w_cin = L.F;
+  if (mode == NEOSR_CONV_FWD) { il.N = L.Clast; il.K = L.F; il.seg[0].k_cnt = L.F; }
+  else { il.N = L.F; il.K = L.Clast; il.seg[0].k_cnt = L.Clast; }
+  return neosr_pack::launch_wino4(imgs.data(), (int)imgs.size(), st);
+}
+
+int compact_forward_w4(const neosr_compact_cfg* c, const CompactLayout& L, const float* const* P, const float* x, float* y,
+                       void* st) {
+  const int B = L.B, H = L.H, W = L.W, F = L.F;
+  const bool train = c->training != 0;
+  RUN(neosr_nchw_to_nhwc(x, L.x_nhwc, B, L.Cin, H, W, L.cin_cs, st));
+  RUN(compact_pack_w4(L, P, NEOSR_CONV_FWD, st));
+  auto set_act = [&](neosr_conv_desc& d, int i) {
+    d.act = c->act_type;
+    if (L.has_prelu) d.prelu = P[cp_w(L, i) + 2];
+    else d.slope = c->act_type == NEOSR_ACT_RELU ? 0.f : 0.1f;
+  };
+  {  // conv 0 (3 input channels: thin kernel): a_0, and z_0 for the backward pass
+    neosr_conv_desc d = conv_base(B, H, W);
+    d.in = L.x_nhwc; d.in_cs = L.cin_cs; d.K = L.Cin; d.w_cin = L.Cin;
+    d.w = P[cp_w(L, 0)]; d.bias = P[cp_w(L, 0) + 1]; d.w_cout = F;
+    d.out_cs = F; d.N = F;
+    if (train) {
+      d.out = L.z[0];
+      RUN(neosr_conv3x3(&d, st));
+    }
+    d.out = L.a[0];
+    set_act(d, 0);
+    RUN(neosr_conv3x3(&d, st));
+  }
+  const int na = (int)L.a.size();
+  for (int i = 1; i <= L.NC; ++i) {
+    neosr_conv_desc d = conv_base(B, H, W);
+    d.in = L.a[(i - 1) % na]; d.in_cs = F; d.K = F; d.w_cin = F;
+    d.w = P[cp_w(L, i)]; d.bias = P[cp_w(L, i) + 1]; d.w_cout = F;
+    d.w_wino4 = L.img_f + (int64_t)(i - 1) * L.img_body;
+    d.out = L.a[i % na]; d.out_cs = F; d.N = F;
+    set_act(d, i);
+    if (train) { d.out2 = L.z[i]; d.out2_cs = F; }
+    RUN(neosr_conv3x3(&d, st));
+  }
+  {
+    neosr_conv_desc d = conv_base(B, H, W);
+    d.in = L.a[L.NC % na]; d.in_cs = F; d.K = F; d.w_cin = F;
+    d.w = P[cp_last(L)]; d.bias = P[cp_last(L) + 1]; d.w_cout = L.Clast;
+    d.w_wino4 = L.img_f + (int64_t)L.NC * L.img_body;
+    d.out = L.zl; d.out_cs = L.clast_cs; d.N = L.Clast;
+    RUN(neosr_conv3x3(&d, st));
+  }
+  return neosr_pixel_shuffle_nhwc_to_nchw(L.zl, x, y, B, L.Cout, H, W, L.r, L.clast_cs, st);
+}
+
+int compact_backward_w4(const neosr_compact_cfg* c, const CompactLayout& L, const float* const* P, float* const* Gp,
+                        const float* gy, void* st) {
+  const int B = L.B, H = L.H, W = L.W, F = L.F;
+  RUN(neosr_pixel_unshuffle_nchw_to_nhwc(gy, L.g_zl, B, L.Cout, H, W, L.r, L.clast_cs, st));
+  RUN(compact_pack_w4(L, P, NEOSR_CONV_DGRAD, st));
+  // gradient wrt z_j from the data gradient of the layer above: masked by PReLU'(z_j) in the epilogue, dA_j beside it
+  auto set_mask = [&](neosr_conv_desc& d, int j) {
+    d.out = L.gz[j]; d.out_cs = F; d.N = F;
+    d.out_mask = L.z[j]; d.out_mask_cs = F;
+    if (L.has_prelu) {
+      d.out_mask_slopes = P[cp_w(L, j) + 2];
+      d.out2 = L.dAall[j]; d.out2_cs = F;
+    } else {
+      d.out_mask_slope = c->act_type == NEOSR_ACT_RELU ? 0.f : 0.1f;
+    }
+  };
+  {  // last conv: input a_NC
+    neosr_wgrad_desc w = wgrad_base(B, H, W);
+    w.in = L.a[L.NC]; w.in_cs = F; w.K = F;
+    w.g = L.g_zl; w.g_cs = L.clast_cs; w.N = L.Clast;
+    w.dw = Gp[cp_last(L)]; w.db = Gp[cp_last(L) + 1]; w.workspace = L.wg_ws;
+    RUN(neosr_conv3x3_wgrad(&w, st));
+    neosr_conv_desc d = conv_base(B, H, W);
+    d.mode = NEOSR_CONV_DGRAD;
+    d.in = L.g_zl; d.in_cs = L.clast_cs; d.K = L.Clast;
+    d.w = P[cp_last(L)]; d.w_cout = L.Clast; d.w_cin = F;
+    d.w_wino4 = L.img_d + (int64_t)L.NC * L.img_body;
+    set_mask(d, L.NC);
+    RUN(neosr_conv3x3(&d, st));
+  }
+  for (int i = L.NC; i >= 1; --i) {
+    neosr_conv_desc d = conv_base(B, H, W);
+    d.mode = NEOSR_CONV_DGRAD;
+    d.in = L.gz[i]; d.in_cs = F; d.K = F;
+    d.w = P[cp_w(L, i)]; d.w_cout = F; d.w_cin = F;
+    d.w_wino4 = L.img_d + (int64_t)(i - 1) * L.img_body;
+    set_mask(d, i - 1);
+    RUN(neosr_conv3x3(&d, st));
+  }
+  if (L.has_prelu) {   // all NC + 1 slope gradients: two launches
+    std::vector<neosr_dslope_item> it(L.NC + 1);
+    for (int i = 0; i <= L.NC; ++i) {
+      it[i].dA = L.dAall[i]; it[i].z = L.z[i]; it[i].dslope = Gp[cp_w(L, i) + 2];
+    }
+    RUN(neosr_prelu_dslope_many(it.data(), L.NC + 1, L.psm_ws, L.np, F, F, F, st));
+  }
+  // the body's weight (+ bias) gradients: plain operands (a_{i-1}, g_z_i), up to NEOSR_WGRAD_MAX convolutions per launch
+  for (int i0 = 1; i0 <= L.NC; i0 += NEOSR_WGRAD_MAX) {
+    const int n = L.NC - i0 + 1 < NEOSR_WGRAD_MAX ? L.NC - i0 + 1 : NEOSR_WGRAD_MAX;
+    neosr_wgrad_desc wd[NEOSR_WGRAD_MAX];
+    for (int k = 0; k < n; ++k) {
+      const int i = i0 + k;
+      wd[k] = wgrad_base(B, H, W);
+      wd[k].in = L.a[i - 1]; wd[k].in_cs = F; wd[k].K = F;
+      wd[k].g = L.gz[i]; wd[k].g_cs = F; wd[k].N = F;
+      wd[k].dw = Gp[cp_w(L, i)]; wd[k].db = Gp[cp_w(L, i) + 1];
+    }
+    RUN(neosr_conv3x3_wgrad_multi(wd, n, L.wgm_ws, st));
+  }
+  {  // conv 0
+    neosr_wgrad_desc w = wgrad_base(B, H, W);
+    w.in = L.x_nhwc; w.in_cs = L.cin_cs; w.K = L.Cin;
+    w.g = L.gz[0]; w.g_cs = F; w.N = F;
+    w.dw = Gp[cp_w(L, 0)]; w.db = Gp[cp_w(L, 0) + 1]; w.workspace = L.wg_ws;
+    RUN(neosr_conv3x3_wgrad(&w, st));
+  }
+  return 0;
+}
+
 }  // namespace
 
 extern "C" int32_t neosr_compact_num_params(const neosr_compact_cfg* c) {
@@ -915,6 +1101,7 @@ extern "C" int neosr_compact_forward(const neosr_compact_cfg* c, const float* co
   RUN(compact_check(c));
   NEOSR_CHECK(P && x && y && ws, "compact_forward: null pointer");
   const CompactLayout L = compact_layout(*c, ws);
+  if (L.w4) return compact_forward_w4(c, L, P, x, y, st);
   const int B = L.B, H = L.H, W = L.W, F = L.F;
   if (!L.has_prelu)
     RUN(neosr_fill(L.slopes_const, F, c->act_type == NEOSR_ACT_RELU ? 0.f : 0.1f, st));
@@ -951,6 +1138,7 @@ extern "C" int neosr_compact_backward(const neosr_compact_cfg* c, const float* c
   NEOSR_CHECK(c->training, "compact_backward: cfg.training must be set");
   NEOSR_CHECK(gx == nullptr, "compact_backward: input gradient is not implemented");
   const CompactLayout L = compact_layout(*c, ws);
+  if (L.w4) return compact_backward_w4(c, L, P, Gp, gy, st);
   const int B = L.B, H = L.H, W = L.W, F = L.F;
   RUN(neosr_pixel_unshuffle_nchw_to_nhwc(gy, L.g_zl, B, L.Cout, H, W, L.r, L.clast_cs, st));
   {  // last conv: input prelu(z_NC)
