@@ -480,7 +480,12 @@ __global__ __launch_bounds__(256, KS > WS ? 2 : 1) void flash_wattn_bwd_dq_kerne
         const int dy = RQ * (w.qb - kb) - (RQ - 1) + dyi;
         if (dy > -WS && dy < WS) S.bins[(dy + WS - 1) * NB1 + dx + WS - 1] += s;
       }
-    } else {  // dump this dS tile (rows n, 16 columns per thread) for the bias gradient
+    } else {
+      // dump this dS tile (rows n, 16 columns per thread) for the bias gradient.  (Round 4 tried the owner-computes bin
+      // walk of the self-attention form here — the index is linear in (yj - yi, xj - xi), (RQ + 3) x 39 bins per tile in
+      // two passes — to get rid of the 226 MB dump per call at B = 4 (3.9x the kernel's algorithmic traffic): the call
+      // went 501 -> 597 us.  Sixty-four predicated LDS reads with per-element key-row arithmetic cost more than writing
+      // and re-reading the dump at HBM rate; the dump stays.)
       const float* gr = S.dS + n * PS + part * 16;
       float* o = dump + (int64_t)n * G::NK + kb * QB + part * 16;
 #pragma unroll

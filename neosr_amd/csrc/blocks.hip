@@ -215,7 +215,8 @@ BwdLayout bwd_layout(const neosr_tblock_desc& d, float* base) {
     job(256, (int64_t)3 * C * C + 3 * C);
     job(1024, 2 * C);
     job(1024, 2 * C);
-    job(d.B * nW * (d.attn ? (d.ws * d.ws / 64 > 0 ? d.ws * d.ws / 64 : 1) : 1), (int64_t)d.heads * (2 * d.ws - 1) * (2 * d.ws - 1));
+    const int kk = d.attn ? d.ks : d.ws;
+    job(d.B * nW * (d.attn ? (d.ws * d.ws / 64 > 0 ? d.ws * d.ws / 64 : 1) : 1), (int64_t)d.heads * (d.ws + kk - 1) * (d.ws + kk - 1));
     b.many_n = 2 * neosr_colsum_many_workspace_floats(it, n) + 4096;
   }
   b.many = c.take(b.many_n);
@@ -455,7 +456,7 @@ extern "C" int neosr_tblock_backward(const neosr_tblock_desc* dp, const float* x
       a.qkv = s.qkv; a.rpb_table = d.rpb; a.out = s.att; a.lse = s.lse; a.dout = b.gatt; a.dqkv = b.dqkv;
       a.d_rpb_table = G.rpb; a.workspace = b.attn_ws;
       a.B = d.B; a.H = d.H; a.W = d.W; a.C = C; a.heads = d.heads; a.ws = d.ws; a.shift = d.shift; a.scale = d.scale;
-      a.accumulate_rpb = 2;
+      a.accumulate_rpb = d.ks == d.ws ? 2 : 0;   // (the overlapping form gathers its bins from a dense sum itself)
       rc = neosr_window_attention_bwd(&a, stream);
     } else {
       neosr_fattn_desc a = fattn_bwd_desc(d);

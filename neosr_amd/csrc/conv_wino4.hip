@@ -541,6 +541,8 @@ struct PackTable {
   neosr_pack::Image* dev = nullptr;
   int dev_id = 0;
   uint64_t stamp = 0;
+  hipStream_t up_stream = nullptr;   // the upload was queued on this stream ...
+  hipEvent_t up_done = nullptr;      // ... and this event follows it: a hit from ANOTHER stream waits for it
 };
 std::vector<PackTable> g_tables;
 uint64_t g_table_clock = 0;
@@ -555,8 +557,13 @@ const neosr_pack::Image* device_table(const neosr_pack::Image* images, int n, hi
   for (PackTable& t : g_tables)
     if (t.dev_id == dev && t.bytes.size() == nbytes && memcmp(t.bytes.data(), images, nbytes) == 0) {
       t.stamp = ++g_table_clock;
+      if (t.up_stream != st && t.up_done && hipStreamWaitEvent(st, t.up_done, 0) != hipSuccess) return nullptr;
       return t.dev;
     }
+  // a miss allocates (and, once MAX_TABLES are in use, synchronises and frees): not while the stream is capturing a
+  // hipGraph — the caller then packs by argument-sized batches, which need no device-side table
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;
   PackTable* slot = nullptr;
   if (g_tables.size() < MAX_TABLES) {
     g_tables.emplace_back();
@@ -576,6 +583,9 @@ const neosr_pack::Image* device_table(const neosr_pack::Image* images, int n, hi
   slot->stamp = ++g_table_clock;
   // (from slot->bytes, which lives as long as the entry: the copy may be asynchronous)
   if (hipMemcpyAsync(slot->dev, slot->bytes.data(), nbytes, hipMemcpyHostToDevice, st) != hipSuccess) return nullptr;
+  slot->up_stream = st;
+  if (!slot->up_done && hipEventCreateWithFlags(&slot->up_done, hipEventDisableTiming) != hipSuccess) return nullptr;
+  if (hipEventRecord(slot->up_done, st) != hipSuccess) return nullptr;
   return slot->dev;
 }
 }  // namespace

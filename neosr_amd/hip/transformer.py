@@ -170,8 +170,11 @@ def _defer_colsum(part, rows: int, cols: int, ld: int, out, targets) -> None:
     # one callback per producing backward call, the first one to run does all the work (a pass that dies never runs its
     # callbacks, so "register only when the queue is empty" could strand jobs)
     torch.autograd.Variable._execution_engine.queue_callback(_flush_deferred)  # noqa: SLF001
+    # (each pinned workspace counts once, however many jobs have their partials in it: ADVICE r3)
+    sid = part.untyped_storage().data_ptr()
+    if all(j[0].untyped_storage().data_ptr() != sid for j in _DEFERRED):
+        _DEFERRED_BYTES += part.untyped_storage().nbytes()
     _DEFERRED.append((part, rows, cols, ld, out, targets, task, torch.cuda.current_stream()))
-    _DEFERRED_BYTES += part.untyped_storage().nbytes()
     if len(_DEFERRED) >= DEFER_MAX_JOBS or _DEFERRED_BYTES >= DEFER_MAX_BYTES:
         _flush_deferred()
 

@@ -44,16 +44,18 @@ def test_struct_sizes_match_c_layout():
     from neosr_amd import _C
     import ctypes as C
 
-    src = ('#include "neosr_amd.h"\n#include <stdio.h>\nint main(){printf("%zu %zu %zu %zu %zu\\n",'
+    src = ('#include "neosr_amd.h"\n#include <stdio.h>\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
            "sizeof(neosr_conv_desc),sizeof(neosr_wgrad_desc),sizeof(neosr_adamw_desc),"
-           "sizeof(neosr_rrdbnet_cfg),sizeof(neosr_compact_cfg));return 0;}\n")
+           "sizeof(neosr_rrdbnet_cfg),sizeof(neosr_compact_cfg),sizeof(neosr_tblock_desc),sizeof(neosr_tblock_grads),"
+           "sizeof(neosr_dslope_item),sizeof(neosr_gemm_desc),sizeof(neosr_fattn_desc));return 0;}\n")
     with tempfile.TemporaryDirectory() as td:
         c = Path(td) / "probe.c"
         c.write_text(src)
         exe = Path(td) / "probe"
         subprocess.run(["gcc", "-I", str(ROOT / "include"), str(c), "-o", str(exe)], check=True)
         sizes = [int(v) for v in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
-    got = [C.sizeof(t) for t in (_C.ConvDesc, _C.WgradDesc, _C.AdamWDesc, _C.RRDBNetCfg, _C.CompactCfg)]
+    got = [C.sizeof(t) for t in (_C.ConvDesc, _C.WgradDesc, _C.AdamWDesc, _C.RRDBNetCfg, _C.CompactCfg, _C.TBlockDesc,
+                                 _C.TBlockGrads, _C.DslopeItem, _C.GemmDesc, _C.FattnDesc)]
     assert got == sizes
 
 
