@@ -385,16 +385,29 @@ class _Expand4x4s2(torch.autograd.Function):
         return g.reshape(-1).index_select(0, ctx.inv).view(ctx.shape)
 
 
+# The 3x3 expansion of a 4x4 / stride-2 kernel has 16 live (tap, sub-pixel) blocks of 36.  The direct kernels skip the 20
+# zero blocks (`s2d_c`: 16 C multiplications per output and output channel); the Winograd F(4x4,3x3) kernel cannot skip
+# anything (the transformed weights are dense) but needs only 36 / 16 = 2.25 per input channel of the 4 C — 9 C: 1.78x
+# fewer.  So under Winograd mode 2 the strided layers of the U-Net discriminator (unet_arch.py:20-22: 64 -> 128 -> 256 -> 512)
+# run as PLAIN 3x3 convolutions over the space-to-depth tensor (forward, backward-data and weight gradient; round 4,
+# NEOSR_AMD_S2D_WINO=0 keeps the tap-skipping direct kernels).
+_S2D_WINO = __import__('os').environ.get('NEOSR_AMD_S2D_WINO', '1') != '0'
+
+
+def _s2d_c(c: int) -> int:
+    return 0 if _S2D_WINO and _C.load().neosr_get_winograd() == 2 else c
+
+
 def conv4x4s2(x, w, b=None, act=ACT_NONE, slope=0.0):
     """nn.Conv2d(C, N, 4, 2, 1) on channels-last x, as space-to-depth + the MFMA 3x3 kernel."""
-    return conv3x3(SpaceToDepth2.apply(x), expand_4x4s2_weight(w), b, act, slope, s2d_c=x.shape[3])
+    return conv3x3(SpaceToDepth2.apply(x), expand_4x4s2_weight(w), b, act, slope, s2d_c=_s2d_c(x.shape[3]))
 
 
 def conv4x4s2_skip(x, x_slope, w, b=None, act=ACT_NONE, slope=0.0):
     """conv4x4s2(x, ...) for a LeakyReLU(x_slope) output x that also feeds a skip addition: returns (y, x') with x' to be
     used by the skip INSTEAD of x (see SpaceToDepth2Skip: x must have no other consumer)."""
     t, xs = SpaceToDepth2Skip.apply(x, x_slope)
-    return conv3x3(t, expand_4x4s2_weight(w), b, act, slope, s2d_c=x.shape[3]), xs
+    return conv3x3(t, expand_4x4s2_weight(w), b, act, slope, s2d_c=_s2d_c(x.shape[3])), xs
 
 
 # --------------------------------------------------------------------------------------------
