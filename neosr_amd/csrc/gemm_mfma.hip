@@ -315,25 +315,46 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(const GemmArgs arg
   // last chunk's MFMAs
   __shared__ __attribute__((aligned(16))) float bias_s[BN];
   if (d.bias && tid < BN) bias_s[tid] = n0 + tid < d.N ? d.bias[n0 + tid] : 0.f;
+  // DMA addressing (round 4): a lane's source row and k quad never change — only the chunk does — so the byte offsets are
+  // computed ONCE (rows past M / N: an out-of-range offset = zeros; a second set for the last chunk drops the quads past
+  // K) and a chunk adds its 128-byte step as the SCALAR offset of `buffer_load ... lds`.  Rounds 2-3 rebuilt a 64-bit
+  // address with two range checks and a zero-page select for each of the six loads of every chunk: ~70 of the ~160 vector
+  // instructions a wave issued per chunk beside its 32 MFMAs (SQ counters: 0.64 vector instructions per MFMA op against
+  // 0.34 in the staged NN kernel), on a SIMD where vector and matrix instructions do not overlap.
+  const int kc_last = (K + BK - 1) / BK - 1;
+  constexpr int OOB = 0x7ffffff0;
+  const auto rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.A), 0, 0x7ffffff0, 0x00020000);
+  const auto rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.B), 0, 0x7ffffff0, 0x00020000);
+  int offA[4], offA_l[4], offB[2], offB_l[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = (4 * i + wave) * 8 + rsub;
+    const int kq = 4 * (slot ^ ((r >> 1) & 7));
+    const bool ok = m0 + r < d.M;
+    offA[i] = ok ? ((m0 + r) * d.lda + kq) * 4 : OOB;
+    offA_l[i] = (ok && kc_last * BK + kq < K) ? offA[i] : OOB;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = (4 * i + wave) * 8 + rsub;
+    const int kq = 4 * (slot ^ ((r >> 1) & 7));
+    const bool ok = n0 + r < d.N;
+    offB[i] = ok ? ((n0 + r) * d.ldb + kq) * 4 : OOB;
+    offB_l[i] = (ok && kc_last * BK + kq < K) ? offB[i] : OOB;
+  }
+  typedef __attribute__((address_space(3))) void* lds_vp;
   auto issue = [&](int k0, int buf) {
     float* abuf = lds + buf * (BM + BN) * BK;
     float* bbuf = abuf + BM * BK;
+    const bool last = k0 == kc_last * BK;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int r = (4 * i + wave) * 8 + rsub;
-      const int k = k0 + 4 * (slot ^ ((r >> 1) & 7));
-      const float* src = (m0 + r < d.M && k < K) ? d.A + (int64_t)(m0 + r) * d.lda + k : zp;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(abuf + (4 * i + wave) * 256), 16, 0, 0);
-    }
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_vp)(abuf + (4 * i + wave) * 256), 16, last ? offA_l[i] : offA[i],
+                                               k0 * 4, 0, 0);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int r = (4 * i + wave) * 8 + rsub;
-      const int k = k0 + 4 * (slot ^ ((r >> 1) & 7));
-      const float* src = (n0 + r < d.N && k < K) ? d.B + (int64_t)(n0 + r) * d.ldb + k : zp;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(bbuf + (4 * i + wave) * 256), 16, 0, 0);
-    }
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_vp)(bbuf + (4 * i + wave) * 256), 16, last ? offB_l[i] : offB[i],
+                                               k0 * 4, 0, 0);
   };
   f32x16 acc[2];
 #pragma unroll
@@ -418,19 +439,33 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds64_kernel(const GemmArgs a
   asm volatile("" : "+s"(zp));
   __shared__ __attribute__((aligned(16))) float bias_s[BN];
   if (d.bias && tid < BN) bias_s[tid] = n0 + tid < d.N ? d.bias[n0 + tid] : 0.f;
+  // (DMA addressing as in gemm_nt_glds_kernel: per-lane byte offsets once, the chunk as the scalar offset)
+  const int kc_last = (K + BK - 1) / BK - 1;
+  constexpr int OOB = 0x7ffffff0;
+  const auto rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.A), 0, 0x7ffffff0, 0x00020000);
+  const auto rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.B), 0, 0x7ffffff0, 0x00020000);
+  int offA[2], offA_l[2], offB[2], offB_l[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = (4 * i + wave) * 8 + rsub;
+    const int kq = 4 * (slot ^ ((r >> 1) & 7));
+    const bool oka = m0 + r < d.M, okb = n0 + r < d.N;
+    offA[i] = oka ? ((m0 + r) * d.lda + kq) * 4 : OOB;
+    offA_l[i] = (oka && kc_last * BK + kq < K) ? offA[i] : OOB;
+    offB[i] = okb ? ((n0 + r) * d.ldb + kq) * 4 : OOB;
+    offB_l[i] = (okb && kc_last * BK + kq < K) ? offB[i] : OOB;
+  }
+  typedef __attribute__((address_space(3))) void* lds_vp;
   auto issue = [&](int k0, int buf) {
     float* abuf = lds + buf * (BM2 + BN) * BK;
     float* bbuf = abuf + BM2 * BK;
+    const bool last = k0 == kc_last * BK;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int r = (4 * i + wave) * 8 + rsub;
-      const int k = k0 + 4 * (slot ^ ((r >> 1) & 7));
-      const float* sa = (m0 + r < d.M && k < K) ? d.A + (int64_t)(m0 + r) * d.lda + k : zp;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sa,
-                                       (__attribute__((address_space(3))) void*)(abuf + (4 * i + wave) * 256), 16, 0, 0);
-      const float* sb = (n0 + r < d.N && k < K) ? d.B + (int64_t)(n0 + r) * d.ldb + k : zp;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sb,
-                                       (__attribute__((address_space(3))) void*)(bbuf + (4 * i + wave) * 256), 16, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_vp)(abuf + (4 * i + wave) * 256), 16, last ? offA_l[i] : offA[i],
+                                               k0 * 4, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_vp)(bbuf + (4 * i + wave) * 256), 16, last ? offB_l[i] : offB[i],
+                                               k0 * 4, 0, 0);
     }
   };
   f32x16 acc[1];
@@ -820,7 +855,9 @@ extern "C" int neosr_gemm(const neosr_gemm_desc* dp, void* stream) {
   if (prof)  // algorithmic work of the product itself: 2MNK FLOP, 4(MK + NK + MN) bytes
     neosr_prof_begin(NEOSR_PROF_GEMM_NT + d.mode, stream, 2.0 * d.M * d.N * d.K,
                      4.0 * ((double)d.M * d.K + (double)d.N * d.K + (double)d.M * d.N));
-  if (d.mode == NEOSR_GEMM_NT && a.b_vec && !g_no_glds) {
+  // (the direct-to-LDS kernels address A and B through buffer resources with 32-bit byte offsets)
+  const bool nt_small = (int64_t)d.M * d.lda * 4 < (int64_t(1) << 31) && (int64_t)d.N * d.ldb * 4 < (int64_t(1) << 31);
+  if (d.mode == NEOSR_GEMM_NT && a.b_vec && !g_no_glds && nt_small) {
     // 128-row tiles when they fill the chip's resident workgroup slots at least ~twice, else 64-row tiles
     static const int env64 = [] { const char* e = getenv("NEOSR_GEMM_BM64"); return e ? atoi(e) : -1; }();
     // (768 = 3 resident 128-row workgroups per CU: a launch whose last round is at most 60 % full — M = 16 384: N = 180 is
