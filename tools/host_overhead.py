@@ -6,6 +6,8 @@ import bench
 
 args = types.SimpleNamespace(config=(sys.argv[1] if len(sys.argv) > 1 else "bench_esrgan"), batch=0, arch=None, template_losses=False, augment=False)
 opt = bench.load_opt(args, 1, 0)
+if len(sys.argv) > 2:  # smaller patches: the same launches with a fraction of the device work -> the host's own cost shows
+    opt["datasets"]["train"]["patch_size"] = int(sys.argv[2])
 from neosr_amd.models import build_model
 import logging
 logging.getLogger("neosr").setLevel(logging.WARNING)
