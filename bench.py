@@ -65,7 +65,7 @@ CLASS_NAMES = [
 CLASS_SYMBOL = ["conv3x3_glds_kernel", "conv3x3_glds_kernel", "conv3x3_wgrad_multi_kernel", "conv3x3_wgrad_reduce_kernel",
                 "conv3x3_mfma_kernel", "conv3x3_mfma_kernel", "gemm_nt_glds_kernel|gemm_nt_glds64_kernel",
                 "gemm_mfma_kernel<1, 128>|gemm_mfma_kernel<1, 64>|gemm_mfma_kernel<1>",
-                "gemm_tn_reg_kernel|gemm_mfma_kernel<2",
+                "gemm_tn_reg_group_kernel|gemm_tn_reg_kernel|gemm_mfma_kernel<2",
                 "wattn_wave_fwd_kernel|wattn16_wave_fwd_kernel|flash_wattn_fwd_kernel|window_attention_fwd_kernel",
                 "flash_wattn_bwd_fused_kernel|flash_wattn_bwd_dq_kernel+flash_wattn_bwd_dkv_kernel|window_attention_bwd_kernel"]
 COMPUTE_CLASSES = (0, 1, 2, 4, 5, 6, 7, 8, 9, 10)

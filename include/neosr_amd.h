@@ -456,6 +456,13 @@ typedef struct neosr_gemm_desc {
 } neosr_gemm_desc;
 int64_t neosr_gemm_workspace_bytes(const neosr_gemm_desc* d);
 int neosr_gemm(const neosr_gemm_desc* d, void* stream);
+/* Up to 4 TN problems (weight gradients dW = dY^T X, each described as for neosr_gemm with its own `workspace`) in ONE
+ * launch of the register-fed kernel: the four Linears of a transformer block once its data-gradient chain has run
+ * (swinir_arch.py:15-38,139-143: fc2, fc1, proj, qkv).  The split reductions are left to the caller as with
+ * accumulate == 2: nsplit_out[i] = rows of problem i's partial matrix [rows][M N (+ M)] for neosr_colsum_many.
+ * Returns 0, an error code, or -1 when a problem does not qualify (launch them one by one then).  Same per-task
+ * arithmetic as neosr_gemm: bit-identical partials. */
+int neosr_gemm_tn_group(const neosr_gemm_desc* descs, int32_t n, int32_t* nsplit_out, void* stream);
 /* out[c] (+)= sum_r x[r, c]  (bias gradients); workspace >= 256*cols floats. */
 int neosr_colsum(const float* x, float* out, float* workspace, int32_t rows, int32_t cols, int32_t ld,
                  int32_t accumulate, void* stream);

@@ -384,11 +384,20 @@ extern "C" int neosr_tblock_backward(const neosr_tblock_desc* dp, const float* x
     jobs[nj].accumulate = 0;
     ++nj;
   };
-  // TN GEMM with its split reduction left for the batched pass
+  // TN GEMM with its split reduction left for the batched pass.  Without the side stream the four weight-gradient GEMMs
+  // of the block are only COLLECTED here and go out as ONE launch behind the data-gradient chain (neosr_gemm_tn_group:
+  // one ramp / drain instead of four; NEOSR_AMD_TN_GROUP=0 launches them where they are described)
+  static const bool group_on = [] { const char* e = getenv("NEOSR_AMD_TN_GROUP"); return !(e && e[0] == '0'); }();
+  neosr_gemm_desc tn[4];
+  int ntn = 0;
   auto wgrad = [&](const float* dy, const float* xin, float* dw, float* db, int N, int K, float* ws, const float* rscale,
                    int rscale_n) -> int {
     neosr_gemm_desc g = gemm_desc(NEOSR_GEMM_TN, dy, xin, dw, N, K, M);
     g.colsum_a = db; g.workspace = ws; g.accumulate = 2; g.row_scale = rscale; g.rows_per_scale = rscale_n;
+    if (group_on && !side && ntn < 4) {
+      tn[ntn++] = g;
+      return 0;
+    }
     const int rc = neosr_gemm(&g, sw);
     if (rc >= 0) return rc ? rc : (neosr_set_error("tblock: TN gemm did not defer its reduction"), 1);
     add_job(ws, -rc, (int64_t)N * K + (db ? N : 0), dw);
@@ -482,6 +491,19 @@ extern "C" int neosr_tblock_backward(const neosr_tblock_desc* dp, const float* x
     const int rc = neosr_layernorm_bwd_res(b.gy1, x, s.stats1, d.n1_w, b.dx2, dx, nullptr, nullptr, b.ln1, M, C, 0, stream);
     if (rc >= 0) return rc ? rc : (neosr_set_error("tblock: layernorm did not defer its reduction"), 1);
     add_job(b.ln1, -rc, 2 * C, G.n1_w);
+  }
+  if (ntn) {   // the collected weight-gradient GEMMs: one launch (or, if a shape does not qualify, one each)
+    int32_t ns[4];
+    int rc = neosr_gemm_tn_group(tn, ntn, ns, stream);
+    if (rc > 0) return rc;
+    for (int i = 0; i < ntn; ++i) {
+      if (rc < 0) {
+        const int r1 = neosr_gemm(&tn[i], stream);
+        if (r1 >= 0) return r1 ? r1 : (neosr_set_error("tblock: TN gemm did not defer its reduction"), 1);
+        ns[i] = -r1;
+      }
+      add_job(tn[i].workspace, ns[i], (int64_t)tn[i].M * tn[i].N + (tn[i].colsum_a ? tn[i].M : 0), tn[i].C);
+    }
   }
   if (side) {   // join: the column sums below read the partials of both streams
     NEOSR_HIP(hipEventRecord(side->ev[EV_JOIN], side->s));

@@ -14,6 +14,7 @@
 //
 // Reference call sites: neosr/archs/swinir_arch.py:15-38 (Mlp), :139-143,150-156,209-210
 // (qkv / proj Linears), and the same layers of neosr/archs/hat_arch.py.
+#include <cstring>
 #include <type_traits>
 
 #include "common.h"
@@ -540,15 +541,12 @@ constexpr int RT_M = 96, RT_N = 64;
 // RS: row_scale[token / rows_per_scale] multiplies the dY rows (the DropPath scale of the incoming gradient, per sample):
 // rows_per_scale is a multiple of 32 and so is every run start, so a batch of 32 tokens has ONE scale — a scalar kept
 // beside each fragment batch, three v_mul per token pair.
+// one task = one wave: output tile `tile` over the token run of split `split`.  RS with d.row_scale == nullptr scales by 1
+// (exact): the grouped launch below runs scaled and unscaled problems with one instantiation.
 template <bool RS>
-__global__ __launch_bounds__(256, RT_OCC) void gemm_tn_reg_kernel(const GemmArgs args) {
+__device__ __forceinline__ void tn_reg_task(const GemmArgs& args, int split, int tile) {
   const neosr_gemm_desc& d = args.d;
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tiles = args.tiles_m * args.tiles_n;
-  const int xcd = blockIdx.x & 7, task = (blockIdx.x >> 3) * 4 + wave;  // task index inside this XCD
-  const int split = (task / tiles) * 8 + xcd, tile = task % tiles;
-  if (split >= args.nsplit) return;
   const int m0 = (tile / args.tiles_n) * RT_M, n0 = (tile % args.tiles_n) * RT_N;
   const int M = d.M, N = d.N;
   const int t_lo = split * args.ksplit_len;
@@ -592,10 +590,11 @@ __global__ __launch_bounds__(256, RT_OCC) void gemm_tn_reg_kernel(const GemmArgs
   };
   // scale of the batch in a0 / a1 (sc0 / sc1); grp / left walk the scale groups without a division per batch
   float sc0 = 1.f, sc1 = 1.f;
-  int grp = RS ? t_lo / d.rows_per_scale : 0, left = RS ? d.rows_per_scale - (t_lo - grp * d.rows_per_scale) : 0;
+  const bool rs_on = RS && d.row_scale != nullptr;
+  int grp = rs_on ? t_lo / d.rows_per_scale : 0, left = rs_on ? d.rows_per_scale - (t_lo - grp * d.rows_per_scale) : 0;
   auto next_scale = [&]() {
     float v = 1.f;
-    if (RS) {
+    if (rs_on) {
       v = d.row_scale[grp];
       left -= 2 * RT_P;
       if (left <= 0) {
@@ -689,6 +688,51 @@ __global__ __launch_bounds__(256, RT_OCC) void gemm_tn_reg_kernel(const GemmArgs
     }
     if (do_colsum && lh == 0) args.colsum_part[(int64_t)split * args.slab + m] = csum;
   }
+}
+
+template <bool RS>
+__global__ __launch_bounds__(256, RT_OCC) void gemm_tn_reg_kernel(const GemmArgs args) {
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tiles = args.tiles_m * args.tiles_n;
+  const int xcd = blockIdx.x & 7, task = (blockIdx.x >> 3) * 4 + wave;  // task index inside this XCD
+  const int split = (task / tiles) * 8 + xcd, tile = task % tiles;
+  if (split >= args.nsplit) return;
+  tn_reg_task<RS>(args, split, tile);
+}
+
+// Up to four weight-gradient GEMMs in ONE launch (round 4): the four Linears of a transformer block — fc2, fc1, proj, qkv —
+// whose operands all exist once the block's data-gradient chain has run (csrc/blocks.hip).  Each problem keeps the task
+// list it would have on its own (tiles x token splits, the splits dealt over the XCDs); XCD x runs its tasks of problem 0,
+// then of problem 1, ...: one wave per task as before, but a single ramp / drain and no stream boundaries between the
+// problems (a launch of this kernel is exactly one round of waves over the SIMDs, so four launches drained the chip four
+// times).  Same per-task arithmetic: bit-identical partials.
+constexpr int TN_GROUP = 4;
+struct GemmGroupArgs {
+  GemmArgs p[TN_GROUP];
+  int start[TN_GROUP + 1];   // first task (inside an XCD) of every problem
+  int n;
+};
+__global__ __launch_bounds__(256, RT_OCC) void gemm_tn_reg_group_kernel(const GemmGroupArgs g) {
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int xcd = blockIdx.x & 7, task = (blockIdx.x >> 3) * 4 + wave;
+  if (task >= g.start[g.n]) return;
+  // (an if-chain over the members — every branch reads the kernel arguments at constant offsets, the problem ends up in
+  // scalar registers; indexing the argument array with a run-time value would move it to scratch — and ONE copy of the
+  // task body behind it)
+  GemmArgs a;
+  int t;
+  if (task < g.start[1]) {
+    a = g.p[0]; t = task;
+  } else if (task < g.start[2]) {
+    a = g.p[1]; t = task - g.start[1];
+  } else if (task < g.start[3]) {
+    a = g.p[2]; t = task - g.start[2];
+  } else {
+    a = g.p[3]; t = task - g.start[3];
+  }
+  const int tiles = a.tiles_m * a.tiles_n, split = (t / tiles) * 8 + xcd;
+  if (split >= a.nsplit) return;
+  tn_reg_task<true>(a, split, t % tiles);
 }
 
 // column sums of a row-major [rows, cols] matrix (bias gradients, LayerNorm / relative-position-bias
@@ -933,6 +977,56 @@ extern "C" int neosr_gemm(const neosr_gemm_desc* dp, void* stream) {
       return neosr_colsum(d.workspace + mn, d.colsum_a, stage, nsplit, d.M, (int)a.slab, d.accumulate, stream);
     return 0;
   }
+  if (prof) neosr_prof_end(stream);
+  NEOSR_LAUNCH_CHECK();
+  return 0;
+}
+
+// n <= 4 TN problems (each as neosr_gemm would take it, with its own workspace) in one launch; the split reductions are
+// always left to the caller (neosr_colsum_many): nsplit_out[i] = rows of problem i's partial matrix [rows][M N (+ M)].
+// Returns -1 when a problem does not qualify for the register-fed kernel (the caller then launches them one by one).
+extern "C" int neosr_gemm_tn_group(const neosr_gemm_desc* descs, int32_t n, int32_t* nsplit_out, void* stream) {
+  NEOSR_CHECK(descs && nsplit_out && n >= 1 && n <= TN_GROUP, "gemm_tn_group: 1..%d problems", TN_GROUP);
+  GemmGroupArgs g;
+  memset(&g, 0, sizeof(g));
+  g.n = n;
+  int start = 0;
+  for (int i = 0; i < n; ++i) {
+    const neosr_gemm_desc& d = descs[i];
+    NEOSR_CHECK(d.A && d.B && d.C && d.workspace && d.mode == NEOSR_GEMM_TN && d.M > 0 && d.N > 0 && d.K > 0,
+                "gemm_tn_group: bad problem");
+    auto al = [](const void* p, int ld) { return !p || ((uintptr_t)p % 16 == 0 && ld % 4 == 0); };
+    NEOSR_CHECK(al(d.A, d.lda) && al(d.B, d.ldb) && d.N % 4 == 0 && d.M % 4 == 0 && d.ldc == d.N,
+                "gemm_tn_group: operands must be 16-byte aligned, dense C");
+    NEOSR_CHECK(!d.row_scale || d.rows_per_scale > 0, "gemm_tn_group: row_scale needs rows_per_scale");
+    const int64_t mn = (int64_t)d.M * d.N;
+    NEOSR_CHECK(!d.colsum_a || d.colsum_a == d.C + mn, "gemm_tn_group: colsum_a must sit right behind C");
+    if (!(tn_reg_ok(d.M, d.N, d.K) && (!d.row_scale || d.rows_per_scale % (2 * RT_P) == 0))) return -1;
+    GemmArgs& a = g.p[i];
+    a.d = d;
+    a.b_vec = 1;
+    a.ksplit_len = tn_reg_ksplit(d.M, d.N, d.K);
+    a.tiles_m = ceil_div(d.M, RT_M);
+    a.tiles_n = ceil_div(d.N, RT_N);
+    a.nsplit = ceil_div(d.K, a.ksplit_len);
+    a.slab = mn + (d.colsum_a ? d.M : 0);
+    a.d.C = d.workspace;
+    a.colsum_part = d.colsum_a ? d.workspace + mn : nullptr;
+    nsplit_out[i] = a.nsplit;
+    g.start[i] = start;
+    start += ceil_div(a.nsplit, 8) * a.tiles_m * a.tiles_n;
+  }
+  for (int i = n; i <= TN_GROUP; ++i) g.start[i] = start;
+  const bool prof = neosr_prof_on();
+  if (prof) {
+    double fl = 0, by = 0;
+    for (int i = 0; i < n; ++i) {
+      fl += 2.0 * descs[i].M * descs[i].N * descs[i].K;
+      by += 4.0 * ((double)descs[i].M * descs[i].K + (double)descs[i].N * descs[i].K + (double)descs[i].M * descs[i].N);
+    }
+    neosr_prof_begin(NEOSR_PROF_GEMM_TN, stream, fl, by);
+  }
+  hipLaunchKernelGGL(gemm_tn_reg_group_kernel, dim3(8 * ceil_div(start, 4)), dim3(256), 0, (hipStream_t)stream, g);
   if (prof) neosr_prof_end(stream);
   NEOSR_LAUNCH_CHECK();
   return 0;

@@ -159,6 +159,16 @@ def _can_defer(*params) -> bool:
             and not torch.cuda.is_current_stream_capturing())
 
 
+# leaves with a queued reduction (id -> jobs outstanding): their post-accumulate hook — which also fires for a contribution
+# that reached `.grad` through autograd — must not report them final to the gradient exchange before the flush has added
+# the deferred part (GradSync._on_grad asks `has_pending`)
+_PENDING_LEAVES: dict[int, int] = {}
+
+
+def has_pending(leaf) -> bool:
+    return _PENDING_LEAVES.get(id(leaf), 0) > 0
+
+
 def _defer_colsum(part, rows: int, cols: int, ld: int, out, targets) -> None:
     """queue out[c] = sum_r part[r, c]; afterwards `targets` = [(leaf, view of out), ...] receive their gradients"""
     global _DEFERRED_BYTES
@@ -174,6 +184,8 @@ def _defer_colsum(part, rows: int, cols: int, ld: int, out, targets) -> None:
     sid = part.untyped_storage().data_ptr()
     if all(j[0].untyped_storage().data_ptr() != sid for j in _DEFERRED):
         _DEFERRED_BYTES += part.untyped_storage().nbytes()
+    for leaf, _g in targets:
+        _PENDING_LEAVES[id(leaf)] = _PENDING_LEAVES.get(id(leaf), 0) + 1
     _DEFERRED.append((part, rows, cols, ld, out, targets, task, torch.cuda.current_stream()))
     if len(_DEFERRED) >= DEFER_MAX_JOBS or _DEFERRED_BYTES >= DEFER_MAX_BYTES:
         _flush_deferred()
@@ -184,6 +196,7 @@ def reset_deferred() -> None:
     global _DEFERRED_BYTES
     _DEFERRED.clear()
     _DEFERRED_BYTES = 0
+    _PENDING_LEAVES.clear()
 
 
 def _flush_deferred() -> None:
@@ -207,6 +220,11 @@ def _flush_deferred() -> None:
     with torch.no_grad():
         for job in jobs:
             for leaf, g in job[5]:
+                n = _PENDING_LEAVES.get(id(leaf), 0) - 1
+                if n > 0:
+                    _PENDING_LEAVES[id(leaf)] = n
+                else:
+                    _PENDING_LEAVES.pop(id(leaf), None)
                 if leaf.grad is None:
                     leaf.grad = g
                 else:

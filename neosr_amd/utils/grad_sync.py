@@ -126,8 +126,15 @@ class GradSync:
                 p.register_post_accumulate_grad_hook(self._on_grad)
 
     def _on_grad(self, p) -> None:
-        if self._live:
-            self.grads_ready((p,))
+        if not self._live:
+            return
+        # a parameter with a reduction still queued in hip/transformer.py is reported by the flush (GRADS_READY), not by
+        # the hook of a contribution that came through autograd: its slice must not leave while the flush can still add
+        from neosr_amd.hip import transformer as _tr
+
+        if _tr.has_pending(p):
+            return
+        self.grads_ready((p,))
 
     def arm_backward(self) -> None:
         """Call right before the backward whose gradients will be stepped (model: `armed` and hooks attached)."""
