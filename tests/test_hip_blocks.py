@@ -123,3 +123,70 @@ def test_block_backward_side_stream_does_not_change_results():
             _same(_run(net, x, gy, True, 19), ref)
     finally:
         lib.neosr_set_tblock_streams(prev)
+
+
+def test_grouped_tn_gemm_equals_single_launches_bitwise():
+    """`neosr_gemm_tn_group`: the four weight-gradient GEMMs of a block (fc2 / fc1 / proj / qkv shapes, two of them with a
+    DropPath row scale) in one launch against four `neosr_gemm` launches: identical partial matrices, row counts included"""
+    import ctypes as C
+
+    from neosr_amd import _C
+
+    lib = _C.load()
+    g = torch.Generator().manual_seed(21)
+    M = 2 * 64 * 64
+    rs = torch.tensor([1.25, 0.0], device=DEV)
+    shapes = [(180, 360, True), (360, 180, False), (180, 180, True), (540, 180, False)]   # (N_out, K_in, row scale)
+    descs, keep = (_C.GemmDesc * 4)(), []
+    singles = []
+    for i, (n, k, scaled) in enumerate(shapes):
+        dy, x = torch.randn(M, n, generator=g).to(DEV), torch.randn(M, k, generator=g).to(DEV)
+        d = _C.GemmDesc(A=dy.data_ptr(), B=x.data_ptr(), M=n, N=k, K=M, lda=n, ldb=k, ldc=k, ldres=k, ldaux=k,
+                        mode=_C.GEMM_TN, accumulate=2, rows_per_scale=64 * 64 if scaled else 0,
+                        row_scale=rs.data_ptr() if scaled else None)
+        nws = lib.neosr_gemm_workspace_bytes(d) // 4
+        out = torch.zeros(n * k + n, device=DEV)
+        ws1, ws2 = torch.zeros(nws, device=DEV), torch.zeros(nws, device=DEV)
+        d.C, d.colsum_a, d.workspace = out.data_ptr(), out.data_ptr() + 4 * n * k, ws1.data_ptr()
+        rc = lib.neosr_gemm(d, None)
+        assert rc < 0, lib.neosr_last_error()
+        singles.append((-rc, ws1))
+        d.workspace = ws2.data_ptr()
+        descs[i] = d
+        keep.append((dy, x, out, ws2))
+    ns = (C.c_int32 * 4)()
+    _C.check(lib.neosr_gemm_tn_group(descs, 4, ns, None), "neosr_gemm_tn_group")
+    torch.cuda.synchronize()
+    for i, (n, k, _s) in enumerate(shapes):
+        rows, ws1 = singles[i]
+        assert ns[i] == rows
+        slab = n * k + n
+        assert torch.equal(keep[i][3][: rows * slab], ws1[: rows * slab]), i
+
+
+def test_prelu_dslope_many_equals_single_calls_bitwise():
+    import ctypes as C
+
+    from neosr_amd import _C
+
+    lib = _C.load()
+    g = torch.Generator().manual_seed(22)
+    npix, Cc, n = 2 * 64 * 64, 64, 5
+    dA = [torch.randn(npix, Cc, generator=g).to(DEV) for _ in range(n)]
+    z = [torch.randn(npix, Cc, generator=g).to(DEV) for _ in range(n)]
+    wsb = lib.neosr_prelu_dslope_workspace_bytes(npix, Cc) // 4
+    one = [torch.empty(Cc, device=DEV) for _ in range(n)]
+    ws = torch.empty(wsb + 64, device=DEV)
+    for i in range(n):
+        _C.check(lib.neosr_prelu_dslope(dA[i].data_ptr(), z[i].data_ptr(), one[i].data_ptr(), ws.data_ptr(), npix, Cc, Cc,
+                                        Cc, 0, None), "neosr_prelu_dslope")
+    many = [torch.empty(Cc, device=DEV) for _ in range(n)]
+    items = (_C.DslopeItem * n)(*[_C.DslopeItem(dA=dA[i].data_ptr(), z=z[i].data_ptr(), dslope=many[i].data_ptr())
+                                  for i in range(n)])
+    wsm = torch.empty(n * wsb + 64, device=DEV)
+    _C.check(lib.neosr_prelu_dslope_many(items, n, wsm.data_ptr(), npix, Cc, Cc, Cc, None), "neosr_prelu_dslope_many")
+    torch.cuda.synchronize()
+    for a, b in zip(one, many):
+        assert torch.equal(a, b)
+    ref = (dA[0].double() * z[0].double().clamp(max=0)).sum(0)
+    assert (many[0].double() - ref).abs().max() < 1e-3 * ref.abs().max()
