@@ -432,7 +432,7 @@ def main() -> None:
                     "kernels": kern,
                     "method": "HIP events around every launch of the class on the launch stream, separate "
                               "profiled pass after the timed region with the trunk on ONE stream "
-                              "(neosr_set_num_streams(1)); profiles/r03_<config>_kernel_stats.csv is rocprofv3 "
+                              "(neosr_set_num_streams(1)); profiles/r04_<config>_kernel_stats.csv is rocprofv3 "
                               "--kernel-trace --stats of `NEOSR_AMD_STREAMS=1 python bench.py --config <config>`"}
         if ms[0] + ms[1] > 0:  # forward + backward-data launches of ONE symbol: comparable with its rocprofv3 row
             roofline["packed_conv_kernel_avg_us"] = round(1e3 * (ms[0] + ms[1]) / max(1, ln[0] + ln[1]), 2)

@@ -5,7 +5,7 @@ from __future__ import annotations
 import torch
 from torch import nn
 
-from neosr_amd.hip.nets import flatten_parameters_
+from neosr_amd.hip.nets import flatten_parameters_, parameters_of
 from neosr_amd.utils.options import net_opt  # noqa: F401  (re-export, neosr/archs/arch_util.py:12)
 
 
@@ -22,7 +22,7 @@ class HipNet(nn.Module):
 
     def _plan_params(self) -> list[torch.Tensor]:
         self.flat_parameters()
-        return list(self.parameters())
+        return parameters_of(self)
 
 
 def droppath_ctor_reseed() -> None:

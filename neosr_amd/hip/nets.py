@@ -4,7 +4,9 @@
 
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
+import os
 
 import torch
 from torch import nn
@@ -29,17 +31,50 @@ def arena_layout(tensors) -> tuple[list[int], int]:
     return offs, off
 
 
+def parameter_slots(module: nn.Module) -> list:
+    """[(owning submodule, name)] of every parameter in `module.parameters()` order.  The walk over the module tree
+    (`named_modules` recursion: ~0.1 ms for compact, several ms for hat_l) is done ONCE per module object and kept; the
+    tensors are looked up through the slots on every use, so a re-assigned `nn.Parameter` is still seen.  Adding or
+    removing submodules / parameters after the first call needs `module._neosr_slots = None`."""
+    slots = module.__dict__.get("_neosr_slots")
+    if slots is None:
+        seen, slots = set(), []
+        for m in module.modules():
+            for name, prm in m._parameters.items():  # noqa: SLF001
+                if prm is not None and id(prm) not in seen:
+                    seen.add(id(prm))
+                    slots.append((m, name))
+        module.__dict__["_neosr_slots"] = slots
+    return slots
+
+
+def parameters_of(module: nn.Module) -> list:
+    """`list(module.parameters())` without the tree walk (see `parameter_slots`)."""
+    return [m._parameters[name] for m, name in parameter_slots(module)]  # noqa: SLF001
+
+
 def flatten_parameters_(module: nn.Module, device=None) -> torch.Tensor:
     """Re-home every parameter of ``module`` into one contiguous fp32 arena (in named_parameters
     order, 16-byte aligned starts, zero pads) and make each ``nn.Parameter`` a view of it.
     Idempotent; returns the arena.  `device`: gather where the parameters are, then move the arena there in
     ONE copy (a host-built network reaches the GPU with one transfer instead of one per tensor)."""
-    params = [p for p in module.parameters()]
+    params = parameters_of(module)
     if not params:
         raise ValueError("module has no parameters")
     arena = getattr(module, "_neosr_arena", None)
-    if arena is not None and _is_flat(params, arena) and (device is None or arena.device == torch.device(device)):
-        return arena
+    if arena is not None and (device is None or arena.device == torch.device(device)):
+        # the steady-state call (once or twice per training step): one pointer comparison per parameter against the
+        # offsets computed when the arena was built
+        offs = module.__dict__.get("_neosr_offs")
+        if offs is not None and len(offs) == len(params) + 1 and offs[-1] == arena.numel():
+            base = arena.data_ptr()
+            for prm, off in zip(params, offs):
+                if prm.data_ptr() != base + 4 * off:
+                    break
+            else:
+                return arena
+        elif _is_flat(params, arena):
+            return arena
     offs, total = arena_layout(params)
     with torch.no_grad():
         # ONE gather (a `cat` with zero pads), not a copy per parameter: model construction used to issue ~2 100 (esrgan) /
@@ -57,6 +92,7 @@ def flatten_parameters_(module: nn.Module, device=None) -> torch.Tensor:
         for p, off in zip(params, offs):
             p.data = arena[off : off + p.numel()].view(p.shape)
     module._neosr_arena = arena  # noqa: SLF001
+    module.__dict__["_neosr_offs"] = [*offs, total]
     return arena
 
 
@@ -118,10 +154,91 @@ def pack_grads(params) -> torch.Tensor:
 
 def _alloc_flat_grads(params):
     offs, total = arena_layout(params)
-    packed = total == sum(p.numel() for p in params)
+    sizes = [p.numel() for p in params]
+    packed = total == sum(sizes)
     flat = (torch.empty if packed else torch.zeros)(total, device=params[0].device, dtype=torch.float32)
-    views = [flat[off : off + p.numel()].view(p.shape) for p, off in zip(params, offs)]
+    if packed:  # one split instead of a slice per parameter (the views are made on every backward pass)
+        views = [v.view(p.shape) for v, p in zip(flat.split_with_sizes(sizes), params)]
+    else:
+        views = [flat[off : off + n].view(p.shape) for p, off, n in zip(params, offs, sizes)]
     return flat, views
+
+
+# --------------------------------------------------------------------------------------------
+# direct parameter gradients (opt-in)
+# --------------------------------------------------------------------------------------------
+# A plan network hands autograd one tensor per parameter; per backward pass that is a fresh view per parameter (the
+# engine only adopts a gradient nobody else references — a cached view would be CLONED) and one AccumulateGrad node per
+# parameter: ~1.9 + ~2.5 us each on the host.  For SRVGGNetCompact (68 parameters, ~0.5 ms of device work per step at
+# batch 2) that was 0.3 ms of a 0.8 ms step, which is host-bound.  Inside `direct_param_grads()` — the models put it
+# around their own forward + backward (models/image.py), nothing is switched on process-wide — the plan's backward
+# writes into ONE persistent gradient arena per network and assigns the cached views to `.grad` itself; autograd sees a
+# single 1-element anchor leaf instead of the parameters.  Consequences inside the scope: `torch.autograd.grad(loss,
+# params)` does not see these parameters, parameter hooks do not fire, and `.grad` of step k + 1 lives in the memory
+# `.grad` of step k lived in (the optimizer has consumed it by then; `zero_grad(set_to_none=True)` or not).  A backward
+# pass that finds `.grad` already set (accumulation) adds into it from a temporary arena.  NEOSR_AMD_DIRECT_GRADS=0
+# switches the scope off (A/B).
+_DIRECT_ENV = os.environ.get("NEOSR_AMD_DIRECT_GRADS")
+_DIRECT_SCOPE = 0
+
+
+@contextlib.contextmanager
+def direct_param_grads(on: bool = True):
+    global _DIRECT_SCOPE
+    if not on or _DIRECT_ENV == "0":
+        yield
+        return
+    _DIRECT_SCOPE += 1
+    try:
+        yield
+    finally:
+        _DIRECT_SCOPE -= 1
+
+
+class DirectGrads:
+    """Per-network state of the direct hand-off: parameter list + pointer table, persistent gradient arena + views +
+    pointer table, the anchor leaf that ties the plan's output to autograd."""
+
+    __slots__ = ("key", "params", "ptab", "anchor", "flat", "views", "gtab")
+
+
+def direct_state(module: nn.Module, params: list):
+    """The network's DirectGrads inside a `direct_param_grads()` scope (built on first use, rebuilt when the parameter
+    arena moved), else None.  `params` = the flat parameter list (`HipNet._plan_params()`, flatness just checked)."""
+    if _DIRECT_SCOPE <= 0 or not torch.is_grad_enabled() or not params[0].is_cuda:
+        return None
+    for prm in params:
+        if not prm.requires_grad:
+            return None
+    key = (params[0].data_ptr(), len(params))
+    st = module.__dict__.get("_neosr_direct")
+    if st is None or st.key != key:
+        st = DirectGrads()
+        st.key = key
+        st.params = list(params)
+        st.ptab = _C.ptr_table(st.params)
+        st.anchor = torch.zeros(1, device=params[0].device, dtype=torch.float32, requires_grad=True)
+        st.flat, st.views = _alloc_flat_grads(st.params)
+        st.gtab = _C.ptr_table(st.views)
+        module.__dict__["_neosr_direct"] = st
+    return st
+
+
+def _direct_targets(st: DirectGrads):
+    """(flat, views, pointer table, accumulate) a direct backward pass writes to: the persistent arena, or a temporary
+    one when `.grad` is already populated."""
+    if st.params[0].grad is None:
+        return st.flat, st.views, st.gtab, False
+    flat, views = _alloc_flat_grads(st.params)
+    return flat, views, _C.ptr_table(views), True
+
+
+def _direct_assign(st: DirectGrads, views, accumulate: bool) -> None:
+    if accumulate:
+        torch._foreach_add_([prm.grad for prm in st.params], views)  # noqa: SLF001
+    else:
+        for prm, v in zip(st.params, views):
+            prm.grad = v
 
 
 # --------------------------------------------------------------------------------------------
@@ -199,14 +316,20 @@ class RRDBNetFunction(torch.autograd.Function):
 # SRVGGNetCompact
 # --------------------------------------------------------------------------------------------
 class CompactFunction(torch.autograd.Function):
-    """y = SRVGGNetCompact(x; params) on ``neosr_compact_forward/backward``."""
+    """y = SRVGGNetCompact(x; params) on ``neosr_compact_forward/backward``.  `hp["direct"]` (a DirectGrads, see
+    `direct_param_grads`): the only tensor behind `hp` is then the anchor leaf and backward assigns `.grad` itself."""
 
     @staticmethod
     def forward(ctx, x, hp: dict, *params):
         lib = _C.load()
         _C.require_device(x, "input")
-        for p in params:
-            _C.require_device(p, "parameter")
+        st = hp.get("direct")
+        if st is not None:
+            params, ptab = st.params, st.ptab
+        else:
+            for p in params:
+                _C.require_device(p, "parameter")
+            ptab = _C.ptr_table(params)
         x = x.contiguous()
         B, cin, H, W = x.shape
         training = bool(hp["training"]) and any(ctx.needs_input_grad)
@@ -221,13 +344,13 @@ class CompactFunction(torch.autograd.Function):
         ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
         r = hp["upscale"]
         y = torch.empty(B, hp["num_out_ch"], r * H, r * W, device=x.device, dtype=torch.float32)
-        ptab = _C.ptr_table(params)
         _C.check(lib.neosr_compact_forward(C.byref(cfg), ptab, x.data_ptr(), y.data_ptr(),
                                            ws.data_ptr(), _C.stream_ptr()), "neosr_compact_forward")
         if training:
             ctx.cfg = cfg
             ctx.ws = ws
             ctx.params = params
+            ctx.direct = st
         return y
 
     @staticmethod
@@ -237,13 +360,21 @@ class CompactFunction(torch.autograd.Function):
             raise _C.NeosrAmdError("compact: gradient w.r.t. the input image is not implemented")
         params = ctx.params
         gy = gy.contiguous()
-        _flat, gviews = _alloc_flat_grads(params)
-        ptab = _C.ptr_table(params)
-        gtab = _C.ptr_table(gviews)
+        st = ctx.direct
+        if st is not None:
+            _flat, gviews, gtab, acc = _direct_targets(st)
+            ptab = st.ptab
+        else:
+            _flat, gviews = _alloc_flat_grads(params)
+            ptab = _C.ptr_table(params)
+            gtab = _C.ptr_table(gviews)
         _C.check(lib.neosr_compact_backward(C.byref(ctx.cfg), ptab, gtab, gy.data_ptr(), None,
                                             ctx.ws.data_ptr(), _C.stream_ptr()),
                  "neosr_compact_backward")
         ctx.ws = None
+        if st is not None:
+            _direct_assign(st, gviews, acc)
+            return (None, None, None)
         grads = tuple(g if need else None for g, need in zip(gviews, ctx.needs_input_grad[2:]))
         return (None, None, *grads)
 

@@ -32,6 +32,7 @@ from neosr_amd.archs import build_network
 from neosr_amd.data.augmentations import apply_augment, resize_aa
 from neosr_amd.data.draws import LiveDraws
 from neosr_amd.hip import transformer as _tr
+from neosr_amd.hip import nets as _nets
 from neosr_amd.hip.nets import arena_layout, flat_grad_of, flatten_parameters_, pack_grads
 from neosr_amd.losses import build_loss
 from neosr_amd.losses.consistency_loss import _Clamp
@@ -317,8 +318,14 @@ class image(base):
                      "neosr_lerp")
         return self.net_g(lq_scaled), net_output
 
-    def closure(self, current_iter: int):  # noqa: ARG002
+    def closure(self, current_iter: int):
         """image.py:427-625: G forward, weighted losses, G backward; then D real/fake forward+backward."""
+        # a plan generator may write `.grad` itself (hip/nets.py: direct_param_grads) when this backward is the one stepped
+        # (not on data-parallel runs: the hook-driven gradient exchange listens to autograd's accumulation)
+        with _nets.direct_param_grads(self.accum_iters == 1 and not self._sam_now and not self.opt["dist"]):
+            return self._closure(current_iter)
+
+    def _closure(self, current_iter: int):  # noqa: ARG002
         if self.net_d is not None:
             for p in self._d_params():
                 p.requires_grad = False
@@ -335,15 +342,21 @@ class image(base):
         else:
             self.output = self.net_g(self.lq)
 
-        l_g_total = torch.zeros(1, device=self.device)
+        # (the reference starts from zeros(1) and adds every term, image.py:448: 0 + x = x exactly for these non-negative
+        # terms, so the first term is taken as it is — two launches fewer per step, and none for `/ 1`)
+        l_g_total = None
         loss_dict = OrderedDict()
+
+        def _acc(total, term):
+            return term if total is None else total + term
+
         if self.cri_pix:
             l_g_pix = self.cri_pix(self.output, self.gt)
-            l_g_total = l_g_total + l_g_pix
+            l_g_total = _acc(l_g_total, l_g_pix)
             loss_dict["l_g_pix"] = l_g_pix
         if self.cri_mssim:  # image.py:478-481
             l_g_mssim = self.cri_mssim(self.output, self.gt)
-            l_g_total = l_g_total + l_g_mssim
+            l_g_total = _acc(l_g_total, l_g_mssim)
             loss_dict["l_g_mssim"] = l_g_mssim
         if self.cri_consistency:  # image.py:451-462,483-489
             target = self.gt
@@ -353,20 +366,23 @@ class image(base):
                                    clamp=False)
                     target = _Clamp.apply(up, 1 / 255, 1.0)
             l_g_consistency = self.cri_consistency(self.output, target)
-            l_g_total = l_g_total + l_g_consistency
+            l_g_total = _acc(l_g_total, l_g_consistency)
             loss_dict["l_g_consistency"] = l_g_consistency
         if self.cri_perceptual:
             l_g_percep = self.cri_perceptual(self.output, self.gt)
-            l_g_total = l_g_total + l_g_percep
+            l_g_total = _acc(l_g_total, l_g_percep)
             loss_dict["l_g_percep"] = l_g_percep
         if self.cri_gan:
             self.broadcast_buffers(self.net_d)
             fake_g_pred = self.net_d(self.output)
             l_g_gan = self.cri_gan(fake_g_pred, target_is_real=True, is_disc=False)
-            l_g_total = l_g_total + l_g_gan
+            l_g_total = _acc(l_g_total, l_g_gan)
             loss_dict["l_g_gan"] = l_g_gan
+        if l_g_total is None:
+            l_g_total = torch.zeros(1, device=self.device)
         loss_dict["l_g_total"] = l_g_total
-        l_g_total = l_g_total / self.accum_iters
+        if self.accum_iters != 1:
+            l_g_total = l_g_total / self.accum_iters
         if self._sync_g is not None:
             self._sync_g.arm_backward()   # hook-driven buckets leave from inside this backward (no-op for the RRDB plan)
         with _tr.deferred_reductions():   # parameter-gradient column sums batched at the end of the pass (opt-in)
