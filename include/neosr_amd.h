@@ -863,11 +863,16 @@ int64_t neosr_tblock_bwd_workspace_floats(const neosr_tblock_desc* d);
 int neosr_tblock_forward(const neosr_tblock_desc* d, const float* x, float* out, float* save, void* stream);
 int neosr_tblock_backward(const neosr_tblock_desc* d, const float* x, const float* dout, const float* save, float* dx,
                           const neosr_tblock_grads* grads, float* workspace, void* stream);
-/* Backward runs the block's weight gradients (4 split-K GEMMs, the 2 CAB convolutions' gradients) on a library-owned
- * side stream, forked / joined with events inside the call, beside the dependent data-gradient chain on the caller's
- * stream: 2 (env NEOSR_AMD_BLOCK_STREAMS=2) = on, 1 (default) = everything on the caller's stream — measured neutral on
- * swinir_medium and 4 % slower on the host-bound hat_l config (14 event calls per block).  A scheduling choice:
- * bit-identical results.  Returns the previous setting. */
+/* Library-owned side stream of the block plans (forked / joined with events INSIDE a call: when a call returns, everything
+ * it enqueued is ordered in front of whatever the caller enqueues next on `stream`).
+ *   3 (default; env NEOSR_AMD_BLOCK_STREAMS=3): a HAB's CAB branch — a chain of small launches that meets the attention
+ *     branch only at the sum in front of norm2 (forward) / at norm1's input gradient (backward) — runs beside the attention
+ *     branch: hat_l (B = 4) 95.2 -> 89.1 ms per step.  Blocks without a CAB, and calls on a stream under hipGraph capture,
+ *     stay on the caller's stream.
+ *   2: the block's weight gradients (4 split-K GEMMs, the 2 CAB convolutions' gradients) beside the data-gradient chain
+ *     — measured neutral on swinir_medium and 4 % slower on hat_l (14 event calls per block).
+ *   1: everything on the caller's stream.
+ * A scheduling choice: bit-identical results.  Returns the previous setting. */
 int neosr_set_tblock_streams(int n);
 
 #ifdef __cplusplus

@@ -243,9 +243,9 @@ BwdLayout bwd_layout(const neosr_tblock_desc& d, float* base) {
 // stream, forked / joined with events inside the call (each waits for the event behind the kernel that produced its
 // operand; the caller's stream waits for the side stream before the block's batched column sums), so their workgroups
 // fill the CUs the chain leaves idle at every launch boundary.  Same kernels, same operands: bit-identical results.
-// OFF by default (NEOSR_AMD_BLOCK_STREAMS=2 / neosr_set_tblock_streams(2) turns it on): measured on MI355X in round 4,
-// swinir_medium (B = 8) 38.52 vs 38.54 ms per step (nothing), hat_l (B = 4, host enqueue 80 of 98 ms) 97.9 -> 101.9 ms —
-// the 14 event calls per block cost the host more than the overlap gives the device.
+// Mode 2 (NEOSR_AMD_BLOCK_STREAMS=2 / neosr_set_tblock_streams(2)), not the default: measured on MI355X in round 4,
+// swinir_medium (B = 8) 38.52 vs 38.54 ms per step (nothing), hat_l (B = 4) 97.9 -> 101.9 ms — these GEMMs fill the chip
+// by themselves (928 workgroups), there is nothing for them to fill, and the 14 event calls per block cost host time.
 struct Side {
   int dev = -1;
   hipStream_t s = nullptr;
@@ -253,6 +253,27 @@ struct Side {
 };
 enum { EV_FORK = 0, EV_GPRE, EV_DX2, EV_GT1, EV_GU0, EV_DQKV, EV_JOIN };
 int g_block_streams = -1;
+// mode 3 (NEOSR_AMD_BLOCK_STREAMS=3): the CAB branch of a HAB — a chain of SMALL launches (B = 4: 128-192 twelve-wave
+// workgroups per convolution on 256 CUs, a one-workgroup channel-attention kernel, ~65 us forward / ~150 us backward per
+// block) that only meets the attention branch at the sum in front of norm2 (forward) and at norm1's input gradient
+// (backward) — runs on the side stream beside the attention branch: fork behind norm1 (forward) / behind norm2's
+// backward, join in front of the sum / the qkv data-gradient GEMM.  Two event pairs per block and direction.  THE DEFAULT:
+// hat_l (configs[4], B = 4) 95.2 -> 89.1 ms per step, same-box A/B; rocprofv3: 4 896 of 19 336 launches on the second
+// queue, two kernels in flight for 93 of 365 ms of kernel time (tools/trace_overlap.sh).  Same kernels, same operands,
+// same order inside each chain: bit-identical (tests/test_hip_blocks.py).  A stream under hipGraph capture keeps the
+// whole block on itself.
+bool cab_on_side(const Side* side, const neosr_tblock_desc& d, void* stream) {
+  if (!side || g_block_streams != 3 || d.cab_mid <= 0) return false;
+  if (stream) {   // (the null stream cannot be captured; a stream under hipGraph capture keeps the block on itself)
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing((hipStream_t)stream, &st) != hipSuccess) {
+      (void)hipGetLastError();
+      return false;
+    }
+    if (st != hipStreamCaptureStatusNone) return false;
+  }
+  return true;
+}
 
 Side* side_get() {
   static Side a;
@@ -260,7 +281,8 @@ Side* side_get() {
   std::lock_guard<std::mutex> lk(mu);
   if (g_block_streams < 0) {
     const char* e = getenv("NEOSR_AMD_BLOCK_STREAMS");
-    g_block_streams = (e && atoi(e) == 2) ? 2 : 1;
+    const int v = e ? atoi(e) : 3;
+    g_block_streams = (v == 2 || v == 3) ? v : 1;
   }
   if (g_block_streams < 2) return nullptr;
   int dev = 0;
@@ -278,8 +300,8 @@ Side* side_get() {
 }  // namespace
 
 extern "C" int neosr_set_tblock_streams(int n) {
-  const int prev = g_block_streams < 0 ? 1 : g_block_streams;
-  g_block_streams = n <= 1 ? 1 : 2;
+  const int prev = g_block_streams < 0 ? 3 : g_block_streams;
+  g_block_streams = (n == 2 || n == 3) ? n : 1;
   return prev;
 }
 
@@ -303,6 +325,27 @@ extern "C" int neosr_tblock_forward(const neosr_tblock_desc* dp, const float* x,
   const int M = (int)M64, C = d.C, Hd = d.hidden, rps = d.H * d.W;
   // norm1 (the shortcut is x itself)
   TB_RUN(neosr_layernorm_fwd(x, d.n1_w, d.n1_b, s.y1, s.stats1, M, C, d.eps1, stream));
+  // HAB: x3 = x2 + conv_scale * CAB(norm1(x))   (hat_arch.py:15-52, 347).  The CAB chain is enqueued first: on the side
+  // stream (mode 3) it then runs beside the attention branch; on the caller's stream the order of two independent chains
+  // does not matter
+  Side* side = side_get();
+  const bool cab_side = cab_on_side(side, d, stream);
+  if (d.cab_mid > 0) {
+    const int mid = d.cab_mid;
+    if (cab_side) {
+      NEOSR_HIP(hipEventRecord(side->ev[EV_FORK], (hipStream_t)stream));
+      NEOSR_HIP(hipStreamWaitEvent(side->s, side->ev[EV_FORK], 0));
+    }
+    void* cs = cab_side ? (void*)side->s : stream;
+    TB_RUN(conv_launch(d, NEOSR_CONV_FWD, s.y1, C, d.c0_w, mid, C, d.c0_b, s.u0, nullptr, d.c0_pack_f, d.c0_wino_f,
+                       d.c0_wino4_f, cs));
+    TB_RUN(neosr_gelu(s.u0, nullptr, s.t0, (int64_t)M * mid, cs));
+    TB_RUN(conv_launch(d, NEOSR_CONV_FWD, s.t0, mid, d.c2_w, C, mid, d.c2_b, s.t1, nullptr, d.c2_pack_f, d.c2_wino_f,
+                       d.c2_wino4_f, cs));
+    TB_RUN(neosr_batched_colsum(s.t1, nullptr, s.pooled, s.bcs, d.B, rps, C, 1.0f / rps, cs));
+    TB_RUN(neosr_channel_attention_fwd(s.pooled, d.ca1_w, d.ca1_b, d.ca2_w, d.ca2_b, s.hidden, s.gate, d.B, C, d.cab_sq,
+                                       cs));
+  }
   // qkv
   {
     neosr_gemm_desc g = gemm_desc(NEOSR_GEMM_NT, s.y1, d.qkv_w, s.qkv, M, 3 * C, C);
@@ -317,16 +360,11 @@ extern "C" int neosr_tblock_forward(const neosr_tblock_desc* dp, const float* x,
     TB_RUN(neosr_gemm(&g, stream));
   }
   const float* xm = s.x2;
-  if (d.cab_mid > 0) {   // HAB: x3 = x2 + conv_scale * CAB(norm1(x))   (hat_arch.py:15-52, 347)
-    const int mid = d.cab_mid;
-    TB_RUN(conv_launch(d, NEOSR_CONV_FWD, s.y1, C, d.c0_w, mid, C, d.c0_b, s.u0, nullptr, d.c0_pack_f, d.c0_wino_f,
-                       d.c0_wino4_f, stream));
-    TB_RUN(neosr_gelu(s.u0, nullptr, s.t0, (int64_t)M * mid, stream));
-    TB_RUN(conv_launch(d, NEOSR_CONV_FWD, s.t0, mid, d.c2_w, C, mid, d.c2_b, s.t1, nullptr, d.c2_pack_f, d.c2_wino_f,
-                       d.c2_wino4_f, stream));
-    TB_RUN(neosr_batched_colsum(s.t1, nullptr, s.pooled, s.bcs, d.B, rps, C, 1.0f / rps, stream));
-    TB_RUN(neosr_channel_attention_fwd(s.pooled, d.ca1_w, d.ca1_b, d.ca2_w, d.ca2_b, s.hidden, s.gate, d.B, C, d.cab_sq,
-                                       stream));
+  if (d.cab_mid > 0) {
+    if (cab_side) {
+      NEOSR_HIP(hipEventRecord(side->ev[EV_JOIN], side->s));
+      NEOSR_HIP(hipStreamWaitEvent((hipStream_t)stream, side->ev[EV_JOIN], 0));
+    }
     TB_RUN(neosr_scale_channels_add(s.t1, s.gate, s.x2, s.x3, d.B, rps, C, d.conv_scale, stream));
     xm = s.x3;
   }
@@ -367,7 +405,9 @@ extern "C" int neosr_tblock_backward(const neosr_tblock_desc* dp, const float* x
                   G.fc2_b == G.fc2_w + (int64_t)C * Hd && G.proj_b == G.proj_w + (int64_t)C * C &&
                   (!d.qkv_b || G.qkv_b == G.qkv_w + (int64_t)3 * C * C),
               "tblock backward: (weight, bias) / (gamma, beta) gradient pairs must be contiguous");
-  Side* side = side_get();
+  Side* side_any = side_get();
+  const bool cab_side = cab_on_side(side_any, d, stream);          // mode 3: the CAB branch on the side stream
+  Side* side = (side_any && g_block_streams == 2) ? side_any : nullptr;   // mode 2: the weight gradients on the side stream
   void* sw = side ? (void*)side->s : stream;   // the stream of the weight gradients
   // `after(e)`: the side stream continues behind what the caller's stream has enqueued so far
   auto after = [&](int e) -> int {
@@ -429,23 +469,32 @@ extern "C" int neosr_tblock_backward(const neosr_tblock_desc* dp, const float* x
   // ---- CAB branch (HAB): the gradient that reached x3 (b.dx2) also is the gradient of x2 (x3 = x2 + ...)
   if (d.cab_mid > 0) {
     const int mid = d.cab_mid;
+    // mode 3: the whole branch (its weight gradients included) on the side stream, behind norm2's backward; the caller's
+    // stream goes on with proj / attention and waits for it in front of the qkv data-gradient GEMM (which adds gy1c)
+    void* cs = cab_side ? (void*)side_any->s : stream;
+    void* cw = cab_side ? cs : sw;
+    if (cab_side) {
+      NEOSR_HIP(hipEventRecord(side_any->ev[EV_FORK], (hipStream_t)stream));
+      NEOSR_HIP(hipStreamWaitEvent(side_any->s, side_any->ev[EV_FORK], 0));
+    }
     // channel gate (hip/transformer.py: ChannelGate.backward)
-    TB_RUN(neosr_batched_colsum(b.dx2, s.t1, b.dattn, b.bcs, d.B, rps, C, d.conv_scale, stream));
+    TB_RUN(neosr_batched_colsum(b.dx2, s.t1, b.dattn, b.bcs, d.B, rps, C, d.conv_scale, cs));
     TB_RUN(neosr_channel_attention_bwd(b.dattn, s.gate, s.hidden, s.pooled, d.ca1_w, d.ca2_w, b.dpooled, G.ca1_w, G.ca1_b,
-                                       G.ca2_w, G.ca2_b, d.B, C, d.cab_sq, stream));
-    TB_RUN(neosr_scale_channels_bwd(b.dx2, s.gate, b.dpooled, b.gt1, d.B, rps, C, d.conv_scale, stream));
+                                       G.ca2_w, G.ca2_b, d.B, C, d.cab_sq, cs));
+    TB_RUN(neosr_scale_channels_bwd(b.dx2, s.gate, b.dpooled, b.gt1, d.B, rps, C, d.conv_scale, cs));
     // second convolution: weight + bias gradient (side stream), data gradient (hip/layers.py: Conv3x3.backward)
     TB_RUN(after(EV_GT1));
-    TB_RUN(wgrad_launch(d, s.t0, mid, b.gt1, C, G.c2_w, G.c2_b, b.wg2, sw));
+    TB_RUN(wgrad_launch(d, s.t0, mid, b.gt1, C, G.c2_w, G.c2_b, b.wg2, cw));
     TB_RUN(conv_launch(d, NEOSR_CONV_DGRAD, b.gt1, C, d.c2_w, C, mid, nullptr, b.gt0, nullptr, d.c2_pack_d, d.c2_wino_d,
-                       d.c2_wino4_d, stream));
-    TB_RUN(neosr_gelu(s.u0, b.gt0, b.gu0, (int64_t)M * mid, stream));
+                       d.c2_wino4_d, cs));
+    TB_RUN(neosr_gelu(s.u0, b.gt0, b.gu0, (int64_t)M * mid, cs));
     // first convolution; its data gradient is one of the two contributions to norm1's output (the other comes from qkv,
     // whose GEMM adds this one in its epilogue below: a + b in either order, as autograd's accumulation would)
     TB_RUN(after(EV_GU0));
-    TB_RUN(wgrad_launch(d, s.y1, C, b.gu0, mid, G.c0_w, G.c0_b, b.wg0, sw));
+    TB_RUN(wgrad_launch(d, s.y1, C, b.gu0, mid, G.c0_w, G.c0_b, b.wg0, cw));
     TB_RUN(conv_launch(d, NEOSR_CONV_DGRAD, b.gu0, mid, d.c0_w, mid, C, nullptr, b.gy1c, nullptr, d.c0_pack_d, d.c0_wino_d,
-                       d.c0_wino4_d, stream));
+                       d.c0_wino4_d, cs));
+    if (cab_side) NEOSR_HIP(hipEventRecord(side_any->ev[EV_JOIN], side_any->s));
   }
   // ---- proj (Linear.backward): data gradient with the DropPath scale in the epilogue, weight gradient with it on the rows
   TB_RUN(wgrad(b.dx2, s.att, G.proj_w, G.proj_b, C, C, b.tn_proj, rs, rsn));
@@ -479,6 +528,7 @@ extern "C" int neosr_tblock_backward(const neosr_tblock_desc* dp, const float* x
     else if (rc) return rc;
   }
   // ---- qkv
+  if (cab_side) NEOSR_HIP(hipStreamWaitEvent((hipStream_t)stream, side_any->ev[EV_JOIN], 0));
   TB_RUN(after(EV_DQKV));
   TB_RUN(wgrad(b.dqkv, s.y1, G.qkv_w, d.qkv_b ? G.qkv_b : nullptr, 3 * C, C, b.tn_qkv, nullptr, 0));
   {

@@ -103,8 +103,8 @@ def test_hat_l_block_plans_full_width():
 
 
 def test_block_backward_side_stream_does_not_change_results():
-    """`neosr_set_tblock_streams`: weight gradients on the library's side stream (fork / join by events inside the call)
-    vs everything on the caller's stream — bit-identical, run after run (a missing event wait would show up here)"""
+    """`neosr_set_tblock_streams`: weight gradients (2) or the CAB branch (3) on the library's side stream (fork / join by
+    events inside the call) vs everything on the caller's stream — bit-identical, run after run (a missing event wait would show up here)"""
     from neosr_amd import _C
     from neosr_amd.archs.hat_arch import hat
 
@@ -118,9 +118,10 @@ def test_block_backward_side_stream_does_not_change_results():
     prev = lib.neosr_set_tblock_streams(1)
     try:
         ref = _run(net, x, gy, True, 19)
-        lib.neosr_set_tblock_streams(2)
-        for _ in range(4):
-            _same(_run(net, x, gy, True, 19), ref)
+        for mode in (2, 3):   # 2: weight gradients on the side stream; 3: the CAB branch (forward and backward) on it
+            lib.neosr_set_tblock_streams(mode)
+            for _ in range(4):
+                _same(_run(net, x, gy, True, 19), ref)
     finally:
         lib.neosr_set_tblock_streams(prev)
 
