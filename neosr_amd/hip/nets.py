@@ -201,6 +201,18 @@ class DirectGrads:
 
     __slots__ = ("key", "params", "ptab", "anchor", "flat", "views", "gtab")
 
+    # a cache, not state: a copied / pickled network builds its own on first use (the pointer tables are ctypes arrays,
+    # which cannot be pickled, and the arenas belong to the original's parameters)
+    def __deepcopy__(self, memo):
+        return None
+
+    def __reduce__(self):
+        return (_no_direct_state, ())
+
+
+def _no_direct_state():
+    return None
+
 
 def direct_state(module: nn.Module, params: list):
     """The network's DirectGrads inside a `direct_param_grads()` scope (built on first use, rebuilt when the parameter
