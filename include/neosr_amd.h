@@ -874,6 +874,8 @@ int neosr_tblock_backward(const neosr_tblock_desc* d, const float* x, const floa
  *   1: everything on the caller's stream.
  * A scheduling choice: bit-identical results.  Returns the previous setting. */
 int neosr_set_tblock_streams(int n);
+/* Forks onto the side stream since the library was loaded (diagnostics / tests: was the side-stream path taken?). */
+int64_t neosr_tblock_side_forks(void);
 
 #ifdef __cplusplus
 }

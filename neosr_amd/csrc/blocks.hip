@@ -253,6 +253,7 @@ struct Side {
 };
 enum { EV_FORK = 0, EV_GPRE, EV_DX2, EV_GT1, EV_GU0, EV_DQKV, EV_JOIN };
 int g_block_streams = -1;
+long g_side_forks = 0;   // forks onto the side stream so far (tests ask: was the path taken?)
 // mode 3 (NEOSR_AMD_BLOCK_STREAMS=3): the CAB branch of a HAB — a chain of SMALL launches (B = 4: 128-192 twelve-wave
 // workgroups per convolution on 256 CUs, a one-workgroup channel-attention kernel, ~65 us forward / ~150 us backward per
 // block) that only meets the attention branch at the sum in front of norm2 (forward) and at norm1's input gradient
@@ -299,6 +300,8 @@ Side* side_get() {
 
 }  // namespace
 
+extern "C" int64_t neosr_tblock_side_forks(void) { return g_side_forks; }
+
 extern "C" int neosr_set_tblock_streams(int n) {
   const int prev = g_block_streams < 0 ? 3 : g_block_streams;
   g_block_streams = (n == 2 || n == 3) ? n : 1;
@@ -335,6 +338,7 @@ extern "C" int neosr_tblock_forward(const neosr_tblock_desc* dp, const float* x,
     if (cab_side) {
       NEOSR_HIP(hipEventRecord(side->ev[EV_FORK], (hipStream_t)stream));
       NEOSR_HIP(hipStreamWaitEvent(side->s, side->ev[EV_FORK], 0));
+      ++g_side_forks;
     }
     void* cs = cab_side ? (void*)side->s : stream;
     TB_RUN(conv_launch(d, NEOSR_CONV_FWD, s.y1, C, d.c0_w, mid, C, d.c0_b, s.u0, nullptr, d.c0_pack_f, d.c0_wino_f,
@@ -414,6 +418,7 @@ extern "C" int neosr_tblock_backward(const neosr_tblock_desc* dp, const float* x
     if (!side) return 0;
     NEOSR_HIP(hipEventRecord(side->ev[e], (hipStream_t)stream));
     NEOSR_HIP(hipStreamWaitEvent(side->s, side->ev[e], 0));
+    ++g_side_forks;
     return 0;
   };
   TB_RUN(after(EV_FORK));
@@ -476,6 +481,7 @@ extern "C" int neosr_tblock_backward(const neosr_tblock_desc* dp, const float* x
     if (cab_side) {
       NEOSR_HIP(hipEventRecord(side_any->ev[EV_FORK], (hipStream_t)stream));
       NEOSR_HIP(hipStreamWaitEvent(side_any->s, side_any->ev[EV_FORK], 0));
+      ++g_side_forks;
     }
     // channel gate (hip/transformer.py: ChannelGate.backward)
     TB_RUN(neosr_batched_colsum(b.dx2, s.t1, b.dattn, b.bcs, d.B, rps, C, d.conv_scale, cs));

@@ -118,10 +118,16 @@ def test_block_backward_side_stream_does_not_change_results():
     prev = lib.neosr_set_tblock_streams(1)
     try:
         ref = _run(net, x, gy, True, 19)
+        n0 = lib.neosr_tblock_side_forks()
+        assert n0 >= 0
         for mode in (2, 3):   # 2: weight gradients on the side stream; 3: the CAB branch (forward and backward) on it
             lib.neosr_set_tblock_streams(mode)
+            before = lib.neosr_tblock_side_forks()
             for _ in range(4):
                 _same(_run(net, x, gy, True, 19), ref)
+            # the path was really taken (a silently inactive side stream would also be "bit-identical"): at least one fork per
+            # HAB and direction and run
+            assert lib.neosr_tblock_side_forks() - before >= 4 * 2 * 4, mode
     finally:
         lib.neosr_set_tblock_streams(prev)
 
