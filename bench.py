@@ -62,8 +62,11 @@ CLASS_NAMES = [
 ]
 # rocprofv3 symbol a class is launched as (for the PMC traffic lookup / the profiles cross-check)
 # (alternatives in order of preference; "a+b": one launch of the class = one dispatch of each)
-CLASS_SYMBOL = ["conv3x3_glds_kernel", "conv3x3_glds_kernel", "conv3x3_wgrad_multi_kernel", "conv3x3_wgrad_reduce_kernel",
-                "conv3x3_mfma_kernel", "conv3x3_mfma_kernel", "gemm_nt_glds_kernel|gemm_nt_glds64_kernel",
+# (classes 0-2 are resolved by algorithm in run_config: chain / F(4x4) / F(2x2) / direct symbol of what actually ran)
+CLASS_SYMBOL = ["conv3x3_wino4_chain_kernel|conv3x3_wino4_kernel|conv3x3_wino_kernel|conv3x3_glds_kernel",
+                "conv3x3_wino4_chain_kernel|conv3x3_wino4_kernel|conv3x3_wino_kernel|conv3x3_glds_kernel",
+                "conv3x3_wgrad_wino4_kernel|conv3x3_wgrad_wino_kernel|conv3x3_wgrad_multi_kernel", "conv3x3_wgrad_reduce_kernel",
+                "conv3x3_thin_k_kernel|conv3x3_mfma_kernel", "conv3x3_thin_n_kernel|conv3x3_mfma_kernel", "gemm_nt_glds_kernel|gemm_nt_glds64_kernel",
                 "gemm_mfma_kernel<1, 128>|gemm_mfma_kernel<1, 64>|gemm_mfma_kernel<1>",
                 "gemm_tn_reg_group_kernel|gemm_tn_reg_kernel|gemm_mfma_kernel<2",
                 "wattn_wave_fwd_kernel|wattn16_wave_fwd_kernel|flash_wattn_fwd_kernel|window_attention_fwd_kernel",
@@ -84,7 +87,18 @@ def self_launch(n: int) -> None:
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()), str(Path(__file__).resolve()),
            *sys.argv[1:]]
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    rccl_env()
     os.execv(sys.executable, cmd)
+
+
+def rccl_env() -> None:
+    """RCCL's CU footprint beside the chain launches (one persistent workgroup per CU: a CU a collective holds delays the whole
+    launch).  profiles/r04_ddp_contention_esrgan.jsonl: what costs is HOW LONG CUs are held, not how many — 16, 32 or 64 held
+    CUs x 0.5 ms three times per step all cost +1.9 %, 64 x 1 ms +5.1 %, 64 x 2 ms +10.1 % — so the cap must not stretch the
+    collective: 32 channels (32 workgroups = 12.5 % of the CUs) is an UPPER bound on the footprint that still leaves a ring
+    over 7 xGMI links more channels than links x 4; RCCL picks fewer for 22 MB messages on its own.  A value already in the
+    environment wins."""
+    os.environ.setdefault("NCCL_MAX_NCHANNELS", "32")
 
 
 def load_opt(args, world: int, rank: int) -> dict:
@@ -252,67 +266,25 @@ def cpu_baseline(opt: dict, budget_s: float) -> dict:
                       f"host has {os.cpu_count()} logical cpus"}
 
 
-def main() -> None:
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default=None,
-                    help="option file: a name under options/ (bench_esrgan [default], bench_compact, bench_esrgan_otf_gan, "
-                         "bench_swinir_medium, bench_hat_l_otf_gan) or a path to a neosr TOML")
-    ap.add_argument("--workload", default=None, choices=list(ALIASES), help="round-1 spelling of --config")
-    ap.add_argument("--batch", type=int, default=0, help="override datasets.train.batch_size (per GPU)")
-    ap.add_argument("--arch", default=None, help="override network_g.type (not the named config any more)")
-    ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU-oracle timing (0 = skip)")
-    ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--template-losses", action="store_true",
-                    help="the shipped template loss stack instead of L1: mssim + consistency (+ perceptual + gan)")
-    ap.add_argument("--augment", action="store_true", help="also enable the template batch augmentations")
-    args = ap.parse_args()
-    if args.config is None:
-        args.config = ALIASES.get(args.workload, "bench_esrgan")
-        if args.workload == "otf_gan" and (args.arch or "").startswith("hat_l"):
-            args.config, args.arch = "bench_hat_l_otf_gan", None
-
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        self_launch(args.gpus)  # does not return
+def run_config(args, config: str, world: int, rank: int, dev, steps: int, warmup: int, prof_steps: int,
+               overrides: bool = True) -> dict:
+    """Build the model of one option file, run `warmup` untimed and EXACTLY `steps` timed iterations (feed_data +
+    optimize_parameters) bracketed by barrier + synchronize, then (prof_steps > 0) the profiled pass the roofline record
+    comes from.  Returns the measurements; the model is dropped before returning."""
+    import gc
 
     import torch
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device (MI355X); there is no CPU fallback")
-    backend = os.environ.get("NEOSR_BENCH_BACKEND", "nccl")  # "nccl" IS RCCL on ROCm
-    ndev = torch.cuda.device_count()
-    if world > 1 and backend == "nccl" and ndev < world:
-        raise SystemExit(f"bench.py: {world} ranks need {world} GPUs, {ndev} visible "
-                         "(NEOSR_BENCH_BACKEND=gloo shares one device for a control-flow smoke test)")
-    torch.cuda.set_device(local % ndev)
-    dev = torch.device("cuda", local % ndev)
-    if world > 1:
-        import torch.distributed as dist
-
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend)
-        assert dist.get_world_size() == args.gpus
-        mine = f"rank{rank}:cuda:{local % ndev}:{torch.cuda.get_device_name(dev)}"
-        devices: list = [None] * world
-        dist.all_gather_object(devices, mine)
-    else:
-        devices = [f"rank0:cuda:{local % ndev}:{torch.cuda.get_device_name(dev)}"]
+    import torch.distributed as dist
 
     from neosr_amd import _C
     from neosr_amd.models import build_model
 
-    import logging
-    logging.getLogger("neosr").setLevel(logging.WARNING)
-
-    opt = load_opt(args, world, rank)
-    cfg_name = Path(args.config).stem
+    a2 = argparse.Namespace(**vars(args))
+    a2.config = config
+    if not overrides:
+        a2.batch, a2.arch, a2.template_losses, a2.augment = 0, None, False, False
+    opt = load_opt(a2, world, rank)
+    cfg_name = Path(config).stem
     torch.manual_seed(1024 + rank)
     model = build_model(opt)
     B = opt["datasets"]["train"]["batch_size"]
@@ -328,33 +300,46 @@ def main() -> None:
         torch.cuda.synchronize()
 
     it = 0
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         it += 1
         step(it)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         it += 1
         step(it)
     barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed = mine = time.perf_counter() - t0
+    per_rank = [mine]
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
     log = model.get_current_log()
     loss = log.get("l_g_pix", log.get("l_g_total"))
+    # data-parallel diagnostics of the generator's exchange (utils/grad_sync.py), per rank
+    diag = None
+    sync = getattr(model, "_sync_g", None)
+    if world > 1:
+        mine_d = {"rank": rank, "chain_fallback": bool(getattr(model, "chain_fallback", False)),
+                  "in_backward_buckets": int(sync.in_backward_buckets) if sync is not None else None,
+                  "bucket_MB": [round(4e-6 * (hi - lo), 2) for lo, hi in sync.buckets] if sync is not None else None}
+        diag = [None] * world
+        dist.all_gather_object(diag, mine_d)
 
+    args_named = not (a2.batch or a2.arch)
     workload, gflop_patch = describe(opt)
     roofline = None
     # every rank runs the profiled steps (they contain the gradient all-reduce); rank 0 reports
-    if not args.no_roofline:
+    if prof_steps > 0:
         lib = _C.load()
         # per-kernel durations are only meaningful without overlap: the trunk's launch chains are put
         # back on one stream for this pass (the timed region above ran the default, two chains)
         prev_streams = lib.neosr_set_num_streams(1)
         lib.neosr_prof_enable(1)
-        nprof = max(1, min(args.steps, 3))
+        nprof = prof_steps
         for _ in range(nprof):
             it += 1
             step(it)
@@ -395,9 +380,9 @@ def main() -> None:
                else {0: "conv3x3_glds_kernel", 1: "conv3x3_wino_kernel", 2: "conv3x3_wino4_kernel"}[dom_algo] if dom in (0, 1)
                else {0: "conv3x3_wgrad_multi_kernel", 1: "conv3x3_wgrad_wino_kernel", 2: "conv3x3_wgrad_wino4_kernel"}[dom_algo] if dom == 2
                else CLASS_SYMBOL[dom])
-        tr = pmc_traffic(cfg_name, sym) if not (args.batch or args.arch) else None
-        sq = sq_counters(cfg_name, sym) if not (args.batch or args.arch) else None
-        step_s = elapsed / args.steps
+        tr = pmc_traffic(cfg_name, sym) if args_named else None
+        sq = sq_counters(cfg_name, sym) if args_named else None
+        step_s = elapsed / steps
         roofline = {"bound": "mfma", "kernel": CLASS_NAMES[dom], "symbol": sym,
                     # `achieved` / `frac`: the FLOPs the matrix pipe EXECUTED per second against the dense fp32 MFMA peak
                     # (the hardware fraction, <= 1 by construction).  The Winograd kernels execute fewer
@@ -437,20 +422,117 @@ def main() -> None:
         if ms[0] + ms[1] > 0:  # forward + backward-data launches of ONE symbol: comparable with its rocprofv3 row
             roofline["packed_conv_kernel_avg_us"] = round(1e3 * (ms[0] + ms[1]) / max(1, ln[0] + ln[1]), 2)
 
+    del model, batch
+    gc.collect()
+    torch.cuda.empty_cache()
+    return {"opt": opt, "cfg_name": cfg_name, "B": B, "elapsed": elapsed, "per_rank_elapsed": per_rank, "loss": loss,
+            "workload": workload, "gflop_patch": gflop_patch, "roofline": roofline, "diag": diag}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default=None,
+                    help="option file: a name under options/ (bench_esrgan [default], bench_compact, bench_esrgan_otf_gan, "
+                         "bench_swinir_medium, bench_hat_l_otf_gan) or a path to a neosr TOML")
+    ap.add_argument("--workload", default=None, choices=list(ALIASES), help="round-1 spelling of --config")
+    ap.add_argument("--batch", type=int, default=0, help="override datasets.train.batch_size (per GPU)")
+    ap.add_argument("--arch", default=None, help="override network_g.type (not the named config any more)")
+    ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU-oracle timing (0 = skip)")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--template-losses", action="store_true",
+                    help="the shipped template loss stack instead of L1: mssim + consistency (+ perceptual + gan)")
+    ap.add_argument("--augment", action="store_true", help="also enable the template batch augmentations")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="default run only: skip the 5-step timing of the other four BASELINE configs (`other_configs`)")
+    args = ap.parse_args()
+    if args.config is None:
+        args.config = ALIASES.get(args.workload, "bench_esrgan")
+        if args.workload == "otf_gan" and (args.arch or "").startswith("hat_l"):
+            args.config, args.arch = "bench_hat_l_otf_gan", None
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus)  # does not return
+
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (MI355X); there is no CPU fallback")
+    backend = os.environ.get("NEOSR_BENCH_BACKEND", "nccl")  # "nccl" IS RCCL on ROCm
+    ndev = torch.cuda.device_count()
+    if world > 1 and backend == "nccl" and ndev < world:
+        raise SystemExit(f"bench.py: {world} ranks need {world} GPUs, {ndev} visible "
+                         "(NEOSR_BENCH_BACKEND=gloo shares one device for a control-flow smoke test)")
+    torch.cuda.set_device(local % ndev)
+    dev = torch.device("cuda", local % ndev)
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        rccl_env()   # (also when the DRIVER's torch.distributed.run started the ranks: read at communicator creation)
+        dist.init_process_group(backend)
+        assert dist.get_world_size() == args.gpus
+        mine = f"rank{rank}:cuda:{local % ndev}:{torch.cuda.get_device_name(dev)}"
+        devices: list = [None] * world
+        dist.all_gather_object(devices, mine)
+    else:
+        devices = [f"rank0:cuda:{local % ndev}:{torch.cuda.get_device_name(dev)}"]
+
+    import logging
+    logging.getLogger("neosr").setLevel(logging.WARNING)
+    from neosr_amd import _C
+
+    cfg_name = Path(args.config).stem
+    res = run_config(args, args.config, world, rank, dev, args.steps, args.warmup,
+                     0 if args.no_roofline else max(1, min(args.steps, 3)))
+    opt, B, elapsed, loss, roofline = res["opt"], res["B"], res["elapsed"], res["loss"], res["roofline"]
+    workload, gflop_patch = res["workload"], res["gflop_patch"]
+
+    # the other four BASELINE configs, driver-observed: only on the default invocation (headline config, one
+    # GPU, no overrides), 5 timed steps each after 2 warm-up steps, one profiled step for the executed-FLOP fraction
+    others = None
+    named = not (args.batch or args.arch or args.template_losses or args.augment)
+    if world == 1 and named and cfg_name == "bench_esrgan" and not args.no_other_configs:
+        others = []
+        for oc in ("bench_compact", "bench_esrgan_otf_gan", "bench_swinir_medium", "bench_hat_l_otf_gan"):
+            t0 = time.perf_counter()
+            try:
+                r = run_config(args, oc, 1, 0, dev, 5, 2, 0 if args.no_roofline else 1, overrides=False)
+            except Exception as e:  # noqa: BLE001  (a failing side config must not take the headline line with it)
+                others.append({"config": oc, "error": f"{type(e).__name__}: {e}"[:300]})
+                continue
+            rf = r["roofline"] or {}
+            others.append({"config": oc, "baseline_config": opt_doc(oc), "value": round(r["B"] * 5 / r["elapsed"], 3),
+                           "unit": "LR-patches/s", "ms_per_step": round(1e3 * r["elapsed"] / 5, 3), "steps": 5, "warmup": 2,
+                           "batch": r["B"], "step_executed_frac": rf.get("step_executed_frac"),
+                           "dominant_kernel": rf.get("symbol"), "dominant_frac": rf.get("frac"),
+                           "final_loss": r["loss"], "wall_s": round(time.perf_counter() - t0, 1)})
+
     # a chain launch that never got all its workgroups resident leaves a sticky status (results invalid): looked at on every
     # rank, but only raised behind the barrier so that no rank is left waiting for one that stopped
     chain_status = _C.load().neosr_conv_chain_status()
+    statuses = [chain_status]
     if world > 1:
+        import torch.distributed as dist
+
+        statuses = [None] * world
+        dist.all_gather_object(statuses, chain_status)
         dist.barrier()
         if rank != 0:
             dist.destroy_process_group()
-    if chain_status != 0:
-        raise RuntimeError(f"chain kernel: a flag wait ran into its bound (status {chain_status}); results invalid")
+    if any(statuses):
+        raise RuntimeError(f"chain kernel: a flag wait ran into its bound (status per rank {statuses}); results invalid")
     if rank != 0:
         return
     patches = world * B * args.steps
     value = patches / elapsed
-    named = not (args.batch or args.arch or args.template_losses or args.augment)
     out = {
         "metric": "LR-patches/sec (64x64 -> 256x256 x4) fwd+bwd+optimizer step",
         "value": round(value, 3), "unit": "LR-patches/s", "n_gpus": world, "steps": args.steps,
@@ -465,6 +547,15 @@ def main() -> None:
         "final_loss": loss,
         "roofline": roofline,
     }
+    if world > 1:   # what the scaling run needs to be read: VERDICT r4 #7a
+        pr = [1e3 * t / args.steps for t in res["per_rank_elapsed"]]
+        out["data_parallel"] = {
+            "ms_per_step_per_rank": [round(t, 3) for t in pr], "ms_per_step_min": round(min(pr), 3),
+            "ms_per_step_max": round(max(pr), 3),
+            "exchange": res["diag"], "chain_status_per_rank": statuses,
+            "rccl_max_nchannels": os.environ.get("NCCL_MAX_NCHANNELS"),
+            "rccl_env": {k: v for k, v in os.environ.items() if k.startswith(("NCCL_", "RCCL_"))}}
+    out["other_configs"] = others
     if world == 1 and args.cpu_budget > 0:
         out["cpu_baseline"] = cpu_baseline(opt, args.cpu_budget)
     else:

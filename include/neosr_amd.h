@@ -149,7 +149,12 @@ int neosr_set_wgrad4(int on);
  * setting.  neosr_conv_chain_status: 0 while no flag wait ever ran into its spin bound on this device (it synchronises;
  * a non-zero value means a chain launch did not get all its workgroups resident: its
  * results are invalid, and from this read on the library uses one launch per convolution in this process).
- * neosr_set_conv_chain_sync(0) skips the flag waits (timing experiments only: results are then racy); default 1. */
+ * neosr_set_conv_chain_sync(0) skips the flag waits (timing experiments only: results are then racy); default 1.
+ * neosr_conv_chain_health(dst, stream): enqueues a copy of the device's two health words into dst[0..1] (floats, device
+ * memory) without synchronising — dst[0] = 1 when a flag wait lasted about a millisecond or more since the last neosr_conv_chain_ack
+ * (results valid; the mark stays until neosr_conv_chain_ack), dst[1] = the sticky abort word neosr_conv_chain_status returns.  The
+ * models reduce them over the ranks with their loss scalars (neosr/models/base.py:498-526) so that all ranks leave the
+ * chain launches — or stop — at the same iteration. */
 int neosr_set_conv_chain(int on);
 /* Behind a chain launch the fifteen weight gradients of an RRDB run as ONE neosr_conv3x3_wgrad_multi launch (1, default;
  * env NEOSR_AMD_WGRAD_RRDB) or as one launch per RDB (0): another split of the pixel range, i.e. another summation
@@ -157,6 +162,9 @@ int neosr_set_conv_chain(int on);
 int neosr_set_wgrad_rrdb(int on);
 int neosr_set_conv_chain_sync(int mode);
 int neosr_conv_chain_status(void);
+int neosr_conv_chain_health(float* dst, void* stream);
+int neosr_conv_chain_ack(void* stream);
+int neosr_debug_chain_mark_slow(void* stream);   /* tests: the mark a slow flag wait leaves */
 int64_t neosr_conv3x3_pack_wino4_bytes(int32_t N, int32_t K);
 int neosr_conv3x3_pack_wino4(const float* w, int32_t w_cout, int32_t w_cin, int32_t mode, float* dst, void* stream);
 /* Both images of MANY weight tensors in ceil(n / 24) launches per image kind (the per-layer calls above cost one launch

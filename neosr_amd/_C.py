@@ -295,6 +295,9 @@ SIGNATURES: dict[str, tuple] = {
     "neosr_set_wgrad_rrdb": (C.c_int, [C.c_int]),
     "neosr_set_conv_chain_sync": (C.c_int, [C.c_int]),
     "neosr_conv_chain_status": (C.c_int, []),
+    "neosr_conv_chain_health": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "neosr_conv_chain_ack": (C.c_int, [C.c_void_p]),
+    "neosr_debug_chain_mark_slow": (C.c_int, [C.c_void_p]),
     "neosr_conv3x3_pack_wino_bytes": (_i64, [_i32, _i32]),
     "neosr_conv3x3_pack_wino": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp]),
     "neosr_conv3x3_pack_wino4_bytes": (_i64, [_i32, _i32]),

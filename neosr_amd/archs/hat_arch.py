@@ -125,18 +125,18 @@ class HAB(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:  # (B, H, W, C)
         b, h, w, _ = x.shape
         a = self.attn
-        if T.BLOCK_PLANS and a.qkv.bias is not None:   # the whole block as one library call per direction (csrc/blocks.hip)
+        if T.use_block_plan(x) and a.qkv.bias is not None:   # the whole block as one library call per direction (csrc/blocks.hip)
             meta = getattr(self, "_plan_meta", None)
             cab, ca = self.conv_block.cab, self.conv_block.cab[3].attention
             if meta is None:
-                meta = self._plan_meta = {
+                meta = self._plan_meta = T.PlanMeta({
                     "names": _C.TBLOCK_PARAMS[:7] + _C.TBLOCK_CAB_PARAMS + _C.TBLOCK_PARAMS[7:],
                     "ints": {"heads": self.num_heads, "ws": self.window_size, "ks": self.window_size,
                              "shift": self.shift_size, "hidden": self.mlp.fc1.out_features, "attn": 1,
                              "cab_mid": cab[0].weight.shape[0], "cab_sq": ca[1].weight.shape[0]},
                     "floats": {"scale": float(a.scale), "eps1": self.norm1.eps, "eps2": self.norm2.eps,
                                "conv_scale": float(self.conv_scale)},
-                    "images": self._plan_images}
+                    "images": self._plan_images})
             m = self.mlp
             params = (self.norm1.weight, self.norm1.bias, a.relative_position_bias_table, a.qkv.weight, a.qkv.bias,
                       a.proj.weight, a.proj.bias, cab[0].weight, cab[0].bias, cab[2].weight, cab[2].bias,
@@ -173,14 +173,14 @@ class OCAB(nn.Module):
         self.mlp = Mlp(dim, int(dim * mlp_ratio))
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        if T.BLOCK_PLANS and self.qkv.bias is not None:   # one library call per direction (csrc/blocks.hip)
+        if T.use_block_plan(x) and self.qkv.bias is not None:   # one library call per direction (csrc/blocks.hip)
             meta = getattr(self, "_plan_meta", None)
             if meta is None:
-                meta = self._plan_meta = {
+                meta = self._plan_meta = T.PlanMeta({
                     "names": ("rpb", "n1_w", "n1_b") + _C.TBLOCK_PARAMS[3:],   # named_parameters(): the table comes first
                     "ints": {"heads": self.num_heads, "ws": self.window_size, "ks": self.overlap_win_size, "shift": 0,
                              "hidden": self.mlp.fc1.out_features, "attn": 1},
-                    "floats": {"scale": float(self.scale), "eps1": self.norm1.eps, "eps2": self.norm2.eps}}
+                    "floats": {"scale": float(self.scale), "eps1": self.norm1.eps, "eps2": self.norm2.eps}})
             m = self.mlp
             params = (self.relative_position_bias_table, self.norm1.weight, self.norm1.bias, self.qkv.weight,
                       self.qkv.bias, self.proj.weight, self.proj.bias, self.norm2.weight, self.norm2.bias,

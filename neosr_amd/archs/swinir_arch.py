@@ -95,14 +95,14 @@ class SwinTransformerBlock(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:  # x: (B, H, W, C) channels-last tokens
         b, h, w, _ = x.shape
         a = self.attn
-        if T.BLOCK_PLANS and a.qkv.bias is not None:   # the whole block as one library call per direction (csrc/blocks.hip)
+        if T.use_block_plan(x) and a.qkv.bias is not None:   # the whole block as one library call per direction (csrc/blocks.hip)
             meta = getattr(self, "_plan_meta", None)
             if meta is None:
-                meta = self._plan_meta = {
+                meta = self._plan_meta = T.PlanMeta({
                     "names": _C.TBLOCK_PARAMS,
                     "ints": {"heads": self.num_heads, "ws": self.window_size, "ks": self.window_size,
                              "shift": self.shift_size, "hidden": self.mlp.fc1.out_features, "attn": 0},
-                    "floats": {"scale": float(a.scale), "eps1": self.norm1.eps, "eps2": self.norm2.eps}}
+                    "floats": {"scale": float(a.scale), "eps1": self.norm1.eps, "eps2": self.norm2.eps}})
             rs = drop_scale(self.drop_prob, self.training, b, x.device)    # two sites, two draws (swinir_arch.py:387,390)
             rs2 = drop_scale(self.drop_prob, self.training, b, x.device)
             return T.tblock(x, rs, rs2, meta, self._plan_params())

@@ -16,6 +16,7 @@
 // the backward pass in a caller-owned workspace (sizes from the *_floats functions).
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 
 #include "common.h"
@@ -252,8 +253,8 @@ struct Side {
   hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 enum { EV_FORK = 0, EV_GPRE, EV_DX2, EV_GT1, EV_GU0, EV_DQKV, EV_JOIN };
-int g_block_streams = -1;
-long g_side_forks = 0;   // forks onto the side stream so far (tests ask: was the path taken?)
+std::atomic<int> g_block_streams{-1};   // (read by the forward thread and the autograd thread, written by the setter)
+std::atomic<long> g_side_forks{0};      // forks onto the side stream so far (tests ask: was the path taken?)
 // mode 3 (NEOSR_AMD_BLOCK_STREAMS=3): the CAB branch of a HAB — a chain of SMALL launches (B = 4: 128-192 twelve-wave
 // workgroups per convolution on 256 CUs, a one-workgroup channel-attention kernel, ~65 us forward / ~150 us backward per
 // block) that only meets the attention branch at the sum in front of norm2 (forward) and at norm1's input gradient
@@ -263,6 +264,28 @@ long g_side_forks = 0;   // forks onto the side stream so far (tests ask: was th
 // queue, two kernels in flight for 93 of 365 ms of kernel time (tools/trace_overlap.sh).  Same kernels, same operands,
 // same order inside each chain: bit-identical (tests/test_hip_blocks.py).  A stream under hipGraph capture keeps the
 // whole block on itself.
+// Joins the caller's stream with the side stream when the call leaves — on the normal path through join(), on an error
+// return through the destructor: the caller frees `save` / the workspace right after an error, and the caching allocator
+// may hand them out again while side-stream kernels still use them.  Errors inside the guard are swallowed:
+// the call is already returning one.
+struct SideJoin {
+  Side* side = nullptr;
+  hipStream_t caller = nullptr;
+  bool armed = false;
+  void arm(Side* s, void* st) { side = s; caller = (hipStream_t)st; armed = true; }
+  int join() {   // record behind everything the side stream holds, make the caller's stream wait for it
+    if (!armed) return 0;
+    armed = false;
+    NEOSR_HIP(hipEventRecord(side->ev[EV_JOIN], side->s));
+    NEOSR_HIP(hipStreamWaitEvent(caller, side->ev[EV_JOIN], 0));
+    return 0;
+  }
+  ~SideJoin() {
+    if (armed && hipEventRecord(side->ev[EV_JOIN], side->s) == hipSuccess)
+      (void)hipStreamWaitEvent(caller, side->ev[EV_JOIN], 0);
+  }
+};
+
 bool cab_on_side(const Side* side, const neosr_tblock_desc& d, void* stream) {
   if (!side || g_block_streams != 3 || d.cab_mid <= 0) return false;
   if (stream) {   // (the null stream cannot be captured; a stream under hipGraph capture keeps the block on itself)
@@ -303,7 +326,8 @@ Side* side_get() {
 extern "C" int64_t neosr_tblock_side_forks(void) { return g_side_forks; }
 
 extern "C" int neosr_set_tblock_streams(int n) {
-  const int prev = g_block_streams < 0 ? 3 : g_block_streams;
+  const int cur = g_block_streams.load();
+  const int prev = cur < 0 ? 3 : cur;
   g_block_streams = (n == 2 || n == 3) ? n : 1;
   return prev;
 }
@@ -333,11 +357,13 @@ extern "C" int neosr_tblock_forward(const neosr_tblock_desc* dp, const float* x,
   // does not matter
   Side* side = side_get();
   const bool cab_side = cab_on_side(side, d, stream);
+  SideJoin sj;
   if (d.cab_mid > 0) {
     const int mid = d.cab_mid;
     if (cab_side) {
       NEOSR_HIP(hipEventRecord(side->ev[EV_FORK], (hipStream_t)stream));
       NEOSR_HIP(hipStreamWaitEvent(side->s, side->ev[EV_FORK], 0));
+      sj.arm(side, stream);
       ++g_side_forks;
     }
     void* cs = cab_side ? (void*)side->s : stream;
@@ -365,10 +391,7 @@ extern "C" int neosr_tblock_forward(const neosr_tblock_desc* dp, const float* x,
   }
   const float* xm = s.x2;
   if (d.cab_mid > 0) {
-    if (cab_side) {
-      NEOSR_HIP(hipEventRecord(side->ev[EV_JOIN], side->s));
-      NEOSR_HIP(hipStreamWaitEvent((hipStream_t)stream, side->ev[EV_JOIN], 0));
-    }
+    TB_RUN(sj.join());
     TB_RUN(neosr_scale_channels_add(s.t1, s.gate, s.x2, s.x3, d.B, rps, C, d.conv_scale, stream));
     xm = s.x3;
   }
@@ -413,11 +436,13 @@ extern "C" int neosr_tblock_backward(const neosr_tblock_desc* dp, const float* x
   const bool cab_side = cab_on_side(side_any, d, stream);          // mode 3: the CAB branch on the side stream
   Side* side = (side_any && g_block_streams == 2) ? side_any : nullptr;   // mode 2: the weight gradients on the side stream
   void* sw = side ? (void*)side->s : stream;   // the stream of the weight gradients
+  SideJoin sj;                                 // armed by the first fork of either mode
   // `after(e)`: the side stream continues behind what the caller's stream has enqueued so far
   auto after = [&](int e) -> int {
     if (!side) return 0;
     NEOSR_HIP(hipEventRecord(side->ev[e], (hipStream_t)stream));
     NEOSR_HIP(hipStreamWaitEvent(side->s, side->ev[e], 0));
+    if (!sj.armed) sj.arm(side, stream);
     ++g_side_forks;
     return 0;
   };
@@ -481,6 +506,7 @@ extern "C" int neosr_tblock_backward(const neosr_tblock_desc* dp, const float* x
     if (cab_side) {
       NEOSR_HIP(hipEventRecord(side_any->ev[EV_FORK], (hipStream_t)stream));
       NEOSR_HIP(hipStreamWaitEvent(side_any->s, side_any->ev[EV_FORK], 0));
+      sj.arm(side_any, stream);
       ++g_side_forks;
     }
     // channel gate (hip/transformer.py: ChannelGate.backward)
@@ -500,7 +526,6 @@ extern "C" int neosr_tblock_backward(const neosr_tblock_desc* dp, const float* x
     TB_RUN(wgrad_launch(d, s.y1, C, b.gu0, mid, G.c0_w, G.c0_b, b.wg0, cw));
     TB_RUN(conv_launch(d, NEOSR_CONV_DGRAD, b.gu0, mid, d.c0_w, mid, C, nullptr, b.gy1c, nullptr, d.c0_pack_d, d.c0_wino_d,
                        d.c0_wino4_d, cs));
-    if (cab_side) NEOSR_HIP(hipEventRecord(side_any->ev[EV_JOIN], side_any->s));
   }
   // ---- proj (Linear.backward): data gradient with the DropPath scale in the epilogue, weight gradient with it on the rows
   TB_RUN(wgrad(b.dx2, s.att, G.proj_w, G.proj_b, C, C, b.tn_proj, rs, rsn));
@@ -534,7 +559,9 @@ extern "C" int neosr_tblock_backward(const neosr_tblock_desc* dp, const float* x
     else if (rc) return rc;
   }
   // ---- qkv
-  if (cab_side) NEOSR_HIP(hipStreamWaitEvent((hipStream_t)stream, side_any->ev[EV_JOIN], 0));
+  // (mode 3: the side stream holds only the CAB branch — recording the join event here, behind the attention launches of
+  // the caller's stream, orders the same work as recording it right behind the branch)
+  if (cab_side) TB_RUN(sj.join());
   TB_RUN(after(EV_DQKV));
   TB_RUN(wgrad(b.dqkv, s.y1, G.qkv_w, d.qkv_b ? G.qkv_b : nullptr, 3 * C, C, b.tn_qkv, nullptr, 0));
   {
@@ -561,10 +588,7 @@ extern "C" int neosr_tblock_backward(const neosr_tblock_desc* dp, const float* x
       add_job(tn[i].workspace, ns[i], (int64_t)tn[i].M * tn[i].N + (tn[i].colsum_a ? tn[i].M : 0), tn[i].C);
     }
   }
-  if (side) {   // join: the column sums below read the partials of both streams
-    NEOSR_HIP(hipEventRecord(side->ev[EV_JOIN], side->s));
-    NEOSR_HIP(hipStreamWaitEvent((hipStream_t)stream, side->ev[EV_JOIN], 0));
-  }
+  if (side) TB_RUN(sj.join());   // the column sums below read the partials of both streams
   NEOSR_CHECK(neosr_colsum_many_workspace_floats(jobs, nj) <= b.many_n, "tblock backward: column-sum workspace too small");
   return neosr_colsum_many(jobs, nj, b.many, stream);
 }

@@ -43,6 +43,12 @@ constexpr int AUX_SC1 = 16;  // cache-policy bit of buffer loads / stores: sc1 (
 // microseconds, or — when another kernel holds CUs for a while, e.g. an RCCL collective that itself waits for a peer
 // rank during warm-up — as long as that kernel runs.
 constexpr unsigned SPIN_LIMIT = 1u << 25;
+// A wait that has lasted this many polls (~64 short ones, then ~2.5-3 us each: about a millisecond) leaves a mark in
+// status[1] — nothing is aborted, the results stay valid.  The models read the word through neosr_conv_chain_health with
+// their loss scalars and, on data-parallel runs, agree through that all-reduce to leave the chain launches on EVERY rank
+// at the same iteration (a collective that holds CUs for milliseconds costs a chain launch ~40 % of that time; one launch
+// per convolution almost nothing: DESIGN §5) instead of one rank raising while the others sit in an all-reduce.
+constexpr unsigned SLOW_SPINS = 400;
 
 #ifdef NEOSR_TIMELINE
 #define CTL_MARK(l, m)                                                                            \
@@ -166,7 +172,9 @@ void conv3x3_wino4_chain_kernel(const W4ChainArgs args) {
       if (spins < 64) __builtin_amdgcn_s_sleep(4);   // back off: a long wait should not load the memory system
       else __builtin_amdgcn_s_sleep(64);
       v = poll_load();
-      if (++spins > SPIN_LIMIT) {
+      if (++spins == SLOW_SPINS && lane == 0)
+        __hip_atomic_store((gu32*)args.status + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (spins > SPIN_LIMIT) {
         if (lane == 0) __hip_atomic_store((gu32*)args.status, 1u + need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         break;
       }
@@ -574,6 +582,44 @@ extern "C" int neosr_conv_chain_status(void) {
   if (!p || hipMemcpy(&v, p, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
   if (v) g_chain_tripped = true;
   return (int)v;
+}
+
+namespace {
+__global__ void chain_health_kernel(unsigned* status, float* dst) {
+  // dst[0]: 1 when a flag wait lasted ~1 ms or more since the last neosr_conv_chain_ack; dst[1]: the sticky abort word
+  const unsigned slow = __hip_atomic_load(status + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  dst[0] = slow ? 1.f : 0.f;
+  dst[1] = (float)__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+}  // namespace
+
+// The two health words of this device's chain launches as floats in dst[0..1] (device memory), enqueued on `stream` — no
+// host synchronisation: the models append them to the loss scalars they reduce over the ranks.
+extern "C" int neosr_conv_chain_health(float* dst, void* stream) {
+  NEOSR_CHECK(dst, "conv_chain_health: null destination");
+  unsigned* p = status_word();
+  NEOSR_CHECK(p, "conv chain: no status word");
+  hipLaunchKernelGGL(chain_health_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, p, dst);
+  NEOSR_LAUNCH_CHECK();
+  return 0;
+}
+
+// forget the slow-wait mark (enqueued on `stream`)
+extern "C" int neosr_conv_chain_ack(void* stream) {
+  unsigned* p = status_word();
+  NEOSR_CHECK(p, "conv chain: no status word");
+  NEOSR_HIP(hipMemsetAsync(p + 1, 0, 4, (hipStream_t)stream));
+  return 0;
+}
+
+// tests: leave the mark a slow flag wait would leave
+extern "C" int neosr_debug_chain_mark_slow(void* stream) {
+  unsigned* p = status_word();
+  NEOSR_CHECK(p, "conv chain: no status word");
+  const unsigned one = 1;
+  NEOSR_HIP(hipMemcpyAsync(p + 1, &one, 4, hipMemcpyHostToDevice, (hipStream_t)stream));
+  NEOSR_HIP(hipStreamSynchronize((hipStream_t)stream));
+  return 0;
 }
 
 // Workgroups of a chain launch that are certainly co-resident: one per CU of the current device (MI355X: 256 when no

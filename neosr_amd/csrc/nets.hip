@@ -861,10 +861,15 @@ struct CompactLayout {
 // epilogue writes a_i = PReLU(z_i) (per-channel slopes) AND z_i (second output), the backward-data epilogue writes
 // g_z_{i-1} = dA_{i-1} . PReLU'(z_{i-1}) AND dA_{i-1} (for the slope gradient), so every convolution and every weight
 // gradient of the body is a plain Winograd launch and the NC body weight gradients are one neosr_conv3x3_wgrad_multi
-// launch.  NEOSR_AMD_COMPACT_W4=0, a Winograd mode other than 2 or num_feat % 4 != 0 keep the on-load scheme.
+// launch.  NEOSR_AMD_COMPACT_W4=0, a Winograd mode other than 2 or num_feat % 4 != 0 keep the on-load scheme; so does a PReLU net
+// whose last convolution has a channel count that is not a multiple of 4 (upscale 3 -> 27, upscale 1 -> 3): its backward-data
+// launch reduces over those channels and needs the Winograd kernel's masked epilogue, which the packed image (K % 4) does
+// not cover.
 bool compact_w4(const neosr_compact_cfg& c) {
   static const bool on = [] { const char* e = getenv("NEOSR_AMD_COMPACT_W4"); return !(e && e[0] == '0'); }();
+  const int clast = c.num_out_ch * c.upscale * c.upscale;
   return on && neosr_conv::wino_mode() == 2 && c.num_feat % 4 == 0 && c.num_conv >= 1 &&
+         (clast % 4 == 0 || c.act_type != NEOSR_ACT_PRELU) &&
          (int64_t)c.B * c.H * c.W * c.num_feat * 4 < (int64_t(1) << 31);
 }
 

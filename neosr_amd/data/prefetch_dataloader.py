@@ -1,51 +1,16 @@
-"""Input prefetching either side of `feed_data` (neosr/data/prefetch_dataloader.py):
-
-* `PrefetchGenerator` / `PrefetchDataLoader` — a daemon thread keeps `num_prefetch_queue` batches ready;
-* `DevicePrefetcher` (the reference's `CUDAPrefetcher`, same interface: `next()` / `reset()`): the next
-  batch's host->HBM copies run on a side HIP stream while the current iteration computes; `next()` makes
-  the compute stream wait for that copy only.
+"""Input staging in front of `feed_data` (neosr/data/prefetch_dataloader.py:69-125, the `prefetch_mode = "cuda"` path of
+train.py:204-212): `DevicePrefetcher` (the reference's `CUDAPrefetcher`, same interface: `next()` / `reset()`) runs the
+next batch's host->HBM copies on a side HIP stream while the current iteration computes; `next()` makes the compute
+stream wait for that copy only.  The reference's CPU-side thread prefetcher (`prefetch_mode = "cpu"`) is host data-loader
+plumbing outside SURVEY §8 and is not restated here: any iterable of batch dicts (a plain `torch.utils.data.DataLoader`
+with workers) feeds this class.
 """
 
 from __future__ import annotations
 
-import queue
-from collections.abc import Iterator
-from threading import Thread
 from typing import Any
 
 import torch
-from torch.utils.data import DataLoader
-
-
-class PrefetchGenerator(Thread):
-    def __init__(self, generator, num_prefetch_queue: int) -> None:
-        super().__init__(daemon=True)
-        self.queue: queue.Queue[Any] = queue.Queue(num_prefetch_queue)
-        self.generator = generator
-        self.start()
-
-    def run(self) -> None:
-        for item in self.generator:
-            self.queue.put(item)
-        self.queue.put(None)  # end marker
-
-    def __next__(self) -> Any:
-        item = self.queue.get()
-        if item is None:
-            raise StopIteration
-        return item
-
-    def __iter__(self) -> Iterator:
-        return self
-
-
-class PrefetchDataLoader(DataLoader):
-    def __init__(self, num_prefetch_queue: int, **kwargs) -> None:
-        self.num_prefetch_queue = num_prefetch_queue
-        super().__init__(**kwargs)
-
-    def __iter__(self):
-        return PrefetchGenerator(super().__iter__(), self.num_prefetch_queue)
 
 
 class DevicePrefetcher:

@@ -476,6 +476,18 @@ def window_attention(qkv, table, heads, ws, shift, scale):
 # autograd.Function + ctypes call per fused op.  NEOSR_AMD_BLOCK_PLANS=0 keeps the op-by-op composition (same kernels,
 # same descriptors: bit-identical; tests/test_hip_blocks.py).
 BLOCK_PLANS = os.environ.get("NEOSR_AMD_BLOCK_PLANS", "1") != "0"
+# A plan keeps every intermediate of its block in ONE `save` buffer (about M * (7 C + 2 hidden) floats) — what backward
+# needs.  Without autograd nothing is kept by the op-by-op composition, which frees as it goes: above this many tokens an
+# inference pass (validation of whole images, untiled `test()`) takes that path instead (same kernels, same
+# bits).  65 536 tokens = a 256 x 256 LR image; swinir_medium's block then saves ~0.5 GB.
+PLAN_NOGRAD_MAX_TOKENS = int(os.environ.get("NEOSR_AMD_PLAN_NOGRAD_MAX_TOKENS", str(1 << 16)))
+
+
+def use_block_plan(x) -> bool:
+    """whether a transformer block should run as its C++ plan for this input (B, H, W, C)"""
+    if not BLOCK_PLANS:
+        return False
+    return torch.is_grad_enabled() or x.shape[0] * x.shape[1] * x.shape[2] <= PLAN_NOGRAD_MAX_TOKENS
 
 
 def _block_grad_buffer(params, like, meta=None):
@@ -503,6 +515,23 @@ def _block_grad_buffer(params, like, meta=None):
         flat = _new((total,), like)
     base = flat.storage_offset()
     return flat, [flat.as_strided(sh, st, base + o) for sh, st, o in zip(shapes, strides, offs)]
+
+
+def _no_plan_meta():
+    return None
+
+
+class PlanMeta(dict):
+    """A block module's plan cache (`module._plan_meta`): static descriptor fields plus the cached ctypes descriptor / gradient
+    structs (`_desc`, `_G`, `_layout`).  A cache, not state: ctypes structs with pointer fields can be neither deep-copied
+    nor pickled, and their addresses belong to the original's parameters — a copied / pickled module gets None and
+    rebuilds its own on the next forward (`DirectGrads` in hip/nets.py does the same)."""
+
+    def __deepcopy__(self, memo):
+        return None
+
+    def __reduce__(self):
+        return (_no_plan_meta, ())
 
 
 class TBlock(torch.autograd.Function):

@@ -64,6 +64,8 @@ def flatten_sn_buffers_(net: nn.Module) -> torch.Tensor | None:
 class base:
     """Default model."""
 
+    CHAIN_SLOW_GRACE_READS = 1   # log reads whose slow-wait marks are ignored (RCCL warm-up inside the first collectives)
+
     def __init__(self, opt: dict[str, Any]) -> None:
         self.opt = opt
         self.device = torch.device("cuda")
@@ -73,6 +75,9 @@ class base:
         self.log_dict: dict[str, Any] = OrderedDict()
         self._log_dev: tuple[list[str], torch.Tensor] | None = None
         self._log_work = None
+        self._log_health = False     # the reduced scalars end with the chain launches' two health words
+        self._log_reads = 0
+        self.chain_fallback = False  # all ranks left the chain launches after a slow flag wait (get_current_log)
         self.n_accumulated = 0
         if self.is_train:
             self.sf_optim_g = opt["train"]["optim_g"].get("schedule_free", False)
@@ -125,22 +130,40 @@ class base:
             if self._log_work is not None:  # the rank reduce of these scalars was only enqueued (reduce_loss_dict)
                 self._log_work.wait()
                 self._log_work = None
-                if self.opt["rank"] == 0:
-                    vals = vals / self.opt["world_size"]
+                vals = vals / self.opt["world_size"]   # (an all-reduce: every rank holds the sums)
             host = vals.detach().float().cpu().tolist()
+            # The chain launches of the RRDB trunk need all their workgroups resident at once.  Two health words travel with
+            # the loss scalars (neosr_conv_chain_health; on data-parallel runs through the same all-reduce, so EVERY rank sees
+            # their sum and acts at the same iteration — a rank that raised alone would leave the others in a collective):
+            #   slow   > 0: some chain launch waited a millisecond or more for missing workgroups (a collective or another
+            #               process held CUs).  Results are valid; all ranks switch to one launch per convolution, which
+            #               loses almost nothing under held CUs.  Marks of the first iterations (RCCL sets
+            #               its connections up inside the first collectives) are ignored.
+            #   status > 0: a wait ran into its spin bound and the launch finished on unfinished neighbour data: raise,
+            #               on every rank, instead of training on from garbage.
+            slow = st = 0.0
+            if self._log_health:
+                slow, st = host[-2] * self.opt["world_size"], host[-1] * self.opt["world_size"]
+                host = host[:-2]
+            elif vals.is_cuda:   # one process: the device was just synchronised by the read above, the word is one 4-byte copy
+                st = float(_C.load().neosr_conv_chain_status())
             self.log_dict = OrderedDict(zip(keys, host))
             self._log_dev = None
-            # The chain launches of the RRDB trunk need all their workgroups resident at once; one that never got them
-            # (another process or a long collective holding CUs) gives up after its spin bound, finishes on
-            # unfinished neighbour data and leaves a sticky status word.  The device was just synchronised by the read above, so looking
-            # at the word costs one 4-byte copy: raise instead of training on from garbage.  Reading a
-            # non-zero word also makes the library drop chain launches for the rest of the process.
-            st = _C.load().neosr_conv_chain_status() if vals.is_cuda else 0
+            self._log_reads += 1
             if st > 0:
-                msg = (f"conv chain launch aborted (status {st}): a chain launch did not get all its workgroups resident; "
+                _C.load().neosr_set_conv_chain(0)
+                msg = (f"conv chain launch aborted (status {int(st)}): a chain launch did not get all its workgroups resident; "
                        "the iterations since the last log read are invalid.  Chain launches are now off in this process "
                        "(NEOSR_AMD_CHAIN=0 avoids them from the start when the GPU is shared).")
                 raise _C.NeosrAmdError(msg)
+            if slow > 0:
+                _C.check(_C.load().neosr_conv_chain_ack(_C.stream_ptr()), "neosr_conv_chain_ack")
+            if slow > 0 and self._log_reads > self.CHAIN_SLOW_GRACE_READS:
+                _C.load().neosr_set_conv_chain(0)
+                get_root_logger().warning(
+                    "conv chain launches waited >= 1 ms for resident workgroups on %d rank(s): switching every rank to one "
+                    "launch per convolution (results unaffected)", int(slow))
+                self.chain_fallback = True
             tot = self.log_dict.get("l_g_total")
             if tot is not None and tot != tot:
                 msg = (f"{tc.red}NaN found, aborting training. Make sure you're using a proper "
@@ -153,10 +176,17 @@ class base:
         with torch.no_grad():
             keys = list(loss_dict.keys())
             vals = torch.stack([v.detach().reshape(-1)[0].float() for v in loss_dict.values()])
+            self._log_health = False
             if self.opt["dist"]:
+                if vals.is_cuda:   # the chain launches' health words ride along (see get_current_log)
+                    health = torch.empty(2, device=vals.device, dtype=torch.float32)
+                    _C.check(_C.load().neosr_conv_chain_health(health.data_ptr(), _C.stream_ptr()), "neosr_conv_chain_health")
+                    vals = torch.cat((vals, health))
+                    self._log_health = True
                 # asynchronous: nothing on the compute stream waits for it (it queues behind the gradient buckets
-                # on the communication stream); completed and divided when the caller reads the log
-                self._log_work = dist.reduce(vals, dst=0, async_op=True)
+                # on the communication stream); completed and divided when the caller reads the log.  An all-reduce
+                # rather than the reference's reduce-to-0: the health words must reach every rank.
+                self._log_work = dist.all_reduce(vals, async_op=True)
             self._log_dev = (keys, vals)
 
     # -- device / parallel ----------------------------------------------------------------

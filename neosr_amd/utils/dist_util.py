@@ -10,7 +10,6 @@ from __future__ import annotations
 
 import functools
 import os
-import subprocess
 from collections.abc import Callable
 
 import torch
@@ -27,10 +26,8 @@ def init_dist(launcher: str, backend: str | None = None, **kwargs) -> None:
     backend = backend or _default_backend()
     if launcher == "pytorch":
         _init_dist_pytorch(backend, **kwargs)
-    elif launcher == "slurm":
-        _init_dist_slurm(backend, **kwargs)
-    else:
-        msg = f"Invalid launcher type: {launcher}"
+    else:   # ("slurm" in the reference is multi-node glue: one node of 8 MI355X over xGMI is this path's scope)
+        msg = f"Invalid launcher type: {launcher} (neosr_amd runs one process per GPU of ONE node: use 'pytorch')"
         raise ValueError(msg)
 
 
@@ -43,23 +40,6 @@ def _init_dist_pytorch(backend: str, **kwargs) -> None:
     rank = int(os.environ["RANK"])
     _bind_device(int(os.environ.get("LOCAL_RANK", rank)))
     dist.init_process_group(backend=backend, **kwargs)
-
-
-def _init_dist_slurm(backend: str, port: int | None = None) -> None:
-    proc_id = int(os.environ["SLURM_PROCID"])
-    ntasks = int(os.environ["SLURM_NTASKS"])
-    node_list = os.environ["SLURM_NODELIST"]
-    _bind_device(proc_id)
-    addr = subprocess.getoutput(f"scontrol show hostname {node_list} | head -n1")
-    if port is not None:
-        os.environ["MASTER_PORT"] = str(port)
-    os.environ.setdefault("MASTER_PORT", "29500")
-    os.environ["MASTER_ADDR"] = addr
-    os.environ["WORLD_SIZE"] = str(ntasks)
-    ngpu = max(torch.cuda.device_count(), 1)
-    os.environ["LOCAL_RANK"] = str(proc_id % ngpu)
-    os.environ["RANK"] = str(proc_id)
-    dist.init_process_group(backend=backend)
 
 
 def get_dist_info() -> tuple[int, int]:

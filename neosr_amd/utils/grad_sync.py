@@ -172,12 +172,17 @@ class GradSync:
         """Where the FIRST gradient contribution of `p` in this backward may be written directly: its view of the gradient
         arena (shape of `p`), or None (no hook-driven exchange in progress, `p` not ours, or `p` already has a gradient —
         a second contribution accumulates through autograd as usual)."""
+        if not p.is_leaf:   # (derived weights — spectral norm, the expanded 4x4/s2 kernel — have no slice; reading .grad of a
+            return None     # non-leaf would also emit autograd's UserWarning)
         if not self._live or p.grad is not None or id(p) in self._seen or id(p) in self._taken:
             return None
         slot = self._slot_of.get(id(p))
-        if slot is not None:
-            self._taken.add(id(p))   # handed out once per backward: a second producer of the same parameter gets None
-        return slot
+        if slot is None:
+            return None
+        self._taken.add(id(p))   # handed out once per backward: a second producer of the same parameter gets None
+        # a FRESH view per call: AccumulateGrad adopts a gradient only when nobody else references the tensor object — the
+        # cached view would be cloned and copied back onto the identical slice by _send_bucket (ADVICE r4)
+        return slot.view_as(slot)
 
     def _send_in_order(self, force: bool) -> None:
         while self._next >= 0 and (force or self._pending[self._next] == 0):

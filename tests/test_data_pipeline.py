@@ -30,11 +30,3 @@ def test_enlarged_sampler_contract():
     assert min(counts) >= (n * world) // len(ds)
 
 
-def test_prefetch_dataloader_yields_everything_in_order():
-    from neosr_amd.data.prefetch_dataloader import PrefetchDataLoader
-
-    data = [{"lq": torch.full((2,), float(i))} for i in range(7)]
-    loader = PrefetchDataLoader(num_prefetch_queue=2, dataset=data, batch_size=None, shuffle=False)
-    for _ in range(2):  # re-iterable
-        got = [int(b["lq"][0]) for b in loader]
-        assert got == list(range(7))

@@ -74,6 +74,25 @@ def test_swinir_block_plan_under_no_grad_and_twice():
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
+def test_network_copies_after_a_forward():
+    """copy.deepcopy / torch.save of a network whose blocks have cached their ctypes descriptors: the copy
+    drops the caches, rebuilds them on its own parameters and gives the same bits"""
+    import copy
+    import io
+    from neosr_amd.archs import swinir_arch as A
+
+    torch.manual_seed(5)
+    net = A.swinir_small(upscale=4, drop_path_rate=0.0).to(DEV).train()
+    x = torch.rand(1, 3, 24, 40, device=DEV)
+    y = net(x)
+    y.sum().backward()
+    twin = copy.deepcopy(net)
+    buf = io.BytesIO()
+    torch.save(net, buf)
+    with torch.no_grad():
+        assert torch.equal(twin(x), net(x))
+
+
 @pytest.mark.parametrize("ws,res,drop,cr", [(16, 32, 0.1, 3), (8, 16, 0.0, 3), (16, 64, 0.0, 3), (16, 32, 0.1, 4)])
 def test_hat_block_plans_are_bit_identical_to_op_by_op(ws, res, drop, cr):
     """HAB (CAB branch, both of its convolutions' gradients, the channel gate, shifted windows) and OCAB; compress_ratio 4

@@ -138,6 +138,23 @@ TWO_RANK = textwrap.dedent("""
             if init_d is not None:
                 for (k, a), b in zip(m.net_d.state_dict().items(), ref.net_d.state_dict().values()):
                     assert rel_err(a, b) < 2e-4, (cfg, "net_d", k, rel_err(a, b))
+        if cfg == "golden_esrgan.toml":
+            # a slow flag wait on ONE rank (the mark a chain launch leaves after ~1 ms): the health words ride in the loss
+            # all-reduce, so BOTH ranks leave the chain launches at the same log read — nobody raises alone
+            from neosr_amd import _C
+            lib = _C.load()
+            assert not m.chain_fallback
+            if rank == 1:
+                _C.check(lib.neosr_debug_chain_mark_slow(_C.stream_ptr()), "mark")
+            m.feed_data({{"lq": LQ[1, sl], "gt": GT[1, sl]}})
+            m.optimize_parameters(3)
+            m.get_current_log()
+            assert m.chain_fallback and lib.neosr_set_conv_chain(1) == 0, (rank, m.chain_fallback)
+            m.feed_data({{"lq": LQ[1, sl], "gt": GT[1, sl]}})     # the mark was acknowledged: no second fallback
+            m.optimize_parameters(4)
+            m.chain_fallback = False
+            m.get_current_log()
+            assert not m.chain_fallback and lib.neosr_set_conv_chain(1) == 1
         dist.barrier()
     dist.destroy_process_group()
     if rank == 0:

@@ -629,7 +629,7 @@ def test_esrgan_scale_2_and_1_vs_oracle(scale):
     assert errs[worst] < 1e-3, (worst, errs[worst])
 
 
-@pytest.mark.parametrize("upscale,act", [(2, "prelu"), (3, "leakyrelu"), (1, "relu")])
+@pytest.mark.parametrize("upscale,act", [(2, "prelu"), (3, "leakyrelu"), (1, "relu"), (3, "prelu"), (1, "prelu")])
 def test_compact_other_scales_vs_oracle(upscale, act):
     """compact with upscale 1 / 2 / 3 (PixelShuffle factor, nearest-upsampled residual; compact_arch.py:56-85)."""
     from neosr_amd.archs import build_network

@@ -60,3 +60,20 @@ def test_direct_grad_cache_is_not_copied_or_pickled():
     assert twin.__dict__["_neosr_direct"] is None
     with nets.direct_param_grads():      # CPU parameters never take the direct path
         assert nets.direct_state(net, nets.parameters_of(net)) is None
+
+
+def test_block_plan_cache_is_not_copied_or_pickled():
+    """`module._plan_meta` holds ctypes structs with pointer fields after the first forward: a cache that copies drop
+    (copy.deepcopy / torch.save of a SwinIR / HAT network after a forward raised)."""
+    import ctypes
+    from neosr_amd.hip import transformer as T
+
+    class S(ctypes.Structure):
+        _fields_ = [("p", ctypes.c_void_p)]
+
+    m = T.PlanMeta({"names": ("a",), "_desc": ((1, 2), (S(), 3, 4))})
+    assert copy.deepcopy(m) is None and pickle.loads(pickle.dumps(m)) is None
+    mod = torch.nn.Linear(2, 2)
+    mod._plan_meta = m
+    twin = copy.deepcopy(mod)
+    assert twin._plan_meta is None and torch.equal(twin.weight, mod.weight)
