@@ -156,6 +156,14 @@ int neosr_set_wgrad4(int on);
  * models reduce them over the ranks with their loss scalars (neosr/models/base.py:498-526) so that all ranks leave the
  * chain launches — or stop — at the same iteration. */
 int neosr_set_conv_chain(int on);
+/* The `fast_matmul` tier of the F(4x4,3x3) forward / backward-data kernels (reference: neosr/train.py:168-173 enables TF32
+ * convolutions and "medium" matmul precision; neosr/models/image.py:117-127 autocast): 1 = every fp32 operand of the
+ * Winograd-domain products as two bf16 pieces (hi + lo: 16 significant bits; TF32 has 11), all four cross products on
+ * v_mfma_f32_16x16x32_bf16, fp32 accumulation; transforms, epilogues, weight gradients, every other kernel and all storage
+ * stay fp32.  ~1e-4 of the output scale per layer against the float64 convolution (fp32 path: ~5e-6) — a labelled
+ * reduced-precision tier, never the default (0; env NEOSR_AMD_FAST_MATMUL=1).  The weight images are packed for the mode
+ * (same size): switch BEFORE packing / re-pack after a switch.  Returns the previous setting. */
+int neosr_set_fast_matmul(int on);
 /* Behind a chain launch the fifteen weight gradients of an RRDB run as ONE neosr_conv3x3_wgrad_multi launch (1, default;
  * env NEOSR_AMD_WGRAD_RRDB) or as one launch per RDB (0): another split of the pixel range, i.e. another summation
  * order (~1e-7 relative).  Returns the previous setting. */

@@ -292,6 +292,7 @@ SIGNATURES: dict[str, tuple] = {
     "neosr_set_wino4_n64": (C.c_int, [C.c_int]),
     "neosr_set_wgrad4": (C.c_int, [C.c_int]),
     "neosr_set_conv_chain": (C.c_int, [C.c_int]),
+    "neosr_set_fast_matmul": (C.c_int, [C.c_int]),
     "neosr_set_wgrad_rrdb": (C.c_int, [C.c_int]),
     "neosr_set_conv_chain_sync": (C.c_int, [C.c_int]),
     "neosr_conv_chain_status": (C.c_int, []),
@@ -447,12 +448,35 @@ def params_changed() -> None:
     WEIGHTS_EPOCH += 1
 
 
+# The `fast_matmul` tier of the F(4x4,3x3) kernels (include/neosr_amd.h: neosr_set_fast_matmul).  The weight images are
+# packed FOR the mode, so the mode is part of every packed-image cache key (hip/layers.py: also for frozen weights, which
+# ignore the epoch) and a switch invalidates whatever was packed before it.
+FAST_MATMUL = 0
+
+
+def set_fast_matmul(on: bool) -> bool:
+    """Switch the tier on / off for this process; returns the previous setting."""
+    global FAST_MATMUL
+    prev = bool(load().neosr_set_fast_matmul(1 if on else 0))
+    FAST_MATMUL = 1 if on else 0
+    params_changed()
+    return prev
+
+
 class NeosrAmdError(RuntimeError):
     pass
 
 
 def lib_path() -> Path:
     return Path(os.environ.get("NEOSR_AMD_LIB", str(_LIB_PATH)))
+
+
+def _sync_fast_matmul(lib) -> None:
+    """(an environment default, NEOSR_AMD_FAST_MATMUL=1, is read by the library: mirror it)"""
+    global FAST_MATMUL
+    prev = lib.neosr_set_fast_matmul(0)
+    lib.neosr_set_fast_matmul(prev)
+    FAST_MATMUL = int(prev)
 
 
 def load():
@@ -474,6 +498,7 @@ def load():
         fn.restype = res
         fn.argtypes = args
     _lib = lib
+    _sync_fast_matmul(lib)
     return lib
 
 

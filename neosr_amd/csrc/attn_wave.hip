@@ -248,7 +248,11 @@ __device__ __forceinline__ int region16(int c, int Wc, int nWc, int shift) {
 
 template <int HALF>
 __global__ __launch_bounds__(256, 2) void wattn16_wave_fwd_kernel(const neosr_fattn_desc d, int units) {
-  __shared__ float tabs[4][NBIN16 + 63];
+  // the 31 x 31 relative-position table with a row stride of 48 floats: a ds_read_b32 lane group is two query rows (lanes
+  // 0-15 / 16-31 = rows yi, yi + 1) of 16 consecutive columns — 31 apart they shared 15 banks (SQ: bank conflicts 46 % of the
+  // LDS cycles, profiles/r04_bench_hat_l_otf_gan_sq_summary.json), 48 apart they take the two halves of the 32 banks
+  constexpr int TS16 = 48;
+  __shared__ float tabs[4][NB16 * TS16];
   const int lane = threadIdx.x & 63, l31 = lane & 31, lh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   float* tab = tabs[wave];
@@ -266,7 +270,7 @@ __global__ __launch_bounds__(256, 2) void wattn16_wave_fwd_kernel(const neosr_fa
     };
     float qf[NS];
     load_rows<HALF>(d.qkv, ld, pix(32 * ti + l31), w.head * hd, hd, lh, d.scale, qf);
-    for (int n = lane; n < NBIN16; n += 64) tab[n] = d.rpb_table[n * d.heads + w.head];
+    for (int n = lane; n < NBIN16; n += 64) tab[(n / NB16) * TS16 + n % NB16] = d.rpb_table[n * d.heads + w.head];
     // S^T tiles: rows (registers) = keys 32 tj + 8 g + 4 lh + r, column (lane) = query 32 ti + l31
     f32x16 st[NKT];
 #pragma unroll
@@ -280,7 +284,7 @@ __global__ __launch_bounds__(256, 2) void wattn16_wave_fwd_kernel(const neosr_fa
     // bias + mask, softmax over the 256 keys (registers + the other half-wave)
     const bool masked = d.shift > 0 && (w.Wy == w.nWy - 1 || w.Wx == w.nWx - 1);
     const int yi = 2 * ti + (l31 >> 4), xi = l31 & 15;
-    const float* tb = tab + (yi + W16 - 1) * NB16 + xi + W16 - 1 - 4 * lh;
+    const float* tb = tab + (yi + W16 - 1) * TS16 + xi + W16 - 1 - 4 * lh;
     const int ri = region16(yi, w.Wy, w.nWy, d.shift) * 3 + region16(xi, w.Wx, w.nWx, d.shift);
     float m = -3.0e38f;
 #pragma unroll
@@ -292,7 +296,7 @@ __global__ __launch_bounds__(256, 2) void wattn16_wave_fwd_kernel(const neosr_fa
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int xj0 = 8 * (g & 1) + r;  // + 4 lh
-          float sc = st[tj][4 * g + r] + tb[-(yj * NB16 + xj0)];
+          float sc = st[tj][4 * g + r] + tb[-(yj * TS16 + xj0)];
           if (masked && ryj + region16(xj0 + 4 * lh, w.Wx, w.nWx, d.shift) != ri) sc -= 100.f;
           st[tj][4 * g + r] = sc;
           m = fmaxf(m, sc);

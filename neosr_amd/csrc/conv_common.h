@@ -161,6 +161,7 @@ void launch_wino(const ConvArgs& a, hipStream_t st);  // sizes its own grid (8 x
 extern int g_wino4_concurrency;                        // see conv_wino4.hip
 int wino4_n64_mode();                                  // neosr_set_wino4_n64: -1 by the fill estimate, 0 never, 1 whenever N > 32
 void launch_wino4(const ConvArgs& a, hipStream_t st); // F(4x4,3x3): 16 x 16-pixel tiles x 32-cout blocks, 768 threads
+bool fast_matmul();                                    // neosr_set_fast_matmul / NEOSR_AMD_FAST_MATMUL=1: the two-piece bf16 tier of the F(4x4,3x3) kernels
 bool wino_enabled();                                   // NEOSR_AMD_WINOGRAD=0 / neosr_set_winograd(0): direct kernel
 int wino_mode();                                       // 0 direct, 1 F(2x2,3x3) everywhere, 2 F(4x4,3x3) where an image is given
 void launch_thin_k(const ConvArgs& a, dim3 grid, hipStream_t st);

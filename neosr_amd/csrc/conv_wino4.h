@@ -23,6 +23,28 @@ __device__ __forceinline__ f32x4 ld4f(const float* p) { return *reinterpret_cast
 __device__ __forceinline__ f32x4 splat(float v) { return (f32x4){v, v, v, v}; }
 __device__ __forceinline__ f32x4 fma4(f32x4 a, f32x4 b, f32x4 c) { return __builtin_elementwise_fma(a, b, c); }
 
+// ---- the `fast_matmul` tier (neosr_set_fast_matmul; reference: train.py:168-173 turns TF32 on): every fp32 operand of the
+// F(4x4,3x3) products as TWO bf16 pieces hi + lo (16 significant bits instead of TF32's 11), all four cross products on
+// v_mfma_f32_16x16x32_bf16 with fp32 accumulation.  The K = 32 slots of one MFMA hold {4 channels x (w_hi, w_lo)} of the
+// lane's k quad on the weight side — exactly the 16 bytes the lane loads anyway, so the weight image keeps its size and
+// the kernels their loads (bytes per MAC is what bounds this loop: profiles/NEGATIVE_RESULTS.md 5.1) — against
+// {a_hi, a_hi} in the first MFMA and {a_lo, a_lo} in the second: 2 bf16 MFMAs of 16 cycles instead of 4 f32 MFMAs of 32.
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4_bits __attribute__((ext_vector_type(4)));
+
+// hi = the upper 16 bits of the fp32 pattern (truncation: hi is a bf16 number, x - hi is exact), lo = bf16_rne(x - hi)
+__device__ __forceinline__ void split_hi_lo(const f32x4 v, bf16x8& hi2, bf16x8& lo2) {
+  const unsigned b0 = __float_as_uint(v[0]), b1 = __float_as_uint(v[1]), b2 = __float_as_uint(v[2]), b3 = __float_as_uint(v[3]);
+  const unsigned h01 = __builtin_amdgcn_perm(b1, b0, 0x07060302u), h23 = __builtin_amdgcn_perm(b3, b2, 0x07060302u);
+  const float r0 = v[0] - __uint_as_float(b0 & 0xffff0000u), r1 = v[1] - __uint_as_float(b1 & 0xffff0000u);
+  const float r2 = v[2] - __uint_as_float(b2 & 0xffff0000u), r3 = v[3] - __uint_as_float(b3 & 0xffff0000u);
+  unsigned l01, l23;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(l01) : "v"(r0), "v"(r1));
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(l23) : "v"(r2), "v"(r3));
+  hi2 = __builtin_bit_cast(bf16x8, (u32x4_bits){h01, h23, h01, h23});
+  lo2 = __builtin_bit_cast(bf16x8, (u32x4_bits){l01, l23, l01, l23});
+}
+
 // Raw tile image: pixel (y, x) of the 18 x 18 tile, channel quad q (0..7) of the chunk lives at float offset
 //   32 * slot(y, x) + 4 * (q ^ swz(y, x)),   slot = 2 * (yy * 18 + x) + odd,  odd = 1 for rows 8..15 (yy = y - 8),
 //   else 0 with yy = y (rows 0..7) or y - 8 (rows 16, 17);  swz = ((x >> 2) & 3) | (((y >> 2) & 1) << 2).

@@ -48,7 +48,8 @@ namespace {
 // wave (ti, ch) the 32 channels of cout half ch for BOTH k-parities, one after the other (two sub-chunks per barrier) —
 // the raw tile is staged once for 64 channels instead of twice, one prologue / epilogue per 2 x the matrix work, and
 // the accumulator exchange needs no k-parity sum.
-template <bool N64>
+// SPLIT: the fast_matmul tier (conv_wino4.h: two bf16 pieces per operand, the image packed by the same mode).
+template <bool N64, bool SPLIT>
 __global__ __attribute__((amdgpu_flat_work_group_size(768, 768), amdgpu_waves_per_eu(3, 3)))
 void conv3x3_wino4_kernel(const ConvArgs args) {
   const neosr_conv_desc& d = args.d;
@@ -172,13 +173,29 @@ void conv3x3_wino4_kernel(const ConvArgs args) {
     for (int nb = 0; nb < 2; ++nb) acc[j][nb] = splat(0.f);
 
   auto mac3 = [&](int j0, const f32x4 (&v)[3], const f32x4 (&u)[3][2]) {
+    if constexpr (SPLIT) {
+      bf16x8 bh[3], bl[3];
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
+      for (int j = 0; j < 3; ++j) split_hi_lo(v[j], bh[j], bl[j]);
 #pragma unroll
       for (int j = 0; j < 3; ++j)
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb)
-          acc[j0 + j][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[j][nb][e], v[j][e], acc[j0 + j][nb], 0, 0, 0);
+          acc[j0 + j][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, u[j][nb]), bh[j], acc[j0 + j][nb], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+          acc[j0 + j][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, u[j][nb]), bl[j], acc[j0 + j][nb], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb)
+            acc[j0 + j][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[j][nb][e], v[j][e], acc[j0 + j][nb], 0, 0, 0);
+    }
   };
 
   // column pass (row ti of B^T d) then row pass ((B^T d) B) for the lane's four channels; xr = 16 selects k-parity 1 of
@@ -429,7 +446,7 @@ void conv3x3_wino4_kernel(const ConvArgs args) {
 // U = G g G^T of every (cin, cout) pair of an image, in float64, rounded once:
 //   dst[nblk][chunk 32 k][pos = i * 6 + j][kp 2][cout block 2][k quad 4][cout 16][4]
 // one thread per (n-block, chunk, k quad 0..7, n 0..31) loads the 4 x 9 taps of its four channels and writes 36 granules.
-__device__ __forceinline__ void pack_wino4_image(const neosr_pack::Image& im) {
+__device__ __forceinline__ void pack_wino4_image(const neosr_pack::Image& im, const int split) {
   const int nch = (im.K + 31) >> 5, nblk = (im.N + 31) >> 5;
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (t >= nblk * nch * 256) return;
@@ -479,18 +496,33 @@ __device__ __forceinline__ void pack_wino4_image(const neosr_pack::Image& im) {
       v.y = (float)fma(G2[i], cg[1][2][j], fma(G1[i], cg[1][1][j], G0[i] * cg[1][0][j]));
       v.z = (float)fma(G2[i], cg[2][2][j], fma(G1[i], cg[2][1][j], G0[i] * cg[2][0][j]));
       v.w = (float)fma(G2[i], cg[3][2][j], fma(G1[i], cg[3][1][j], G0[i] * cg[3][0][j]));
+      if (split) {   // fast_matmul tier: (hi, lo) bf16 pieces of the four channels in the same 16 bytes (conv_wino4.h)
+        const float f[4] = {v.x, v.y, v.z, v.w};
+        unsigned hb[4], lb[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const unsigned b = __float_as_uint(f[e]);
+          hb[e] = b >> 16;
+          const unsigned r = __float_as_uint(f[e] - __uint_as_float(b & 0xffff0000u));
+          lb[e] = (r + 0x7fffu + ((r >> 16) & 1u)) >> 16;   // round to nearest even (the remainder is far from overflow)
+        }
+        v.x = __uint_as_float(hb[0] | (hb[1] << 16));
+        v.y = __uint_as_float(hb[2] | (hb[3] << 16));
+        v.z = __uint_as_float(lb[0] | (lb[1] << 16));
+        v.w = __uint_as_float(lb[2] | (lb[3] << 16));
+      }
       *reinterpret_cast<float4*>(dst + (i * 6 + j) * 1024) = v;
     }
 }
 
-__global__ __launch_bounds__(256) void conv_pack_wino4_kernel(const neosr_pack::Batch batch) {
-  pack_wino4_image(batch.im[blockIdx.y]);
+__global__ __launch_bounds__(256) void conv_pack_wino4_kernel(const neosr_pack::Batch batch, const int split) {
+  pack_wino4_image(batch.im[blockIdx.y], split);
 }
 
 // the same over a table of images in device memory (any number of images in one launch)
-__global__ __launch_bounds__(256) void conv_pack_wino4_table_kernel(const neosr_pack::Image* __restrict__ tab) {
+__global__ __launch_bounds__(256) void conv_pack_wino4_table_kernel(const neosr_pack::Image* __restrict__ tab, const int split) {
   const neosr_pack::Image im = tab[blockIdx.y];
-  pack_wino4_image(im);
+  pack_wino4_image(im, split);
 }
 
 }  // namespace
@@ -501,6 +533,23 @@ int neosr_conv::g_wino4_concurrency = 1;
 
 namespace {
 int g_n64 = -1;  // -1: by the fill estimate (default); 0: never; 1: whenever the launch has more than 32 output channels
+int g_fast = -1; // -1: read NEOSR_AMD_FAST_MATMUL on first use (default 0)
+}
+
+bool neosr_conv::fast_matmul() {
+  if (g_fast < 0) {
+    const char* e = getenv("NEOSR_AMD_FAST_MATMUL");
+    g_fast = (e && e[0] == '1') ? 1 : 0;
+  }
+  return g_fast == 1;
+}
+
+// The F(4x4,3x3) weight images are packed FOR the mode (same bytes, different contents): every image packed before a
+// switch must be packed again before it is used (the Python side bumps its weights epoch: _C.set_fast_matmul).
+extern "C" int neosr_set_fast_matmul(int on) {
+  const int prev = neosr_conv::fast_matmul() ? 1 : 0;
+  g_fast = on ? 1 : 0;
+  return prev;
 }
 
 int neosr_conv::wino4_n64_mode() { return g_n64; }
@@ -524,10 +573,12 @@ void neosr_conv::launch_wino4(const ConvArgs& a, hipStream_t st) {
   const int64_t r32 = (tiles * ceil_div(a.d.N, 32) + 255) / 256, r64 = (tiles * ceil_div(a.d.N, 64) + 255) / 256;
   if (a.d.N > 32 && (g_n64 < 0 ? 7 * r64 <= 4 * r32 : g_n64 == 1)) {
     dim3 grid(w.tiles_x * w.tiles_y * a.d.B, ceil_div(a.d.N, 64));
-    hipLaunchKernelGGL(conv3x3_wino4_kernel<true>, grid, dim3(768), 0, st, w);
+    if (fast_matmul()) hipLaunchKernelGGL((conv3x3_wino4_kernel<true, true>), grid, dim3(768), 0, st, w);
+    else hipLaunchKernelGGL((conv3x3_wino4_kernel<true, false>), grid, dim3(768), 0, st, w);
   } else {
     dim3 grid(w.tiles_x * w.tiles_y * a.d.B, ceil_div(a.d.N, 32));
-    hipLaunchKernelGGL(conv3x3_wino4_kernel<false>, grid, dim3(768), 0, st, w);
+    if (fast_matmul()) hipLaunchKernelGGL((conv3x3_wino4_kernel<false, true>), grid, dim3(768), 0, st, w);
+    else hipLaunchKernelGGL((conv3x3_wino4_kernel<false, false>), grid, dim3(768), 0, st, w);
   }
 }
 
@@ -601,7 +652,7 @@ int neosr_pack::launch_wino4(const Image* images, int n, void* stream) {
         thr = g > thr ? g : thr;
       }
       dim3 grid((unsigned)((thr + 255) / 256), n);
-      hipLaunchKernelGGL(conv_pack_wino4_table_kernel, grid, dim3(256), 0, (hipStream_t)stream, tab);
+      hipLaunchKernelGGL(conv_pack_wino4_table_kernel, grid, dim3(256), 0, (hipStream_t)stream, tab, neosr_conv::fast_matmul() ? 1 : 0);
       NEOSR_LAUNCH_CHECK();
       return 0;
     }
@@ -617,7 +668,7 @@ int neosr_pack::launch_wino4(const Image* images, int n, void* stream) {
       thr = g > thr ? g : thr;
     }
     dim3 grid((unsigned)((thr + 255) / 256), cnt);
-    hipLaunchKernelGGL(conv_pack_wino4_kernel, grid, dim3(256), 0, (hipStream_t)stream, bt);
+    hipLaunchKernelGGL(conv_pack_wino4_kernel, grid, dim3(256), 0, (hipStream_t)stream, bt, neosr_conv::fast_matmul() ? 1 : 0);
   }
   NEOSR_LAUNCH_CHECK();
   return 0;

@@ -75,8 +75,10 @@ __device__ __forceinline__ void store16_sc1(f32x4 v, w4c_i32x4 rsrc, int voff) {
 // where an XCD's band of tiles is two whole samples: 1.2 % SLOWER (632 vs 640 LR-patches/s) and WRONG — the chain tests
 // fail: the block -> XCD map is not a contract and a consumer on another L2 reads stale lines.  The stores stay sc1.)
 
-__global__ __attribute__((amdgpu_flat_work_group_size(768, 768), amdgpu_waves_per_eu(3, 3)))
-void conv3x3_wino4_chain_kernel(const W4ChainArgs args) {
+// SPLIT: the fast_matmul tier (conv_wino4.h), as conv3x3_wino4_kernel<., true>.  (The body is a device function template
+// behind two plain kernels: as a kernel TEMPLATE hipcc 7.2 failed the host-side substitution without a diagnostic.)
+template <bool SPLIT>
+__device__ __forceinline__ void chain_body(const W4ChainArgs& args) {
   __shared__ __attribute__((aligned(1024))) float ldsA[QBUF];
   __shared__ __attribute__((aligned(1024))) float ldsB[QBUF];
   __shared__ __attribute__((aligned(1024))) float ldsC[QSLOTS * 32];  // chunk 0 of every layer
@@ -292,13 +294,29 @@ void conv3x3_wino4_chain_kernel(const W4ChainArgs args) {
       for (int nb = 0; nb < 2; ++nb) acc[j][nb] = splat(0.f);
 
     auto mac3 = [&](int j0, const f32x4 (&v)[3], const f32x4 (&u)[3][2]) {
+      if constexpr (SPLIT) {
+        bf16x8 bh[3], bl[3];
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
+        for (int j = 0; j < 3; ++j) split_hi_lo(v[j], bh[j], bl[j]);
 #pragma unroll
         for (int j = 0; j < 3; ++j)
 #pragma unroll
           for (int nb = 0; nb < 2; ++nb)
-            acc[j0 + j][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[j][nb][e], v[j][e], acc[j0 + j][nb], 0, 0, 0);
+            acc[j0 + j][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, u[j][nb]), bh[j], acc[j0 + j][nb], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb)
+            acc[j0 + j][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, u[j][nb]), bl[j], acc[j0 + j][nb], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+              acc[j0 + j][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[j][nb][e], v[j][e], acc[j0 + j][nb], 0, 0, 0);
+      }
     };
     auto transform = [&](const float* rb, int xr, f32x4 (&vlo)[3], f32x4 (&vhi)[3]) {
       f32x4 t[6];
@@ -525,6 +543,10 @@ void conv3x3_wino4_chain_kernel(const W4ChainArgs args) {
     else layer(std::false_type{}, l);
   }
 }
+__global__ __attribute__((amdgpu_flat_work_group_size(768, 768), amdgpu_waves_per_eu(3, 3)))
+void conv3x3_wino4_chain_kernel(const W4ChainArgs args) { chain_body<false>(args); }
+__global__ __attribute__((amdgpu_flat_work_group_size(768, 768), amdgpu_waves_per_eu(3, 3)))
+void conv3x3_wino4_chain_split_kernel(const W4ChainArgs args) { chain_body<true>(args); }
 
 // ---- host side -------------------------------------------------------------------------------------------------
 std::mutex g_mu;
@@ -695,7 +717,8 @@ int neosr_conv::launch_wino4_chain(const neosr_conv_desc* d, const int* dep, int
     neosr_prof_algo(2);
     neosr_prof_layers(n);
   }
-  hipLaunchKernelGGL(conv3x3_wino4_chain_kernel, dim3((unsigned)tiles), dim3(768), 0, st, a);
+  if (fast_matmul()) hipLaunchKernelGGL(conv3x3_wino4_chain_split_kernel, dim3((unsigned)tiles), dim3(768), 0, st, a);
+  else hipLaunchKernelGGL(conv3x3_wino4_chain_kernel, dim3((unsigned)tiles), dim3(768), 0, st, a);
   if (profile && neosr_prof_on()) neosr_prof_end(stream);
   NEOSR_LAUNCH_CHECK();
   return 0;

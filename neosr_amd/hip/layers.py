@@ -99,7 +99,7 @@ _S2D_PREMASK = __import__('os').environ.get('NEOSR_AMD_S2D_PREMASK', '1') != '0'
 
 
 def _pack_key(w):
-    return (w._version, 0 if getattr(w, "_neosr_frozen", False) else _C.WEIGHTS_EPOCH, w.data_ptr())
+    return (w._version, 0 if getattr(w, "_neosr_frozen", False) else _C.WEIGHTS_EPOCH, w.data_ptr(), _C.FAST_MATMUL)
 
 
 def _image_floats(w, kind, mode):

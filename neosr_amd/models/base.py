@@ -193,9 +193,7 @@ class base:
     def model_to_device(self, net: nn.Module) -> nn.Module:
         """Move to the HIP device and re-home the parameters into one flat arena
         (base.py:120-149 wraps in DDP here; we all-reduce the flat gradient arena instead)."""
-        if self.opt.get("use_amp", False) is True:
-            msg = "use_amp: the HIP kernels on this path are fp32 (north_star: 1e-3 rel fp32)"
-            raise NotImplementedError(msg)
+        self.precision_options()
         if not torch.cuda.is_available():
             msg = "neosr_amd models need a HIP device (no CPU fallback on the product path)"
             raise RuntimeError(msg)
@@ -210,6 +208,29 @@ class base:
                     dist.broadcast(b, src=0)
             net._neosr_sn_arena = flatten_sn_buffers_(net)  # noqa: SLF001
         return net
+
+    def precision_options(self) -> None:
+        """`fast_matmul` (train.py:168-173: TF32 convolutions, "medium" matmul precision), `use_amp` / `bfloat16`
+        (neosr/models/image.py:117-127, 438-440: autocast + GradScaler) ask the reference for NARROWER arithmetic than fp32.
+        Here each of them selects the one reduced-precision tier this path has — `neosr_set_fast_matmul(1)`: the F(4x4,3x3)
+        forward / backward-data convolutions with two bf16 pieces per operand (16 significant bits; TF32 has 11, bf16
+        autocast 8) on the bf16 MFMA, fp32 accumulation, everything else fp32 — and nothing else: no autocast region, fp32
+        storage and gradients, so the GradScaler is the identity (scale 1, never skips a step; fp32 gradients do not
+        underflow the way fp16 ones do) and the `log_dict` keys are the reference's.  Process-wide (the library switch is),
+        logged once.  Without these keys the path is fp32 throughout."""
+        asked = [k for k in ("fast_matmul", "use_amp", "bfloat16") if self.opt.get(k, False) is True]
+        env = os.environ.get("NEOSR_AMD_FAST_MATMUL", "")   # "1" / "0" force the tier on / off whatever the options say (A/B runs)
+        want = env == "1" or (bool(asked) and env != "0")
+        _C.load()
+        if want != bool(_C.FAST_MATMUL):   # (every model build sets it from ITS options: a later model without the keys is fp32)
+            _C.set_fast_matmul(want)
+        if asked and not getattr(base, "_precision_note", False):
+            base._precision_note = True
+            get_root_logger().warning(
+                "%s: the F(4x4,3x3) convolutions run their products on the bf16 MFMA with two bf16 pieces per fp32 operand "
+                "(16-bit significands, fp32 accumulation; ~1e-4 per layer); storage, gradients, weight gradients and every "
+                "other kernel stay fp32, GradScaler = identity", " / ".join(asked))
+        self.use_amp = False   # (what the closures test: nothing to scale)
 
     def graph_generator(self) -> None:
         """`compile = true` (base.py:136-137 gives the network to torch.compile): capture the train-mode forward /

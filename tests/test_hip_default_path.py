@@ -119,3 +119,73 @@ def test_image_step_default_path_vs_oracle():
     sd, esd = model.net_g.state_dict(), model.net_g_ema.state_dict()
     assert max(rel_err(sd[k], v) for k, v in tr.P.items()) < 1e-3
     assert max(rel_err(esd[k if k in esd else "module." + k], e) for k, e in zip(tr.names, tr.ema)) < 1e-3
+
+
+def test_fast_matmul_tier_default_path_vs_oracle():
+    """The `fast_matmul` tier (neosr_set_fast_matmul: two bf16 pieces per operand of the F(4x4,3x3) products, bf16 MFMA, fp32
+    accumulation; reference train.py:168-173 / image.py:117-127) on the SAME launches as the default path — chain launches
+    asserted through the profiler — against the CPU oracle at the tier's stated tolerance: 2e-3 on the output of the
+    23-block net and 1e-2 on its gradients (fp32 path: 1e-4 / 1e-3; per layer the tier is ~1e-4 of the output scale,
+    TF32 — what the reference switches on — ~5e-4).  It must also DIFFER from the fp32 run (the tier was taken), and
+    switching back restores the fp32 bits (the weight images are re-packed for the mode)."""
+    from neosr_amd import _C
+    from neosr_amd.archs import build_network
+    from oracle import neosr_oracle as orc
+
+    torch.manual_seed(1024)
+    net = build_network({"type": "esrgan", "scale": 4})
+    P = {k: v.detach().clone().requires_grad_(True) for k, v in net.state_dict().items()}
+    x = torch.rand(4, 3, 64, 64)
+    gt = torch.rand(4, 3, 256, 256)
+    y_ref = orc.rrdbnet_forward(P, x, 4)
+    orc.l1_loss(y_ref, gt).backward()
+    net = net.to(DEV).train()
+    runs = []
+    try:
+        for fast in (False, True, False):
+            _C.set_fast_matmul(fast)
+            net.zero_grad(set_to_none=True)
+            with _Prof() as prof:
+                y = net(x.to(DEV))
+                F.l1_loss(y, gt.to(DEV)).backward()
+                torch.cuda.synchronize()
+            _assert_default_trunk(prof, 23)
+            named = dict(net.named_parameters())
+            errs = {k: rel_err(named[k].grad, P[k].grad) for k in P}
+            worst = max(errs, key=errs.get)
+            runs.append((y.detach().clone(), rel_err(y, y_ref), errs[worst], worst,
+                         torch.cat([named[k].grad.flatten() for k in P])))
+    finally:
+        _C.set_fast_matmul(False)
+    print("fast_matmul tier: output rel err %.2e (fp32 %.2e), worst gradient %.2e at %s (fp32 %.2e)"
+          % (runs[1][1], runs[0][1], runs[1][2], runs[1][3], runs[0][2]))
+    assert runs[0][1] < 1e-4 and runs[0][2] < 1e-3
+    assert runs[1][1] < 2e-3 and runs[1][2] < 1e-2, (runs[1][1], runs[1][2], runs[1][3])
+    assert not torch.equal(runs[0][0], runs[1][0])
+    assert torch.equal(runs[0][0], runs[2][0]) and torch.equal(runs[0][4], runs[2][4])
+
+
+def test_fast_matmul_and_amp_option_keys_select_the_tier():
+    """`fast_matmul` / `use_amp` / `bfloat16` in an option file switch the tier on at model build; a model built afterwards
+    without them is fp32 again (the switch is process-wide and every model build sets it from its own options)."""
+    from neosr_amd import _C
+    from neosr_amd.models import build_model
+    from neosr_amd.utils.options import parse_options, set_global_opt
+
+    try:
+        for keys in ({}, {"fast_matmul": True}, {"use_amp": True, "bfloat16": True}, {}):
+            opt, _ = parse_options(str(ROOT), True, argv=["-opt", str(ROOT / "options" / "bench_esrgan.toml")])
+            opt["network_g"]["num_block"] = 1
+            opt["datasets"]["train"]["batch_size"] = 4
+            opt["dist"], opt["rank"], opt["world_size"], opt["num_gpu"] = False, 0, 1, 1
+            opt.update(keys)
+            set_global_opt(opt)
+            model = build_model(opt)
+            assert model.use_amp is False and bool(_C.FAST_MATMUL) == bool(keys), keys
+            assert bool(_C.load().neosr_set_fast_matmul(int(bool(keys)))) == bool(keys)
+            g = torch.Generator().manual_seed(3)
+            model.feed_data({"lq": torch.rand(4, 3, 64, 64, generator=g), "gt": torch.rand(4, 3, 256, 256, generator=g)})
+            model.optimize_parameters(1)
+            assert model.get_current_log()["l_g_pix"] > 0
+    finally:
+        _C.set_fast_matmul(False)

@@ -26,3 +26,15 @@ for it in range(6, 16):
     t2 = time.perf_counter()
     host.append(t1 - t0); total.append(t2 - t0)
 print("host enqueue ms/step: %.2f   enqueue + drain ms/step: %.2f" % (1e3 * sum(host) / len(host), 1e3 * sum(total) / len(total)))
+if os.environ.get("HOST_PROFILE"):   # where the host time goes: cProfile of 3 steps, cumulative time by function (our modules)
+    import cProfile, pstats
+    pr = cProfile.Profile()
+    torch.cuda.synchronize()
+    pr.enable()
+    for it in range(16, 19):
+        model.feed_data(batch); model.optimize_parameters(it)
+    pr.disable()
+    torch.cuda.synchronize()
+    st = pstats.Stats(pr)
+    st.sort_stats("cumulative").print_stats(r"neosr_amd|run_backward", 45)
+    st.sort_stats("tottime").print_stats(25)
