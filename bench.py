@@ -41,6 +41,7 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA (MI355X_MICROARCH.md; the fast_matmul tier's products)
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X dense fp32 MFMA = fp32 vector peak (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
 # algorithmic GFLOP per LR patch (fwd + bwd) of the generator / of one D fwd + full bwd / VGG taps
@@ -48,6 +49,9 @@ GFLOP_G = {"compact": 15.20, "esrgan": 440.56, "swinir_medium": 321.30, "hat_l":
 GFLOP_UNET_FWD_BWD = 155.30
 GFLOP_VGG = 153.0
 ALGO_MB_PER_PATCH = {"esrgan": 2852.8}
+
+DTYPE_FAST = ("f32 storage and accumulation; F(4x4,3x3) forward / backward-data products as two bf16 pieces per operand "
+              "(16-bit significands) on the bf16 MFMA - the `fast_matmul` tier, not the headline")
 
 ALIASES = {"paired_l1": "bench_esrgan", "otf_gan": "bench_esrgan_otf_gan", "swinir_percep": "bench_swinir_medium"}
 
@@ -126,6 +130,8 @@ def load_opt(args, world: int, rank: int) -> dict:
                                          "aug_prob": [0.5, 0.1, 0.1, 0.1, 0.5]})
     if opt["model_type"] == "otf":  # train.py:69-70
         opt["datasets"]["train"].update(opt.get("degradations", {}))
+    if getattr(args, "fast_matmul", False):  # reference train.py:168-173; here: the two-piece bf16 tier of the F(4x4,3x3) kernels
+        opt["fast_matmul"] = True
     set_global_opt(opt)
     return opt
 
@@ -267,7 +273,7 @@ def cpu_baseline(opt: dict, budget_s: float) -> dict:
 
 
 def run_config(args, config: str, world: int, rank: int, dev, steps: int, warmup: int, prof_steps: int,
-               overrides: bool = True) -> dict:
+               overrides: bool = True, fast_matmul: bool | None = None) -> dict:
     """Build the model of one option file, run `warmup` untimed and EXACTLY `steps` timed iterations (feed_data +
     optimize_parameters) bracketed by barrier + synchronize, then (prof_steps > 0) the profiled pass the roofline record
     comes from.  Returns the measurements; the model is dropped before returning."""
@@ -283,6 +289,8 @@ def run_config(args, config: str, world: int, rank: int, dev, steps: int, warmup
     a2.config = config
     if not overrides:
         a2.batch, a2.arch, a2.template_losses, a2.augment = 0, None, False, False
+    if fast_matmul is not None:
+        a2.fast_matmul = fast_matmul
     opt = load_opt(a2, world, rank)
     cfg_name = Path(config).stem
     torch.manual_seed(1024 + rank)
@@ -419,6 +427,15 @@ def run_config(args, config: str, world: int, rank: int, dev, steps: int, warmup
                               "profiled pass after the timed region with the trunk on ONE stream "
                               "(neosr_set_num_streams(1)); profiles/r04_<config>_kernel_stats.csv is rocprofv3 "
                               "--kernel-trace --stats of `NEOSR_AMD_STREAMS=1 python bench.py --config <config>`"}
+        if opt.get("fast_matmul") and dom in (0, 1) and dom_algo == 2:
+            # the tier runs FOUR bf16 products per executed fp32-equivalent multiplication on the bf16 MFMA: priced against
+            # that pipe's dense peak too (VERDICT r4 #1 "Done (iii)"); neither roof binds — the chunk loop waits for the
+            # weight stream out of L2 (76 GB/s per CU into VGPRs: profiles/NEGATIVE_RESULTS.md 5.1 / 5.4)
+            roofline["fast_matmul_tier"] = {
+                "bf16_product_tflops": round(4 * ach, 2), "bf16_mfma_peak_tflops": PEAK_BF16_MFMA_TFLOPS,
+                "bf16_mfma_frac": round(4 * ach / PEAK_BF16_MFMA_TFLOPS, 4),
+                "hbm_algo_frac_of_8TBps": roofline["hbm_algo_frac_of_8TBps"],
+                "limiter": "per-CU weight stream from L2 (76 GB/s into VGPRs, 147 KB per 32-channel chunk and CU)"}
         if ms[0] + ms[1] > 0:  # forward + backward-data launches of ONE symbol: comparable with its rocprofv3 row
             roofline["packed_conv_kernel_avg_us"] = round(1e3 * (ms[0] + ms[1]) / max(1, ln[0] + ln[1]), 2)
 
@@ -445,6 +462,9 @@ def main() -> None:
     ap.add_argument("--template-losses", action="store_true",
                     help="the shipped template loss stack instead of L1: mssim + consistency (+ perceptual + gan)")
     ap.add_argument("--augment", action="store_true", help="also enable the template batch augmentations")
+    ap.add_argument("--fast-matmul", action="store_true",
+                    help="`fast_matmul = true` (reference train.py:168-173): the reduced-precision tier of the F(4x4,3x3) "
+                         "convolutions (two bf16 pieces per operand on the bf16 MFMA, fp32 accumulate) - NOT the headline")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="default run only: skip the 5-step timing of the other four BASELINE configs (`other_configs`)")
     args = ap.parse_args()
@@ -498,18 +518,21 @@ def main() -> None:
     # the other four BASELINE configs, driver-observed: only on the default invocation (headline config, one
     # GPU, no overrides), 5 timed steps each after 2 warm-up steps, one profiled step for the executed-FLOP fraction
     others = None
-    named = not (args.batch or args.arch or args.template_losses or args.augment)
+    named = not (args.batch or args.arch or args.template_losses or args.augment or args.fast_matmul)
     if world == 1 and named and cfg_name == "bench_esrgan" and not args.no_other_configs:
         others = []
-        for oc in ("bench_compact", "bench_esrgan_otf_gan", "bench_swinir_medium", "bench_hat_l_otf_gan"):
+        # (+ the headline config once more under `fast_matmul = true`: the labelled reduced-precision tier, never the headline)
+        for oc, fast in (("bench_compact", False), ("bench_esrgan_otf_gan", False), ("bench_swinir_medium", False),
+                         ("bench_hat_l_otf_gan", False), ("bench_esrgan", True)):
             t0 = time.perf_counter()
             try:
-                r = run_config(args, oc, 1, 0, dev, 5, 2, 0 if args.no_roofline else 1, overrides=False)
+                r = run_config(args, oc, 1, 0, dev, 5, 2, 0 if args.no_roofline else 1, overrides=False, fast_matmul=fast)
             except Exception as e:  # noqa: BLE001  (a failing side config must not take the headline line with it)
                 others.append({"config": oc, "error": f"{type(e).__name__}: {e}"[:300]})
                 continue
             rf = r["roofline"] or {}
-            others.append({"config": oc, "baseline_config": opt_doc(oc), "value": round(r["B"] * 5 / r["elapsed"], 3),
+            others.append({"config": oc + (" + fast_matmul" if fast else ""), "dtype": DTYPE_FAST if fast else "f32",
+                           "baseline_config": opt_doc(oc), "value": round(r["B"] * 5 / r["elapsed"], 3),
                            "unit": "LR-patches/s", "ms_per_step": round(1e3 * r["elapsed"] / 5, 3), "steps": 5, "warmup": 2,
                            "batch": r["B"], "step_executed_frac": rf.get("step_executed_frac"),
                            "dominant_kernel": rf.get("symbol"), "dominant_frac": rf.get("frac"),
@@ -537,7 +560,7 @@ def main() -> None:
         "metric": "LR-patches/sec (64x64 -> 256x256 x4) fwd+bwd+optimizer step",
         "value": round(value, 3), "unit": "LR-patches/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE_FAST if args.fast_matmul else "f32",
         "data": "synthetic",
         "config": {"workload": workload + (f" ({opt_doc(cfg_name)})" if named else " (NOT a named BASELINE config)"),
                    "options_file": f"options/{cfg_name}.toml" if (ROOT / "options" / f"{cfg_name}.toml").exists() else args.config,
