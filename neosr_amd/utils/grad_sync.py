@@ -77,6 +77,7 @@ class GradSync:
     def begin(self, flat: torch.Tensor) -> None:
         self.finish()
         self._flat, self._lo, self.buckets = flat, flat.numel(), []
+        self.in_backward_buckets = 0
 
     def reduce_suffix(self, lo: int, event_index: int | None) -> None:
         """[lo, previous lo) of the arena is final once event `event_index` has completed: reduce it."""
@@ -84,6 +85,7 @@ class GradSync:
         hi, self._lo = self._lo, lo
         if hi <= lo:
             return
+        self.in_backward_buckets += 1   # (called by the marked backward plan: this suffix leaves while backward still runs)
         self._issue(lo, hi, self.events[event_index] if event_index is not None and self.cuda else None)
 
     def _issue(self, lo: int, hi: int, event) -> None:
@@ -234,6 +236,7 @@ class GradSync:
         if self._flat is None or self._flat.data_ptr() != flat.data_ptr() or self._flat.numel() != flat.numel():
             self.finish()
             self._flat, self._lo, self.buckets = flat, flat.numel(), []
+        self.in_backward_buckets = 0
         hi = self._lo
         self._lo = 0
         event = None

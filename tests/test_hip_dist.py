@@ -197,3 +197,29 @@ def test_two_ranks_rccl_step_equals_big_batch(tmp_path):
     if torch.cuda.device_count() < 2:
         pytest.skip("needs >= 2 MI355X (RCCL refuses two ranks on one device)")
     _run_two_ranks(tmp_path, "nccl")
+
+
+def test_bench_two_ranks_reports_data_parallel_diagnostics():
+    """`bench.py --gpus 2` (self-launch under torch.distributed.run; gloo so that both ranks may share this one MI355X): one
+    JSON line from rank 0 with the whole-job value and the `data_parallel` record VERDICT r4 #7a asks for — per-rank step
+    times, the exchange's bucket sizes and how many left from inside backward, chain status per rank, RCCL channel cap."""
+    import json
+
+    env = dict(os.environ, NEOSR_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4",
+                        "--cpu-budget", "0", "--no-roofline"], env=env, capture_output=True, text=True, timeout=900, cwd=str(ROOT))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 8 and d["scaling"] == "weak" and d["value"] > 0
+    dp = d["data_parallel"]
+    assert len(dp["ms_per_step_per_rank"]) == 2 and dp["ms_per_step_min"] <= dp["ms_per_step_max"]
+    assert dp["chain_status_per_rank"] == [0, 0] and dp["rccl_max_nchannels"] == "32"
+    ex = sorted(dp["exchange"], key=lambda e: e["rank"])
+    assert [e["rank"] for e in ex] == [0, 1]
+    for e in ex:   # esrgan: the RRDB plan sends suffix buckets from inside backward; together they are the whole arena
+        assert e["in_backward_buckets"] >= 1 and len(e["bucket_MB"]) >= 2
+        assert abs(sum(e["bucket_MB"]) - 4e-6 * 16_697_987) < 0.5, e
+    assert d["other_configs"] is None and d["cpu_baseline"] is None
