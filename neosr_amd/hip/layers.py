@@ -135,6 +135,15 @@ def _packed(w: torch.Tensor, mode: int, kind: int):
     return cache[(kind, mode)][1]
 
 
+_FRESH: dict = {}   # device -> (weights epoch, fast_matmul mode) of the last completed _repack_stale
+
+
+def images_fresh(device) -> bool:
+    """every registered packed image of `device` was refreshed for the current weights epoch and arithmetic mode (callers that
+    hold on to image tensors — the HAB block plans — skip their per-image lookups then; the tensors are re-packed in place)"""
+    return _FRESH.get(device) == (_C.WEIGHTS_EPOCH, _C.FAST_MATMUL)
+
+
 def _repack_stale(device, force: bool = False) -> None:
     lib = _C.load()
     todo = []
@@ -151,14 +160,18 @@ def _repack_stale(device, force: bool = False) -> None:
         if hit is not None and hit[0] == key and not (force and w.requires_grad):
             continue
         assert w.is_contiguous() and w.shape[2:] == (3, 3)
-        n = _image_floats(w, kind, mode)
-        dst = hit[1] if hit is not None and hit[1].numel() == n else torch.empty(n, device=device, dtype=torch.float32)
+        if hit is not None and hit[1].device == device:   # (a parameter's shape is fixed: the image keeps its size)
+            dst = hit[1]
+        else:
+            dst = torch.empty(_image_floats(w, kind, mode), device=device, dtype=torch.float32)
         cache[(kind, mode)] = (key, dst)
         todo.append(_C.PackItem(w=w.data_ptr(), dst=dst.data_ptr(), w_cout=w.shape[0], w_cin=w.shape[1], mode=mode,
                                 kind=kind))
     if todo:
         arr = (_C.PackItem * len(todo))(*todo)
         _C.check(lib.neosr_conv3x3_pack_many(arr, len(todo), _st()), "neosr_conv3x3_pack_many")
+    if not torch.cuda.is_current_stream_capturing():
+        _FRESH[device] = (_C.WEIGHTS_EPOCH, _C.FAST_MATMUL)
 
 
 def packed_weights(w: torch.Tensor, mode: int):

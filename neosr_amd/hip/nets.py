@@ -124,6 +124,40 @@ def flat_view_of(tensors) -> torch.Tensor | None:
     return flat
 
 
+def group_arena(cache: dict, plist: list):
+    """(flat view of the parameters | None, [parameters with requires_grad]) of an optimizer group.  The fused optimizer
+    steps ask this once per group and step; for a layer-composed generator (hat_l: 1 710 parameters) building `.data` views,
+    the layout and the contiguity checks from scratch cost ~2 ms per call (tools/host_overhead.py, HOST_PROFILE=1).  The
+    layout of a group is cached on the optimizer (`cache`, keyed by the group's own list object); the steady-state call
+    is one pass of `requires_grad` + pointer compares against it.  Anything that does not match falls back to the full
+    check (a re-homed parameter, a changed `requires_grad`)."""
+    ent = cache.get(id(plist))
+    if ent is not None and ent[5] is plist and ent[0] == len(plist):   # (the entry keeps the list alive: its id is not re-used)
+        _n, params, offs, total, n_frozen, _keep = ent
+        base = params[0].data_ptr()
+        ok = True
+        for prm, off in zip(params, offs):
+            if prm.data_ptr() != base + 4 * off or not prm.requires_grad:
+                ok = False
+                break
+        if ok and n_frozen:   # (a group with frozen members: none of them may have become trainable)
+            ok = sum(1 for prm in plist if not prm.requires_grad) == n_frozen
+        if ok:
+            t0 = params[0]
+            if t0.untyped_storage().nbytes() >= (t0.storage_offset() + total) * 4:
+                flat = torch.empty(0, device=t0.device, dtype=torch.float32)
+                flat.set_(t0.untyped_storage(), t0.storage_offset(), (total,), (1,))
+                return flat, params
+    params = [prm for prm in plist if prm.requires_grad]
+    flat = flat_view_of([prm.data for prm in params]) if params else None
+    if flat is not None:
+        offs, total = arena_layout(params)
+        cache[id(plist)] = (len(plist), params, offs, total, len(plist) - len(params), plist)
+    else:
+        cache.pop(id(plist), None)
+    return flat, params
+
+
 def flat_grad_of(params) -> torch.Tensor | None:
     """If all ``p.grad`` sit in one buffer at the arena layout (as our plans emit them), return that
     buffer as a 1-D tensor without copying; else None."""

@@ -16,7 +16,7 @@ import torch
 from torch.optim.optimizer import Optimizer
 
 from neosr_amd import _C
-from neosr_amd.hip.nets import arena_layout, flat_grad_of, flat_view_of, pack_grads
+from neosr_amd.hip.nets import arena_layout, flat_grad_of, flat_view_of, group_arena, pack_grads
 
 
 class AdamW(Optimizer):
@@ -53,8 +53,7 @@ class AdamW(Optimizer):
     # -- state ---------------------------------------------------------------------------
     def _group_arena(self, group):
         """(param_flat, params) if the group's params sit in one buffer at the arena layout."""
-        params = [p for p in group["params"] if p.requires_grad]
-        return flat_view_of([p.data for p in params]), params
+        return group_arena(self.__dict__.setdefault("_neosr_group_cache", {}), group["params"])
 
     def _ensure_state(self, gi, params, total):
         st = self._flat.get(gi)

@@ -236,7 +236,7 @@ class GradSync:
         if self._flat is None or self._flat.data_ptr() != flat.data_ptr() or self._flat.numel() != flat.numel():
             self.finish()
             self._flat, self._lo, self.buckets = flat, flat.numel(), []
-        self.in_backward_buckets = 0
+            self.in_backward_buckets = 0   # (nothing of this arena left during backward; else the count of the pass stands)
         hi = self._lo
         self._lo = 0
         event = None
