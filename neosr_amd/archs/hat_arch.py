@@ -111,10 +111,10 @@ class HAB(nn.Module):
         # is valid again without eight per-image lookups per block and pass (~100 us of host time per HAB, hat_l: 7 ms / step)
         key = (c0._version, c2._version, c0.data_ptr(), b, h, w)
         hit = getattr(self, "_plan_imgs", None)
-        # (not while a hipGraph capture is pending / running: `L._packed` must see the request — its first one inside a
-        # capture re-packs every image as a node of the graph, utils/graph.py)
-        if (hit is not None and hit[0] == key and L.images_fresh(c0.device) and not L.FORCE_REPACK_IN_CAPTURE
-                and not torch.cuda.is_current_stream_capturing()):
+        # (not while a hipGraph capture is PENDING: `L._packed` must see the first request inside the capture — it re-packs
+        # every image as a node of the graph, utils/graph.py — and clears the flag; a refresh made inside a capture does
+        # not mark the images fresh, so the blocks of a captured pass keep asking)
+        if hit is not None and hit[0] == key and not L.FORCE_REPACK_IN_CAPTURE and L.images_fresh(c0.device):
             return hit[1]
         out = {}
         for tag, conv in (("c0", self.conv_block.cab[0]), ("c2", self.conv_block.cab[2])):
