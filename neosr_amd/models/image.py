@@ -8,9 +8,10 @@ and the same `log_dict` keys; the work is re-staged for one MI355X per process:
   step:      (RCCL all-reduce of the flat arena) -> fused clip + AdamW + EMA kernel
   logging:   loss scalars stay on the device until `get_current_log()`
 
-Options the reference supports but that are not on the benchmarked path (SAM, ECO, wavelet
-guidance, AMP) raise `NotImplementedError` instead of silently
-doing something else.
+Built besides the plain step: gradient accumulation, `train.sam` (fsam), `train.eco`, `match_lq_colors`, the GAN / perceptual /
+mssim / consistency loss stack, every optimizer of the factory.  `use_amp` / `bfloat16` / `fast_matmul` select the one
+reduced-precision tier of this path (models/base.py:precision_options).  What is NOT built raises `NotImplementedError`
+instead of silently doing something else: `wavelet_guided`, the dists / ldl / ff / gw losses.
 """
 
 from __future__ import annotations

@@ -2,9 +2,9 @@
 # CPU baseline included), JSON lines -> gpurun_out/final_${1:-r04}_<config>.json
 cd /root/repo
 mkdir -p gpurun_out
-TAG=${1:-r04}
+TAG=${1:-r05}
 for c in bench_esrgan bench_compact bench_esrgan_otf_gan bench_swinir_medium bench_hat_l_otf_gan; do
-  python bench.py --config $c 2> gpurun_out/final_${TAG}_$c.err | tail -1 > gpurun_out/final_${TAG}_$c.json
+  python bench.py --config $c --no-other-configs 2> gpurun_out/final_${TAG}_$c.err | tail -1 > gpurun_out/final_${TAG}_$c.json
 done
 python bench.py 2>/dev/null | tail -1 > gpurun_out/final_${TAG}_default.json
 for c in bench_esrgan bench_compact bench_esrgan_otf_gan bench_swinir_medium bench_hat_l_otf_gan; do

@@ -10,7 +10,7 @@ done
 for rep in 1 2; do
 for f in 0 1; do
 for c in bench_swinir_medium bench_hat_l_otf_gan; do
-  NEOSR_GEMM_FULLK=$f python bench.py --config $c --no-roofline --cpu-budget 0 --steps 20 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$c fullk=$f', d['value'], d['ms_per_step'])" >> gpurun_out/r04_g10_ab.log
+  NEOSR_GEMM_FULLK=$f python bench.py --config $c --no-roofline --cpu-budget 0 --no-other-configs --steps 20 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$c fullk=$f', d['value'], d['ms_per_step'])" >> gpurun_out/r04_g10_ab.log
 done
 done
 done

@@ -4,7 +4,7 @@ mkdir -p gpurun_out
 for rep in 1 2; do
   for v in old new; do
     if [ $v = old ]; then export NEOSR_AMD_LIB=$PWD/experiments/old/libneosr_amd.so; else unset NEOSR_AMD_LIB; fi
-    python bench.py --no-roofline --cpu-budget 0 --steps 30 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v', d['value'], d['ms_per_step'])" >> gpurun_out/r04_g2_ab.log
+    python bench.py --no-roofline --cpu-budget 0 --no-other-configs --steps 30 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v', d['value'], d['ms_per_step'])" >> gpurun_out/r04_g2_ab.log
   done
 done
 unset NEOSR_AMD_LIB

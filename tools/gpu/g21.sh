@@ -6,7 +6,7 @@ for rep in 1 2; do
 for v in old new; do
   if [ $v = old ]; then export NEOSR_AMD_LIB=$PWD/experiments/old/libneosr_amd.so; else unset NEOSR_AMD_LIB; fi
 for c in bench_swinir_medium bench_hat_l_otf_gan; do
-  python bench.py --config $c --no-roofline --cpu-budget 0 --steps 20 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$c $v', d['value'], d['ms_per_step'])" >> gpurun_out/r04_g21_ab.log
+  python bench.py --config $c --no-roofline --cpu-budget 0 --no-other-configs --steps 20 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$c $v', d['value'], d['ms_per_step'])" >> gpurun_out/r04_g21_ab.log
 done
 done
 done

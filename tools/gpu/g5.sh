@@ -6,6 +6,6 @@ for c in bench_swinir_medium bench_hat_l_otf_gan; do
 for v in 0 1; do
   echo "== $c NEOSR_AMD_BLOCK_PLANS=$v" >> gpurun_out/r04_g5_host.log
   NEOSR_AMD_BLOCK_PLANS=$v timeout 300 python tools/host_overhead.py $c 2>&1 | tail -1 >> gpurun_out/r04_g5_host.log
-  NEOSR_AMD_BLOCK_PLANS=$v python bench.py --config $c --no-roofline --cpu-budget 0 --steps 20 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('plans=$v', d['value'], d['ms_per_step'])" >> gpurun_out/r04_g5_host.log
+  NEOSR_AMD_BLOCK_PLANS=$v python bench.py --config $c --no-roofline --cpu-budget 0 --no-other-configs --steps 20 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('plans=$v', d['value'], d['ms_per_step'])" >> gpurun_out/r04_g5_host.log
 done
 done

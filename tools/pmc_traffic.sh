@@ -7,7 +7,7 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 export NEOSR_AMD_STREAMS=1
-BENCH="python $R/bench.py --steps 2 --warmup 1 --cpu-budget 0 --no-roofline $@"
+BENCH="python $R/bench.py --steps 2 --warmup 1 --cpu-budget 0 --no-other-configs --no-roofline $@"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o fetch --output-format csv -- $BENCH > $OUT/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o write --output-format csv -- $BENCH > $OUT/write.log 2>&1
 python - <<PY

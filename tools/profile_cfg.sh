@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_${ROUND}_${CFG}
 mkdir -p $OUT
-ARGS="--config $CFG --cpu-budget 0"
+ARGS="--config $CFG --cpu-budget 0 --no-other-configs"
 NEOSR_AMD_STREAMS=1 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace --output-format csv -- python $R/bench.py $ARGS --steps 5 --warmup 2 > $OUT/trace.log 2>&1
 rocprofv3 --kernel-trace --stats -d $OUT/trace2 -o trace --output-format csv -- python $R/bench.py $ARGS --steps 5 --warmup 2 > $OUT/trace2.log 2>&1
 cp $(find $OUT/trace -name '*kernel_stats.csv' | head -1) $OUT/kernel_stats.csv

@@ -10,9 +10,9 @@ mkdir -p $OUT
 # per-kernel numbers are taken with the RRDB trunk on one stream (no overlapping launches), as in
 # bench.py's profiled pass; trace2 is the default two-chain run of the same command
 export NEOSR_AMD_STREAMS=1
-BENCH="python $R/bench.py --steps 3 --warmup 1 --cpu-budget 0 --no-roofline"
-rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace --output-format csv -- python $R/bench.py --steps 5 --warmup 2 --cpu-budget 0 > $OUT/trace.log 2>&1
-NEOSR_AMD_STREAMS=2 rocprofv3 --kernel-trace --stats -d $OUT/trace2 -o trace --output-format csv -- python $R/bench.py --steps 5 --warmup 2 --cpu-budget 0 > $OUT/trace2.log 2>&1
+BENCH="python $R/bench.py --steps 3 --warmup 1 --cpu-budget 0 --no-other-configs --no-roofline"
+rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace --output-format csv -- python $R/bench.py --steps 5 --warmup 2 --cpu-budget 0 --no-other-configs > $OUT/trace.log 2>&1
+NEOSR_AMD_STREAMS=2 rocprofv3 --kernel-trace --stats -d $OUT/trace2 -o trace --output-format csv -- python $R/bench.py --steps 5 --warmup 2 --cpu-budget 0 --no-other-configs > $OUT/trace2.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o fetch --output-format csv -- $BENCH > $OUT/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o write --output-format csv -- $BENCH > $OUT/write.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $OUT/sq -o sq --output-format csv -- $BENCH > $OUT/sq.log 2>&1

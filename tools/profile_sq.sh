@@ -9,7 +9,7 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_${ROUND}_${CFG}
 mkdir -p $OUT
 export NEOSR_AMD_STREAMS=1
-BENCH="python $R/bench.py --config $CFG --cpu-budget 0 --steps 2 --warmup 1 --no-roofline"
+BENCH="python $R/bench.py --config $CFG --cpu-budget 0 --no-other-configs --steps 2 --warmup 1 --no-roofline"
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 -d $OUT/sq1 -o sq1 --output-format csv -- $BENCH > $OUT/sq1.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_INSTS_VALU -d $OUT/sq2 -o sq2 --output-format csv -- $BENCH > $OUT/sq2.log 2>&1
 python - <<PY

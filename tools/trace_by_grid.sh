@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/bygrid_$CFG
 mkdir -p $OUT
-rocprofv3 --kernel-trace -d $OUT/t -o t --output-format csv -- python $R/bench.py --config $CFG --cpu-budget 0 --no-roofline --steps $STEPS --warmup 2 > $OUT/log 2>&1
+rocprofv3 --kernel-trace -d $OUT/t -o t --output-format csv -- python $R/bench.py --config $CFG --cpu-budget 0 --no-other-configs --no-roofline --steps $STEPS --warmup 2 > $OUT/log 2>&1
 python - <<PY
 import csv, glob, collections
 agg = collections.defaultdict(lambda: [0, 0.0])
