@@ -164,6 +164,10 @@ int neosr_set_conv_chain(int on);
  * reduced-precision tier, never the default (0; env NEOSR_AMD_FAST_MATMUL=1).  The weight images are packed for the mode
  * (same size): switch BEFORE packing / re-pack after a switch.  Returns the previous setting. */
 int neosr_set_fast_matmul(int on);
+/* nn.Linear GEMMs (neosr/archs/swinir_arch.py:15-38, 139-143; hat_arch.py): 1 (default; env NEOSR_AMD_GEMM_X3) = products on
+ * v_mfma_f32_32x32x16_bf16 from bf16x3 operands (each fp32 value as three bf16 pieces, the six leading cross products, fp32
+ * accumulation: fp32-faithful, ~2^-24 per product); 0 = v_mfma_f32_32x32x2_f32.  Returns the previous setting. */
+int neosr_set_gemm_x3(int on);
 /* Behind a chain launch the fifteen weight gradients of an RRDB run as ONE neosr_conv3x3_wgrad_multi launch (1, default;
  * env NEOSR_AMD_WGRAD_RRDB) or as one launch per RDB (0): another split of the pixel range, i.e. another summation
  * order (~1e-7 relative).  Returns the previous setting. */

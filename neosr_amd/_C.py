@@ -293,6 +293,7 @@ SIGNATURES: dict[str, tuple] = {
     "neosr_set_wgrad4": (C.c_int, [C.c_int]),
     "neosr_set_conv_chain": (C.c_int, [C.c_int]),
     "neosr_set_fast_matmul": (C.c_int, [C.c_int]),
+    "neosr_set_gemm_x3": (C.c_int, [C.c_int]),
     "neosr_set_wgrad_rrdb": (C.c_int, [C.c_int]),
     "neosr_set_conv_chain_sync": (C.c_int, [C.c_int]),
     "neosr_conv_chain_status": (C.c_int, []),

@@ -71,6 +71,54 @@ __device__ __forceinline__ f32x4 ld4(const float* p, int vec) {
   return r;
 }
 
+// ---- bf16x3 operands (round 5).  An fp32 value as three bf16 pieces, x = p0 + p1 + p2 with p0 = the upper 16 bits of the
+// pattern, p1 = the upper 16 bits of the exact remainder x - p0 and p2 = bf16_rne(x - p0 - p1): 8 + 8 + 8 significant
+// bits.  A product of two such values from the six leading cross terms p0q0, p0q1, p1q0, p0q2, p1q1, p2q0 on the bf16 MFMA
+// (fp32 accumulate) differs from the fp32 product by ~2^-24 of it — the dropped terms are 2^-24 and below — so a GEMM built
+// from them is as accurate as the fp32 MFMA one (tools/micro/split_err.py: 1.5e-6 vs 2.8e-6 rel. L2 on a K = 192 Winograd
+// product against float64) while v_mfma_f32_32x32x16_bf16 retires 16 K-values per 32 cycles against 2 per 64 for
+// v_mfma_f32_32x32x2_f32: 6 x 32 cycles per 16 reduction indices instead of 8 x 64.
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// the 8 reduction values of a lane (two 16-byte LDS quads) -> the three 8 x bf16 MFMA operands
+__device__ __forceinline__ void split3(const f32x4 lo4, const f32x4 hi4, bf16x8 (&P)[3]) {
+  unsigned b[8];
+  float r1[8], r2[8];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    b[e] = __float_as_uint(lo4[e]);
+    b[4 + e] = __float_as_uint(hi4[e]);
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    r1[e] = __uint_as_float(b[e]) - __uint_as_float(b[e] & 0xffff0000u);
+    r2[e] = r1[e] - __uint_as_float(__float_as_uint(r1[e]) & 0xffff0000u);
+  }
+  u32x4 p0, p1, p2;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    p0[i] = __builtin_amdgcn_perm(b[2 * i + 1], b[2 * i], 0x07060302u);
+    p1[i] = __builtin_amdgcn_perm(__float_as_uint(r1[2 * i + 1]), __float_as_uint(r1[2 * i]), 0x07060302u);
+    unsigned t;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(t) : "v"(r2[2 * i]), "v"(r2[2 * i + 1]));
+    p2[i] = t;
+  }
+  P[0] = __builtin_bit_cast(bf16x8, p0);
+  P[1] = __builtin_bit_cast(bf16x8, p1);
+  P[2] = __builtin_bit_cast(bf16x8, p2);
+}
+// acc += sum over the six leading cross terms of (weight pieces W) x (activation pieces X), smallest terms first
+__device__ __forceinline__ f32x16 mac6(const bf16x8 (&W)[3], const bf16x8 (&X)[3], f32x16 acc) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[2], X[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[0], X[2], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[1], X[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[1], X[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[0], X[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[0], X[0], acc, 0, 0, 0);
+  return acc;
+}
+
 // epilogue shared by all GEMM kernels: lane owns C row m = m0 + 32*wave + l31 and the column quads
 // 32t + 8g + 4lh + {0..3} (D was formed as Bfrag x Afrag)
 struct NoPref {};
@@ -297,9 +345,17 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(const GemmArgs args) 
 // distinct slots each: conflict-free.
 // Fragment convention: lanes with lh = 0 read quad 2s, lanes with lh = 1 quad 2s+1; MFMA e of step s then
 // multiplies k = 8s + e (lh 0) and k = 8s + 4 + e (lh 1) — the same pairing for both operands.
-__global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(const GemmArgs args) {
+// X3: the products on the bf16 MFMA from bf16x3 operands (see split3 / mac6), everything else unchanged.
+template <bool X3>
+__device__ __forceinline__ void gemm_nt_glds_body(const GemmArgs& args) {
   const neosr_gemm_desc& d = args.d;
-  __shared__ __attribute__((aligned(1024))) float lds[2 * (BM + BN) * BK];
+  // X3: the B (weight) tile lives in LDS as three bf16 planes — 12 slots of 16 bytes per row (slot = 4 piece + 2 pair-step
+  // + lane half: the 8 reduction indices one lane half feeds to one MFMA), split ONCE per workgroup when the tile is staged
+  // through registers, instead of by every wave at every fragment read; slot s of row n sits at s ^ ((n >> 2) & 3)
+  // (a ds_read_b128 lane group then covers sixteen distinct 16-byte bank slots).  The A tile stays an fp32 LDS-DMA image:
+  // every A element is read by exactly one wave, so splitting it at the fragment read costs the same as at staging.
+  constexpr int BSZ = X3 ? BN * 48 : BN * BK;   // floats per B buffer (X3: 64 rows x 192 bytes)
+  __shared__ __attribute__((aligned(1024))) float lds[2 * (BM * BK + BSZ)];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
   const int tiles = args.tiles_m * args.tiles_n;
   const int chunk = gridDim.x >> 3;
@@ -345,17 +401,40 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(const GemmArgs arg
   }
   typedef __attribute__((address_space(3))) void* lds_vp;
   auto issue = [&](int k0, int buf) {
-    float* abuf = lds + buf * (BM + BN) * BK;
+    float* abuf = lds + buf * (BM * BK + BSZ);
     float* bbuf = abuf + BM * BK;
     const bool last = k0 == kc_last * BK;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_vp)(abuf + (4 * i + wave) * 256), 16, last ? offA_l[i] : offA[i],
                                                k0 * 4, 0, 0);
+    if constexpr (!X3) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_vp)(bbuf + (4 * i + wave) * 256), 16, last ? offB_l[i] : offB[i],
-                                               k0 * 4, 0, 0);
+      for (int i = 0; i < 2; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_vp)(bbuf + (4 * i + wave) * 256), 16, last ? offB_l[i] : offB[i],
+                                                 k0 * 4, 0, 0);
+    }
+  };
+  // X3: thread (row tid >> 2, octet tid & 3) carries 8 consecutive reduction values of the NEXT B chunk in registers
+  const int bn = tid >> 2, bo = tid & 3;
+  const bool bn_ok = n0 + bn < d.N;
+  const int offB3 = bn_ok ? ((n0 + bn) * d.ldb + 8 * bo) * 4 : OOB;
+  const int offB3_l0 = (bn_ok && kc_last * BK + 8 * bo < K) ? offB3 : OOB;
+  const int offB3_l1 = (bn_ok && kc_last * BK + 8 * bo + 4 < K) ? offB3 + 16 : OOB;
+  f32x4 breg0 = {0.f, 0.f, 0.f, 0.f}, breg1 = {0.f, 0.f, 0.f, 0.f};
+  typedef decltype(__builtin_amdgcn_raw_buffer_load_b128(rB, 0, 0, 0)) rawq_t;
+  auto bload = [&](int k0) {
+    const bool last = k0 == kc_last * BK;
+    breg0 = __builtin_bit_cast(f32x4, (rawq_t)__builtin_amdgcn_raw_buffer_load_b128(rB, last ? offB3_l0 : offB3, k0 * 4, 0));
+    breg1 = __builtin_bit_cast(f32x4, (rawq_t)__builtin_amdgcn_raw_buffer_load_b128(rB, last ? offB3_l1 : (offB3 == OOB ? OOB : offB3 + 16), k0 * 4, 0));
+  };
+  auto bstore = [&](int buf) {
+    float* bbuf = lds + buf * (BM * BK + BSZ) + BM * BK;
+    bf16x8 P[3];
+    split3(breg0, breg1, P);
+#pragma unroll
+    for (int p3 = 0; p3 < 3; ++p3)
+      *reinterpret_cast<bf16x8*>(bbuf + bn * 48 + 4 * ((4 * p3 + bo) ^ ((bn >> 2) & 3))) = P[p3];
   };
   f32x16 acc[2];
 #pragma unroll
@@ -364,6 +443,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(const GemmArgs arg
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   const int nchunks = (K + BK - 1) / BK;
   issue(0, 0);
+  if constexpr (X3) {
+    bload(0);
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    bstore(0);
+  }
   __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
   __syncthreads();
   const int arow = wave * 32 + l31;
@@ -376,8 +460,31 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(const GemmArgs arg
   auto run = [&](auto two_tag) {
     constexpr bool TWO = decltype(two_tag)::value;
     auto mac = [&](int c, int nsteps) {
-      const float* abuf = lds + (c & 1) * (BM + BN) * BK;
+      const float* abuf = lds + (c & 1) * (BM * BK + BSZ);
       const float* bbuf = abuf + BM * BK;
+      if constexpr (X3) {
+        // pair-step ps = the 16 reduction indices 16 ps .. 16 ps + 15; lane half lh owns 8 consecutive ones (two A quads,
+        // one 16-byte slot of each B plane)
+        const int sa = (arow >> 1) & 7, sb = (l31 >> 2) & 3;
+#pragma unroll
+        for (int ps = 0; ps < BK / 16; ++ps) {
+          if (2 * ps < nsteps) {
+            const int q = 4 * ps + 2 * lh;
+            bf16x8 X[3], W0[3], W1[3];
+            split3(*reinterpret_cast<const f32x4*>(abuf + arow * BK + 4 * (q ^ sa)),
+                   *reinterpret_cast<const f32x4*>(abuf + arow * BK + 4 * ((q + 1) ^ sa)), X);
+#pragma unroll
+            for (int p3 = 0; p3 < 3; ++p3) {
+              const int sl = 4 * ((4 * p3 + 2 * ps + lh) ^ sb);
+              W0[p3] = *reinterpret_cast<const bf16x8*>(bbuf + l31 * 48 + sl);
+              if (TWO) W1[p3] = *reinterpret_cast<const bf16x8*>(bbuf + (32 + l31) * 48 + sl);
+            }
+            acc[0] = mac6(W0, X, acc[0]);
+            if (TWO) acc[1] = mac6(W1, X, acc[1]);
+          }
+        }
+        return;
+      }
 #pragma unroll
       for (int s = 0; s < BK / 8; ++s) {
         if (s < nsteps) {
@@ -396,8 +503,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(const GemmArgs arg
     };
     for (int c = 0; c + 1 < nchunks; ++c) {
       issue((c + 1) * BK, (c + 1) & 1);
+      if constexpr (X3) bload((c + 1) * BK);
       mac(c, BK / 8);
       __builtin_amdgcn_s_waitcnt(0x0f70);  // the next chunk has landed ...
+      if constexpr (X3) bstore((c + 1) & 1);   // (... its B values in registers: split and written as planes)
       __syncthreads();                      // ... for every wave, and this buffer is free to overwrite
     }
     if (d.res) {
@@ -418,15 +527,19 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(const GemmArgs arg
     run(std::false_type{});
   epilogue<0, float4[8]>(args, acc, m0, n0, 0, bias_s, resq);
 }
+__global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(const GemmArgs args) { gemm_nt_glds_body<false>(args); }
+__global__ __launch_bounds__(256, 2) void gemm_nt_glds_x3_kernel(const GemmArgs args) { gemm_nt_glds_body<true>(args); }
 
 // 64-row variant of gemm_nt_glds_kernel for launches that would not fill the chip with 128-row tiles (M = 16 384 tokens:
 // 384 tiles of 128 x 64 for N = 180 on 768 resident slots).  The 4 waves form a 2 x 2 grid of 32 x 32 tiles (one
 // accumulator each: one A and one B ds_read_b128 per 4 MFMAs), everything else — DMA staging, XOR-swizzled images, one
 // barrier per chunk, trimmed last chunk, bias tile in LDS, residual quads requested under the last chunk — as above.
 constexpr int BM2 = 64;
-__global__ __launch_bounds__(256, 2) void gemm_nt_glds64_kernel(const GemmArgs args) {
+template <bool X3>
+__device__ __forceinline__ void gemm_nt_glds64_body(const GemmArgs& args) {
   const neosr_gemm_desc& d = args.d;
-  __shared__ __attribute__((aligned(1024))) float lds[2 * (BM2 + BN) * BK];
+  constexpr int BSZ = X3 ? BN * 48 : BN * BK;   // (X3: the B tile as three bf16 planes, see gemm_nt_glds_body)
+  __shared__ __attribute__((aligned(1024))) float lds[2 * (BM2 * BK + BSZ)];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
   const int wm = wave & 1, wn = wave >> 1;
   const int tiles = args.tiles_m * args.tiles_n;
@@ -458,29 +571,72 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds64_kernel(const GemmArgs a
   }
   typedef __attribute__((address_space(3))) void* lds_vp;
   auto issue = [&](int k0, int buf) {
-    float* abuf = lds + buf * (BM2 + BN) * BK;
+    float* abuf = lds + buf * (BM2 * BK + BSZ);
     float* bbuf = abuf + BM2 * BK;
     const bool last = k0 == kc_last * BK;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_vp)(abuf + (4 * i + wave) * 256), 16, last ? offA_l[i] : offA[i],
                                                k0 * 4, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_vp)(bbuf + (4 * i + wave) * 256), 16, last ? offB_l[i] : offB[i],
-                                               k0 * 4, 0, 0);
+      if constexpr (!X3)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_vp)(bbuf + (4 * i + wave) * 256), 16, last ? offB_l[i] : offB[i],
+                                                 k0 * 4, 0, 0);
     }
+  };
+  const int bn = tid >> 2, bo = tid & 3;
+  const bool bn_ok = n0 + bn < d.N;
+  const int offB3 = bn_ok ? ((n0 + bn) * d.ldb + 8 * bo) * 4 : OOB;
+  const int offB3_l0 = (bn_ok && kc_last * BK + 8 * bo < K) ? offB3 : OOB;
+  const int offB3_l1 = (bn_ok && kc_last * BK + 8 * bo + 4 < K) ? offB3 + 16 : OOB;
+  f32x4 breg0 = {0.f, 0.f, 0.f, 0.f}, breg1 = {0.f, 0.f, 0.f, 0.f};
+  typedef decltype(__builtin_amdgcn_raw_buffer_load_b128(rB, 0, 0, 0)) rawq_t;
+  auto bload = [&](int k0) {
+    const bool last = k0 == kc_last * BK;
+    breg0 = __builtin_bit_cast(f32x4, (rawq_t)__builtin_amdgcn_raw_buffer_load_b128(rB, last ? offB3_l0 : offB3, k0 * 4, 0));
+    breg1 = __builtin_bit_cast(f32x4, (rawq_t)__builtin_amdgcn_raw_buffer_load_b128(rB, last ? offB3_l1 : (offB3 == OOB ? OOB : offB3 + 16), k0 * 4, 0));
+  };
+  auto bstore = [&](int buf) {
+    float* bbuf = lds + buf * (BM2 * BK + BSZ) + BM2 * BK;
+    bf16x8 P[3];
+    split3(breg0, breg1, P);
+#pragma unroll
+    for (int p3 = 0; p3 < 3; ++p3)
+      *reinterpret_cast<bf16x8*>(bbuf + bn * 48 + 4 * ((4 * p3 + bo) ^ ((bn >> 2) & 3))) = P[p3];
   };
   f32x16 acc[1];
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
   const int nchunks = (K + BK - 1) / BK;
   issue(0, 0);
+  if constexpr (X3) {
+    bload(0);
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    bstore(0);
+  }
   __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
   __syncthreads();
   const int arow = wm * 32 + l31, brow = wn * 32 + l31;
   const int last_steps = (K - (nchunks - 1) * BK + 7) >> 3;
   auto mac = [&](int c, int nsteps) {
-    const float* abuf = lds + (c & 1) * (BM2 + BN) * BK;
+    const float* abuf = lds + (c & 1) * (BM2 * BK + BSZ);
     const float* bbuf = abuf + BM2 * BK;
+    if constexpr (X3) {
+      const int sa = (arow >> 1) & 7, sb = (brow >> 2) & 3;
+#pragma unroll
+      for (int ps = 0; ps < BK / 16; ++ps) {
+        if (2 * ps < nsteps) {
+          const int q = 4 * ps + 2 * lh;
+          bf16x8 X[3], W[3];
+          split3(*reinterpret_cast<const f32x4*>(abuf + arow * BK + 4 * (q ^ sa)),
+                 *reinterpret_cast<const f32x4*>(abuf + arow * BK + 4 * ((q + 1) ^ sa)), X);
+#pragma unroll
+          for (int p3 = 0; p3 < 3; ++p3)
+            W[p3] = *reinterpret_cast<const bf16x8*>(bbuf + brow * 48 + 4 * ((4 * p3 + 2 * ps + lh) ^ sb));
+          acc[0] = mac6(W, X, acc[0]);
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int s = 0; s < BK / 8; ++s) {
       if (s < nsteps) {
@@ -494,8 +650,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds64_kernel(const GemmArgs a
   };
   for (int c = 0; c + 1 < nchunks; ++c) {
     issue((c + 1) * BK, (c + 1) & 1);
+    if constexpr (X3) bload((c + 1) * BK);
     mac(c, BK / 8);
     __builtin_amdgcn_s_waitcnt(0x0f70);
+    if constexpr (X3) bstore((c + 1) & 1);
     __syncthreads();
   }
   float4 resq[4];
@@ -510,6 +668,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_glds64_kernel(const GemmArgs a
   mac(nchunks - 1, last_steps);
   epilogue<0, float4[4], 1>(args, acc, m0, n0, 0, bias_s, resq, wm * 32, wn * 32);
 }
+__global__ __launch_bounds__(256, 2) void gemm_nt_glds64_kernel(const GemmArgs args) { gemm_nt_glds64_body<false>(args); }
+__global__ __launch_bounds__(256, 2) void gemm_nt_glds64_x3_kernel(const GemmArgs args) { gemm_nt_glds64_body<true>(args); }
 
 
 // (Round 4 tried a whole-K-panel variant for the K = 180 Linears — a 32 x 64 tile whose six chunks are all requested at
@@ -831,6 +991,14 @@ constexpr bool g_no_tnreg = false;
 #endif
 int g_tn_rounds = TN_REG_ROUNDS;
 int g_bm64_below = 600;   // 128 x 64 tiles of a launch below which the NT GEMM switches to 64-row tiles
+int g_gemm_x3 = -1;       // bf16x3 products in the NT kernels: -1 = read NEOSR_AMD_GEMM_X3 on first use (default on)
+bool gemm_x3() {
+  if (g_gemm_x3 < 0) {
+    const char* e = getenv("NEOSR_AMD_GEMM_X3");
+    g_gemm_x3 = (e && e[0] == '0') ? 0 : 1;
+  }
+  return g_gemm_x3 == 1;
+}
 
 // register-fed TN kernel: usable when the ragged last m tile still splits into whole 3-column lane groups
 bool tn_reg_ok(int M, int N, int K) {
@@ -911,9 +1079,11 @@ extern "C" int neosr_gemm(const neosr_gemm_desc* dp, void* stream) {
     if (bm64) {
       a.tiles_m = ceil_div(d.M, BM2);
       grid.x = ceil_div(a.tiles_m * a.tiles_n, 8) * 8;
-      hipLaunchKernelGGL(gemm_nt_glds64_kernel, grid, dim3(256), 0, st, a);
+      if (gemm_x3()) hipLaunchKernelGGL(gemm_nt_glds64_x3_kernel, grid, dim3(256), 0, st, a);
+      else hipLaunchKernelGGL(gemm_nt_glds64_kernel, grid, dim3(256), 0, st, a);
     } else {
-      hipLaunchKernelGGL(gemm_nt_glds_kernel, grid, dim3(256), 0, st, a);
+      if (gemm_x3()) hipLaunchKernelGGL(gemm_nt_glds_x3_kernel, grid, dim3(256), 0, st, a);
+      else hipLaunchKernelGGL(gemm_nt_glds_kernel, grid, dim3(256), 0, st, a);
     }
   } else if (d.mode == NEOSR_GEMM_NT) {
     hipLaunchKernelGGL(gemm_mfma_kernel<0>, grid, dim3(256), 0, st, a);
@@ -1121,4 +1291,12 @@ extern "C" int neosr_colsum_many(const neosr_colsum_item* items, int32_t n, floa
   }
   NEOSR_LAUNCH_CHECK();
   return 0;
+}
+
+// The Linear GEMMs' products on the bf16 MFMA from bf16x3 operands (1, default; env NEOSR_AMD_GEMM_X3) or on the fp32 MFMA
+// (0).  Both are fp32-faithful (see split3); the results differ in the last bits.  Returns the previous setting.
+extern "C" int neosr_set_gemm_x3(int on) {
+  const int prev = gemm_x3() ? 1 : 0;
+  g_gemm_x3 = on ? 1 : 0;
+  return prev;
 }
