@@ -346,8 +346,11 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(const GemmArgs args) 
 // Fragment convention: lanes with lh = 0 read quad 2s, lanes with lh = 1 quad 2s+1; MFMA e of step s then
 // multiplies k = 8s + e (lh 0) and k = 8s + 4 + e (lh 1) — the same pairing for both operands.
 // X3: the products on the bf16 MFMA from bf16x3 operands (see split3 / mac6), everything else unchanged.
-template <bool X3>
+// BT (X3 only): B is given as [K][N] (the NN form: Linear backward-data, B = weight (out, in) with K = out) — only the
+// register staging of the B tile differs: a thread gathers its 8 reduction values of column n with 8 dword loads.
+template <bool X3, bool BT = false>
 __device__ __forceinline__ void gemm_nt_glds_body(const GemmArgs& args) {
+  static_assert(X3 || !BT, "the [K][N] form of B needs the register-staged (X3) B tile");
   const neosr_gemm_desc& d = args.d;
   // X3: the B (weight) tile lives in LDS as three bf16 planes — 12 slots of 16 bytes per row (slot = 4 piece + 2 pair-step
   // + lane half: the 8 reduction indices one lane half feeds to one MFMA), split ONCE per workgroup when the tile is staged
@@ -423,7 +426,19 @@ __device__ __forceinline__ void gemm_nt_glds_body(const GemmArgs& args) {
   const int offB3_l1 = (bn_ok && kc_last * BK + 8 * bo + 4 < K) ? offB3 + 16 : OOB;
   f32x4 breg0 = {0.f, 0.f, 0.f, 0.f}, breg1 = {0.f, 0.f, 0.f, 0.f};
   typedef decltype(__builtin_amdgcn_raw_buffer_load_b128(rB, 0, 0, 0)) rawq_t;
+  // BT: rows of B are reduction indices: the resource ends behind row K - 1 (rows past K read zeros), the row is the
+  // scalar offset, the column the lane offset
+  const auto rBt = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.B), 0, BT ? (unsigned)(((int64_t)K * d.ldb) * 4) : 0u, 0x00020000);
+  const int offBt = bn_ok ? (8 * bo * d.ldb + n0 + bn) * 4 : OOB;
   auto bload = [&](int k0) {
+    if constexpr (BT) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        breg0[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rBt, offBt, (k0 + e) * d.ldb * 4, 0));
+        breg1[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rBt, offBt, (k0 + 4 + e) * d.ldb * 4, 0));
+      }
+      return;
+    }
     const bool last = k0 == kc_last * BK;
     breg0 = __builtin_bit_cast(f32x4, (rawq_t)__builtin_amdgcn_raw_buffer_load_b128(rB, last ? offB3_l0 : offB3, k0 * 4, 0));
     breg1 = __builtin_bit_cast(f32x4, (rawq_t)__builtin_amdgcn_raw_buffer_load_b128(rB, last ? offB3_l1 : (offB3 == OOB ? OOB : offB3 + 16), k0 * 4, 0));
@@ -529,14 +544,18 @@ __device__ __forceinline__ void gemm_nt_glds_body(const GemmArgs& args) {
 }
 __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(const GemmArgs args) { gemm_nt_glds_body<false>(args); }
 __global__ __launch_bounds__(256, 2) void gemm_nt_glds_x3_kernel(const GemmArgs args) { gemm_nt_glds_body<true>(args); }
+__global__ __launch_bounds__(256, 2) void gemm_nn_glds_x3_kernel(const GemmArgs args) { gemm_nt_glds_body<true, true>(args); }
 
 // 64-row variant of gemm_nt_glds_kernel for launches that would not fill the chip with 128-row tiles (M = 16 384 tokens:
 // 384 tiles of 128 x 64 for N = 180 on 768 resident slots).  The 4 waves form a 2 x 2 grid of 32 x 32 tiles (one
 // accumulator each: one A and one B ds_read_b128 per 4 MFMAs), everything else — DMA staging, XOR-swizzled images, one
 // barrier per chunk, trimmed last chunk, bias tile in LDS, residual quads requested under the last chunk — as above.
 constexpr int BM2 = 64;
-template <bool X3>
+// BT (X3 only): B is given as [K][N] (the NN form: Linear backward-data, B = weight (out, in) with K = out) — only the
+// register staging of the B tile differs: a thread gathers its 8 reduction values of column n with 8 dword loads.
+template <bool X3, bool BT = false>
 __device__ __forceinline__ void gemm_nt_glds64_body(const GemmArgs& args) {
+  static_assert(X3 || !BT, "the [K][N] form of B needs the register-staged (X3) B tile");
   const neosr_gemm_desc& d = args.d;
   constexpr int BSZ = X3 ? BN * 48 : BN * BK;   // (X3: the B tile as three bf16 planes, see gemm_nt_glds_body)
   __shared__ __attribute__((aligned(1024))) float lds[2 * (BM2 * BK + BSZ)];
@@ -590,7 +609,19 @@ __device__ __forceinline__ void gemm_nt_glds64_body(const GemmArgs& args) {
   const int offB3_l1 = (bn_ok && kc_last * BK + 8 * bo + 4 < K) ? offB3 + 16 : OOB;
   f32x4 breg0 = {0.f, 0.f, 0.f, 0.f}, breg1 = {0.f, 0.f, 0.f, 0.f};
   typedef decltype(__builtin_amdgcn_raw_buffer_load_b128(rB, 0, 0, 0)) rawq_t;
+  // BT: rows of B are reduction indices: the resource ends behind row K - 1 (rows past K read zeros), the row is the
+  // scalar offset, the column the lane offset
+  const auto rBt = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.B), 0, BT ? (unsigned)(((int64_t)K * d.ldb) * 4) : 0u, 0x00020000);
+  const int offBt = bn_ok ? (8 * bo * d.ldb + n0 + bn) * 4 : OOB;
   auto bload = [&](int k0) {
+    if constexpr (BT) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        breg0[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rBt, offBt, (k0 + e) * d.ldb * 4, 0));
+        breg1[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rBt, offBt, (k0 + 4 + e) * d.ldb * 4, 0));
+      }
+      return;
+    }
     const bool last = k0 == kc_last * BK;
     breg0 = __builtin_bit_cast(f32x4, (rawq_t)__builtin_amdgcn_raw_buffer_load_b128(rB, last ? offB3_l0 : offB3, k0 * 4, 0));
     breg1 = __builtin_bit_cast(f32x4, (rawq_t)__builtin_amdgcn_raw_buffer_load_b128(rB, last ? offB3_l1 : (offB3 == OOB ? OOB : offB3 + 16), k0 * 4, 0));
@@ -670,6 +701,7 @@ __device__ __forceinline__ void gemm_nt_glds64_body(const GemmArgs& args) {
 }
 __global__ __launch_bounds__(256, 2) void gemm_nt_glds64_kernel(const GemmArgs args) { gemm_nt_glds64_body<false>(args); }
 __global__ __launch_bounds__(256, 2) void gemm_nt_glds64_x3_kernel(const GemmArgs args) { gemm_nt_glds64_body<true>(args); }
+__global__ __launch_bounds__(256, 2) void gemm_nn_glds64_x3_kernel(const GemmArgs args) { gemm_nt_glds64_body<true, true>(args); }
 
 
 // (Round 4 tried a whole-K-panel variant for the K = 180 Linears — a 32 x 64 tile whose six chunks are all requested at
@@ -1091,6 +1123,20 @@ extern "C" int neosr_gemm(const neosr_gemm_desc* dp, void* stream) {
     // (same last-round rule as the NT kernel; the staged kernel keeps 5 workgroups of 128 rows per CU resident)
     static const int env64 = [] { const char* e = getenv("NEOSR_GEMM_NN64"); return e ? atoi(e) : -1; }();
     const int t128 = a.tiles_m * a.tiles_n, tail = t128 % 768;
+    // bf16x3 products: the direct-to-LDS kernels with the [K][N] weight tile gathered into their register staging
+    const bool nn_small = (int64_t)d.M * d.lda * 4 < (int64_t(1) << 31) && (int64_t)d.K * d.ldb * 4 < (int64_t(1) << 31);
+    if (gemm_x3() && !g_no_glds && nn_small) {
+      if (env64 >= 0 ? env64 != 0 : (d.aux_in || t128 < g_bm64_below || (t128 < 2 * 768 && tail > 0 && tail <= 460))) {
+        a.tiles_m = ceil_div(d.M, BM2);
+        grid.x = ceil_div(a.tiles_m * a.tiles_n, 8) * 8;
+        hipLaunchKernelGGL(gemm_nn_glds64_x3_kernel, grid, dim3(256), 0, st, a);
+      } else {
+        hipLaunchKernelGGL(gemm_nn_glds_x3_kernel, grid, dim3(256), 0, st, a);
+      }
+      if (prof) neosr_prof_end(stream);
+      NEOSR_LAUNCH_CHECK();
+      return 0;
+    }
     // ... and always under the GELU' epilogue (fc2's data gradient): half-size accumulators interleave that long
     // vector epilogue with other workgroups' MFMAs (M = 32 768: 71.6 -> 62.9 us)
     if (env64 >= 0 ? env64 != 0 : (d.aux_in || t128 < g_bm64_below || (t128 < 2 * 768 && tail > 0 && tail <= 460))) {
