@@ -81,6 +81,22 @@ __device__ __forceinline__ f32x4 ld4(const float* p, int vec) {
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+// One LDS-DMA instruction (64 lanes x 16 bytes -> 1 KB at `lds_addr`) as inline assembly.  hipcc waits `vmcnt(0)` in front of
+// any ds_read that MAY alias the target of an LDS-DMA it knows about — with both chunk buffers in one __shared__ array that
+// is every fragment read, i.e. the DMA of chunk c + 1 was waited for BEFORE chunk c was computed (the ISA of the round 2-4
+// kernels shows the wait right behind the loads).  Hidden from the wait-count pass, the DMA runs under the chunk's MFMAs;
+// the explicit `s_waitcnt vmcnt(0)` in front of each chunk barrier is the only wait it needs.  (Counted waits the compiler
+// places for its own register loads only become stronger: vmcnt counts the hidden loads too.)
+typedef int gm_i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void gm_dma16(gm_i32x4 rsrc, const float* lds_ptr, int voff, int soff) {
+  // (wave-uniform: the wave index inside it comes from the thread id)
+  const unsigned lds_addr = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(const __attribute__((address_space(3))) float*)lds_ptr);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+               :
+               : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
+               : "memory", "m0");
+}
+
 // the 8 reduction values of a lane (two 16-byte LDS quads) -> the three 8 x bf16 MFMA operands
 __device__ __forceinline__ void split3(const f32x4 lo4, const f32x4 hi4, bf16x8 (&P)[3]) {
   unsigned b[8];
@@ -385,6 +401,8 @@ __device__ __forceinline__ void gemm_nt_glds_body(const GemmArgs& args) {
   constexpr int OOB = 0x7ffffff0;
   const auto rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.A), 0, 0x7ffffff0, 0x00020000);
   const auto rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.B), 0, 0x7ffffff0, 0x00020000);
+  const gm_i32x4 rA_w = {__builtin_amdgcn_readfirstlane((int)(uintptr_t)d.A),
+                         __builtin_amdgcn_readfirstlane((int)(((uintptr_t)d.A >> 32) & 0xffff)), 0x7ffffff0, 0x00020000};
   int offA[4], offA_l[4], offB[2], offB_l[2];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -408,9 +426,13 @@ __device__ __forceinline__ void gemm_nt_glds_body(const GemmArgs& args) {
     float* bbuf = abuf + BM * BK;
     const bool last = k0 == kc_last * BK;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_vp)(abuf + (4 * i + wave) * 256), 16, last ? offA_l[i] : offA[i],
-                                               k0 * 4, 0, 0);
+    for (int i = 0; i < 4; ++i) {
+      if constexpr (X3)
+        gm_dma16(rA_w, abuf + (4 * i + wave) * 256, last ? offA_l[i] : offA[i], k0 * 4);
+      else
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_vp)(abuf + (4 * i + wave) * 256), 16, last ? offA_l[i] : offA[i],
+                                                 k0 * 4, 0, 0);
+    }
     if constexpr (!X3) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -577,6 +599,8 @@ __device__ __forceinline__ void gemm_nt_glds64_body(const GemmArgs& args) {
   constexpr int OOB = 0x7ffffff0;
   const auto rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.A), 0, 0x7ffffff0, 0x00020000);
   const auto rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.B), 0, 0x7ffffff0, 0x00020000);
+  const gm_i32x4 rA_w = {__builtin_amdgcn_readfirstlane((int)(uintptr_t)d.A),
+                         __builtin_amdgcn_readfirstlane((int)(((uintptr_t)d.A >> 32) & 0xffff)), 0x7ffffff0, 0x00020000};
   int offA[2], offA_l[2], offB[2], offB_l[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -595,8 +619,11 @@ __device__ __forceinline__ void gemm_nt_glds64_body(const GemmArgs& args) {
     const bool last = k0 == kc_last * BK;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_vp)(abuf + (4 * i + wave) * 256), 16, last ? offA_l[i] : offA[i],
-                                               k0 * 4, 0, 0);
+      if constexpr (X3)
+        gm_dma16(rA_w, abuf + (4 * i + wave) * 256, last ? offA_l[i] : offA[i], k0 * 4);
+      else
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_vp)(abuf + (4 * i + wave) * 256), 16, last ? offA_l[i] : offA[i],
+                                                 k0 * 4, 0, 0);
       if constexpr (!X3)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_vp)(bbuf + (4 * i + wave) * 256), 16, last ? offB_l[i] : offB[i],
                                                  k0 * 4, 0, 0);
