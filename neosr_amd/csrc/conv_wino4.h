@@ -38,9 +38,11 @@ __device__ __forceinline__ void split_hi_lo(const f32x4 v, bf16x8& hi2, bf16x8& 
   const unsigned h01 = __builtin_amdgcn_perm(b1, b0, 0x07060302u), h23 = __builtin_amdgcn_perm(b3, b2, 0x07060302u);
   const float r0 = v[0] - __uint_as_float(b0 & 0xffff0000u), r1 = v[1] - __uint_as_float(b1 & 0xffff0000u);
   const float r2 = v[2] - __uint_as_float(b2 & 0xffff0000u), r3 = v[3] - __uint_as_float(b3 & 0xffff0000u);
-  unsigned l01, l23;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(l01) : "v"(r0), "v"(r1));
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(l23) : "v"(r2), "v"(r3));
+  // (C conversions, not inline assembly: behind an `asm` hipcc pads no wait states between the vector write and an MFMA that
+  // reads the register — see split3 in gemm_mfma.hip)
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  const bf16x2_t t01 = {(__bf16)r0, (__bf16)r1}, t23 = {(__bf16)r2, (__bf16)r3};
+  const unsigned l01 = __builtin_bit_cast(unsigned, t01), l23 = __builtin_bit_cast(unsigned, t23);
   hi2 = __builtin_bit_cast(bf16x8, (u32x4_bits){h01, h23, h01, h23});
   lo2 = __builtin_bit_cast(bf16x8, (u32x4_bits){l01, l23, l01, l23});
 }

@@ -116,9 +116,14 @@ __device__ __forceinline__ void split3(const f32x4 lo4, const f32x4 hi4, bf16x8 
   for (int i = 0; i < 4; ++i) {
     p0[i] = __builtin_amdgcn_perm(b[2 * i + 1], b[2 * i], 0x07060302u);
     p1[i] = __builtin_amdgcn_perm(__float_as_uint(r1[2 * i + 1]), __float_as_uint(r1[2 * i]), 0x07060302u);
-    unsigned t;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(t) : "v"(r2[2 * i]), "v"(r2[2 * i + 1]));
-    p2[i] = t;
+    // (a C conversion, not inline assembly: hipcc emits v_cvt_pk_bf16_f32 for it AND knows that a vector instruction wrote the
+    // register — behind an `asm` it pads no wait states, and an MFMA issued right after may read the operand's OLD contents.
+    // Seen in a bf16x3 form of the register-fed TN kernel: the last token pair of the last column came out wrong by ~1e-4;
+    // that form was measured at the fp32 kernel's speed once correct — 79.9 vs 79.7 us for qkv at M = 32 768, every value
+    // feeds one MFMA there, so the split is not amortised — and is not kept.)
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    const bf16x2_t t = {(__bf16)r2[2 * i], (__bf16)r2[2 * i + 1]};
+    p2[i] = __builtin_bit_cast(unsigned, t);
   }
   P[0] = __builtin_bit_cast(bf16x8, p0);
   P[1] = __builtin_bit_cast(bf16x8, p1);

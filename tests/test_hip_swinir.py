@@ -47,6 +47,39 @@ def test_gemm_modes_vs_float64(M, N, K):
     assert rel_err(cs, Y.double().sum(0)) < 1e-5
 
 
+@pytest.mark.parametrize("M,N,K", [(4096, 540, 180), (1000, 180, 360), (32768, 180, 180)])
+def test_gemm_bf16x3_products_are_fp32_faithful(M, N, K):
+    """The default Linear GEMMs (NT forward, NN backward-data) run their products on the bf16 MFMA from three bf16 pieces per
+    fp32 operand (six cross products, fp32 accumulate: `neosr_set_gemm_x3`).  Against float64 they must be as accurate as the
+    fp32-MFMA kernels they replace (error <= 1.5x theirs, both ~1e-7 relative), on well-scaled operands and on operands that
+    span 12 orders of magnitude per row (a piece that underflowed or a dropped cross term would show there), and the two
+    forms must really differ in their bits (the switch is wired)."""
+    from neosr_amd import _C
+    from neosr_amd.hip import transformer as tr
+
+    lib = _C.load()
+    g = torch.Generator().manual_seed(5 * M + N + K)
+    for wide in (False, True):
+        A, W = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g)
+        Y = torch.randn(M, N, generator=g)
+        if wide:
+            A = A * torch.pow(10.0, torch.randint(-6, 7, (M, K), generator=g).float())
+            W = W * torch.pow(10.0, torch.randint(-6, 7, (N, K), generator=g).float())
+        ref_nt, ref_nn = A.double() @ W.double().t(), Y.double() @ W.double()
+        out = {}
+        prev = lib.neosr_set_gemm_x3(1)
+        try:
+            for x3 in (1, 0):
+                lib.neosr_set_gemm_x3(x3)
+                out[x3] = (tr.gemm(_C.GEMM_NT, A.to(DEV), W.to(DEV), M, N, K), tr.gemm(_C.GEMM_NN, Y.to(DEV), W.to(DEV), M, K, N))
+        finally:
+            lib.neosr_set_gemm_x3(prev)
+        for i, ref in enumerate((ref_nt, ref_nn)):
+            e3, e1 = rel_err(out[1][i], ref), rel_err(out[0][i], ref)
+            assert e3 < 1e-6 and e3 <= 1.5 * e1 + 2e-8, (wide, i, e3, e1)
+            assert not torch.equal(out[1][i], out[0][i])
+
+
 @pytest.mark.parametrize("Mo,No,T_", [(96, 64, 16), (180, 180, 1), (540, 180, 32768), (192, 8, 37), (12, 4, 5001),
                                      (360, 180, 8191), (180, 360, 4100), (128, 64, 777)])
 def test_gemm_tn_weight_gradient_with_bias_sum(Mo, No, T_):
