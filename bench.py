@@ -70,8 +70,9 @@ CLASS_NAMES = [
 CLASS_SYMBOL = ["conv3x3_wino4_chain_kernel|conv3x3_wino4_kernel|conv3x3_wino_kernel|conv3x3_glds_kernel",
                 "conv3x3_wino4_chain_kernel|conv3x3_wino4_kernel|conv3x3_wino_kernel|conv3x3_glds_kernel",
                 "conv3x3_wgrad_wino4_kernel|conv3x3_wgrad_wino_kernel|conv3x3_wgrad_multi_kernel", "conv3x3_wgrad_reduce_kernel",
-                "conv3x3_thin_k_kernel|conv3x3_mfma_kernel", "conv3x3_thin_n_kernel|conv3x3_mfma_kernel", "gemm_nt_glds_kernel|gemm_nt_glds64_kernel",
-                "gemm_mfma_kernel<1, 128>|gemm_mfma_kernel<1, 64>|gemm_mfma_kernel<1>",
+                "conv3x3_thin_k_kernel|conv3x3_mfma_kernel", "conv3x3_thin_n_kernel|conv3x3_mfma_kernel",
+                "gemm_nt_glds_x3_kernel|gemm_nt_glds64_x3_kernel|gemm_nt_glds_kernel|gemm_nt_glds64_kernel",
+                "gemm_nn_glds_x3_kernel|gemm_nn_glds64_x3_kernel|gemm_mfma_kernel<1, 128>|gemm_mfma_kernel<1, 64>|gemm_mfma_kernel<1>",
                 "gemm_tn_reg_group_kernel|gemm_tn_reg_kernel|gemm_mfma_kernel<2",
                 "wattn_wave_fwd_kernel|wattn16_wave_fwd_kernel|flash_wattn_fwd_kernel|window_attention_fwd_kernel",
                 "flash_wattn_bwd_fused_kernel|flash_wattn_bwd_dq_kernel+flash_wattn_bwd_dkv_kernel|window_attention_bwd_kernel"]
@@ -425,7 +426,7 @@ def run_config(args, config: str, world: int, rank: int, dev, steps: int, warmup
                     "kernels": kern,
                     "method": "HIP events around every launch of the class on the launch stream, separate "
                               "profiled pass after the timed region with the trunk on ONE stream "
-                              "(neosr_set_num_streams(1)); profiles/r04_<config>_kernel_stats.csv is rocprofv3 "
+                              "(neosr_set_num_streams(1)); profiles/r05_<config>_kernel_stats.csv is rocprofv3 "
                               "--kernel-trace --stats of `NEOSR_AMD_STREAMS=1 python bench.py --config <config>`"}
         if opt.get("fast_matmul") and dom in (0, 1) and dom_algo == 2:
             # the tier runs FOUR bf16 products per executed fp32-equivalent multiplication on the bf16 MFMA: priced against
@@ -436,6 +437,17 @@ def run_config(args, config: str, world: int, rank: int, dev, steps: int, warmup
                 "bf16_mfma_frac": round(4 * ach / PEAK_BF16_MFMA_TFLOPS, 4),
                 "hbm_algo_frac_of_8TBps": roofline["hbm_algo_frac_of_8TBps"],
                 "limiter": "per-CU weight stream from L2 (76 GB/s into VGPRs, 147 KB per 32-channel chunk and CU)"}
+        if dom in (6, 7):   # nn.Linear NT / NN GEMMs: by default their products run on the bf16 MFMA from bf16x3 pieces
+            prev = lib.neosr_set_gemm_x3(1)
+            lib.neosr_set_gemm_x3(prev)
+            if prev:
+                roofline["bf16x3"] = {
+                    "note": "six bf16 cross products per fp32 multiplication on v_mfma_f32_32x32x16_bf16 (fp32-faithful); `achieved` "
+                            "/ `frac` above price the fp32-equivalent FLOPs against the fp32 MFMA peak",
+                    "bf16_product_tflops": round(6 * ach, 2), "bf16_mfma_peak_tflops": PEAK_BF16_MFMA_TFLOPS,
+                    "bf16_mfma_frac": round(6 * ach / PEAK_BF16_MFMA_TFLOPS, 4)}
+                roofline["symbol"] = ("gemm_nt_glds_x3_kernel|gemm_nt_glds64_x3_kernel" if dom == 6
+                                      else "gemm_nn_glds_x3_kernel|gemm_nn_glds64_x3_kernel")
         if ms[0] + ms[1] > 0:  # forward + backward-data launches of ONE symbol: comparable with its rocprofv3 row
             roofline["packed_conv_kernel_avg_us"] = round(1e3 * (ms[0] + ms[1]) / max(1, ln[0] + ln[1]), 2)
 
