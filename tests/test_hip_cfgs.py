@@ -125,10 +125,14 @@ def test_hat_l_forward_backward_vs_reference_fixture():
 
 
 # ---------------------------------------------------------------------------------------------- config combinations
-@pytest.mark.parametrize("name", ["cfg3", "cfg2", "cfg4"])
-def test_config_combination_trajectory_vs_reference_fixture(name):
+@pytest.mark.parametrize("name,chained", [("cfg3", False), ("cfg2", False), ("cfg4", False), ("cfg2", True), ("cfg4", True)])
+def test_config_combination_trajectory_vs_reference_fixture(name, chained):
     """OUR `image` / `otf` model from the fixture's TOML, initial weights, batches and (otf) recorded draws: every
-    log_dict entry per iteration, the outputs, the final G / D weights and spectral-norm buffers."""
+    log_dict entry per iteration, the outputs, the final G / D weights and spectral-norm buffers.
+    `chained` (otf configs; VERDICT r4 "JPEG-flip decoupling"): the step runs on the model's OWN degraded LQ instead of the
+    reference's — feed and step checked end to end, not piecewise.  DiffJPEG's rounding may flip a quantised coefficient
+    (<= 1/255 on < 1 % of the LQ pixels, asserted), which the generator and three further iterations through the pair pool
+    carry forward: the gates are 2e-2 there (1e-3 with the reference LQ substituted)."""
     from neosr_amd.data.draws import ReplayDraws
     from neosr_amd.models import build_model
     from neosr_amd.utils.options import parse_options
@@ -160,20 +164,22 @@ def test_config_combination_trajectory_vs_reference_fixture(name):
             diff = (model.lq.cpu() - ref_lq).abs()
             assert float(diff.max()) <= 1.0 / 255 + 1e-6 and float((diff > 1e-6).float().mean()) < 0.01
             assert torch.equal(model.gt.cpu(), T(fix[f"it{it}/gt_out"]))
-            model.lq = ref_lq.to(DEV)  # a JPEG rounding flip (<= 1/255 on < 1 % of the pixels) stays out of the step check
+            if not chained:
+                model.lq = ref_lq.to(DEV)  # a JPEG rounding flip (<= 1/255 on < 1 % of the pixels) stays out of the step check
             # (the pair pool keeps the model's own pixels, so later iterations dequeue them: also covered by the bound)
         else:
             model.feed_data({"lq": T(fix[f"it{it}/lq"]), "gt": T(fix[f"it{it}/gt"])})
         model.optimize_parameters(it)
         log = model.get_current_log()
         assert list(log.keys()) == keys
+        tol = 2e-2 if chained else 1e-3
         for j, k in enumerate(keys):
             ref = fix["log"][it - 1, j]
-            assert abs(log[k] - ref) < 1e-3 * max(abs(ref), 1e-2), (it, k, log[k], ref)
-        assert rel_err(model.output, T(fix[f"it{it}/out"])) < 1e-3
+            assert abs(log[k] - ref) < tol * max(abs(ref), 1e-2), (it, k, log[k], ref)
+        assert rel_err(model.output, T(fix[f"it{it}/out"])) < tol
     G = OrderedDict((k, v.cpu()) for k, v in model.net_g.state_dict().items())
     D = OrderedDict((k, v.cpu()) for k, v in model.net_d.state_dict().items()) if model.net_d is not None else {}
-    check_final(fix, G, D, 1e-3)
+    check_final(fix, G, D, 2e-2 if chained else 1e-3)
 
 
 # ---------------------------------------------------------------------------------------------- full-size properties
