@@ -129,6 +129,10 @@ __device__ __forceinline__ void split3(const f32x4 lo4, const f32x4 hi4, bf16x8 
   P[1] = __builtin_bit_cast(bf16x8, p1);
   P[2] = __builtin_bit_cast(bf16x8, p2);
 }
+// the same for 8 values that live in 8 separate registers
+__device__ __forceinline__ void split3v(const float (&x)[8], bf16x8 (&P)[3]) {
+  split3((f32x4){x[0], x[1], x[2], x[3]}, (f32x4){x[4], x[5], x[6], x[7]}, P);
+}
 // acc += sum over the six leading cross terms of (weight pieces W) x (activation pieces X), smallest terms first
 __device__ __forceinline__ f32x16 mac6(const bf16x8 (&W)[3], const bf16x8 (&X)[3], f32x16 acc) {
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[2], X[0], acc, 0, 0, 0);
@@ -959,6 +963,168 @@ __global__ __launch_bounds__(256, RT_OCC) void gemm_tn_reg_group_kernel(const Ge
   tn_reg_task<true>(a, split, t % tiles);
 }
 
+// ---- TN GEMM, bf16x3 form (round 5, default with neosr_set_gemm_x3): weight gradients dW[m][n] = sum_t dY[t][m] X[t][n].
+// In the register-fed kernel above every loaded value feeds ONE MFMA, so splitting it into bf16 pieces there costs as much
+// as it saves (measured at parity: profiles/NEGATIVE_RESULTS.md 5.8).  Here a workgroup of four waves owns a 192 x 192
+// output tile over a run of tokens; per step of 16 tokens the 384 columns (192 of dY, 192 of X) x 16 tokens are gathered
+// by the 256 threads — thread = (column, token octet), 8 coalesced dword loads down the column — split ONCE into three
+// bf16 pieces and written to LDS as [piece 3][octet 2][column 384] x 16 bytes: exactly the 8-token operand a lane of
+// v_mfma_f32_32x32x16_bf16 needs, so the MFMA loop is 18 conflict-free ds_read_b128 + 54 MFMAs per wave and step (a wave
+// owns 3 x 3 tiles of 32 x 32; every staged value feeds 6 tiles x 6 cross products) with no vector arithmetic in it.
+// Two stages of 36 KB (two workgroups per CU), the next step's 24 loads per thread in flight under the current step's
+// MFMAs, one barrier per step.  Token runs are a function of K alone (tn_lds_ksplit), so a problem gets the same partial
+// slabs from a single launch and from a grouped one; they are summed in split order by the caller as before.
+constexpr int LT = 192;                          // tile side
+constexpr int LT_STAGE = 6 * 2 * LT * 4;         // floats per stage: [piece * 2 + octet][column 0..383][4 floats = 8 bf16]
+template <bool RS>
+__device__ __forceinline__ void tn_lds_task(const GemmArgs& args, int split, int tile) {
+  __shared__ __attribute__((aligned(1024))) float stage[2 * LT_STAGE];
+  __shared__ float cs_lds[2 * LT];
+  const neosr_gemm_desc& d = args.d;
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 1, wn = wave >> 1;
+  const int m0 = (tile / args.tiles_n) * LT, n0 = (tile % args.tiles_n) * LT;
+  const int M = d.M, N = d.N;
+  const int t_lo = split * args.ksplit_len;
+  const int t_hi = min(d.K, t_lo + args.ksplit_len);
+  const int nsteps = (t_hi - t_lo + 15) >> 4;
+  // rows past the run read zeros (the resources end behind token t_hi - 1), columns past the matrix get an out-of-range offset
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.A), 0, t_hi * d.lda * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.B), 0, t_hi * d.ldb * 4, 0x00020000);
+  // the three staging units of this thread: unit u = tid + 256 k -> column u % 384 (0..191: dY, 192..383: X), octet u / 384;
+  // which matrix and which octet a unit has is the same for the 64 lanes of a wave
+  int vo[3], col[3];
+  bool isa[3];
+  int oct[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int u = tid + 256 * k;
+    col[k] = u % (2 * LT);
+    oct[k] = __builtin_amdgcn_readfirstlane(u / (2 * LT));
+    isa[k] = __builtin_amdgcn_readfirstlane(col[k] < LT ? 1 : 0) != 0;
+    const int c = isa[k] ? m0 + col[k] : n0 + col[k] - LT;
+    vo[k] = (c < (isa[k] ? M : N)) ? c * 4 : 0x7ffffff0;
+  }
+  float raw[3][8];
+  auto gload = [&](int step) {
+    const int t = t_lo + 16 * step;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int row = t + 8 * oct[k] + e;
+        raw[k][e] = isa[k] ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra, vo[k], row * d.lda * 4, 0))
+                           : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, vo[k], row * d.ldb * 4, 0));
+      }
+  };
+  float cs[3] = {0.f, 0.f, 0.f};   // column sums of dY (the bias gradient) of this thread's dY units
+  auto sstore = [&](int step, int buf) {
+    float* sb = stage + buf * LT_STAGE;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      float v[8];
+      float sc = 1.f;
+      if (RS && isa[k] && d.row_scale) sc = d.row_scale[(t_lo + 16 * step + 8 * oct[k]) / d.rows_per_scale];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v[e] = (RS && isa[k]) ? raw[k][e] * sc : raw[k][e];
+        if (isa[k]) cs[k] += v[e];
+      }
+      bf16x8 P[3];
+      split3v(v, P);
+#pragma unroll
+      for (int p3 = 0; p3 < 3; ++p3)
+        *reinterpret_cast<bf16x8*>(sb + ((2 * p3 + oct[k]) * (2 * LT) + col[k]) * 4) = P[p3];
+    }
+  };
+  f32x16 acc[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  auto mac = [&](int buf) {
+    const float* sb = stage + buf * LT_STAGE;
+    bf16x8 Bf[3][3];
+#pragma unroll
+    for (int bn = 0; bn < 3; ++bn)
+#pragma unroll
+      for (int p3 = 0; p3 < 3; ++p3)
+        Bf[bn][p3] = *reinterpret_cast<const bf16x8*>(sb + ((2 * p3 + lh) * (2 * LT) + LT + wn * 96 + 32 * bn + l31) * 4);
+#pragma unroll
+    for (int bm = 0; bm < 3; ++bm) {
+      bf16x8 Af[3];
+#pragma unroll
+      for (int p3 = 0; p3 < 3; ++p3)
+        Af[p3] = *reinterpret_cast<const bf16x8*>(sb + ((2 * p3 + lh) * (2 * LT) + wm * 96 + 32 * bm + l31) * 4);
+#pragma unroll
+      for (int bn = 0; bn < 3; ++bn) acc[bm][bn] = mac6(Bf[bn], Af, acc[bm][bn]);   // D rows <-> n, columns <-> m
+    }
+  };
+  if (nsteps > 0) {
+    gload(0);
+    sstore(0, 0);
+    __syncthreads();
+    for (int s = 0; s < nsteps; ++s) {
+      if (s + 1 < nsteps) gload(s + 1);
+      mac(s & 1);
+      if (s + 1 < nsteps) sstore(s + 1, (s + 1) & 1);
+      __syncthreads();
+    }
+  }
+  // partial tile -> this split's slab (caller sums the slabs in split order)
+  float* slab = d.C + (int64_t)split * args.slab;
+#pragma unroll
+  for (int bm = 0; bm < 3; ++bm) {
+    const int m = m0 + wm * 96 + 32 * bm + l31;
+    if (m >= M) continue;
+#pragma unroll
+    for (int bn = 0; bn < 3; ++bn)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = n0 + wn * 96 + 32 * bn + 8 * g + 4 * lh;
+        if (n < N)
+          *reinterpret_cast<float4*>(slab + (int64_t)m * N + n) =
+              make_float4(acc[bm][bn][4 * g], acc[bm][bn][4 * g + 1], acc[bm][bn][4 * g + 2], acc[bm][bn][4 * g + 3]);
+      }
+  }
+  if (args.colsum_part && n0 == 0) {   // (uniform) the two octet halves of every dY column, summed in a fixed order
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      if (isa[k]) cs_lds[oct[k] * LT + col[k]] = cs[k];
+    __syncthreads();
+    if (tid < LT && m0 + tid < M) args.colsum_part[(int64_t)split * args.slab + m0 + tid] = cs_lds[tid] + cs_lds[LT + tid];
+  }
+}
+__global__ __launch_bounds__(256, 2) void gemm_tn_lds_x3_kernel(const GemmArgs args) {
+  const int tiles = args.tiles_m * args.tiles_n;
+  const int split = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+  if (split >= args.nsplit) return;
+  tn_lds_task<true>(args, split, tile);
+}
+// up to four problems in one launch (the four Linears of a transformer block, csrc/blocks.hip): workgroup -> (problem,
+// split, tile); `start` counts workgroups.  (The body as a macro-free if-chain over the kernel arguments, as in the
+// register-fed group kernel.)
+__global__ __launch_bounds__(256, 2) void gemm_tn_lds_x3_group_kernel(const GemmGroupArgs g) {
+  const int wg = blockIdx.x;
+  if (wg >= g.start[g.n]) return;
+  GemmArgs a;
+  int t;
+  if (wg < g.start[1]) {
+    a = g.p[0]; t = wg;
+  } else if (wg < g.start[2]) {
+    a = g.p[1]; t = wg - g.start[1];
+  } else if (wg < g.start[3]) {
+    a = g.p[2]; t = wg - g.start[2];
+  } else {
+    a = g.p[3]; t = wg - g.start[3];
+  }
+  const int tiles = a.tiles_m * a.tiles_n;
+  tn_lds_task<true>(a, t / tiles, t % tiles);
+}
+
 // column sums of a row-major [rows, cols] matrix (bias gradients, LayerNorm / relative-position-bias
 // partials): 64 columns x 4 row lanes per workgroup, each row lane walks its rows with 256-byte
 // coalesced wave loads, the 4 lanes are combined through LDS in a fixed order.  Two launches when
@@ -1080,6 +1246,17 @@ int tn_reg_ksplit(int M, int N, int K) {
   return len;
 }
 
+// bf16x3 LDS kernel: tokens per split — a function of K alone (single and grouped launches of a problem cut it the same way):
+// 64 splits of a whole number of 32-token pairs of steps, at least 128 tokens each
+int tn_lds_ksplit(int K) {
+  int len = ceil_div(ceil_div(K, 64), 32) * 32;
+  return len < 128 ? 128 : len;
+}
+bool tn_lds_ok(const neosr_gemm_desc& d) {
+  return gemm_x3() && d.M % 4 == 0 && d.N % 4 == 0 && (int64_t)d.K * (d.lda > d.ldb ? d.lda : d.ldb) * 4 < (int64_t(1) << 31) &&
+         (!d.row_scale || d.rows_per_scale % 32 == 0);
+}
+
 int tn_splits(int M, int N, int K) {
   const int tiles = ceil_div(M, BM) * ceil_div(N, BN);
   int s = ceil_div(TN_TARGET_BLOCKS, tiles);
@@ -1100,6 +1277,10 @@ extern "C" int64_t neosr_gemm_workspace_bytes(const neosr_gemm_desc* d) {
   if (tn_reg_ok(d->M, d->N, d->K)) {
     const int nr = ceil_div(d->K, tn_reg_ksplit(d->M, d->N, d->K));
     if (nr > ns) ns = nr;
+  }
+  {   // (the bf16x3 LDS kernel's split count; sized whatever neosr_set_gemm_x3 says now, so a cached size serves both forms)
+    const int nl = ceil_div(d->K, tn_lds_ksplit(d->K));
+    if (nl > ns) ns = nl;
   }
   return ((int64_t)(ns + 1) * slab + 16384 + 256 * 64 + 64) * 4;
 }
@@ -1182,7 +1363,12 @@ extern "C" int neosr_gemm(const neosr_gemm_desc* dp, void* stream) {
     NEOSR_CHECK(d.workspace, "gemm TN: workspace missing");
     // (a row scale must be constant over the register kernel's 32-token batches)
     const bool reg = tn_reg_ok(d.M, d.N, d.K) && (!d.row_scale || d.rows_per_scale % (2 * RT_P) == 0);
-    if (reg) {
+    const bool ldsx3 = tn_lds_ok(d);
+    if (ldsx3) {
+      a.ksplit_len = tn_lds_ksplit(d.K);
+      a.tiles_m = ceil_div(d.M, LT);
+      a.tiles_n = ceil_div(d.N, LT);
+    } else if (reg) {
       a.ksplit_len = tn_reg_ksplit(d.M, d.N, d.K);
       a.tiles_m = ceil_div(d.M, RT_M);
       a.tiles_n = ceil_div(d.N, RT_N);
@@ -1202,9 +1388,12 @@ extern "C" int neosr_gemm(const neosr_gemm_desc* dp, void* stream) {
     a.nsplit = nsplit;
     a.colsum_part = d.colsum_a ? d.workspace + mn : nullptr;
     float* stage = d.workspace + (int64_t)nsplit * a.slab;
-    grid.x = reg ? 8 * ceil_div(ceil_div(nsplit, 8) * a.tiles_m * a.tiles_n, 4)
-                 : ceil_div(nsplit, 8) * 8 * a.tiles_m * a.tiles_n;
-    if (reg && d.row_scale)
+    grid.x = ldsx3 ? nsplit * a.tiles_m * a.tiles_n
+             : reg ? 8 * ceil_div(ceil_div(nsplit, 8) * a.tiles_m * a.tiles_n, 4)
+                   : ceil_div(nsplit, 8) * 8 * a.tiles_m * a.tiles_n;
+    if (ldsx3)
+      hipLaunchKernelGGL(gemm_tn_lds_x3_kernel, grid, dim3(256), 0, st, a);
+    else if (reg && d.row_scale)
       hipLaunchKernelGGL(gemm_tn_reg_kernel<true>, grid, dim3(256), 0, st, a);
     else if (reg)
       hipLaunchKernelGGL(gemm_tn_reg_kernel<false>, grid, dim3(256), 0, st, a);
@@ -1239,6 +1428,8 @@ extern "C" int neosr_gemm_tn_group(const neosr_gemm_desc* descs, int32_t n, int3
   memset(&g, 0, sizeof(g));
   g.n = n;
   int start = 0;
+  bool all_lds = true;   // every problem takes the bf16x3 LDS kernel -> its group form
+  for (int i = 0; i < n; ++i) all_lds = all_lds && descs[i].mode == NEOSR_GEMM_TN && tn_lds_ok(descs[i]);
   for (int i = 0; i < n; ++i) {
     const neosr_gemm_desc& d = descs[i];
     NEOSR_CHECK(d.A && d.B && d.C && d.workspace && d.mode == NEOSR_GEMM_TN && d.M > 0 && d.N > 0 && d.K > 0,
@@ -1249,20 +1440,20 @@ extern "C" int neosr_gemm_tn_group(const neosr_gemm_desc* descs, int32_t n, int3
     NEOSR_CHECK(!d.row_scale || d.rows_per_scale > 0, "gemm_tn_group: row_scale needs rows_per_scale");
     const int64_t mn = (int64_t)d.M * d.N;
     NEOSR_CHECK(!d.colsum_a || d.colsum_a == d.C + mn, "gemm_tn_group: colsum_a must sit right behind C");
-    if (!(tn_reg_ok(d.M, d.N, d.K) && (!d.row_scale || d.rows_per_scale % (2 * RT_P) == 0))) return -1;
+    if (!all_lds && !(tn_reg_ok(d.M, d.N, d.K) && (!d.row_scale || d.rows_per_scale % (2 * RT_P) == 0))) return -1;
     GemmArgs& a = g.p[i];
     a.d = d;
     a.b_vec = 1;
-    a.ksplit_len = tn_reg_ksplit(d.M, d.N, d.K);
-    a.tiles_m = ceil_div(d.M, RT_M);
-    a.tiles_n = ceil_div(d.N, RT_N);
+    a.ksplit_len = all_lds ? tn_lds_ksplit(d.K) : tn_reg_ksplit(d.M, d.N, d.K);
+    a.tiles_m = ceil_div(d.M, all_lds ? LT : RT_M);
+    a.tiles_n = ceil_div(d.N, all_lds ? LT : RT_N);
     a.nsplit = ceil_div(d.K, a.ksplit_len);
     a.slab = mn + (d.colsum_a ? d.M : 0);
     a.d.C = d.workspace;
     a.colsum_part = d.colsum_a ? d.workspace + mn : nullptr;
     nsplit_out[i] = a.nsplit;
     g.start[i] = start;
-    start += ceil_div(a.nsplit, 8) * a.tiles_m * a.tiles_n;
+    start += (all_lds ? a.nsplit : ceil_div(a.nsplit, 8)) * a.tiles_m * a.tiles_n;
   }
   for (int i = n; i <= TN_GROUP; ++i) g.start[i] = start;
   const bool prof = neosr_prof_on();
@@ -1274,7 +1465,8 @@ extern "C" int neosr_gemm_tn_group(const neosr_gemm_desc* descs, int32_t n, int3
     }
     neosr_prof_begin(NEOSR_PROF_GEMM_TN, stream, fl, by);
   }
-  hipLaunchKernelGGL(gemm_tn_reg_group_kernel, dim3(8 * ceil_div(start, 4)), dim3(256), 0, (hipStream_t)stream, g);
+  if (all_lds) hipLaunchKernelGGL(gemm_tn_lds_x3_group_kernel, dim3(start), dim3(256), 0, (hipStream_t)stream, g);
+  else hipLaunchKernelGGL(gemm_tn_reg_group_kernel, dim3(8 * ceil_div(start, 4)), dim3(256), 0, (hipStream_t)stream, g);
   if (prof) neosr_prof_end(stream);
   NEOSR_LAUNCH_CHECK();
   return 0;
