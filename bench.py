@@ -73,7 +73,7 @@ CLASS_SYMBOL = ["conv3x3_wino4_chain_kernel|conv3x3_wino4_kernel|conv3x3_wino_ke
                 "conv3x3_thin_k_kernel|conv3x3_mfma_kernel", "conv3x3_thin_n_kernel|conv3x3_mfma_kernel",
                 "gemm_nt_glds_x3_kernel|gemm_nt_glds64_x3_kernel|gemm_nt_glds_kernel|gemm_nt_glds64_kernel",
                 "gemm_nn_glds_x3_kernel|gemm_nn_glds64_x3_kernel|gemm_mfma_kernel<1, 128>|gemm_mfma_kernel<1, 64>|gemm_mfma_kernel<1>",
-                "gemm_tn_reg_group_kernel|gemm_tn_reg_kernel|gemm_mfma_kernel<2",
+                "gemm_tn_lds_x3_group_kernel|gemm_tn_lds_x3_kernel|gemm_tn_reg_group_kernel|gemm_tn_reg_kernel|gemm_mfma_kernel<2",
                 "wattn_wave_fwd_kernel|wattn16_wave_fwd_kernel|flash_wattn_fwd_kernel|window_attention_fwd_kernel",
                 "flash_wattn_bwd_fused_kernel|flash_wattn_bwd_dq_kernel+flash_wattn_bwd_dkv_kernel|window_attention_bwd_kernel"]
 COMPUTE_CLASSES = (0, 1, 2, 4, 5, 6, 7, 8, 9, 10)
@@ -437,7 +437,7 @@ def run_config(args, config: str, world: int, rank: int, dev, steps: int, warmup
                 "bf16_mfma_frac": round(4 * ach / PEAK_BF16_MFMA_TFLOPS, 4),
                 "hbm_algo_frac_of_8TBps": roofline["hbm_algo_frac_of_8TBps"],
                 "limiter": "per-CU weight stream from L2 (76 GB/s into VGPRs, 147 KB per 32-channel chunk and CU)"}
-        if dom in (6, 7):   # nn.Linear NT / NN GEMMs: by default their products run on the bf16 MFMA from bf16x3 pieces
+        if dom in (6, 7, 8):   # nn.Linear NT / NN / TN GEMMs: by default their products run on the bf16 MFMA from bf16x3 pieces
             prev = lib.neosr_set_gemm_x3(1)
             lib.neosr_set_gemm_x3(prev)
             if prev:
@@ -447,7 +447,8 @@ def run_config(args, config: str, world: int, rank: int, dev, steps: int, warmup
                     "bf16_product_tflops": round(6 * ach, 2), "bf16_mfma_peak_tflops": PEAK_BF16_MFMA_TFLOPS,
                     "bf16_mfma_frac": round(6 * ach / PEAK_BF16_MFMA_TFLOPS, 4)}
                 roofline["symbol"] = ("gemm_nt_glds_x3_kernel|gemm_nt_glds64_x3_kernel" if dom == 6
-                                      else "gemm_nn_glds_x3_kernel|gemm_nn_glds64_x3_kernel")
+                                      else "gemm_nn_glds_x3_kernel|gemm_nn_glds64_x3_kernel" if dom == 7
+                                      else "gemm_tn_lds_x3_group_kernel|gemm_tn_lds_x3_kernel")
         if ms[0] + ms[1] > 0:  # forward + backward-data launches of ONE symbol: comparable with its rocprofv3 row
             roofline["packed_conv_kernel_avg_us"] = round(1e3 * (ms[0] + ms[1]) / max(1, ln[0] + ln[1]), 2)
 

@@ -21,7 +21,7 @@ int g_last_cls = 0;
 hipEvent_t get_event() {
   if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
   hipEvent_t e;
-  hipEventCreate(&e);
+  (void)hipEventCreate(&e);
   return e;
 }
 }  // namespace
@@ -33,7 +33,7 @@ void neosr_prof_begin(int cls, void* stream, double flops, double bytes) {
   r.a = get_event();
   r.b = get_event();
   r.cls = cls;
-  hipEventRecord(r.a, (hipStream_t)stream);
+  (void)hipEventRecord(r.a, (hipStream_t)stream);
   g_recs.push_back(r);
   g_flops[cls] += flops;
   g_bytes[cls] += bytes;
@@ -61,7 +61,7 @@ void neosr_prof_layers(int n) {
   g_chain_layers[g_last_cls] += n;
 }
 
-void neosr_prof_end(void* stream) { hipEventRecord(g_recs.back().b, (hipStream_t)stream); }
+void neosr_prof_end(void* stream) { (void)hipEventRecord(g_recs.back().b, (hipStream_t)stream); }
 
 extern "C" int neosr_prof_enable(int on) {
   g_on = on != 0;

@@ -765,7 +765,7 @@ __device__ __forceinline__ void wgrad_w4_body(const WgradMultiArgs& args, const 
     const float* xs = buf + lane + st * 256;            // + (row * 10 + cc) * 64
     const float* gs = buf + W4_XF + lane + st * 256;    // + (row * 8 + cc) * 64
     // ---- LDS reads of this step: input column pairs (0,1) [first step], (2,3), (4,5) and the gradient tile's column pairs
-    w4_f32x2 c1, c2, c3, c4, cA, cB, cC;
+    w4_f32x2 c1, c2, c3, c4, cA = {0.f, 0.f}, cB = {0.f, 0.f}, cC = {0.f, 0.f};   // (cA..cC: image-edge rows only)
     if (st == 0) {
       c1 = ld2(xs + 640); c2 = ld2(xs + 2 * 640); c3 = ld2(xs + 3 * 640); c4 = ld2(xs + 4 * 640);
       if (EDGE) { cA = ld2(xs + xa * 640); cB = ld2(xs + (xa + 2) * 640); cC = ld2(xs + (xa + 4) * 640); }
@@ -1069,7 +1069,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_thin_kernel(const ThinAr
     const unsigned fxrow = (unsigned)((b * H + y) * W) * (XWIDE ? thin_cs : wide_cs) + (XWIDE ? tw : cw);
     const float* __restrict__ shp = XWIDE ? wide : thin;   // shifted operand = the layer input x
     const float* __restrict__ fxp = XWIDE ? thin : wide;   // unshifted operand = g
-    const bool sh_lane_ok = XWIDE ? c_ok : t_ok, fx_lane_ok = XWIDE ? t_ok : c_ok;
+    const bool fx_lane_ok = XWIDE ? t_ok : c_ok;   // (lanes outside the shifted operand's range produce rows / columns nobody stores)
     for (int x = x_lo; x < x_hi; x += THIN_UNROLL) {
       float wv[THIN_UNROLL][9], tv[THIN_UNROLL][9];
       // every load of the batch of pixels first (global latency >> 72 cycles of MFMA per pixel)
