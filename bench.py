@@ -50,6 +50,7 @@ GFLOP_UNET_FWD_BWD = 155.30
 GFLOP_VGG = 153.0
 ALGO_MB_PER_PATCH = {"esrgan": 2852.8}
 
+MEASURED_BF16_MFMA_TFLOPS = 2013.0   # all-MFMA micro-kernel, profiles/r05_mfma_rate.txt
 DTYPE_FAST = ("f32 storage and accumulation; F(4x4,3x3) forward / backward-data products as two bf16 pieces per operand "
               "(16-bit significands) on the bf16 MFMA - the `fast_matmul` tier, not the headline")
 
@@ -445,7 +446,11 @@ def run_config(args, config: str, world: int, rank: int, dev, steps: int, warmup
                     "note": "six bf16 cross products per fp32 multiplication on v_mfma_f32_32x32x16_bf16 (fp32-faithful); `achieved` "
                             "/ `frac` above price the fp32-equivalent FLOPs against the fp32 MFMA peak",
                     "bf16_product_tflops": round(6 * ach, 2), "bf16_mfma_peak_tflops": PEAK_BF16_MFMA_TFLOPS,
-                    "bf16_mfma_frac": round(6 * ach / PEAK_BF16_MFMA_TFLOPS, 4)}
+                    "bf16_mfma_frac": round(6 * ach / PEAK_BF16_MFMA_TFLOPS, 4),
+                    # v_mfma_f32_32x32x16_bf16 issues every 16.7 ns per SIMD on this part (tools/micro/mfma_rate.hip,
+                    # profiles/r05_mfma_rate.txt): what the chip reaches with nothing but MFMAs in flight
+                    "bf16_mfma_measured_issue_peak_tflops": MEASURED_BF16_MFMA_TFLOPS,
+                    "bf16_mfma_frac_of_measured_peak": round(6 * ach / MEASURED_BF16_MFMA_TFLOPS, 4)}
                 roofline["symbol"] = ("gemm_nt_glds_x3_kernel|gemm_nt_glds64_x3_kernel" if dom == 6
                                       else "gemm_nn_glds_x3_kernel|gemm_nn_glds64_x3_kernel" if dom == 7
                                       else "gemm_tn_lds_x3_group_kernel|gemm_tn_lds_x3_kernel")
