@@ -655,7 +655,7 @@ int neosr_cosine_dist_bwd(const float* a, const float* b, const float* stats, co
  * exact-erf GELU between the two convs: out = g ? g * GELU'(x) : GELU(x). */
 int neosr_gelu(const float* x, const float* g, float* out, int64_t n, void* stream);
 /* out[b, c] = scale * sum_r x[b, r, c] (* y[b, r, c] if y): AdaptiveAvgPool2d(1) on channels-last data
- * and the gate gradient; fixed-order two-stage; workspace >= B*32*cols floats. */
+ * and the gate gradient; fixed-order two-stage (128 row slabs per sample); workspace >= B*128*cols floats. */
 int neosr_batched_colsum(const float* x, const float* y, float* out, float* workspace, int32_t B, int32_t rows,
                          int32_t cols, float scale, void* stream);
 /* squeeze-excite gate: hidden = relu(W1 pooled + b1) (Cs <= 16), attn = sigmoid(W2 hidden + b2);

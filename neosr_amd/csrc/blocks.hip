@@ -62,7 +62,7 @@ SaveLayout save_layout(const neosr_tblock_desc& d, float* base) {
     s.gate = c.take((int64_t)d.B * d.C);
     s.hidden = c.take((int64_t)d.B * d.cab_sq);
     s.x3 = c.take(M * d.C);
-    s.bcs = c.take((int64_t)d.B * 32 * d.C);   // scratch of the forward pooling pass
+    s.bcs = c.take((int64_t)d.B * 128 * d.C);   // scratch of the forward pooling pass
   }
   s.stats2 = c.take(2 * M);
   s.y2 = c.take(M * d.C);
@@ -229,7 +229,7 @@ BwdLayout bwd_layout(const neosr_tblock_desc& d, float* base) {
     b.gt0 = c.take(M * mid);
     b.gu0 = c.take(M * mid);
     b.gy1c = c.take(M * C);
-    b.bcs = c.take((int64_t)d.B * 32 * C);
+    b.bcs = c.take((int64_t)d.B * 128 * C);
     b.wg2 = c.take(neosr_conv3x3_wgrad_workspace_bytes(d.B, d.H, d.W, mid, C) / 4 + 64);
     b.wg0 = c.take(neosr_conv3x3_wgrad_workspace_bytes(d.B, d.H, d.W, C, mid) / 4 + 64);
   }

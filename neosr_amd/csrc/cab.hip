@@ -13,19 +13,50 @@ inline int grid_for(int64_t n, int cap = 4096) {
   return (int)(g < 1 ? 1 : (g > cap ? cap : g));
 }
 
-__device__ __forceinline__ float gelu_f(float z) { return 0.5f * z * (1.f + erff(z * 0.70710678118654752f)); }
+// erf as in the GEMM GELU epilogues (csrc/gemm_mfma.hip): Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7, from one v_rcp, one
+// v_exp and five FMAs; the Gaussian exp(-z^2 / 2) is shared with GELU'.  (The library erff made this elementwise pass
+// compute-bound: 17 us for one million values.)
+__device__ __forceinline__ float gauss_half(float z) { return __expf(-0.5f * z * z); }
+__device__ __forceinline__ float erf_from_gauss(float z, float e) {  // erf(z / sqrt 2), e = exp(-z^2 / 2)
+  const float x = fabsf(z) * 0.70710678118654752f;
+  const float t = __frcp_rn(fmaf(0.3275911f, x, 1.f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  return copysignf(fmaf(-p * t, e, 1.f), z);
+}
+__device__ __forceinline__ float gelu_f(float z) { return 0.5f * z * (1.f + erf_from_gauss(z, gauss_half(z))); }
 __device__ __forceinline__ float gelu_d(float z) {
-  return 0.5f * (1.f + erff(z * 0.70710678118654752f)) + z * 0.3989422804014327f * expf(-0.5f * z * z);
+  const float e = gauss_half(z);
+  return 0.5f * (1.f + erf_from_gauss(z, e)) + z * 0.3989422804014327f * e;
 }
 
+// VEC: 16-byte accesses (n a multiple of 4, pointers 16-byte aligned)
+template <bool VEC>
 __global__ __launch_bounds__(256) void gelu_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                                    float* __restrict__ out, int64_t n) {
+  if (VEC) {
+    const int64_t nq = n >> 2;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < nq; q += (int64_t)gridDim.x * 256) {
+      const float4 v = reinterpret_cast<const float4*>(x)[q];
+      float4 o;
+      if (g) {
+        const float4 u = reinterpret_cast<const float4*>(g)[q];
+        o = make_float4(u.x * gelu_d(v.x), u.y * gelu_d(v.y), u.z * gelu_d(v.z), u.w * gelu_d(v.w));
+      } else {
+        o = make_float4(gelu_f(v.x), gelu_f(v.y), gelu_f(v.z), gelu_f(v.w));
+      }
+      reinterpret_cast<float4*>(out)[q] = o;
+    }
+    return;
+  }
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256)
     out[e] = g ? g[e] * gelu_d(x[e]) : gelu_f(x[e]);
 }
 
 // part[b][slab][c] = sum over the slab's rows of x[b][r][c] (* y[b][r][c]); 64 columns x 4 row lanes
-constexpr int SLABS = 32;
+constexpr int SLABS = 128;
 __global__ __launch_bounds__(256) void bcolsum_stage1(const float* __restrict__ x, const float* __restrict__ y,
                                                       float* __restrict__ part, int rows, int cols) {
   __shared__ float red[4][64];
@@ -49,13 +80,57 @@ __global__ __launch_bounds__(256) void bcolsum_stage1(const float* __restrict__ 
   if (ty == 0 && c < cols)
     part[((int64_t)b * SLABS + slab) * cols + c] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
 }
+// the same partials for cols % 4 == 0, cols <= 1024 (the channels-last activations: cols = 180): one workgroup covers ALL
+// columns of its slab — lane (quad qx = tid % (cols / 4), row lane ry = tid / (cols / 4)) reads 16 bytes, the 256 / (cols / 4)
+// row lanes together read whole consecutive rows (contiguous memory); the row lanes are combined through LDS in order.
+// (The 64-column form above read 256 bytes per wave and row and left the pass at 0.7 TB/s: 16.7 us for 11.8 MB.)
+__global__ __launch_bounds__(256) void bcolsum_stage1_vec(const float* __restrict__ x, const float* __restrict__ y,
+                                                          float* __restrict__ part, int rows, int cols) {
+  __shared__ float4 red[256];
+  const int c4 = cols >> 2, rp = 256 / c4;
+  const int tid = threadIdx.x, qx = tid % c4, ry = tid / c4;
+  const int slab = blockIdx.y, b = blockIdx.z;
+  const int rpb = (rows + SLABS - 1) / SLABS;
+  const int r0 = slab * rpb, r1 = min(rows, r0 + rpb);
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (ry < rp) {
+    const int64_t base = (int64_t)b * rows * cols + 4 * qx;
+#pragma unroll 4
+    for (int r = r0 + ry; r < r1; r += rp) {
+      const float4 v = *reinterpret_cast<const float4*>(x + base + (int64_t)r * cols);
+      if (y) {
+        const float4 w = *reinterpret_cast<const float4*>(y + base + (int64_t)r * cols);
+        s.x += v.x * w.x; s.y += v.y * w.y; s.z += v.z * w.z; s.w += v.w * w.w;
+      } else {
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+    }
+  }
+  red[tid] = s;
+  __syncthreads();
+  if (tid < c4) {
+    float4 t = red[tid];
+    for (int k = 1; k < rp; ++k) {
+      const float4 u = red[k * c4 + tid];
+      t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+    }
+    *reinterpret_cast<float4*>(part + ((int64_t)b * SLABS + slab) * cols + 4 * tid) = t;
+  }
+}
 __global__ __launch_bounds__(256) void bcolsum_stage2(const float* __restrict__ part, float* __restrict__ out,
                                                       int cols, int n, float scale) {
   const int e = blockIdx.x * 256 + threadIdx.x;  // b * cols + c
   if (e >= n) return;
   const int b = e / cols, c = e - b * cols;
+  // (sixteen partials requested at a time, added in slab order: one dependent load per trip left this pass latency-bound)
   float s = 0.f;
-  for (int k = 0; k < SLABS; ++k) s += part[((int64_t)b * SLABS + k) * cols + c];
+  for (int k0 = 0; k0 < SLABS; k0 += 16) {
+    float v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = part[((int64_t)b * SLABS + k0 + k) * cols + c];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += v[k];
+  }
   out[e] = s * scale;
 }
 
@@ -100,9 +175,14 @@ __global__ __launch_bounds__(256) void chan_attn_bwd_kernel(const float* __restr
                                                             float* __restrict__ dw1, float* __restrict__ db1,
                                                             float* __restrict__ dw2, float* __restrict__ db2, int B,
                                                             int C, int Cs) {
-  __shared__ float dz2[512], dh[CS_MAX], db1_acc[CS_MAX];
-  __shared__ float red[4][CS_MAX];
+  // Everything the sample loop reads is fetched ONCE in front of it — the gate inputs of all samples into LDS (B C <= 8 192
+  // values: HAT trains with B = 4, C = 180), the weights a thread multiplies with into registers: the loop used to pay
+  // three dependent global round trips per sample in a single workgroup (22 us for B = 4).  Same sums in the same order.
+  constexpr int STAGE = 8192;
+  __shared__ float dz2_all[STAGE], pooled_all[STAGE], hidden_all[64 * CS_MAX];
+  __shared__ float dh[CS_MAX], db1_acc[CS_MAX];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool staged = B * C <= STAGE && B <= 64;
   // thread owns channels c = tid and tid + 256 (C <= 512)
   float gw2[2][CS_MAX], gb2[2] = {0.f, 0.f}, gw1[2][CS_MAX];
 #pragma unroll
@@ -110,26 +190,63 @@ __global__ __launch_bounds__(256) void chan_attn_bwd_kernel(const float* __restr
 #pragma unroll
     for (int j = 0; j < CS_MAX; ++j) gw2[k][j] = gw1[k][j] = 0.f;
   if (tid < CS_MAX) db1_acc[tid] = 0.f;
+  if (staged) {
+    for (int i = tid; i < B * C; i += 256) {
+      const float a = attn[i];
+      dz2_all[i] = dattn[i] * a * (1.f - a);
+      pooled_all[i] = pooled[i];
+    }
+    for (int i = tid; i < B * Cs; i += 256) hidden_all[i] = hidden[i];
+  }
+  // w2[c][j] for the (j = wave + 4 jj, c = lane + 64 kk) products of this lane, w1[j][c] for its two channels
+  float w2r[CS_MAX / 4][8], w1r[2][CS_MAX];
+#pragma unroll
+  for (int jj = 0; jj < CS_MAX / 4; ++jj)
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      const int j = wave + 4 * jj, c = lane + 64 * kk;
+      w2r[jj][kk] = (j < Cs && c < C) ? w2[c * Cs + j] : 0.f;
+    }
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+#pragma unroll
+    for (int j = 0; j < CS_MAX; ++j) {
+      const int c = tid + 256 * k;
+      w1r[k][j] = (j < Cs && c < C) ? w1[j * C + c] : 0.f;
+    }
+  __shared__ float dz2_one[512];
   for (int b = 0; b < B; ++b) {
     __syncthreads();
+    const float* dz2 = staged ? dz2_all + b * C : dz2_one;
+    if (!staged) {
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int c = tid + 256 * k;
-      if (c < C) {
-        const float a = attn[(int64_t)b * C + c];
-        dz2[c] = dattn[(int64_t)b * C + c] * a * (1.f - a);
+      for (int k = 0; k < 2; ++k) {
+        const int c = tid + 256 * k;
+        if (c < C) {
+          const float a = attn[(int64_t)b * C + c];
+          dz2_one[c] = dattn[(int64_t)b * C + c] * a * (1.f - a);
+        }
       }
+      __syncthreads();
     }
-    __syncthreads();
     // dh[j] = relu'(h) * sum_c dz2[c] w2[c][j]
-    for (int j = wave; j < Cs; j += 4) {
-      float s = 0.f;
-      for (int c = lane; c < C; c += 64) s += dz2[c] * w2[c * Cs + j];
-      s = wave_reduce_sum(s);
-      if (lane == 0) {
-        const float v = hidden[b * Cs + j] > 0.f ? s : 0.f;
-        dh[j] = v;
-        db1_acc[j] += v;
+#pragma unroll
+    for (int jj = 0; jj < CS_MAX / 4; ++jj) {
+      const int j = wave + 4 * jj;
+      if (j < Cs) {
+        float s = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+          const int c = lane + 64 * kk;
+          if (c < C) s += dz2[c] * w2r[jj][kk];
+        }
+        s = wave_reduce_sum(s);
+        if (lane == 0) {
+          const float h = staged ? hidden_all[b * Cs + j] : hidden[b * Cs + j];
+          const float v = h > 0.f ? s : 0.f;
+          dh[j] = v;
+          db1_acc[j] += v;
+        }
       }
     }
     __syncthreads();
@@ -137,15 +254,15 @@ __global__ __launch_bounds__(256) void chan_attn_bwd_kernel(const float* __restr
     for (int k = 0; k < 2; ++k) {
       const int c = tid + 256 * k;
       if (c < C) {
-        const float z = dz2[c], pc = pooled[(int64_t)b * C + c];
+        const float z = dz2[c], pc = staged ? pooled_all[b * C + c] : pooled[(int64_t)b * C + c];
         gb2[k] += z;
         float dp = 0.f;
 #pragma unroll
         for (int j = 0; j < CS_MAX; ++j)
           if (j < Cs) {
-            gw2[k][j] += z * hidden[b * Cs + j];
+            gw2[k][j] += z * (staged ? hidden_all[b * Cs + j] : hidden[b * Cs + j]);
             gw1[k][j] += dh[j] * pc;
-            dp += dh[j] * w1[j * C + c];
+            dp += dh[j] * w1r[k][j];
           }
         dpooled[(int64_t)b * C + c] = dp;
       }
@@ -166,14 +283,32 @@ __global__ __launch_bounds__(256) void chan_attn_bwd_kernel(const float* __restr
     }
   }
   if (tid < Cs) db1[tid] = db1_acc[tid];
-  (void)red;
 }
 
+// VEC: C a multiple of 4 and 16-byte aligned pointers: one quad of channels per thread, 32-bit index arithmetic (the scalar
+// form spends two 64-bit divisions per element: 21 us for 2.9 million values)
+template <bool VEC>
 __global__ __launch_bounds__(256) void scale_channels_add_kernel(const float* __restrict__ y,
                                                                  const float* __restrict__ attn,
                                                                  const float* __restrict__ res,
                                                                  float* __restrict__ out, int64_t n, int rows, int C,
                                                                  float alpha) {
+  if (VEC) {
+    const int c4 = C >> 2;
+    const unsigned per4 = (unsigned)rows * c4, nq = (unsigned)(n >> 2);
+    for (unsigned q = blockIdx.x * 256u + threadIdx.x; q < nq; q += gridDim.x * 256u) {
+      const unsigned b = q / per4, c = (q % c4) * 4;
+      const float4 v = reinterpret_cast<const float4*>(y)[q];
+      const float4 a = *reinterpret_cast<const float4*>(attn + (int64_t)b * C + c);
+      float4 o = make_float4(alpha * v.x * a.x, alpha * v.y * a.y, alpha * v.z * a.z, alpha * v.w * a.w);
+      if (res) {
+        const float4 r = reinterpret_cast<const float4*>(res)[q];
+        o = make_float4(r.x + o.x, r.y + o.y, r.z + o.z, r.w + o.w);
+      }
+      reinterpret_cast<float4*>(out)[q] = o;
+    }
+    return;
+  }
   const int64_t per = (int64_t)rows * C;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
     const int b = (int)(e / per), c = (int)(e % C);
@@ -182,11 +317,25 @@ __global__ __launch_bounds__(256) void scale_channels_add_kernel(const float* __
   }
 }
 
+template <bool VEC>
 __global__ __launch_bounds__(256) void scale_channels_bwd_kernel(const float* __restrict__ g,
                                                                  const float* __restrict__ attn,
                                                                  const float* __restrict__ dpooled,
                                                                  float* __restrict__ dy, int64_t n, int rows, int C,
                                                                  float alpha, float inv_rows) {
+  if (VEC) {
+    const int c4 = C >> 2;
+    const unsigned per4 = (unsigned)rows * c4, nq = (unsigned)(n >> 2);
+    for (unsigned q = blockIdx.x * 256u + threadIdx.x; q < nq; q += gridDim.x * 256u) {
+      const unsigned b = q / per4, c = (q % c4) * 4;
+      const float4 v = reinterpret_cast<const float4*>(g)[q];
+      const float4 a = *reinterpret_cast<const float4*>(attn + (int64_t)b * C + c);
+      const float4 p = *reinterpret_cast<const float4*>(dpooled + (int64_t)b * C + c);
+      reinterpret_cast<float4*>(dy)[q] = make_float4(alpha * v.x * a.x + p.x * inv_rows, alpha * v.y * a.y + p.y * inv_rows,
+                                                      alpha * v.z * a.z + p.z * inv_rows, alpha * v.w * a.w + p.w * inv_rows);
+    }
+    return;
+  }
   const int64_t per = (int64_t)rows * C;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
     const int b = (int)(e / per), c = (int)(e % C);
@@ -194,11 +343,16 @@ __global__ __launch_bounds__(256) void scale_channels_bwd_kernel(const float* __
   }
 }
 
+inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
 }  // namespace
 
 extern "C" int neosr_gelu(const float* x, const float* g, float* out, int64_t n, void* stream) {
   NEOSR_CHECK(x && out && n > 0, "gelu: bad args");
-  hipLaunchKernelGGL(gelu_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, g, out, n);
+  if (n % 4 == 0 && al16(x) && al16(g) && al16(out))
+    hipLaunchKernelGGL(gelu_kernel<true>, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, x, g, out, n);
+  else
+    hipLaunchKernelGGL(gelu_kernel<false>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, g, out, n);
   NEOSR_LAUNCH_CHECK();
   return 0;
 }
@@ -206,8 +360,11 @@ extern "C" int neosr_gelu(const float* x, const float* g, float* out, int64_t n,
 extern "C" int neosr_batched_colsum(const float* x, const float* y, float* out, float* workspace, int32_t B,
                                     int32_t rows, int32_t cols, float scale, void* stream) {
   NEOSR_CHECK(x && out && workspace && B > 0 && rows > 0 && cols > 0, "batched_colsum: bad args");
-  hipLaunchKernelGGL(bcolsum_stage1, dim3(ceil_div(cols, 64), SLABS, B), dim3(256), 0, (hipStream_t)stream, x, y,
-                     workspace, rows, cols);
+  if (cols % 4 == 0 && cols <= 1024 && al16(x) && al16(y) && al16(workspace))
+    hipLaunchKernelGGL(bcolsum_stage1_vec, dim3(1, SLABS, B), dim3(256), 0, (hipStream_t)stream, x, y, workspace, rows, cols);
+  else
+    hipLaunchKernelGGL(bcolsum_stage1, dim3(ceil_div(cols, 64), SLABS, B), dim3(256), 0, (hipStream_t)stream, x, y,
+                       workspace, rows, cols);
   hipLaunchKernelGGL(bcolsum_stage2, dim3(ceil_div(B * cols, 256)), dim3(256), 0, (hipStream_t)stream, workspace, out,
                      cols, B * cols, scale);
   NEOSR_LAUNCH_CHECK();
@@ -242,8 +399,12 @@ extern "C" int neosr_scale_channels_add(const float* y, const float* attn, const
                                         int32_t rows, int32_t C, float alpha, void* stream) {
   NEOSR_CHECK(y && attn && out && B > 0 && rows > 0 && C > 0, "scale_channels_add: bad args");
   const int64_t n = (int64_t)B * rows * C;
-  hipLaunchKernelGGL(scale_channels_add_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, y, attn, res, out,
-                     n, rows, C, alpha);
+  if (C % 4 == 0 && n < (int64_t(1) << 32) && al16(y) && al16(attn) && al16(res) && al16(out))
+    hipLaunchKernelGGL(scale_channels_add_kernel<true>, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, y, attn, res,
+                       out, n, rows, C, alpha);
+  else
+    hipLaunchKernelGGL(scale_channels_add_kernel<false>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, y, attn, res,
+                       out, n, rows, C, alpha);
   NEOSR_LAUNCH_CHECK();
   return 0;
 }
@@ -252,8 +413,12 @@ extern "C" int neosr_scale_channels_bwd(const float* g, const float* attn, const
                                         int32_t rows, int32_t C, float alpha, void* stream) {
   NEOSR_CHECK(g && attn && dpooled && dy && B > 0 && rows > 0 && C > 0, "scale_channels_bwd: bad args");
   const int64_t n = (int64_t)B * rows * C;
-  hipLaunchKernelGGL(scale_channels_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, g, attn, dpooled,
-                     dy, n, rows, C, alpha, 1.f / rows);
+  if (C % 4 == 0 && n < (int64_t(1) << 32) && al16(g) && al16(attn) && al16(dpooled) && al16(dy))
+    hipLaunchKernelGGL(scale_channels_bwd_kernel<true>, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, g, attn,
+                       dpooled, dy, n, rows, C, alpha, 1.f / rows);
+  else
+    hipLaunchKernelGGL(scale_channels_bwd_kernel<false>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, g, attn,
+                       dpooled, dy, n, rows, C, alpha, 1.f / rows);
   NEOSR_LAUNCH_CHECK();
   return 0;
 }

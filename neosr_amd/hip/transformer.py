@@ -754,7 +754,7 @@ class ChannelGate(torch.autograd.Function):
         rows, Cs = H * W, w1.shape[0]
         w1c, w2c = w1.contiguous(), w2.contiguous()
         pooled, attn, hidden = _new((B, C_), y), _new((B, C_), y), _new((B, Cs), y)
-        ws = _new((B * 32 * C_,), y)
+        ws = _new((B * 128 * C_,), y)
         _C.check(lib.neosr_batched_colsum(y.data_ptr(), None, pooled.data_ptr(), ws.data_ptr(), B, rows, C_,
                                           1.0 / rows, _st()), "neosr_batched_colsum")
         _C.check(lib.neosr_channel_attention_fwd(pooled.data_ptr(), w1c.data_ptr(), b1.data_ptr(), w2c.data_ptr(),
@@ -777,7 +777,7 @@ class ChannelGate(torch.autograd.Function):
         B, rows, C_, Cs, alpha, has_res, s1, s2 = ctx.meta
         g = g.contiguous()
         dattn, dpooled = _new((B, C_), y), _new((B, C_), y)
-        ws = _new((B * 32 * C_,), y)
+        ws = _new((B * 128 * C_,), y)
         _C.check(lib.neosr_batched_colsum(g.data_ptr(), y.data_ptr(), dattn.data_ptr(), ws.data_ptr(), B, rows, C_,
                                           alpha, _st()), "neosr_batched_colsum")
         dw1, db1, dw2, db2 = _new((Cs, C_), y), _new((Cs,), y), _new((C_, Cs), y), _new((C_,), y)

@@ -38,7 +38,7 @@ class gan_loss(nn.Module):
         with torch.no_grad():  # logging value mean(net_output) on the HIP column-sum kernel
             lib, x = _C.load(), net_output.detach().contiguous()
             mean = torch.empty(1, device=x.device, dtype=torch.float32)
-            ws = torch.empty(32, device=x.device, dtype=torch.float32)
+            ws = torch.empty(128, device=x.device, dtype=torch.float32)
             _C.check(lib.neosr_batched_colsum(x.data_ptr(), None, mean.data_ptr(), ws.data_ptr(), 1, x.numel(), 1,
                                               1.0 / x.numel(), _C.stream_ptr()), "neosr_batched_colsum")
         self.last_mean = mean.reshape(())
