@@ -52,7 +52,8 @@ ALGO_MB_PER_PATCH = {"esrgan": 2852.8}
 
 MEASURED_BF16_MFMA_TFLOPS = 2013.0   # all-MFMA micro-kernel, profiles/r05_mfma_rate.txt
 DTYPE_FAST = ("f32 storage and accumulation; F(4x4,3x3) forward / backward-data products as two bf16 pieces per operand "
-              "(16-bit significands) on the bf16 MFMA - the `fast_matmul` tier, not the headline")
+              "(16-bit significands), nn.Linear products from the three leading bf16 cross terms (~2e-5 per product) on the "
+              "bf16 MFMA - the `fast_matmul` tier, not the headline")
 
 ALIASES = {"paired_l1": "bench_esrgan", "otf_gan": "bench_esrgan_otf_gan", "swinir_percep": "bench_swinir_medium"}
 
@@ -532,6 +533,8 @@ def main() -> None:
                      0 if args.no_roofline else max(1, min(args.steps, 3)))
     opt, B, elapsed, loss, roofline = res["opt"], res["B"], res["elapsed"], res["loss"], res["roofline"]
     workload, gflop_patch = res["workload"], res["gflop_patch"]
+    # the tier the timed steps really ran in (the option, --fast-matmul, or NEOSR_AMD_FAST_MATMUL forcing it): labels `dtype`
+    main_fast = bool(_C.FAST_MATMUL)
 
     # the other four BASELINE configs, driver-observed: only on the default invocation (headline config, one
     # GPU, no overrides), 5 timed steps each after 2 warm-up steps, one profiled step for the executed-FLOP fraction
@@ -539,9 +542,10 @@ def main() -> None:
     named = not (args.batch or args.arch or args.template_losses or args.augment or args.fast_matmul)
     if world == 1 and named and cfg_name == "bench_esrgan" and not args.no_other_configs:
         others = []
-        # (+ the headline config once more under `fast_matmul = true`: the labelled reduced-precision tier, never the headline)
+        # (+ the headline config and the GEMM-heavy one once more under `fast_matmul = true`: the labelled reduced-precision
+        # tier, never the headline)
         for oc, fast in (("bench_compact", False), ("bench_esrgan_otf_gan", False), ("bench_swinir_medium", False),
-                         ("bench_hat_l_otf_gan", False), ("bench_esrgan", True)):
+                         ("bench_hat_l_otf_gan", False), ("bench_esrgan", True), ("bench_swinir_medium", True)):
             t0 = time.perf_counter()
             try:
                 r = run_config(args, oc, 1, 0, dev, 5, 2, 0 if args.no_roofline else 1, overrides=False, fast_matmul=fast)
@@ -578,7 +582,7 @@ def main() -> None:
         "metric": "LR-patches/sec (64x64 -> 256x256 x4) fwd+bwd+optimizer step",
         "value": round(value, 3), "unit": "LR-patches/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE_FAST if args.fast_matmul else "f32",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE_FAST if (args.fast_matmul or main_fast) else "f32",
         "data": "synthetic",
         "config": {"workload": workload + (f" ({opt_doc(cfg_name)})" if named else " (NOT a named BASELINE config)"),
                    "options_file": f"options/{cfg_name}.toml" if (ROOT / "options" / f"{cfg_name}.toml").exists() else args.config,

@@ -162,7 +162,9 @@ int neosr_set_conv_chain(int on);
  * v_mfma_f32_16x16x32_bf16, fp32 accumulation; transforms, epilogues, weight gradients, every other kernel and all storage
  * stay fp32.  ~1e-4 of the output scale per layer against the float64 convolution (fp32 path: ~5e-6) — a labelled
  * reduced-precision tier, never the default (0; env NEOSR_AMD_FAST_MATMUL=1).  The weight images are packed for the mode
- * (same size): switch BEFORE packing / re-pack after a switch.  Returns the previous setting. */
+ * (same size): switch BEFORE packing / re-pack after a switch.  The bf16x3 nn.Linear GEMMs (neosr_gemm, neosr_gemm_tn_group)
+ * follow the same switch: they keep the three leading cross terms p0q0 + p0q1 + p1q0 of their six (a product good to ~2e-5
+ * instead of 2^-24), half the matrix work.  Returns the previous setting. */
 int neosr_set_fast_matmul(int on);
 /* nn.Linear GEMMs (neosr/archs/swinir_arch.py:15-38, 139-143; hat_arch.py): 1 (default; env NEOSR_AMD_GEMM_X3) = products on
  * v_mfma_f32_32x32x16_bf16 from bf16x3 operands (each fp32 value as three bf16 pieces, the six leading cross products, fp32

@@ -18,6 +18,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "conv_common.h"
 #include "../../include/neosr_amd.h"
 #include "prof.h"
 
@@ -61,6 +62,7 @@ struct GemmArgs {
   int tiles_m, tiles_n, nsplit;
   float* colsum_part;  // TN with d.colsum_a: per-split partial column sums of A, row stride slab
   int64_t slab;        // TN: floats per split-K slab (M*N, + M when the column sums ride behind it)
+  int fast3;       // bf16x3 kernels: the three-product fast_matmul tier (mac6)
   int b_vec;       // B (and bias) 16-byte aligned -> float4 loads; else dword loads (weights that sit
                    // at a 4-byte-aligned offset of a packed parameter arena)
 };
@@ -133,11 +135,16 @@ __device__ __forceinline__ void split3(const f32x4 lo4, const f32x4 hi4, bf16x8 
 __device__ __forceinline__ void split3v(const float (&x)[8], bf16x8 (&P)[3]) {
   split3((f32x4){x[0], x[1], x[2], x[3]}, (f32x4){x[4], x[5], x[6], x[7]}, P);
 }
-// acc += sum over the six leading cross terms of (weight pieces W) x (activation pieces X), smallest terms first
-__device__ __forceinline__ f32x16 mac6(const bf16x8 (&W)[3], const bf16x8 (&X)[3], f32x16 acc) {
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[2], X[0], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[0], X[2], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[1], X[1], acc, 0, 0, 0);
+// acc += sum over the six leading cross terms of (weight pieces W) x (activation pieces X), smallest terms first.
+// `fast` (wave-uniform; the `fast_matmul` tier, neosr_set_fast_matmul): only p0q0 + p0q1 + p1q0 — the three terms of
+// relative size 2^-16 are dropped, a product is then good to ~2e-5 instead of 2^-24 (train.py:168-173 ships a far looser
+// mode behind the same option); never the default.
+__device__ __forceinline__ f32x16 mac6(const bf16x8 (&W)[3], const bf16x8 (&X)[3], f32x16 acc, bool fast = false) {
+  if (!fast) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[2], X[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[0], X[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[1], X[1], acc, 0, 0, 0);
+  }
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[1], X[0], acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[0], X[1], acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[0], X[0], acc, 0, 0, 0);
@@ -391,6 +398,7 @@ __device__ __forceinline__ void gemm_nt_glds_body(const GemmArgs& args) {
   if (logical >= tiles) return;
   const int m0 = (logical / args.tiles_n) * BM, n0 = (logical % args.tiles_n) * BN;
   const int K = d.K;
+  const bool fast3 = __builtin_amdgcn_readfirstlane(args.fast3) != 0;
   // per-lane source rows: instruction i of this wave covers tile rows (4 i + wave) * 8 + lane / 8
   const int rsub = lane >> 3, slot = lane & 7;
   const float* zp = gm_zero_page;  // pinned in SGPRs (else its address is re-read through the GOT in every chunk)
@@ -525,8 +533,8 @@ __device__ __forceinline__ void gemm_nt_glds_body(const GemmArgs& args) {
               W0[p3] = *reinterpret_cast<const bf16x8*>(bbuf + l31 * 48 + sl);
               if (TWO) W1[p3] = *reinterpret_cast<const bf16x8*>(bbuf + (32 + l31) * 48 + sl);
             }
-            acc[0] = mac6(W0, X, acc[0]);
-            if (TWO) acc[1] = mac6(W1, X, acc[1]);
+            acc[0] = mac6(W0, X, acc[0], fast3);
+            if (TWO) acc[1] = mac6(W1, X, acc[1], fast3);
           }
         }
         return;
@@ -598,6 +606,7 @@ __device__ __forceinline__ void gemm_nt_glds64_body(const GemmArgs& args) {
   if (logical >= tiles) return;
   const int m0 = (logical / args.tiles_n) * BM2, n0 = (logical % args.tiles_n) * BN;
   const int K = d.K;
+  const bool fast3 = __builtin_amdgcn_readfirstlane(args.fast3) != 0;
   const int rsub = lane >> 3, slot = lane & 7;
   const float* zp = gm_zero_page;
   asm volatile("" : "+s"(zp));
@@ -699,7 +708,7 @@ __device__ __forceinline__ void gemm_nt_glds64_body(const GemmArgs& args) {
 #pragma unroll
           for (int p3 = 0; p3 < 3; ++p3)
             W[p3] = *reinterpret_cast<const bf16x8*>(bbuf + brow * 48 + 4 * ((4 * p3 + 2 * ps + lh) ^ sb));
-          acc[0] = mac6(W, X, acc[0]);
+          acc[0] = mac6(W, X, acc[0], fast3);
         }
       }
       return;
@@ -986,6 +995,7 @@ __device__ __forceinline__ void tn_lds_task(const GemmArgs& args, int split, int
   const int wm = wave & 1, wn = wave >> 1;
   const int m0 = (tile / args.tiles_n) * LT, n0 = (tile % args.tiles_n) * LT;
   const int M = d.M, N = d.N;
+  const bool fast3 = __builtin_amdgcn_readfirstlane(args.fast3) != 0;
   const int t_lo = split * args.ksplit_len;
   const int t_hi = min(d.K, t_lo + args.ksplit_len);
   const int nsteps = (t_hi - t_lo + 15) >> 4;
@@ -1060,7 +1070,7 @@ __device__ __forceinline__ void tn_lds_task(const GemmArgs& args, int split, int
       for (int p3 = 0; p3 < 3; ++p3)
         Af[p3] = *reinterpret_cast<const bf16x8*>(sb + ((2 * p3 + lh) * (2 * LT) + wm * 96 + 32 * bm + l31) * 4);
 #pragma unroll
-      for (int bn = 0; bn < 3; ++bn) acc[bm][bn] = mac6(Bf[bn], Af, acc[bm][bn]);   // D rows <-> n, columns <-> m
+      for (int bn = 0; bn < 3; ++bn) acc[bm][bn] = mac6(Bf[bn], Af, acc[bm][bn], fast3);   // D rows <-> n, columns <-> m
     }
   };
   if (nsteps > 0) {
@@ -1305,6 +1315,7 @@ extern "C" int neosr_gemm(const neosr_gemm_desc* dp, void* stream) {
   a.colsum_part = nullptr;
   a.slab = 0;
   a.b_vec = al(d.B, d.ldb) && al(d.bias, 0);
+  a.fast3 = (gemm_x3() && neosr_conv::fast_matmul()) ? 1 : 0;
   a.tiles_m = ceil_div(d.M, BM);
   a.tiles_n = ceil_div(d.N, BN);
   dim3 grid(ceil_div(a.tiles_m * a.tiles_n, 8) * 8, 1, 1);
@@ -1444,6 +1455,7 @@ extern "C" int neosr_gemm_tn_group(const neosr_gemm_desc* descs, int32_t n, int3
     GemmArgs& a = g.p[i];
     a.d = d;
     a.b_vec = 1;
+    a.fast3 = (gemm_x3() && neosr_conv::fast_matmul()) ? 1 : 0;
     a.ksplit_len = all_lds ? tn_lds_ksplit(d.K) : tn_reg_ksplit(d.M, d.N, d.K);
     a.tiles_m = ceil_div(d.M, all_lds ? LT : RT_M);
     a.tiles_n = ceil_div(d.N, all_lds ? LT : RT_N);

@@ -47,6 +47,35 @@ def test_gemm_modes_vs_float64(M, N, K):
     assert rel_err(cs, Y.double().sum(0)) < 1e-5
 
 
+@pytest.mark.parametrize("M,N,K", [(4096, 540, 180), (1000, 180, 360)])
+def test_gemm_fast_matmul_tier_is_labelled_precision(M, N, K):
+    """`fast_matmul` (reference train.py:168-173: TF32 / "medium" matmul precision) switches the bf16x3 Linear GEMMs to their
+    three leading cross terms: the result is within 1e-4 of float64 (TF32 would be ~1e-3), measurably looser than the default
+    (~1e-7: the switch is wired), and the default comes back bit for bit when it is switched off."""
+    from neosr_amd import _C
+    from neosr_amd.hip import transformer as tr
+
+    g = torch.Generator().manual_seed(3 * M + N + K)
+    A, W, Y = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g), torch.randn(M, N, generator=g)
+    refs = (A.double() @ W.double().t(), Y.double() @ W.double(), Y.double().t() @ A.double())
+
+    def run():
+        return (tr.gemm(_C.GEMM_NT, A.to(DEV), W.to(DEV), M, N, K), tr.gemm(_C.GEMM_NN, Y.to(DEV), W.to(DEV), M, K, N),
+                tr.gemm(_C.GEMM_TN, Y.to(DEV), A.to(DEV), N, K, M))
+
+    base = run()
+    prev = _C.set_fast_matmul(True)
+    try:
+        fast = run()
+    finally:
+        _C.set_fast_matmul(prev)
+    again = run()
+    for b, f, a2, r in zip(base, fast, again, refs):
+        eb, ef = rel_err(b, r), rel_err(f, r)
+        assert eb < 1e-6 and 3e-7 < ef < 1e-4, (eb, ef)
+        assert torch.equal(b, a2)
+
+
 @pytest.mark.parametrize("M,N,K", [(4096, 540, 180), (1000, 180, 360), (32768, 180, 180)])
 def test_gemm_bf16x3_products_are_fp32_faithful(M, N, K):
     """The default Linear GEMMs (NT forward, NN backward-data) run their products on the bf16 MFMA from three bf16 pieces per
