@@ -267,3 +267,57 @@ def test_image_model_trajectory_hat_s_vs_reference_fixture():
     sd = model.net_g.state_dict()
     for k in [f for f in fix if f.startswith("final/w/")]:
         assert rel_err(sd[k[len("final/w/"):]], T(fix[k])) < 1e-3, k
+
+
+@pytest.mark.parametrize("C,Cs,rows,B", [(180, 6, 4096, 3), (60, 4, 1024, 3), (6, 2, 100, 3), (10, 2, 77, 70)])
+def test_channel_gate_vector_and_scalar_forms_vs_torch(C, Cs, rows, B):
+    """ChannelAttention + HAB's gated residual (hat_arch.py:15-37, 347) through the side kernels of csrc/cab.hip: channel
+    counts that are multiples of 4 take the 16-byte forms (whole-row pooling pass, quad gate scale / gradient), the others
+    the scalar forms; more than 64 samples (the B = 70 case) take the gate backward's unstaged path.  Reference: the same
+    formulas in torch float64."""
+    from neosr_amd.hip import transformer as tr
+
+    g = torch.Generator().manual_seed(C + rows)
+    alpha = 0.01
+    H, W = (rows // 64, 64) if rows % 64 == 0 else (1, rows)
+    y = torch.randn(B, H, W, C, generator=g)
+    res = torch.randn(B, H, W, C, generator=g)
+    w1, b1 = torch.randn(Cs, C, generator=g) * 0.3, torch.randn(Cs, generator=g) * 0.1
+    w2, b2 = torch.randn(C, Cs, generator=g) * 0.3, torch.randn(C, generator=g) * 0.1
+    go = torch.randn(B, H, W, C, generator=g)
+
+    def ref(y, w1, b1, w2, b2, res):
+        pooled = y.mean(dim=(1, 2))
+        attn = torch.sigmoid(torch.relu(pooled @ w1.t() + b1) @ w2.t() + b2)
+        return res + alpha * y * attn[:, None, None, :]
+
+    leaves = [t.double().requires_grad_(True) for t in (y, w1, b1, w2, b2, res)]
+    out_ref = ref(*leaves)
+    grads_ref = torch.autograd.grad(out_ref, leaves, go.double())
+    dl = [t.to(DEV).requires_grad_(True) for t in (y, w1, b1, w2, b2, res)]
+    out = tr.ChannelGate.apply(dl[0], dl[1], dl[2], dl[3], dl[4], dl[5], alpha)
+    grads = torch.autograd.grad(out, dl, go.to(DEV))
+    assert rel_err(out, out_ref) < 1e-5
+    for a, b in zip(grads, grads_ref):
+        assert rel_err(a, b) < 1e-4, (a.shape, rel_err(a, b))
+
+
+@pytest.mark.parametrize("n,off", [(60 * 4096, 0), (1003, 0), (4096, 1)])
+def test_gelu_and_leaky_relu_vector_and_scalar_forms(n, off):
+    """exact-erf GELU (hat_arch.py:46) and the leaky-ReLU / add passes of hip/layers.py: sizes that are multiples of 4 on
+    16-byte aligned storage take the float4 kernels, an odd size or a view that starts one float into its storage the scalar
+    ones.  GELU's erf is the A&S 7.1.26 form of the GEMM epilogues (|error| <= 1.5e-7)."""
+    from neosr_amd.hip import layers as L
+    from neosr_amd.hip import transformer as tr
+
+    g = torch.Generator().manual_seed(n + off)
+    x = (torch.randn(n + off, generator=g) * 2.0).to(DEV)[off:].requires_grad_(True)
+    go = torch.randn(n + off, generator=g).to(DEV)[off:]
+    xd = x.detach().cpu().double().requires_grad_(True)
+    y_ref = torch.nn.functional.gelu(xd)
+    (gx_ref,) = torch.autograd.grad(y_ref, xd, go.cpu().double())
+    y = tr.Gelu.apply(x)
+    (gx,) = torch.autograd.grad(y, x, go)
+    assert rel_err(y, y_ref) < 1e-6 and rel_err(gx, gx_ref) < 1e-6
+    lr = L.LeakyReLU.apply(x.detach(), 0.2)
+    assert torch.equal(lr.cpu(), torch.nn.functional.leaky_relu(x.detach().cpu(), 0.2))
