@@ -12,6 +12,15 @@
 // multiply by GELU'(aux_in) (backward through the activation); per-sample row scale (DropPath);
 // + residual.  TN writes split-K partial slabs that `colsum_kernel` sums in a fixed order.
 //
+//
+// Default since round 5 (neosr_set_gemm_x3): the same three products from bf16x3 pieces — every fp32 operand as
+// p0 + p1 + p2 (8 + 8 + 8 significant bits), the six leading cross terms on v_mfma_f32_32x32x16_bf16 with fp32
+// accumulation: as accurate as the fp32 MFMA (split3 / mac6 below), 6 x 32 cycles per 16 reduction indices instead of
+// 8 x 64.  NT / NN: gemm_nt_glds_x3_kernel & co (the fp32 kernels' tiles and epilogues, weight tile pre-split into LDS
+// planes); TN: gemm_tn_lds_x3_kernel / _group_kernel (192 x 192 tiles, both operands split once at staging).  Under
+// neosr_set_fast_matmul the three 2^-16 terms are dropped (the labelled reduced-precision tier).  The fp32 kernels stay
+// selectable (neosr_set_gemm_x3(0)) and take the shapes the bf16x3 forms do not.
+//
 // Reference call sites: neosr/archs/swinir_arch.py:15-38 (Mlp), :139-143,150-156,209-210
 // (qkv / proj Linears), and the same layers of neosr/archs/hat_arch.py.
 #include <cstring>
