@@ -167,19 +167,28 @@ __global__ __launch_bounds__(256, 2) void wattn_wave_fwd_kernel(const neosr_watt
     const float* tb = tab + (yi + WS - 1) * (2 * WS - 1) + xi + WS - 1 - 4 * lh;
     const int ri = region1(yi, w.Wy, w.nWy, d.shift) * 3 + region1(xi, w.Wx, w.nWx, d.shift);
     float m = -3.0e38f;
+    // (the table values of a tile are read in one batch, and the mask is a select on a penalty that is 0 in unmasked windows:
+    // `if (masked && ..) sc -= 100` compiled to one LDS read + wait + branch per score — 32 exposed LDS round trips per tile)
+    const float mpen = masked ? 100.f : 0.f;
 #pragma unroll
-    for (int tj = 0; tj < 2; ++tj)
+    for (int tj = 0; tj < 2; ++tj) {
+      float bv[16];
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[4 * g + r] = tb[-((4 * tj + g) * (2 * WS - 1) + r)];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int ryj = region1(4 * tj + g, w.Wy, w.nWy, d.shift) * 3;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float sc = st[tj][4 * g + r] + tb[-((4 * tj + g) * (2 * WS - 1) + r)];
-          if (masked && ryj + region1(4 * lh + r, w.Wx, w.nWx, d.shift) != ri) sc -= 100.f;
+          float sc = st[tj][4 * g + r] + bv[4 * g + r];
+          sc -= (ryj + region1(4 * lh + r, w.Wx, w.nWx, d.shift) != ri) ? mpen : 0.f;
           st[tj][4 * g + r] = sc;
           m = fmaxf(m, sc);
         }
       }
+    }
     m = fmaxf(m, __shfl_xor(m, 32));
     float sum = 0.f;
 #pragma unroll
@@ -287,8 +296,16 @@ __global__ __launch_bounds__(256, 2) void wattn16_wave_fwd_kernel(const neosr_fa
     const float* tb = tab + (yi + W16 - 1) * TS16 + xi + W16 - 1 - 4 * lh;
     const int ri = region16(yi, w.Wy, w.nWy, d.shift) * 3 + region16(xi, w.Wx, w.nWx, d.shift);
     float m = -3.0e38f;
+    // (as in the 8 x 8 kernel: the 16 table values of a key tile in one batch of LDS reads, the mask as a select on a
+    // penalty that is 0 in unmasked windows — the `if (masked && ..)` form was one LDS read + wait + branch per score)
+    const float mpen = masked ? 100.f : 0.f;
 #pragma unroll
-    for (int tj = 0; tj < NKT; ++tj)
+    for (int tj = 0; tj < NKT; ++tj) {
+      float bv[16];
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[4 * g + r] = tb[-((2 * tj + (g >> 1)) * TS16 + 8 * (g & 1) + r)];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int yj = 2 * tj + (g >> 1);
@@ -296,12 +313,13 @@ __global__ __launch_bounds__(256, 2) void wattn16_wave_fwd_kernel(const neosr_fa
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int xj0 = 8 * (g & 1) + r;  // + 4 lh
-          float sc = st[tj][4 * g + r] + tb[-(yj * TS16 + xj0)];
-          if (masked && ryj + region16(xj0 + 4 * lh, w.Wx, w.nWx, d.shift) != ri) sc -= 100.f;
+          float sc = st[tj][4 * g + r] + bv[4 * g + r];
+          sc -= (ryj + region16(xj0 + 4 * lh, w.Wx, w.nWx, d.shift) != ri) ? mpen : 0.f;
           st[tj][4 * g + r] = sc;
           m = fmaxf(m, sc);
         }
       }
+    }
     m = fmaxf(m, __shfl_xor(m, 32));
     float sum = 0.f;
 #pragma unroll
