@@ -233,6 +233,33 @@ __device__ __forceinline__ void load_tile(const Tables& T, const float* src, int
   }
 }
 
+// the same slice in two halves — request (into 8 registers) and store — so that a kernel can have the loads of all its
+// slices in flight before it waits for the first (three load_tile calls in a row are three dependent global round trips)
+__device__ __forceinline__ void fetch_tile(const Tables& T, const float* src, int ld, int col0, int hd, float (&v)[8]) {
+  const int n = threadIdx.x >> 2, part = threadIdx.x & 3;
+  const float* row = src + (int64_t)T.tok[n] * ld + col0;
+  if (((ld | col0 | hd) & 1) == 0 && (reinterpret_cast<uintptr_t>(src) & 7) == 0) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = part * 8 + 2 * e;
+      const float2 t = c < hd ? *reinterpret_cast<const float2*>(row + c) : make_float2(0.f, 0.f);
+      v[2 * e] = t.x;
+      v[2 * e + 1] = t.y;
+    }
+    return;
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = part * 8 + e;
+    v[e] = c < hd ? row[c] : 0.f;
+  }
+}
+__device__ __forceinline__ void put_tile(const float (&v)[8], float mul, float* dst) {
+  const int n = threadIdx.x >> 2, part = threadIdx.x & 3;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) dst[n * QS + part * 8 + e] = v[e] * mul;
+}
+
 // D[i][j] (one 32x32 tile: rows 32*ti.., cols 32*tj..) = sum_k A[i][k] * B[j][k], k < kdim (even)
 // A, B in LDS with row strides sa, sb.  Returns the tile in MFMA layout (col j = lane&31).
 __device__ __forceinline__ f32x16 tile_abt(const float* A, int sa, const float* B, int sb, int ti, int tj,
@@ -242,6 +269,8 @@ __device__ __forceinline__ f32x16 tile_abt(const float* A, int sa, const float* 
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   const float* ap = A + (32 * ti + l31) * sa + lh;
   const float* bp = B + (32 * tj + l31) * sb + lh;
+  // (five steps' operands requested per batch — head_dim 30 is 15 steps: a rolled loop is a chain of read, wait, MFMA)
+#pragma unroll 5
   for (int ks = 0; ks < kdim / 2; ++ks)
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * ks], bp[2 * ks], acc, 0, 0, 0);
   return acc;
@@ -285,12 +314,23 @@ __device__ __forceinline__ void scores_to_lds(const Tables& T, const f32x16& acc
   const int rj = T.reg[j];
   const float* tb = T.tab + (WS - 1 - (j >> 3) + 4 * ti) * (2 * WS - 1) + (WS - 1 - (j & 7)) + 4 * lh;
   const int i0 = 32 * ti + 4 * lh;
+  // (table values, query regions and row LSEs of the 16 scores in three batches of LDS reads, the mask as a select: the
+  // per-score `if` form was a read + wait + branch chain)
+  float bv[16], lv[16];
+  int rv[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int di = (r & 3) + 8 * (r >> 2);  // i = i0 + di: yi = 4 ti + (r>>2), xi = (r&3) + 4 lh
-    float s = acc[r] + tb[(r >> 2) * (2 * WS - 1) + (r & 3)];
-    if (T.reg[i0 + di] != rj) s -= 100.f;
-    P[(i0 + di) * PS + j] = lse_row ? __expf(s - lse_row[i0 + di]) : s;
+    bv[r] = tb[(r >> 2) * (2 * WS - 1) + (r & 3)];
+    rv[r] = T.reg[i0 + di];
+    lv[r] = lse_row ? lse_row[i0 + di] : 0.f;
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int di = (r & 3) + 8 * (r >> 2);
+    float s = acc[r] + bv[r];
+    s -= rv[r] != rj ? 100.f : 0.f;
+    P[(i0 + di) * PS + j] = lse_row ? __expf(s - lv[r]) : s;
   }
 }
 
@@ -364,10 +404,17 @@ __global__ __launch_bounds__(256) void window_attention_bwd_kernel(const neosr_w
   build_tables(d, w, T);
   if (tid < NTOK) lse_s[tid] = d.lse[(int64_t)bid * NTOK + tid];
   __syncthreads();
-  load_tile(T, d.qkv, ld, w.head * hd, hd, d.scale, Qs);
-  load_tile(T, d.qkv, ld, d.C + w.head * hd, hd, 1.f, Ks);
-  load_tile(T, d.qkv, ld, 2 * d.C + w.head * hd, hd, 1.f, Vs);
+  // all five slices (q, k, v, and below dO, O) are requested before the first is waited for
+  float rq[8], rk[8], rv[8];
+  fetch_tile(T, d.qkv, ld, w.head * hd, hd, rq);
+  fetch_tile(T, d.qkv, ld, d.C + w.head * hd, hd, rk);
+  fetch_tile(T, d.qkv, ld, 2 * d.C + w.head * hd, hd, rv);
   constexpr bool have_o = HAVE_O;
+  if (!have_o) {
+    put_tile(rq, d.scale, Qs);
+    put_tile(rk, 1.f, Ks);
+    put_tile(rv, 1.f, Vs);
+  }
   if (have_o) {
     // delta[i] = sum_j P dP = sum_d dO[i][d] O[i][d]: with the forward output at hand the row sums come from two
     // 30-float rows instead of two 64 x 64 LDS tiles, and dS is finished in the score tile's registers.  The O row is
@@ -392,6 +439,9 @@ __global__ __launch_bounds__(256) void window_attention_bwd_kernel(const neosr_w
         ov[e] = c < hd ? d.out[row + c] : 0.f;
       }
     }
+    put_tile(rq, d.scale, Qs);
+    put_tile(rk, 1.f, Ks);
+    put_tile(rv, 1.f, Vs);
     float s = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
