@@ -368,19 +368,39 @@ __device__ __forceinline__ void recompute_p_ds(SharedBwd& S, int kq, int wave, i
     const int kp = S.kpk[j];
     const bool none = kp == KEY_NONE;
     const int kterm = kp >> 4, kreg = kp & 15;
+    // (the per-row terms of 8 scores at a time — packed query geometry, LSE, D — in one batch of LDS reads, then the table
+    // values they index in a second: written as one loop over the scores this is four dependent LDS round trips per score;
+    // 16 at a time spilled registers in the fused kernel)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int i = 32 * ti + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      const int qp = S.qpk[i];
-      int idx = kterm + (qp >> 4);
-      if (!SELF && idx < 0) idx += NBINS;
-      float v = s[r] + S.tab[none ? 0 : idx];
-      if (SELF && (qp & 15) != kreg) v -= 100.f;
-      // dS = P (dP - D) with D = rowsum(dO . O) already in LDS: finished in the tile's own registers (a separate row
-      // pass over the two LDS tiles cost 32 reads + 16 writes per thread and one more barrier per key block)
-      const float p = none ? 0.f : __expf(v - S.lse[i]);
-      if (NEED_P) S.P[i * PS + j] = p;
-      S.dS[i * PS + j] = p * (dp[r] - S.dsum[i]);
+    for (int h = 0; h < 2; ++h) {
+      int qp[8];
+      float ls[8], dsu[8], tv[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int r = 8 * h + q;
+        const int i = 32 * ti + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        qp[q] = S.qpk[i];
+        ls[q] = S.lse[i];
+        dsu[q] = S.dsum[i];
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        int idx = kterm + (qp[q] >> 4);
+        if (!SELF && idx < 0) idx += NBINS;
+        tv[q] = S.tab[none ? 0 : idx];
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int r = 8 * h + q;
+        const int i = 32 * ti + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        float v = s[r] + tv[q];
+        v -= (SELF && (qp[q] & 15) != kreg) ? 100.f : 0.f;
+        // dS = P (dP - D) with D = rowsum(dO . O) already in LDS: finished in the tile's own registers (a separate row
+        // pass over the two LDS tiles cost 32 reads + 16 writes per thread and one more barrier per key block)
+        const float p = none ? 0.f : __expf(v - ls[q]);
+        if (NEED_P) S.P[i * PS + j] = p;
+        S.dS[i * PS + j] = p * (dp[r] - dsu[q]);
+      }
     }
   }
   __syncthreads();
