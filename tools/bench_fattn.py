@@ -10,8 +10,8 @@ C, heads = 180, 6
 dev = "cuda"
 
 
-def timeit(fn, n=20):
-    for _ in range(3):
+def timeit(fn, n=50):
+    for _ in range(30):   # (the first calls of a process run ~2x slower: clocks and caches)
         fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -13,7 +13,7 @@ dev = "cuda"
 
 
 def timeit(fn, n=20):
-    for _ in range(3):
+    for _ in range(10):   # (the first calls of a process run slower: clocks and caches)
         fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
