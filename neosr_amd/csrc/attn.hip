@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t stride = (int64_t)gridDim.x * 4;
   int64_t row = (int64_t)blockIdx.x * 4 + wave;
-  float gm[NI], dg[NI], db[NI], g[NI], xv[NI], ng[NI], nxv[NI];
+  float gm[NI], dg[NI], db[NI], g[NI], xv[NI], ng[NI], nxv[NI], dr[NI], ndr[NI];   // dr: the shortcut gradient of the row
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
     const int c = lane + 64 * i;
@@ -105,7 +105,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     dg[i] = db[i] = 0.f;
     g[i] = ok ? dy[row * C + c] : 0.f;
     xv[i] = ok ? x[row * C + c] : 0.f;
+    dr[i] = (ok && dres) ? dres[row * C + c] : 0.f;
   }
+  // (the row's (mean, rstd) pair travels with the row's prefetch: read at its use it was one exposed global round trip per row)
+  float mean = row < rows ? stats[2 * row] : 0.f, rstd = row < rows ? stats[2 * row + 1] : 0.f;
   for (; row < rows; row += stride) {
     const int64_t nrow = row + stride;
 #pragma unroll
@@ -114,8 +117,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
       const bool ok = nrow < rows && c < C;
       ng[i] = ok ? dy[nrow * C + c] : 0.f;
       nxv[i] = ok ? x[nrow * C + c] : 0.f;
+      ndr[i] = (ok && dres) ? dres[nrow * C + c] : 0.f;
     }
-    const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+    const float nmean = nrow < rows ? stats[2 * nrow] : 0.f, nrstd = nrow < rows ? stats[2 * nrow + 1] : 0.f;
     float gy[NI], xh[NI];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -134,10 +138,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
       const int c = lane + 64 * i;
       // dres: gradient arriving over the shortcut that by-passed this norm (x -> x + f(norm(x))): summed here instead
       // of by a separate elementwise pass
-      if (c < C) dx[row * C + c] = rstd * (gy[i] - s1 - xh[i] * s2) + (dres ? dres[row * C + c] : 0.f);
+      if (c < C) dx[row * C + c] = rstd * (gy[i] - s1 - xh[i] * s2) + dr[i];
       g[i] = ng[i];
       xv[i] = nxv[i];
+      dr[i] = ndr[i];
     }
+    mean = nmean;
+    rstd = nrstd;
   }
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
