@@ -1026,16 +1026,20 @@ __device__ __forceinline__ void tn_lds_task(const GemmArgs& args, int split, int
     vo[k] = (c < (isa[k] ? M : N)) ? c * 4 : 0x7ffffff0;
   }
   float raw[3][8];
+  float rsc[3] = {1.f, 1.f, 1.f};   // DropPath row scale of a dY unit's 8 tokens: requested with the unit (read at the split it
+                                    // was a scalar-memory round trip per unit and step in front of the LDS stores)
   auto gload = [&](int step) {
     const int t = t_lo + 16 * step;
 #pragma unroll
-    for (int k = 0; k < 3; ++k)
+    for (int k = 0; k < 3; ++k) {
+      if (RS && isa[k] && d.row_scale) rsc[k] = d.row_scale[min(t + 8 * oct[k], d.K - 1) / d.rows_per_scale];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int row = t + 8 * oct[k] + e;
         raw[k][e] = isa[k] ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra, vo[k], row * d.lda * 4, 0))
                            : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, vo[k], row * d.ldb * 4, 0));
       }
+    }
   };
   float cs[3] = {0.f, 0.f, 0.f};   // column sums of dY (the bias gradient) of this thread's dY units
   auto sstore = [&](int step, int buf) {
@@ -1043,8 +1047,7 @@ __device__ __forceinline__ void tn_lds_task(const GemmArgs& args, int split, int
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       float v[8];
-      float sc = 1.f;
-      if (RS && isa[k] && d.row_scale) sc = d.row_scale[(t_lo + 16 * step + 8 * oct[k]) / d.rows_per_scale];
+      const float sc = rsc[k];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         v[e] = (RS && isa[k]) ? raw[k][e] * sc : raw[k][e];
