@@ -166,11 +166,13 @@ struct NoPref {};
 // PREF = float4[8]: residual quads already in registers (index 4 t + g), bias tile in LDS (`bias_lds`)
 // NTILE 32-column accumulator tiles per wave; row_off / col_off: position of the wave's tile inside the workgroup tile
 // (default: wave w owns rows 32 w.., columns 0..)
-template <int MODE, typename PREF = NoPref, int NTILE = 2>
+// APREF = float4[..]: the pre-activation quads of `aux_in` already in registers too (same index)
+template <int MODE, typename PREF = NoPref, int NTILE = 2, typename APREF = NoPref>
 __device__ __forceinline__ void epilogue(const GemmArgs& args, const f32x16 (&acc)[NTILE], int m0, int n0, int split,
                                          const float* bias_lds = nullptr, const PREF& res_pref = PREF{},
-                                         int row_off = -1, int col_off = 0) {
+                                         int row_off = -1, int col_off = 0, const APREF& aux_pref = APREF{}) {
   constexpr bool HAS_PREF = !std::is_same<PREF, NoPref>::value;
+  constexpr bool HAS_APREF = !std::is_same<APREF, NoPref>::value;
   const neosr_gemm_desc& d = args.d;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
   const int M = d.M, N = d.N;
@@ -202,7 +204,11 @@ __device__ __forceinline__ void epilogue(const GemmArgs& args, const f32x16 (&ac
           for (int e = 0; e < 4; ++e) v[e] = gelu_exact(v[e]);
         }
         if (d.aux_in) {  // dz = da * GELU'(z)
-          const float4 z = *reinterpret_cast<const float4*>(ok ? d.aux_in + mrow * d.ldaux + n : gm_zero_page);
+          float4 z;
+          if constexpr (HAS_APREF)
+            z = aux_pref[4 * t + g];
+          else
+            z = *reinterpret_cast<const float4*>(ok ? d.aux_in + mrow * d.ldaux + n : gm_zero_page);
           v[0] *= gelu_grad(z.x); v[1] *= gelu_grad(z.y); v[2] *= gelu_grad(z.z); v[3] *= gelu_grad(z.w);
         }
 #pragma unroll
@@ -519,7 +525,7 @@ __device__ __forceinline__ void gemm_nt_glds_body(const GemmArgs& args) {
   // 64-wide tile holds 28 columns) skips its MFMAs
   const int last_steps = (K - (nchunks - 1) * BK + 7) >> 3;
   const bool two = n0 + 32 < d.N;
-  float4 resq[8];
+  float4 resq[8], auxq[8];
   auto run = [&](auto two_tag) {
     constexpr bool TWO = decltype(two_tag)::value;
     auto mac = [&](int c, int nsteps) {
@@ -582,13 +588,23 @@ __device__ __forceinline__ void gemm_nt_glds_body(const GemmArgs& args) {
           resq[4 * t + g] = *reinterpret_cast<const float4*>(m < d.M && n < d.N ? d.res + (int64_t)m * d.ldres + n : zp);
         }
     }
+    if (d.aux_in) {   // (the GELU' operand of the data-gradient epilogue, like the residual: requested under the last chunk)
+      const int m = m0 + wave * 32 + l31;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = n0 + 32 * t + 8 * g + 4 * lh;
+          auxq[4 * t + g] = *reinterpret_cast<const float4*>(m < d.M && n < d.N ? d.aux_in + (int64_t)m * d.ldaux + n : zp);
+        }
+    }
     mac(nchunks - 1, last_steps);
   };
   if (two)
     run(std::true_type{});
   else
     run(std::false_type{});
-  epilogue<0, float4[8]>(args, acc, m0, n0, 0, bias_s, resq);
+  epilogue<0, float4[8], 2, float4[8]>(args, acc, m0, n0, 0, bias_s, resq, -1, 0, auxq);
 }
 __global__ __launch_bounds__(256, 2) void gemm_nt_glds_kernel(const GemmArgs args) { gemm_nt_glds_body<false>(args); }
 __global__ __launch_bounds__(256, 2) void gemm_nt_glds_x3_kernel(const GemmArgs args) { gemm_nt_glds_body<true>(args); }
@@ -741,7 +757,7 @@ __device__ __forceinline__ void gemm_nt_glds64_body(const GemmArgs& args) {
     if constexpr (X3) bstore((c + 1) & 1);
     __syncthreads();
   }
-  float4 resq[4];
+  float4 resq[4], auxq[4];
   if (d.res) {
     const int m = m0 + arow;
 #pragma unroll
@@ -750,8 +766,16 @@ __device__ __forceinline__ void gemm_nt_glds64_body(const GemmArgs& args) {
       resq[g] = *reinterpret_cast<const float4*>(m < d.M && n < d.N ? d.res + (int64_t)m * d.ldres + n : zp);
     }
   }
+  if (d.aux_in) {   // (the GELU' operand, like the residual: requested under the last chunk)
+    const int m = m0 + arow;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int n = n0 + wn * 32 + 8 * g + 4 * lh;
+      auxq[g] = *reinterpret_cast<const float4*>(m < d.M && n < d.N ? d.aux_in + (int64_t)m * d.ldaux + n : zp);
+    }
+  }
   mac(nchunks - 1, last_steps);
-  epilogue<0, float4[4], 1>(args, acc, m0, n0, 0, bias_s, resq, wm * 32, wn * 32);
+  epilogue<0, float4[4], 1, float4[4]>(args, acc, m0, n0, 0, bias_s, resq, wm * 32, wn * 32, auxq);
 }
 __global__ __launch_bounds__(256, 2) void gemm_nt_glds64_kernel(const GemmArgs args) { gemm_nt_glds64_body<false>(args); }
 __global__ __launch_bounds__(256, 2) void gemm_nt_glds64_x3_kernel(const GemmArgs args) { gemm_nt_glds64_body<true>(args); }
