@@ -574,6 +574,31 @@ __global__ __launch_bounds__(256) void pixel_shuffle_nhwc_kernel(const float* __
   }
 }
 
+// r = 2 (every PixelShuffle of the x2 / x4 upsamplers), C * 4 low-resolution channels on 16-byte aligned storage: one thread
+// per (low-resolution pixel, c) moves the quad lo[.., 4 c .. 4 c + 3] = the 2 x 2 output pixels of channel c — one 16-byte
+// access on the low side, four dword accesses on the high side that are contiguous across the threads' c; 32-bit index
+// arithmetic.  (The generic kernel above gathers 4 bytes at a 16-byte stride and divides five times in 64 bits per element:
+// 76 us for the 33 MB map of swinir_medium's upsampler.)
+__global__ __launch_bounds__(256) void pixel_shuffle2_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                                  int B, int H, int W, int C, int inverse) {
+  const unsigned total = (unsigned)B * H * W * C;
+  for (unsigned q = blockIdx.x * 256u + threadIdx.x; q < total; q += gridDim.x * 256u) {
+    const unsigned c = q % C, pix = q / C;
+    const unsigned w = pix % W, t = pix / W, h = t % H, b = t / H;
+    const int64_t hi0 = (((int64_t)b * H * 2 + 2 * h) * (2 * W) + 2 * w) * C + c;   // (i, j) = (0, 0)
+    const int64_t row = (int64_t)2 * W * C;
+    if (!inverse) {
+      const float4 v = reinterpret_cast<const float4*>(in)[q];
+      out[hi0] = v.x;
+      out[hi0 + C] = v.y;
+      out[hi0 + row] = v.z;
+      out[hi0 + row + C] = v.w;
+    } else {
+      reinterpret_cast<float4*>(out)[q] = make_float4(in[hi0], in[hi0 + C], in[hi0 + row], in[hi0 + row + C]);
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void affine_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                      int64_t n, float shift, float scale) {
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256)
@@ -704,8 +729,13 @@ extern "C" int neosr_window_attention_bwd(const neosr_wattn_desc* d, void* strea
 extern "C" int neosr_pixel_shuffle_nhwc(const float* in, float* out, int32_t B, int32_t H, int32_t W,
                                         int32_t C, int32_t r, int32_t inverse, void* stream) {
   NEOSR_CHECK(in && out && B > 0 && H > 0 && W > 0 && C > 0 && r > 0, "pixel_shuffle_nhwc: bad args");
-  hipLaunchKernelGGL(pixel_shuffle_nhwc_kernel, dim3(grid_for((int64_t)B * H * W * C * r * r)), dim3(256), 0,
-                     (hipStream_t)stream, in, out, B, H, W, C, r, inverse);
+  const float* lo = inverse ? out : in;
+  if (r == 2 && ((uintptr_t)lo & 15) == 0 && (int64_t)B * H * W * C < (int64_t(1) << 31))
+    hipLaunchKernelGGL(pixel_shuffle2_nhwc_kernel, dim3(grid_for((int64_t)B * H * W * C)), dim3(256), 0, (hipStream_t)stream,
+                       in, out, B, H, W, C, inverse);
+  else
+    hipLaunchKernelGGL(pixel_shuffle_nhwc_kernel, dim3(grid_for((int64_t)B * H * W * C * r * r)), dim3(256), 0,
+                       (hipStream_t)stream, in, out, B, H, W, C, r, inverse);
   NEOSR_LAUNCH_CHECK();
   return 0;
 }
