@@ -455,7 +455,7 @@ int neosr_spectral_norm_bwd(const float* gw, const float* w, const float* u, con
 #define NEOSR_GEMM_TN 2 /* C[M,N] = A[K,M]^T B[K,N]   nn.Linear backward-weight (A = dY, B = X) */
 /* fp32 MFMA GEMM for the Linear layers (swinir_arch.py:15-38 Mlp, :139-143,209 qkv/proj).
  * NT/NN epilogue, in this order: + bias[n]; aux_out = value (pre-activation kept for backward);
- * exact-erf GELU (gelu=1); * GELU'(aux_in[m,n]); * row_scale[m / rows_per_scale] (DropPath);
+ * erf-form GELU (gelu=1; erf by Abramowitz-Stegun 7.1.26, |err| <= 1.5e-7, with __expf — not libm erff); * GELU'(aux_in[m,n]); * row_scale[m / rows_per_scale] (DropPath);
  * + res[m,n].  TN: fixed-order split-K through `workspace` (neosr_gemm_workspace_bytes), dense C,
  * C = accumulate ? C + result : result; row_scale[k / rows_per_scale] multiplies ROW k of A (the DropPath
  * scale of the incoming gradient dY — the weight and bias gradients of a dropped sample are zero) so that
@@ -654,7 +654,7 @@ int neosr_cosine_dist_bwd(const float* a, const float* b, const float* stats, co
                           int64_t groups, int32_t L, int64_t inner, float eps, void* stream);
 
 /* HAT Channel Attention Block, non-conv parts (hat_arch.py:15-52) ------------------------------------
- * exact-erf GELU between the two convs: out = g ? g * GELU'(x) : GELU(x). */
+ * erf-form GELU (same erf approximation as neosr_gemm, |err| <= 1.5e-7) between the two convs: out = g ? g * GELU'(x) : GELU(x). */
 int neosr_gelu(const float* x, const float* g, float* out, int64_t n, void* stream);
 /* out[b, c] = scale * sum_r x[b, r, c] (* y[b, r, c] if y): AdaptiveAvgPool2d(1) on channels-last data
  * and the gate gradient; fixed-order two-stage (128 row slabs per sample); workspace >= B*128*cols floats. */

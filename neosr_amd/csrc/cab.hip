@@ -1,5 +1,5 @@
 // cab.hip — the non-conv parts of HAT's Channel Attention Block for gfx950
-// (neosr/archs/hat_arch.py:15-52: conv3x3 - GELU - conv3x3 - ChannelAttention): exact-erf GELU,
+// (neosr/archs/hat_arch.py:15-52: conv3x3 - GELU - conv3x3 - ChannelAttention): erf-form GELU (A&S 7.1.26 erf, |err| <= 1.5e-7),
 // global average pool / squeeze-excite MLP / sigmoid gate, and the gated residual combine of
 // HAB.forward (hat_arch.py:347: x = shortcut + drop_path(attn_x) + conv_x * conv_scale).
 // All HBM-bound; activations are channels-last (B, H*W, C).

@@ -36,6 +36,7 @@
 #include <string>
 #include <vector>
 #include <stdlib.h>
+#include <atomic>
 #include "conv_wino4.h"
 
 using namespace neosr_conv;
@@ -533,7 +534,7 @@ int neosr_conv::g_wino4_concurrency = 1;
 
 namespace {
 int g_n64 = -1;  // -1: by the fill estimate (default); 0: never; 1: whenever the launch has more than 32 output channels
-int g_fast = -1; // -1: read NEOSR_AMD_FAST_MATMUL on first use (default 0)
+std::atomic<int> g_fast{-1}; // (read by the forward and the autograd thread) -1: read NEOSR_AMD_FAST_MATMUL on first use (default 0)
 }
 
 bool neosr_conv::fast_matmul() {

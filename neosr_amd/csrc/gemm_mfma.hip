@@ -8,7 +8,7 @@
 // chunks of 32 staged through LDS ([row][32+1] layouts -> conflict-free fragment reads) with the
 // next chunk's global loads in flight in registers.  D is formed as B_frag x A_frag so each lane
 // owns one output row and runs of 4 consecutive columns -> 16-byte epilogue stores.
-// Epilogue (NT/NN): + bias[n]; exact-erf GELU with the pre-activation kept in `aux_out`;
+// Epilogue (NT/NN): + bias[n]; erf-form GELU (A&S 7.1.26 erf, |err| <= 1.5e-7) with the pre-activation kept in `aux_out`;
 // multiply by GELU'(aux_in) (backward through the activation); per-sample row scale (DropPath);
 // + residual.  TN writes split-K partial slabs that `colsum_kernel` sums in a fixed order.
 //
@@ -26,6 +26,7 @@
 #include <cstring>
 #include <type_traits>
 
+#include <atomic>
 #include "common.h"
 #include "conv_common.h"
 #include "../../include/neosr_amd.h"
@@ -1267,7 +1268,7 @@ constexpr bool g_no_tnreg = false;
 #endif
 int g_tn_rounds = TN_REG_ROUNDS;
 int g_bm64_below = 600;   // 128 x 64 tiles of a launch below which the NT GEMM switches to 64-row tiles
-int g_gemm_x3 = -1;       // bf16x3 products in the NT kernels: -1 = read NEOSR_AMD_GEMM_X3 on first use (default on)
+std::atomic<int> g_gemm_x3{-1};   // (read by the forward and the autograd thread) bf16x3 products in the NT kernels: -1 = read NEOSR_AMD_GEMM_X3 on first use (default on)
 bool gemm_x3() {
   if (g_gemm_x3 < 0) {
     const char* e = getenv("NEOSR_AMD_GEMM_X3");

@@ -1,16 +1,65 @@
-"""Input staging in front of `feed_data` (neosr/data/prefetch_dataloader.py:69-125, the `prefetch_mode = "cuda"` path of
-train.py:204-212): `DevicePrefetcher` (the reference's `CUDAPrefetcher`, same interface: `next()` / `reset()`) runs the
-next batch's host->HBM copies on a side HIP stream while the current iteration computes; `next()` makes the compute
-stream wait for that copy only.  The reference's CPU-side thread prefetcher (`prefetch_mode = "cpu"`) is host data-loader
-plumbing outside SURVEY §8 and is not restated here: any iterable of batch dicts (a plain `torch.utils.data.DataLoader`
-with workers) feeds this class.
+"""Input staging either side of `feed_data` (neosr/data/prefetch_dataloader.py, train.py:204-212):
+
+* `PrefetchGenerator` / `PrefetchDataLoader` (`prefetch_mode = "cpu"`, reference lines 9-66): a daemon thread keeps up to
+  `num_prefetch_queue` collated batches ready in a bounded queue;
+* `DevicePrefetcher` (`prefetch_mode = "cuda"`: the reference's `CUDAPrefetcher`, lines 69-125, same `next()` / `reset()`
+  interface) runs the next batch's host->HBM copies on a side HIP stream while the current iteration computes; `next()`
+  makes the compute stream wait for that copy only.
 """
 
 from __future__ import annotations
 
+import queue
+import threading
 from typing import Any
 
 import torch
+from torch.utils.data import DataLoader
+
+_END = object()   # end-of-epoch marker in the queue (a batch may legitimately be None)
+
+
+class PrefetchGenerator(threading.Thread):
+    """Iterator over `source` whose items are produced by a background thread, at most `num_prefetch_queue` ahead."""
+
+    def __init__(self, source, num_prefetch_queue: int) -> None:
+        super().__init__(daemon=True)
+        self._q: queue.Queue[Any] = queue.Queue(maxsize=max(int(num_prefetch_queue), 1))
+        self._source = source
+        self._error: BaseException | None = None
+        self.start()
+
+    def run(self) -> None:
+        try:
+            for item in self._source:
+                self._q.put(item)
+        except BaseException as e:   # surfaced in the consumer, not lost in the thread
+            self._error = e
+        finally:
+            self._q.put(_END)
+
+    def __iter__(self):
+        return self
+
+    def __next__(self) -> Any:
+        item = self._q.get()
+        if item is _END:
+            if self._error is not None:
+                raise self._error
+            raise StopIteration
+        return item
+
+
+class PrefetchDataLoader(DataLoader):
+    """`torch.utils.data.DataLoader` whose iterator is wrapped in a `PrefetchGenerator` (same constructor contract as the
+    reference: `num_prefetch_queue` first, the DataLoader arguments as keywords)."""
+
+    def __init__(self, num_prefetch_queue: int, **kwargs) -> None:
+        self.num_prefetch_queue = num_prefetch_queue
+        super().__init__(**kwargs)
+
+    def __iter__(self):
+        return PrefetchGenerator(super().__iter__(), self.num_prefetch_queue)
 
 
 class DevicePrefetcher:

@@ -140,8 +140,19 @@ def group_arena(cache: dict, plist: list):
             if prm.data_ptr() != base + 4 * off or not prm.requires_grad:
                 ok = False
                 break
-        if ok and n_frozen:   # (a group with frozen members: none of them may have become trainable)
-            ok = sum(1 for prm in plist if not prm.requires_grad) == n_frozen
+        if ok:
+            # the list must still hold exactly these objects (a parameter REPLACED in the group with the length unchanged
+            # would otherwise keep the old tensors alive and the fused step would go on updating the old arena), and none
+            # of its frozen members may have become trainable: one pass over the list
+            k = 0
+            n_par = len(params)
+            for prm in plist:
+                if prm.requires_grad:
+                    if k >= n_par or prm is not params[k]:
+                        ok = False
+                        break
+                    k += 1
+            ok = ok and k == n_par
         if ok:
             t0 = params[0]
             if t0.untyped_storage().nbytes() >= (t0.storage_offset() + total) * 4:

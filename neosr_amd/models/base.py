@@ -64,7 +64,9 @@ def flatten_sn_buffers_(net: nn.Module) -> torch.Tensor | None:
 class base:
     """Default model."""
 
-    CHAIN_SLOW_GRACE_READS = 1   # log reads whose slow-wait marks are ignored (RCCL warm-up inside the first collectives)
+    # Iterations (optimize_parameters calls of this process) whose slow-wait marks are ignored: RCCL sets its connections up
+    # inside the first collectives and holds CUs for milliseconds while it does.  Option: [train] chain_slow_grace_iters.
+    CHAIN_SLOW_GRACE_ITERS = 20
 
     def __init__(self, opt: dict[str, Any]) -> None:
         self.opt = opt
@@ -76,7 +78,9 @@ class base:
         self._log_dev: tuple[list[str], torch.Tensor] | None = None
         self._log_work = None
         self._log_health = False     # the reduced scalars end with the chain launches' two health words
-        self._log_reads = 0
+        self._iters_seen = 0         # optimize_parameters calls (image.optimize_parameters counts)
+        self._log_iters = 0          # ... at the time the pending scalars were reduced
+        self.chain_slow_grace_iters = int((opt.get("train") or {}).get("chain_slow_grace_iters", self.CHAIN_SLOW_GRACE_ITERS))
         self.chain_fallback = False  # all ranks left the chain launches after a slow flag wait (get_current_log)
         self.n_accumulated = 0
         if self.is_train:
@@ -121,10 +125,16 @@ class base:
             rec["val"], rec["iter"] = val, current_iter
 
     # -- logging ------------------------------------------------------------------------
-    def get_current_log(self) -> dict[str, Any]:
+    def get_current_log(self, act_on_health: bool = True) -> dict[str, Any]:
         """Materialise the (possibly rank-reduced) loss scalars: the only device->host read of the
         iteration, paid when the caller actually logs.  NaN in the generator loss raises here
-        (reference: ValueError at image.py:611-619, checked every iteration)."""
+        (reference: ValueError at image.py:611-619, checked every iteration).
+
+        `act_on_health=False` is for callers that run on ONE rank only (the `@master_only` checkpoint writers): the
+        scalars are read and the NaN check runs, but the chain launches' health words are neither acknowledged nor acted
+        on — that happens at the next read EVERY rank makes (both words are sticky on the device until then), so ranks
+        never leave the chain launches, or raise, alone.  The return value of `chain_health_ok` tells such a caller
+        whether the iterations behind the scalars are valid."""
         if self._log_dev is not None:
             keys, vals = self._log_dev
             if self._log_work is not None:  # the rank reduce of these scalars was only enqueued (reduce_loss_dict)
@@ -137,8 +147,8 @@ class base:
             # their sum and acts at the same iteration — a rank that raised alone would leave the others in a collective):
             #   slow   > 0: some chain launch waited a millisecond or more for missing workgroups (a collective or another
             #               process held CUs).  Results are valid; all ranks switch to one launch per convolution, which
-            #               loses almost nothing under held CUs.  Marks of the first iterations (RCCL sets
-            #               its connections up inside the first collectives) are ignored.
+            #               loses almost nothing under held CUs.  Marks of the first `chain_slow_grace_iters`
+            #               iterations (RCCL sets its connections up inside the first collectives) are ignored.
             #   status > 0: a wait ran into its spin bound and the launch finished on unfinished neighbour data: raise,
             #               on every rank, instead of training on from garbage.
             slow = st = 0.0
@@ -149,27 +159,34 @@ class base:
                 st = float(_C.load().neosr_conv_chain_status())
             self.log_dict = OrderedDict(zip(keys, host))
             self._log_dev = None
-            self._log_reads += 1
-            if st > 0:
-                _C.load().neosr_set_conv_chain(0)
-                msg = (f"conv chain launch aborted (status {int(st)}): a chain launch did not get all its workgroups resident; "
-                       "the iterations since the last log read are invalid.  Chain launches are now off in this process "
-                       "(NEOSR_AMD_CHAIN=0 avoids them from the start when the GPU is shared).")
-                raise _C.NeosrAmdError(msg)
-            if slow > 0:
-                _C.check(_C.load().neosr_conv_chain_ack(_C.stream_ptr()), "neosr_conv_chain_ack")
-            if slow > 0 and self._log_reads > self.CHAIN_SLOW_GRACE_READS:
-                _C.load().neosr_set_conv_chain(0)
-                get_root_logger().warning(
-                    "conv chain launches waited >= 1 ms for resident workgroups on %d rank(s): switching every rank to one "
-                    "launch per convolution (results unaffected)", int(slow))
-                self.chain_fallback = True
+            self.chain_health_ok = st <= 0
+            if act_on_health or not self.opt.get("dist", False):
+                self._act_on_chain_health(slow, st)
             tot = self.log_dict.get("l_g_total")
             if tot is not None and tot != tot:
                 msg = (f"{tc.red}NaN found, aborting training. Make sure you're using a proper "
                        f"learning rate.{tc.end}")
                 raise ValueError(msg)
         return self.log_dict
+
+    chain_health_ok = True
+
+    def _act_on_chain_health(self, slow: float, st: float) -> None:
+        """Every rank calls this with the same (all-reduced) words at the same iteration."""
+        if st > 0:
+            _C.load().neosr_set_conv_chain(0)
+            msg = (f"conv chain launch aborted (status {int(st)}): a chain launch did not get all its workgroups resident; "
+                   "the iterations since the last log read are invalid.  Chain launches are now off in this process "
+                   "(NEOSR_AMD_CHAIN=0 avoids them from the start when the GPU is shared).")
+            raise _C.NeosrAmdError(msg)
+        if slow > 0:
+            _C.check(_C.load().neosr_conv_chain_ack(_C.stream_ptr()), "neosr_conv_chain_ack")
+        if slow > 0 and self._log_iters > self.chain_slow_grace_iters:
+            _C.load().neosr_set_conv_chain(0)
+            get_root_logger().warning(
+                "conv chain launches waited >= 1 ms for resident workgroups on %d rank(s): switching every rank to one "
+                "launch per convolution (results unaffected)", int(slow))
+            self.chain_fallback = True
 
     def reduce_loss_dict(self, loss_dict: dict[str, torch.Tensor]) -> None:
         """Average the losses over ranks (intent of base.py:498-526); result read lazily."""
@@ -188,6 +205,7 @@ class base:
                 # rather than the reference's reduce-to-0: the health words must reach every rank.
                 self._log_work = dist.all_reduce(vals, async_op=True)
             self._log_dev = (keys, vals)
+            self._log_iters = self._iters_seen
 
     # -- device / parallel ----------------------------------------------------------------
     def model_to_device(self, net: nn.Module) -> nn.Module:
@@ -214,8 +232,9 @@ class base:
         (neosr/models/image.py:117-127, 438-440: autocast + GradScaler) ask the reference for NARROWER arithmetic than fp32.
         Here each of them selects the one reduced-precision tier this path has — `neosr_set_fast_matmul(1)`: the F(4x4,3x3)
         forward / backward-data convolutions with two bf16 pieces per operand (16 significant bits; TF32 has 11, bf16
-        autocast 8) on the bf16 MFMA, fp32 accumulation, everything else fp32 — and nothing else: no autocast region, fp32
-        storage and gradients, so the GradScaler is the identity (scale 1, never skips a step; fp32 gradients do not
+        autocast 8) on the bf16 MFMA, AND every nn.Linear product (forward NT, backward-data NN, weight-gradient TN) as
+        the 3-term instead of the 6-term bf16 split (~2e-5 per product instead of ~1e-6: gemm_mfma.hip `fast3`), fp32
+        accumulation, everything else fp32 — and nothing else: no autocast region, fp32 storage and gradients, so the GradScaler is the identity (scale 1, never skips a step; fp32 gradients do not
         underflow the way fp16 ones do) and the `log_dict` keys are the reference's.  Process-wide (the library switch is),
         logged once.  Without these keys the path is fp32 throughout."""
         asked = [k for k in ("fast_matmul", "use_amp", "bfloat16") if self.opt.get(k, False) is True]
@@ -228,8 +247,9 @@ class base:
             base._precision_note = True
             get_root_logger().warning(
                 "%s: the F(4x4,3x3) convolutions run their products on the bf16 MFMA with two bf16 pieces per fp32 operand "
-                "(16-bit significands, fp32 accumulation; ~1e-4 per layer); storage, gradients, weight gradients and every "
-                "other kernel stay fp32, GradScaler = identity", " / ".join(asked))
+                "(16-bit significands, fp32 accumulation; ~1e-4 per layer) and the nn.Linear GEMMs (forward, backward-data and "
+                "weight gradients) use the 3-term instead of the 6-term bf16 split (~2e-5 per product); storage, gradients, "
+                "convolution weight gradients and every other kernel stay fp32, GradScaler = identity", " / ".join(asked))
         self.use_amp = False   # (what the closures test: nothing to scale)
 
     def graph_generator(self) -> None:
@@ -326,7 +346,13 @@ class base:
     # -- checkpoints (wire format of base.py:281-475) ----------------------------------------
     @master_only
     def save_network(self, net, net_label: str, current_iter: int, param_key: str = "params") -> None:
-        self.get_current_log()  # the deferred NaN check (image.py:611-619) fires BEFORE anything is written
+        # the deferred NaN check (image.py:611-619) fires BEFORE anything is written.  This runs on rank 0 only: the chain
+        # health words are left for the next read every rank makes (get_current_log), and nothing is written from
+        # iterations an aborted chain launch invalidated — that read raises on all ranks.
+        self.get_current_log(act_on_health=False)
+        if not self.chain_health_ok:
+            get_root_logger().error("save_network(%s): skipped — a conv chain launch was aborted (see the next log read)", net_label)
+            return
         it = "latest" if current_iter == -1 else current_iter
         path = Path(self.opt["path"]["models"]) / f"{net_label}_{it}.pth"
         path.parent.mkdir(parents=True, exist_ok=True)
@@ -381,7 +407,10 @@ class base:
     def save_training_state(self, epoch: int, current_iter: int) -> None:
         if current_iter == -1:
             return
-        self.get_current_log()  # NaN check before the write, as in save_network
+        self.get_current_log(act_on_health=False)  # NaN check before the write, as in save_network (rank 0 only: no health action)
+        if not self.chain_health_ok:
+            get_root_logger().error("save_training_state: skipped — a conv chain launch was aborted (see the next log read)")
+            return
         state = {"epoch": epoch, "iter": current_iter,
                  "optimizers": [o.state_dict() for o in self.optimizers],
                  "schedulers": [s.state_dict() for s in self.schedulers]}

@@ -418,6 +418,7 @@ class image(base):
 
     def optimize_parameters(self, current_iter: int) -> None:
         _tr.reset_deferred()  # (reductions queued by a backward pass that raised)
+        self._iters_seen += 1   # (base.chain_slow_grace_iters counts these)
         self.n_accumulated += 1
         if self.n_accumulated >= self.accum_iters:
             self.n_accumulated = 0

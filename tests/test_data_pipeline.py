@@ -30,3 +30,37 @@ def test_enlarged_sampler_contract():
     assert min(counts) >= (n * world) // len(ds)
 
 
+def test_prefetch_dataloader_yields_everything_in_order():
+    # reference: neosr/data/prefetch_dataloader.py:9-66 (prefetch_mode = "cpu")
+    from neosr_amd.data.prefetch_dataloader import PrefetchDataLoader, PrefetchGenerator
+
+    data = [{"lq": torch.full((2,), float(i))} for i in range(7)]
+    loader = PrefetchDataLoader(num_prefetch_queue=2, dataset=data, batch_size=None, shuffle=False)
+    for _ in range(2):  # re-iterable
+        got = [int(b["lq"][0]) for b in loader]
+        assert got == list(range(7))
+
+    def boom():
+        yield 1
+        raise RuntimeError("loader failed")
+
+    it = PrefetchGenerator(boom(), 2)
+    assert next(it) == 1
+    try:
+        next(it)
+    except RuntimeError as e:
+        assert "loader failed" in str(e)
+    else:
+        raise AssertionError("the producer's exception must reach the consumer")
+
+
+def test_slurm_launcher_env_contract():
+    # reference: neosr/utils/dist_util.py:37-69
+    from neosr_amd.utils.dist_util import _slurm_rendezvous
+
+    env = {"SLURM_PROCID": "11", "SLURM_NTASKS": "16", "SLURM_NODELIST": "n[1-2]"}
+    out = _slurm_rendezvous(env, "n1", 8, None)
+    assert out == {"RANK": "11", "WORLD_SIZE": "16", "LOCAL_RANK": "3", "MASTER_ADDR": "n1", "MASTER_PORT": "29500"}
+    assert _slurm_rendezvous({**env, "MASTER_PORT": "4000"}, "n1", 8, None)["MASTER_PORT"] == "4000"
+    assert _slurm_rendezvous({**env, "MASTER_PORT": "4000"}, "n1", 8, 5000)["MASTER_PORT"] == "5000"
+

@@ -41,7 +41,7 @@ def _worker(rank: int, world: int, port: int, q) -> None:
     m.opt = {"dist": True, "rank": rank, "world_size": world}
     m._log_dev = None
     m._log_work = None
-    m._log_health, m._log_reads = False, 0
+    m._log_health, m._iters_seen, m._log_iters, m.chain_slow_grace_iters = False, 0, 0, 20
     m.log_dict = {}
     m.reduce_loss_dict({"l_g_pix": torch.tensor(float(rank + 1)), "l_g_total": torch.tensor([2.0 * (rank + 1)])})
     log = m.get_current_log()   # an all-reduce since round 5 (the chain health words must reach every rank): mean everywhere

@@ -144,6 +144,7 @@ TWO_RANK = textwrap.dedent("""
             from neosr_amd import _C
             lib = _C.load()
             assert not m.chain_fallback
+            m.chain_slow_grace_iters = 2   # ([train] chain_slow_grace_iters: marks of iterations 1-2 would be ignored)
             if rank == 1:
                 _C.check(lib.neosr_debug_chain_mark_slow(_C.stream_ptr()), "mark")
             m.feed_data({{"lq": LQ[1, sl], "gt": GT[1, sl]}})

@@ -338,6 +338,37 @@ def test_gemm_epilogues():
     assert rel_err(out, hp.grad) < 1e-5
 
 
+def test_gelu_forward_backward_vs_float64_erf():
+    """`neosr_gelu` (and the GELU epilogues of neosr_gemm / the CAB kernels, which share its `gelu_f` / `gelu_grad_f`) use
+    the Abramowitz-Stegun 7.1.26 erf (|err| <= 1.5e-7) with `__expf`, not libm `erff`: forward and derivative
+    against float64 erf over [-10, 10], tails included.  Reference: nn.GELU() = x * Phi(x), neosr/archs/hat_arch.py:46,
+    swinir_arch.py:23."""
+    import math
+
+    from neosr_amd.hip.transformer import Gelu
+
+    x64 = torch.linspace(-10.0, 10.0, 200_001, dtype=torch.float64)
+    x64 = torch.cat([x64, torch.tensor([0.0, -0.0, 1e-8, -1e-8, 1e-4, -1e-4], dtype=torch.float64)])
+    phi = 0.5 * (1.0 + torch.erf(x64 / math.sqrt(2.0)))
+    pdf = torch.exp(-0.5 * x64 * x64) / math.sqrt(2.0 * math.pi)
+    y64 = x64 * phi
+    d64 = phi + x64 * pdf
+    x = x64.float().to(DEV).requires_grad_(True)
+    y = Gelu.apply(x)
+    g = torch.ones_like(y)
+    (dx,) = torch.autograd.grad(y, x, g)
+    torch.cuda.synchronize()
+    ey = (y.detach().double().cpu() - y64).abs()
+    ed = (dx.double().cpu() - d64).abs()
+    # absolute bounds: erf error 1.5e-7 enters Phi as 0.75e-7, times |x| <= 10 in the forward; fp32 rounding of y on top
+    assert float(ey.max()) <= 2e-6, float(ey.max())
+    assert float((ey / y64.abs().clamp_min(1.0)).max()) <= 5e-7, float((ey / y64.abs().clamp_min(1.0)).max())
+    assert float(ed.max()) <= 1e-6, float(ed.max())
+    # deep negative tail: GELU -> -0 from below, never positive, never NaN
+    tail = y.detach()[x.detach() < -6.0]
+    assert bool(torch.isfinite(tail).all()) and float(tail.max()) <= 0.0 and float(tail.min()) > -1e-6
+
+
 def test_linear_and_mlp_autograd_vs_torch():
     from neosr_amd.hip import transformer as tr
 

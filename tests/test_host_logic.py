@@ -180,3 +180,38 @@ def test_check_resume_rewrites_pretrain_paths_like_the_reference():
     g = state["optimizers"][0]["param_groups"][0]
     assert g["train_mode"] is True and g["betas"] == [0.98, 0.92, 0.987] and g["step"] == 2
     assert state["schedulers"][0]["milestones"] == {1: 1, 3: 1} and state["schedulers"][0]["last_epoch"] == 2
+
+
+def test_master_only_log_read_leaves_chain_health_to_the_common_read(monkeypatch):
+    """the @master_only checkpoint writers read the pending scalars on rank 0 alone.  That read must neither
+    acknowledge the chain launches' slow-wait mark nor switch the launches off nor raise on the abort word — the next read
+    every rank makes does (reference: neosr/models/base.py:281-475 writes checkpoints under @master_only)."""
+    from collections import OrderedDict
+
+    import neosr_amd.models.base as mb
+
+    acted = []
+    monkeypatch.setattr(mb.base, "_act_on_chain_health", lambda self, slow, st: acted.append((slow, st)))
+    m = mb.base.__new__(mb.base)
+    m.opt = {"dist": True, "rank": 0, "world_size": 2}
+    m.log_dict = OrderedDict()
+    m._log_work = None
+    m._log_health = True
+    m._iters_seen, m._log_iters, m.chain_slow_grace_iters = 30, 30, 20
+    # scalars as the all-reduce left them (sums over 2 ranks; the division by world_size happens after `_log_work.wait()`,
+    # skipped here): l_g_pix, l_g_total, then the two health words — slow mark on one rank, no abort
+    m._log_dev = (["l_g_pix", "l_g_total"], torch.tensor([0.25, 0.5, 0.5, 0.0]))
+    log = m.get_current_log(act_on_health=False)
+    assert log["l_g_pix"] == 0.25 and acted == [] and m.chain_health_ok
+    # the common read acts (with the words scaled back to rank counts)
+    m._log_dev = (["l_g_pix", "l_g_total"], torch.tensor([0.25, 0.5, 0.5, 0.0]))
+    m.get_current_log()
+    assert acted == [(1.0, 0.0)]
+    # an abort word seen by the lone read: nothing raised, but the caller is told not to write
+    m._log_dev = (["l_g_pix", "l_g_total"], torch.tensor([0.25, 0.5, 0.0, 1.5]))
+    m.get_current_log(act_on_health=False)
+    assert not m.chain_health_ok and len(acted) == 1
+    # NaN still raises on the lone read (the reference's per-iteration check, image.py:611-619)
+    m._log_dev = (["l_g_pix", "l_g_total"], torch.tensor([0.25, float("nan"), 0.0, 0.0]))
+    with pytest.raises(ValueError):
+        m.get_current_log(act_on_health=False)
