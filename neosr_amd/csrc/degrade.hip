@@ -227,15 +227,7 @@ __global__ __launch_bounds__(256) void poisson_noise_kernel(
 }
 
 // --------------------------------------------------------------------------------- DiffJPEG
-__device__ const float c_cos[8][8] = {
-    {1.0f, 0.980785251f, 0.923879504f, 0.831469595f, 0.707106769f, 0.555570245f, 0.382683426f, 0.195090324f},
-    {1.0f, 0.831469595f, 0.382683426f, -0.195090324f, -0.707106769f, -0.980785251f, -0.923879504f, -0.555570245f},
-    {1.0f, 0.555570245f, -0.382683426f, -0.980785251f, -0.707106769f, 0.195090324f, 0.923879504f, 0.831469595f},
-    {1.0f, 0.195090324f, -0.923879504f, -0.555570245f, 0.707106769f, 0.831469595f, -0.382683426f, -0.980785251f},
-    {1.0f, -0.195090324f, -0.923879504f, 0.555570245f, 0.707106769f, -0.831469595f, -0.382683426f, 0.980785251f},
-    {1.0f, -0.555570245f, -0.382683426f, 0.980785251f, -0.707106769f, -0.195090324f, 0.923879504f, -0.831469595f},
-    {1.0f, -0.831469595f, 0.382683426f, 0.195090324f, -0.707106769f, 0.980785251f, -0.923879504f, 0.555570245f},
-    {1.0f, -0.980785251f, 0.923879504f, -0.831469595f, 0.707106769f, -0.555570245f, 0.382683426f, -0.195090324f}};
+#include "diffjpeg_table.h"
 // quantisation tables AS STORED by the reference (diffjpeg.py:16-38: the standard tables transposed)
 __device__ const float c_ytab[8][8] = {
     {16, 12, 14, 14, 18, 24, 49, 72},  {11, 12, 13, 17, 22, 35, 64, 92},
@@ -251,12 +243,21 @@ __device__ const float c_ctab[8][8] = {
 // One wavefront per 16x16 MCU (4 MCUs per workgroup).  Lane l = (u, v) = (l>>3, l&7) is at once
 // the DCT coefficient index and the pixel position inside an 8x8 block.  Everything between the
 // single read and the single write of the image lives in LDS/registers.
+//
+// ROUNDING CONTRACT (round 6): every fp32 operation below is the reference's operation in the reference's
+// order, so the quantised coefficients — and the output — are the reference's bit for bit (no coefficient "rounds the other
+// way").  `torch.tensordot` (diffjpeg.py:93, 183, 374, 473) is a matrix product whose reduction the CPU library runs as ONE
+// chain of fused multiply-adds in index order starting from 0 (checked against the reference run: tests/golden/
+// degrade_prims.npz is reproduced exactly): fmaf chains here, never a product-then-add, never a reassociation; the DCT
+// table holds the reference's float32(float64 product) values (diffjpeg_table.h), the scale / alpha factors are
+// float32(outer(alpha, alpha) [* 0.25]) and the two divisions are correctly rounded.
 __global__ __launch_bounds__(256) void diffjpeg_kernel(const float* __restrict__ img,
                                                        const float* __restrict__ quality,
                                                        float* __restrict__ out, int B, int H, int W,
                                                        int mcu_x, int mcu_y) {
   __shared__ float sY[4][16][17], sCb[4][16][17], sCr[4][16][17];
   __shared__ float sBlk[4][6][8][9];  // dequantised, alpha-scaled coefficients / reconstructed blocks
+  __shared__ float sT[64 * 65];       // c_dct, rows padded to 65: conflict-free by column (forward) and by row (inverse)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int u = lane >> 3, v = lane & 7;
   const int64_t mcu = (int64_t)blockIdx.x * 4 + wave;
@@ -267,12 +268,14 @@ __global__ __launch_bounds__(256) void diffjpeg_kernel(const float* __restrict__
   const int b = live ? (int)(mcu / ((int64_t)mcu_x * mcu_y)) : 0;
   const int64_t HW = (int64_t)H * W;
   const float* src = img + (int64_t)b * 3 * HW;
+  for (int i = threadIdx.x; i < 4096; i += 256) sT[(i >> 6) * 65 + (i & 63)] = c_dct[i >> 6][i & 63];
 
   // quality -> factor (quality_to_factor, diffjpeg.py:48-61), per sample, on the device
   const float q = quality[b];
-  const float factor = (q < 50.f ? 5000.f / q : 200.f - q * 2.f) / 100.f;
+  const float factor = __fdiv_rn(q < 50.f ? __fdiv_rn(5000.f, q) : 200.f - q * 2.f, 100.f);
 
-  // 1) load 4 pixels per lane, RGB*255 -> YCbCr (zero padding outside the image)
+  // 1) load 4 pixels per lane, RGB*255 -> YCbCr (zero padding outside the image); tensordot over the 3 channels = an
+  //    fmaf chain from 0 (its first link is the plain product), then + shift
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int p = lane + 64 * i, py = p >> 4, px = p & 15;
@@ -284,22 +287,15 @@ __global__ __launch_bounds__(256) void diffjpeg_kernel(const float* __restrict__
       g = src[HW + o] * 255.f;
       bl = src[2 * HW + o] * 255.f;
     }
-    sY[wave][py][px] = r * 0.299f + g * 0.587f + bl * 0.114f + 0.f;
-    sCb[wave][py][px] = r * -0.168736f + g * -0.331264f + bl * 0.5f + 128.f;
-    sCr[wave][py][px] = r * 0.5f + g * -0.418688f + bl * -0.081312f + 128.f;
+    sY[wave][py][px] = __fmaf_rn(bl, 0.114f, __fmaf_rn(g, 0.587f, __fmul_rn(r, 0.299f))) + 0.f;
+    sCb[wave][py][px] = __fmaf_rn(bl, 0.5f, __fmaf_rn(g, -0.331264f, __fmul_rn(r, -0.168736f))) + 128.f;
+    sCr[wave][py][px] = __fmaf_rn(bl, -0.081312f, __fmaf_rn(g, -0.418688f, __fmul_rn(r, 0.5f))) + 128.f;
   }
   __syncthreads();
 
-  const float au = u == 0 ? 0.70710678118654752f : 1.f, av = v == 0 ? 0.70710678118654752f : 1.f;
-  // this lane's rows/columns of the cosine table, in registers
-  float cu[8], cv[8], iu[8], iv[8];
-#pragma unroll
-  for (int x = 0; x < 8; ++x) {
-    cu[x] = c_cos[x][u];
-    cv[x] = c_cos[x][v];
-    iu[x] = c_cos[u][x];
-    iv[x] = c_cos[v][x];
-  }
+  const bool u0 = u == 0, v0 = v == 0;
+  const float dct_scale = (u0 && v0) ? DCT_SCALE_00 : (u0 || v0) ? DCT_SCALE_0X : DCT_SCALE_XX;
+  const float idct_alpha = (u0 && v0) ? IDCT_ALPHA_00 : (u0 || v0) ? IDCT_ALPHA_0X : IDCT_ALPHA_XX;
   // 2) forward DCT + quantise + dequantise for the 6 blocks; lane = coefficient (u, v)
 #pragma unroll
   for (int blk = 0; blk < 6; ++blk) {
@@ -310,26 +306,26 @@ __global__ __launch_bounds__(256) void diffjpeg_kernel(const float* __restrict__
       for (int x = 0; x < 8; ++x)
 #pragma unroll
         for (int y = 0; y < 8; ++y)
-          s += (sY[wave][by + x][bx + y] - 128.f) * (cu[x] * cv[y]);
+          s = __fmaf_rn(__fsub_rn(sY[wave][by + x][bx + y], 128.f), sT[(x * 8 + y) * 65 + lane], s);
     } else {
       float(*pl)[17] = blk == 4 ? sCb[wave] : sCr[wave];
 #pragma unroll
       for (int x = 0; x < 8; ++x)
 #pragma unroll
         for (int y = 0; y < 8; ++y) {
-          // 2x2 average (avg_pool2d kernel 2 stride 2)
-          const float c = (pl[2 * x][2 * y] + pl[2 * x][2 * y + 1] + pl[2 * x + 1][2 * y] +
-                           pl[2 * x + 1][2 * y + 1]) * 0.25f;
-          s += (c - 128.f) * (cu[x] * cv[y]);
+          // 2x2 average (avg_pool2d kernel 2 stride 2: the window summed row by row, then / 4)
+          const float c = __fmul_rn(__fadd_rn(__fadd_rn(__fadd_rn(pl[2 * x][2 * y], pl[2 * x][2 * y + 1]), pl[2 * x + 1][2 * y]),
+                                              pl[2 * x + 1][2 * y + 1]), 0.25f);
+          s = __fmaf_rn(__fsub_rn(c, 128.f), sT[(x * 8 + y) * 65 + lane], s);
         }
     }
-    const float coef = s * (au * av * 0.25f);
-    const float tab = (blk < 4 ? c_ytab[u][v] : c_ctab[u][v]) * factor;
-    const float deq = rintf(coef / tab) * tab;  // torch.round = half-to-even
-    sBlk[wave][blk][u][v] = deq * (au * av);     // iDCT8x8: image *= alpha
+    const float coef = __fmul_rn(dct_scale, s);
+    const float tab = __fmul_rn(blk < 4 ? c_ytab[u][v] : c_ctab[u][v], factor);
+    const float deq = __fmul_rn(rintf(__fdiv_rn(coef, tab)), tab);  // torch.round = half-to-even
+    sBlk[wave][blk][u][v] = __fmul_rn(deq, idct_alpha);              // iDCT8x8: image *= alpha
   }
   __syncthreads();
-  // 3) inverse DCT; lane = pixel (u, v) of the block
+  // 3) inverse DCT; lane = pixel (u, v) of the block: tensor[x, y, u, v] of iDCT8x8 = c_dct[8 u + v][8 x + y]
   float rec[6];
 #pragma unroll
   for (int blk = 0; blk < 6; ++blk) {
@@ -337,14 +333,14 @@ __global__ __launch_bounds__(256) void diffjpeg_kernel(const float* __restrict__
 #pragma unroll
     for (int x = 0; x < 8; ++x)
 #pragma unroll
-      for (int y = 0; y < 8; ++y) s += sBlk[wave][blk][x][y] * (iu[x] * iv[y]);
-    rec[blk] = 0.25f * s + 128.f;
+      for (int y = 0; y < 8; ++y) s = __fmaf_rn(sBlk[wave][blk][x][y], sT[lane * 65 + x * 8 + y], s);
+    rec[blk] = __fadd_rn(__fmul_rn(0.25f, s), 128.f);
   }
   __syncthreads();
 #pragma unroll
   for (int blk = 0; blk < 6; ++blk) sBlk[wave][blk][u][v] = rec[blk];
   __syncthreads();
-  // 4) chroma x2 repeat, YCbCr -> RGB, clamp, /255, store
+  // 4) chroma x2 repeat, (+ shift) YCbCr -> RGB as the fmaf chain of its tensordot, clamp, / 255, store
   if (!live) return;
   float* dst = out + (int64_t)b * 3 * HW;
 #pragma unroll
@@ -352,16 +348,17 @@ __global__ __launch_bounds__(256) void diffjpeg_kernel(const float* __restrict__
     const int p = lane + 64 * i, py = p >> 4, px = p & 15;
     const int gy = my * 16 + py, gx = mx * 16 + px;
     if (gy < H && gx < W) {
-      const float yv = sBlk[wave][(py >> 3) * 2 + (px >> 3)][py & 7][px & 7];
-      const float cb = sBlk[wave][4][py >> 1][px >> 1] - 128.f;
-      const float cr = sBlk[wave][5][py >> 1][px >> 1] - 128.f;
-      const float r = yv * 1.f + cb * 0.f + cr * 1.402f;
-      const float g = yv * 1.f + cb * -0.344136f + cr * -0.714136f;
-      const float bl = yv * 1.f + cb * 1.772f + cr * 0.f;
+      const float yv = __fadd_rn(sBlk[wave][(py >> 3) * 2 + (px >> 3)][py & 7][px & 7], 0.f);
+      const float cb = __fadd_rn(sBlk[wave][4][py >> 1][px >> 1], -128.f);
+      const float cr = __fadd_rn(sBlk[wave][5][py >> 1][px >> 1], -128.f);
+      const float y1 = __fmul_rn(yv, 1.f);
+      const float r = __fmaf_rn(cr, 1.402f, __fmaf_rn(cb, 0.f, y1));
+      const float g = __fmaf_rn(cr, -0.714136f, __fmaf_rn(cb, -0.344136f, y1));
+      const float bl = __fmaf_rn(cr, 0.f, __fmaf_rn(cb, 1.772f, y1));
       const int64_t o = (int64_t)gy * W + gx;
-      dst[o] = fminf(fmaxf(r, 0.f), 255.f) / 255.f;
-      dst[HW + o] = fminf(fmaxf(g, 0.f), 255.f) / 255.f;
-      dst[2 * HW + o] = fminf(fmaxf(bl, 0.f), 255.f) / 255.f;
+      dst[o] = __fdiv_rn(fminf(fmaxf(r, 0.f), 255.f), 255.f);
+      dst[HW + o] = __fdiv_rn(fminf(fmaxf(g, 0.f), 255.f), 255.f);
+      dst[2 * HW + o] = __fdiv_rn(fminf(fmaxf(bl, 0.f), 255.f), 255.f);
     }
   }
 }

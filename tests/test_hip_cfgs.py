@@ -130,9 +130,11 @@ def test_config_combination_trajectory_vs_reference_fixture(name, chained):
     """OUR `image` / `otf` model from the fixture's TOML, initial weights, batches and (otf) recorded draws: every
     log_dict entry per iteration, the outputs, the final G / D weights and spectral-norm buffers.
     `chained` (otf configs; VERDICT r4 "JPEG-flip decoupling"): the step runs on the model's OWN degraded LQ instead of the
-    reference's — feed and step checked end to end, not piecewise.  DiffJPEG's rounding may flip a quantised coefficient
-    (<= 1/255 on < 1 % of the LQ pixels, asserted), which the generator and three further iterations through the pair pool
-    carry forward: the gates are 2e-2 there (1e-3 with the reference LQ substituted)."""
+    reference's — feed and step checked end to end, not piecewise.  Since round 6 DiffJPEG reproduces the reference's
+    quantised coefficients bit for bit (csrc/degrade.hip "ROUNDING CONTRACT"): no 8x8 block of the model's LQ differs from
+    the reference's (asserted: at most two isolated pixels per batch, ties of the final 8-bit quantiser) and the chained gates
+    are the same 1e-3 as with the reference LQ substituted (they were 2e-2 while a coefficient could round the other way:
+    VERDICT r5 #7)."""
     from neosr_amd.data.draws import ReplayDraws
     from neosr_amd.models import build_model
     from neosr_amd.utils.options import parse_options
@@ -162,24 +164,27 @@ def test_config_combination_trajectory_vs_reference_fixture(name, chained):
             assert d.exhausted()
             ref_lq = T(fix[f"it{it}/lq"])
             diff = (model.lq.cpu() - ref_lq).abs()
-            assert float(diff.max()) <= 1.0 / 255 + 1e-6 and float((diff > 1e-6).float().mean()) < 0.01
+            # no JPEG coefficient flip (one moves up to 64 pixels of a block).  What can remain is the final 8-bit quantiser
+            # on an exact tie: filter2D / resize agree with the CPU reference to ~1e-7, and a value within that of k + 0.5
+            # rounds either way — isolated single pixels, one step of 1/255 (cfg2, iteration 1: one pixel of 6 144)
+            nflip = int((diff > 1e-6).sum())
+            assert float(diff.max()) <= 1.0 / 255 + 1e-6 and nflip <= 2, (it, float(diff.max()), nflip)
             assert torch.equal(model.gt.cpu(), T(fix[f"it{it}/gt_out"]))
             if not chained:
-                model.lq = ref_lq.to(DEV)  # a JPEG rounding flip (<= 1/255 on < 1 % of the pixels) stays out of the step check
-            # (the pair pool keeps the model's own pixels, so later iterations dequeue them: also covered by the bound)
+                model.lq = ref_lq.to(DEV)  # (piecewise variant: the step is checked on the reference's LQ)
         else:
             model.feed_data({"lq": T(fix[f"it{it}/lq"]), "gt": T(fix[f"it{it}/gt"])})
         model.optimize_parameters(it)
         log = model.get_current_log()
         assert list(log.keys()) == keys
-        tol = 2e-2 if chained else 1e-3
+        tol = 1e-3
         for j, k in enumerate(keys):
             ref = fix["log"][it - 1, j]
             assert abs(log[k] - ref) < tol * max(abs(ref), 1e-2), (it, k, log[k], ref)
         assert rel_err(model.output, T(fix[f"it{it}/out"])) < tol
     G = OrderedDict((k, v.cpu()) for k, v in model.net_g.state_dict().items())
     D = OrderedDict((k, v.cpu()) for k, v in model.net_d.state_dict().items()) if model.net_d is not None else {}
-    check_final(fix, G, D, 2e-2 if chained else 1e-3)
+    check_final(fix, G, D, 1e-3)
 
 
 # ---------------------------------------------------------------------------------------------- full-size properties
