@@ -117,11 +117,16 @@ __device__ __forceinline__ void zero(f32x16& a) {
   for (int r = 0; r < 16; ++r) a[r] = 0.f;
 }
 
+// Row stride of the bias table in LDS.  A 32-lane group of the score epilogue reads (row yi + a, column xi), a = 0..3, xi =
+// 0..7: with the table's own stride of 15 the four 8-float runs start 15 apart and rows a, a + 2 share banks (SQ counters,
+// profiles/r05_bench_swinir_medium_sq_summary.json: bank conflicts 44 % of the kernel's LDS cycles); 40 apart they are the
+// four disjoint quarters of the 32 banks (the HAT kernel below got the same re-stride in round 5).
+constexpr int TS8 = 40;
 __device__ __forceinline__ void load_table(const neosr_wattn_desc& d, int head, int lane, float* tab) {
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int n = lane + 64 * k;
-    tab[n] = n < NBIN ? d.rpb_table[n * d.heads + head] : 0.f;
+    if (n < NBIN) tab[(n / (2 * WS - 1)) * TS8 + n % (2 * WS - 1)] = d.rpb_table[n * d.heads + head];
   }
 }
 
@@ -129,7 +134,7 @@ __device__ __forceinline__ void load_table(const neosr_wattn_desc& d, int head, 
 // unit = (window, head, query tile ti): S^T tiles [tj] with rows (registers) = keys j, column (lane) = query i
 template <int HALF>
 __global__ __launch_bounds__(256, 2) void wattn_wave_fwd_kernel(const neosr_wattn_desc d, int units) {
-  __shared__ float tabs[4][256];
+  __shared__ float tabs[4][(2 * WS - 1) * TS8];
   const int lane = threadIdx.x & 63, l31 = lane & 31, lh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   float* tab = tabs[wave];
@@ -164,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void wattn_wave_fwd_kernel(const neosr_watt
     // bias + mask, softmax over the keys (registers + the other half-wave)
     const bool masked = d.shift > 0 && (w.Wy == w.nWy - 1 || w.Wx == w.nWx - 1);
     const int yi = 4 * ti + (l31 >> 3), xi = l31 & 7;
-    const float* tb = tab + (yi + WS - 1) * (2 * WS - 1) + xi + WS - 1 - 4 * lh;
+    const float* tb = tab + (yi + WS - 1) * TS8 + xi + WS - 1 - 4 * lh;
     const int ri = region1(yi, w.Wy, w.nWy, d.shift) * 3 + region1(xi, w.Wx, w.nWx, d.shift);
     float m = -3.0e38f;
     // (the table values of a tile are read in one batch, and the mask is a select on a penalty that is 0 in unmasked windows:
@@ -176,7 +181,7 @@ __global__ __launch_bounds__(256, 2) void wattn_wave_fwd_kernel(const neosr_watt
 #pragma unroll
       for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) bv[4 * g + r] = tb[-((4 * tj + g) * (2 * WS - 1) + r)];
+        for (int r = 0; r < 4; ++r) bv[4 * g + r] = tb[-((4 * tj + g) * TS8 + r)];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int ryj = region1(4 * tj + g, w.Wy, w.nWy, d.shift) * 3;

@@ -488,8 +488,14 @@ __device__ __forceinline__ void gemm_nt_glds_body(const GemmArgs& args) {
           if (2 * ps < nsteps) {
             const int q = 4 * ps + 2 * lh;
             bf16x8 X[3], W0[3], W1[3];
+#ifdef GEMM_FAKE_PRESPLIT   // timing probe only: three plane reads instead of two fp32 reads + split3; WRONG numbers
+            X[0] = *reinterpret_cast<const bf16x8*>(abuf + arow * BK + 4 * (q ^ sa));
+            X[1] = *reinterpret_cast<const bf16x8*>(abuf + arow * BK + 4 * ((q + 1) ^ sa));
+            X[2] = *reinterpret_cast<const bf16x8*>(abuf + arow * BK + 4 * (((q + 2) & 7) ^ sa));
+#else
             split3(*reinterpret_cast<const f32x4*>(abuf + arow * BK + 4 * (q ^ sa)),
                    *reinterpret_cast<const f32x4*>(abuf + arow * BK + 4 * ((q + 1) ^ sa)), X);
+#endif
 #pragma unroll
             for (int p3 = 0; p3 < 3; ++p3) {
               const int sl = 4 * ((4 * p3 + 2 * ps + lh) ^ sb);
