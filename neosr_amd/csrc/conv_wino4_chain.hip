@@ -53,7 +53,7 @@ constexpr unsigned SLOW_SPINS = 400;
 #ifdef NEOSR_TIMELINE
 #define CTL_MARK(l, m)                                                                            \
   do {                                                                                            \
-    if (args.timeline && blockIdx.x == 0 && (threadIdx.x & 63) == 0 && (l) < 16)                  \
+    if (args.timeline && !args.indep && blockIdx.x == 0 && (threadIdx.x & 63) == 0 && (l) < 16)   \
       args.timeline[((threadIdx.x >> 6) * 16 + (l)) * 16 + (m)] = clock64();                       \
   } while (0)
 #else
@@ -265,7 +265,11 @@ __device__ __forceinline__ void chain_body(const W4ChainArgs& args) {
     // (args.indep: sample strips of one convolution) has nobody to tell: no drain, no flag — chunk 0 was requested during
     // the previous layer's last iteration, every wave's pieces had landed before it left that layer's last MFMAs (their
     // weights were loaded behind the request; the wait for them is vmcnt(0)) and its exchange barrier made them visible.
+#ifdef CHAIN_NO_DRAIN   // timing probe only (round 6): the layer-start drain skipped behind layer 0 — RACY, wrong results
+    if (l == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
     if (!args.indep || l == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
     CTL_MARK(l, 1);
     __syncthreads();
     CTL_MARK(l, 2);
@@ -363,6 +367,7 @@ __device__ __forceinline__ void chain_body(const W4ChainArgs& args) {
 
     for (int c = 0; c < nchunks; ++c) {
       const float* rb = c == 0 ? ldsC : ((c & 1) ? ldsA : ldsB);
+      if (c < 6) CTL_MARK(l, 10 + c);
       unsigned fv = 0;
       if (wave == 0 && c == pollc) fv = poll_load();
       if (c > 0) mac3(3, vhi, uhi);  // positions (ti, 3..5) of the previous (sub-)chunk

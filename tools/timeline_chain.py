@@ -32,6 +32,11 @@ for l in range(15):
         r = t[w, l][:10]
         vals = [int(v) - base if int(v) else None for v in r]
         print(f"   wave{w:2d}: " + " ".join(f"{n}@{v}" for n, v in zip(names, vals)))
+print("== chunk starts of wave 0 / wave 8 per layer (ticks since the layer's loop mark)")
+for l in range(15):
+    for w in (0, 8):
+        r = t[w, l]
+        print(f" layer {l:2d} wave {w}: loop@0 " + " ".join(f"c{c}@{int(r[10 + c]) - int(r[3])}" for c in range(6) if int(r[10 + c])) + f" loopend@{int(r[4]) - int(r[3])}")
 # summary: per layer, max over waves of each mark, as deltas
 print("== per layer (max over waves), cycles: start->bar1, bar1->loop, loop, loopend->exbar, exbar->stored(max fin), total")
 prev_end = None
