@@ -455,7 +455,7 @@ def run_config(args, config: str, world: int, rank: int, dev, steps: int, warmup
                     "kernels": kern,
                     "method": "HIP events around every launch of the class on the launch stream, separate "
                               "profiled pass after the timed region with the trunk on ONE stream "
-                              "(neosr_set_num_streams(1)); profiles/r05_<config>_kernel_stats.csv is rocprofv3 "
+                              "(neosr_set_num_streams(1)); profiles/r06_<config>_kernel_stats.csv is rocprofv3 "
                               "--kernel-trace --stats of `NEOSR_AMD_STREAMS=1 python bench.py --config <config>`"}
         if opt.get("fast_matmul") and dom in (0, 1) and dom_algo == 2:
             # the tier runs FOUR bf16 products per executed fp32-equivalent multiplication on the bf16 MFMA: priced against
