@@ -167,6 +167,14 @@ class image(base):
 
         # data-parallel exchange (base.py:140-146 wraps the nets in DDP): one GradSync per network; the RRDB plan
         # reduces gradient buckets during its backward when the step follows directly (no accumulation, no SAM)
+        # discriminator phase beside the generator's backward on a second stream (see `_closure`): on by default for the
+        # layer-composed generators; the RRDB / compact plans are left alone — a chain launch of the RRDB trunk needs every
+        # CU for its co-resident workgroups.  NEOSR_AMD_D_OVERLAP=0|1 forces it off / on (A/B runs).
+        from neosr_amd.archs.arch_util import HipNet as _HipNet
+
+        env_ov = os.environ.get("NEOSR_AMD_D_OVERLAP", "")
+        self._d_overlap = env_ov == "1" or (env_ov != "0" and not isinstance(self.net_g, _HipNet))
+        self._d_stream = None
         self._sync_g = self._sync_d = None
         if self.opt["dist"]:
             self._sync_g = GradSync()
@@ -338,7 +346,17 @@ class image(base):
 
         if self._sync_g is not None:  # buckets may go during backward only if this backward is the one stepped
             self._sync_g.armed = step_now and self.accum_iters == 1 and not self._sam_now
-        if self.eco and current_iter <= self.eco_iters and not (current_iter < self.eco_init and self.pretrain is None):
+        eco_now = self.eco and current_iter <= self.eco_iters and not (current_iter < self.eco_init and self.pretrain is None)
+        if self._d_overlap and self.cri_perceptual and not eco_now and hasattr(self.cri_perceptual, "prefetch_gt"):
+            # the perceptual loss's target features beside the generator's forward (second stream; see `d_phase` below)
+            main = torch.cuda.current_stream(self.device)
+            if self._d_stream is None:
+                self._d_stream = torch.cuda.Stream(self.device)
+                self._d_fork, self._d_join = torch.cuda.Event(), torch.cuda.Event()
+            self._d_fork.record(main)
+            self._d_stream.wait_event(self._d_fork)
+            self.cri_perceptual.prefetch_gt(self.gt, self._d_stream)
+        if eco_now:
             self.output, self.gt = self.eco_strategy(current_iter)  # image.py:441-446
         else:
             self.output = self.net_g(self.lq)
@@ -384,18 +402,16 @@ class image(base):
         loss_dict["l_g_total"] = l_g_total
         if self.accum_iters != 1:
             l_g_total = l_g_total / self.accum_iters
-        if self._sync_g is not None:
-            self._sync_g.arm_backward()   # hook-driven buckets leave from inside this backward (no-op for the RRDB plan)
-        with _tr.deferred_reductions():   # parameter-gradient column sums batched at the end of the pass (opt-in)
-            l_g_total.backward()
-        if step_now:
-            self._sync_grads(self.sam_optimizer_g if self._sam_now else self.optimizer_g, self._sync_g)
-
-        if self.net_d is not None:
+        # ---- discriminator phase (image.py:546-609): both forwards first, then both backwards (image.py:559,574,593-594).
+        # It needs the generator's OUTPUT and the discriminator's weights, not the generator's gradients, so with
+        # `self._d_overlap` it is enqueued on a second stream BEFORE the generator's backward and runs beside it: a
+        # transformer generator's backward is a chain of dependent launches that leaves CUs idle at every boundary, the
+        # U-Net's convolutions fill them.  Same kernels on the same operands in the same per-network order (the
+        # spectral-norm vectors advance G-phase forward -> real -> fake as in the reference): bit-identical results.
+        def d_phase() -> None:
             for p in self._d_params():
                 p.requires_grad = True
             if self.cri_gan:
-                # both forwards first, then both backwards (image.py:559,574,593-594)
                 self.broadcast_buffers(self.net_d)
                 real_d_pred = self.net_d(self.gt)
                 l_d_real = self.cri_gan(real_d_pred, target_is_real=True, is_disc=True) / self.accum_iters
@@ -410,6 +426,32 @@ class image(base):
                 with _tr.deferred_reductions():
                     l_d_real.backward()
                     l_d_fake.backward()
+
+        overlap = (self._d_overlap and self.net_d is not None and bool(self.cri_gan) and self.accum_iters == 1
+                   and not self._sam_now)
+        if overlap:
+            main = torch.cuda.current_stream(self.device)
+            if self._d_stream is None:
+                self._d_stream = torch.cuda.Stream(self.device)
+                self._d_fork, self._d_join = torch.cuda.Event(), torch.cuda.Event()
+            self._d_fork.record(main)   # behind the G-phase forward through net_d (its spectral-norm update comes first)
+            with torch.cuda.stream(self._d_stream):
+                self._d_stream.wait_event(self._d_fork)
+                d_phase()
+                self._d_join.record(self._d_stream)
+
+        if self._sync_g is not None:
+            self._sync_g.arm_backward()   # hook-driven buckets leave from inside this backward (no-op for the RRDB plan)
+        with _tr.deferred_reductions():   # parameter-gradient column sums batched at the end of the pass (opt-in)
+            l_g_total.backward()
+        if step_now:
+            self._sync_grads(self.sam_optimizer_g if self._sam_now else self.optimizer_g, self._sync_g)
+
+        if self.net_d is not None:
+            if overlap:
+                torch.cuda.current_stream(self.device).wait_event(self._d_join)
+            else:
+                d_phase()
             if step_now:
                 self._sync_grads(self.optimizer_d, self._sync_d)
 

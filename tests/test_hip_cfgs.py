@@ -363,3 +363,44 @@ def test_compile_option_captures_generator_as_hip_graphs_bit_identical():
     assert runs[0][0] == runs[1][0]
     assert torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[0][3], runs[1][3])
     assert all(torch.equal(a, b) for a, b in zip(runs[0][2], runs[1][2]))
+
+
+def test_discriminator_phase_beside_generator_backward_is_bit_identical():
+    """Round 6: for layer-composed generators the discriminator phase (image.py:546-609: D(real), D(fake.detach()), both
+    backwards) is enqueued on a second stream BEFORE the generator's backward and runs beside it.  It reads the generator's
+    output and the discriminator's weights only, the spectral-norm vectors still advance G-phase forward -> real -> fake:
+    the recorded iterations of the cfg4 combination (hat_s + U-Net-SN + VGG + GAN, adan_sf x2) must leave the SAME bits in every
+    log entry, weight and buffer as the serial order — and the serial order is what the reference fixture pins above."""
+    from neosr_amd.data.draws import ReplayDraws
+    from neosr_amd.models import build_model
+    from neosr_amd.utils.options import parse_options
+
+    fix = load_golden("step_cfg4.npz")
+
+    def run(overlap: bool):
+        opt, _ = parse_options(str(ROOT), True, argv=["-opt", str(GOLDEN / "golden_cfg4.toml")])
+        torch.manual_seed(1024)
+        random.seed(1024)
+        model = build_model(opt)
+        assert model._d_overlap, "default: on for a layer-composed generator"
+        model._d_overlap = overlap
+        model.net_d.load_state_dict(group(fix, "init_d"))
+        _load_vgg(model.cri_perceptual.vgg)
+        logs = []
+        n = int(fix["log"].shape[0])
+        for it in range(1, n + 1):
+            d = ReplayDraws(load_draws(fix, f"it{it}/draws"), DEV)
+            model.draws = d
+            model.feed_data({k: T(fix[f"it{it}/{k}"]) for k in ("gt", "kernel1", "kernel2", "sinc_kernel")})
+            model.optimize_parameters(len(logs) + 1)
+            logs.append(dict(model.get_current_log()))
+        torch.cuda.synchronize()
+        sd = {f"g.{k}": v.detach().clone() for k, v in model.net_g.state_dict().items()}
+        sd.update({f"d.{k}": v.detach().clone() for k, v in model.net_d.state_dict().items()})
+        return logs, sd
+
+    logs_a, sd_a = run(True)
+    logs_b, sd_b = run(False)
+    assert logs_a == logs_b, [(a, b) for a, b in zip(logs_a, logs_b) if a != b][:1]
+    for k in sd_a:
+        assert torch.equal(sd_a[k], sd_b[k]), k
