@@ -84,7 +84,11 @@ TWO_RANK = textwrap.dedent("""
     GT = torch.rand(2, 4, 3, 64, 64, generator=g)
 
     def run(cfg, use_dist):
+        hat = cfg.endswith("+hat")   # the GAN combination with a layer-composed generator: the discriminator phase runs on
+        cfg = cfg.replace("+hat", "")  # a second stream beside the generator's backward (models/image.py, round 6)
         opt, _ = parse_options({root!r}, True, argv=["-opt", str(GOLDEN / cfg)])
+        if hat:
+            opt["network_g"] = {{"type": "hat_s", "drop_path_rate": 0.0}}
         opt["dist"], opt["rank"], opt["world_size"] = use_dist, (rank if use_dist else 0), (world if use_dist else 1)
         set_global_opt(opt)
         torch.manual_seed(1024 + (rank if use_dist else 0))   # per-rank seeding as options.py:208 -> different inits
@@ -93,8 +97,9 @@ TWO_RANK = textwrap.dedent("""
             return model
         return model
 
-    for cfg in ("golden_esrgan.toml", "golden_gan.toml", "golden_cfg3.toml"):
+    for cfg in ("golden_esrgan.toml", "golden_gan.toml", "golden_cfg3.toml", "golden_gan.toml+hat"):
         m = run(cfg, True)
+        assert m._d_overlap == cfg.endswith("+hat") or m.net_d is None, (cfg, m._d_overlap)
         init_g = {{k: v.detach().clone() for k, v in m.net_g.state_dict().items()}}
         init_d = {{k: v.detach().clone() for k, v in m.net_d.state_dict().items()}} if m.net_d is not None else None
         for it in (1, 2):
@@ -128,7 +133,7 @@ TWO_RANK = textwrap.dedent("""
             for k in rlog:
                 assert abs(log[k] - rlog[k]) <= 2e-4 * max(1.0, abs(rlog[k])), (cfg, k, log[k], rlog[k])
             for (k, a), b in zip(m.net_g.state_dict().items(), ref.net_g.state_dict().values()):
-                if cfg == "golden_cfg3.toml" and a.is_floating_point():
+                if cfg in ("golden_cfg3.toml", "golden_gan.toml+hat") and a.is_floating_point():
                     # adan_sf on zero-initialised biases / LayerNorm shifts: two steps leave values of ~5e-5 whose
                     # normalised updates amplify rounding (8e-3 RELATIVE on a 5e-5 tensor = 4e-7 absolute, identical
                     # with and without the hook-driven buckets) -> norm-relative 2e-4 OR 2e-6 absolute
