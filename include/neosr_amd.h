@@ -898,6 +898,20 @@ int neosr_tblock_backward(const neosr_tblock_desc* d, const float* x, const floa
 int neosr_set_tblock_streams(int n);
 /* Forks onto the side stream since the library was loaded (diagnostics / tests: was the side-stream path taken?). */
 int64_t neosr_tblock_side_forks(void);
+/* The TAIL of neosr_tblock_backward — the grouped weight-gradient GEMMs and the batched column sums that finish the block's
+ * parameter gradients; nothing in the backward pass reads them — runs on a second library stream and the call returns with
+ * it in flight (1 = default, env NEOSR_AMD_BLOCK_TAIL; only with neosr_set_tblock_streams(3), never under hipGraph capture).
+ * Contract for the caller (neosr_amd/hip/transformer.py implements it; reference call sites: autograd of
+ * neosr/archs/swinir_arch.py:231-392, hat_arch.py:218-515):
+ *   - `workspace`, `save` and `dout` of a call must stay allocated and unwritten until TWO further calls of
+ *     neosr_tblock_backward have returned (each call makes its stream wait for the tail of the call before the last) or
+ *     until neosr_tblock_tail_join;
+ *   - the parameter gradients are complete behind neosr_tblock_tail_join(stream): `stream` waits for every tail issued so
+ *     far; returns how many were outstanding (0: nothing to wait for, -1: error).
+ * neosr_tblock_tails(): tails issued so far (callers compare it around a call to learn whether one was issued). */
+int neosr_set_tblock_tail(int on);
+int64_t neosr_tblock_tail_join(void* stream);
+int64_t neosr_tblock_tails(void);
 
 #ifdef __cplusplus
 }

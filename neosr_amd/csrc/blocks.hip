@@ -250,9 +250,27 @@ BwdLayout bwd_layout(const neosr_tblock_desc& d, float* base) {
 struct Side {
   int dev = -1;
   hipStream_t s = nullptr;
-  hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipStream_t tail = nullptr;   // stream of the backward plans' weight-gradient TAILS (below)
+  hipEvent_t ev[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
-enum { EV_FORK = 0, EV_GPRE, EV_DX2, EV_GT1, EV_GU0, EV_DQKV, EV_JOIN };
+enum { EV_FORK = 0, EV_GPRE, EV_DX2, EV_GT1, EV_GU0, EV_DQKV, EV_JOIN, EV_TAIL_FORK, EV_TAIL_DONE /* , EV_TAIL_DONE + 1 */ };
+// The TAIL of a block's backward plan — the grouped weight-gradient GEMMs and the batched column sums that finish the
+// parameter gradients (~75 us per block at B = 8 / 64 x 64) — feeds nothing in the backward pass: only the optimizer (and
+// the gradient exchange) read what it writes, while the NEXT block's data-gradient chain waits behind it on the caller's
+// stream.  With NEOSR_AMD_BLOCK_TAIL (default on, modes 3 only) it runs on a second library stream and the call returns with
+// it in flight (round 6: swinir_medium +4.0 %, hat_l +3.3 %, same-box).  What that costs the caller:
+//   * everything the tail reads or writes — the workspace, the block's save buffer, the incoming gradient — must stay
+//     untouched until the tail is done.  The plan makes the caller's stream wait for the tail of the call BEFORE THE LAST
+//     at the end of every call (two alternating events), so a caller that keeps those three buffers alive for two more
+//     calls (hip/transformer.py: a two-entry ring) may then free them: whatever reuses the memory is enqueued behind
+//     that wait;
+//   * the parameter gradients are complete only behind neosr_tblock_tail_join(stream), which makes `stream` wait for every
+//     tail issued so far: the Python side calls it at the end of the backward pass (an autograd engine callback), before
+//     a data-parallel bucket leaves (utils/grad_sync.py), and at once when a gradient is going to be ACCUMULATED into an
+//     existing one.
+std::atomic<int> g_block_tail{-1};      // -1: read NEOSR_AMD_BLOCK_TAIL on first use (default 1)
+std::atomic<long> g_tails{0};           // tails issued so far
+std::atomic<long> g_tails_joined{0};    // ... covered by the last neosr_tblock_tail_join
 std::atomic<int> g_block_streams{-1};   // (read by the forward thread and the autograd thread, written by the setter)
 std::atomic<long> g_side_forks{0};      // forks onto the side stream so far (tests ask: was the path taken?)
 // mode 3 (NEOSR_AMD_BLOCK_STREAMS=3): the CAB branch of a HAB — a chain of SMALL launches (B = 4: 128-192 twelve-wave
@@ -286,8 +304,7 @@ struct SideJoin {
   }
 };
 
-bool cab_on_side(const Side* side, const neosr_tblock_desc& d, void* stream) {
-  if (!side || g_block_streams != 3 || d.cab_mid <= 0) return false;
+bool not_capturing(void* stream) {
   if (stream) {   // (the null stream cannot be captured; a stream under hipGraph capture keeps the block on itself)
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing((hipStream_t)stream, &st) != hipSuccess) {
@@ -297,6 +314,17 @@ bool cab_on_side(const Side* side, const neosr_tblock_desc& d, void* stream) {
     if (st != hipStreamCaptureStatusNone) return false;
   }
   return true;
+}
+bool cab_on_side(const Side* side, const neosr_tblock_desc& d, void* stream) {
+  if (!side || g_block_streams != 3 || d.cab_mid <= 0) return false;
+  return not_capturing(stream);
+}
+bool tail_on_side(const Side* side, void* stream) {
+  if (g_block_tail < 0) {
+    const char* e = getenv("NEOSR_AMD_BLOCK_TAIL");
+    g_block_tail = (e && e[0] == '0') ? 0 : 1;
+  }
+  return side && side->tail && g_block_streams == 3 && g_block_tail == 1 && not_capturing(stream);
 }
 
 Side* side_get() {
@@ -315,6 +343,7 @@ Side* side_get() {
   a.dev = dev;
   if (!a.s) {
     if (hipStreamCreateWithFlags(&a.s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    if (hipStreamCreateWithFlags(&a.tail, hipStreamNonBlocking) != hipSuccess) return nullptr;
     for (auto& e : a.ev)
       if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
   }
@@ -434,6 +463,7 @@ extern "C" int neosr_tblock_backward(const neosr_tblock_desc* dp, const float* x
               "tblock backward: (weight, bias) / (gamma, beta) gradient pairs must be contiguous");
   Side* side_any = side_get();
   const bool cab_side = cab_on_side(side_any, d, stream);          // mode 3: the CAB branch on the side stream
+  const bool tail_side = tail_on_side(side_any, stream);           // mode 3: the weight-gradient tail on the tail stream
   Side* side = (side_any && g_block_streams == 2) ? side_any : nullptr;   // mode 2: the weight gradients on the side stream
   void* sw = side ? (void*)side->s : stream;   // the stream of the weight gradients
   SideJoin sj;                                 // armed by the first fork of either mode
@@ -575,13 +605,20 @@ extern "C" int neosr_tblock_backward(const neosr_tblock_desc* dp, const float* x
     if (rc >= 0) return rc ? rc : (neosr_set_error("tblock: layernorm did not defer its reduction"), 1);
     add_job(b.ln1, -rc, 2 * C, G.n1_w);
   }
+  // ---- the tail (see the comment at g_block_tail): behind everything the caller's stream holds so far
+  void* ts = stream;
+  if (tail_side) {
+    NEOSR_HIP(hipEventRecord(side_any->ev[EV_TAIL_FORK], (hipStream_t)stream));
+    NEOSR_HIP(hipStreamWaitEvent(side_any->tail, side_any->ev[EV_TAIL_FORK], 0));
+    ts = (void*)side_any->tail;
+  }
   if (ntn) {   // the collected weight-gradient GEMMs: one launch (or, if a shape does not qualify, one each)
     int32_t ns[4];
-    int rc = neosr_gemm_tn_group(tn, ntn, ns, stream);
+    int rc = neosr_gemm_tn_group(tn, ntn, ns, ts);
     if (rc > 0) return rc;
     for (int i = 0; i < ntn; ++i) {
       if (rc < 0) {
-        const int r1 = neosr_gemm(&tn[i], stream);
+        const int r1 = neosr_gemm(&tn[i], ts);
         if (r1 >= 0) return r1 ? r1 : (neosr_set_error("tblock: TN gemm did not defer its reduction"), 1);
         ns[i] = -r1;
       }
@@ -590,5 +627,34 @@ extern "C" int neosr_tblock_backward(const neosr_tblock_desc* dp, const float* x
   }
   if (side) TB_RUN(sj.join());   // the column sums below read the partials of both streams
   NEOSR_CHECK(neosr_colsum_many_workspace_floats(jobs, nj) <= b.many_n, "tblock backward: column-sum workspace too small");
-  return neosr_colsum_many(jobs, nj, b.many, stream);
+  TB_RUN(neosr_colsum_many(jobs, nj, b.many, ts));
+  if (tail_side) {
+    // the caller's stream waits for the tail of the call before the last (same event slot, waited for BEFORE it is recorded
+    // again), then this call's tail is marked
+    const long n = g_tails.fetch_add(1);
+    hipEvent_t done = side_any->ev[EV_TAIL_DONE + (n & 1)];
+    NEOSR_HIP(hipStreamWaitEvent((hipStream_t)stream, done, 0));
+    NEOSR_HIP(hipEventRecord(done, side_any->tail));
+  }
+  return 0;
 }
+
+// `stream` waits for every tail issued so far; returns how many were outstanding
+extern "C" int64_t neosr_tblock_tail_join(void* stream) {
+  const long n = g_tails.load();
+  const long pending = n - g_tails_joined.load();
+  if (pending <= 0) return 0;
+  Side* side = side_get();
+  if (!side) return -1;
+  // (in-order stream: the newest tail's event covers all of them)
+  if (hipStreamWaitEvent((hipStream_t)stream, side->ev[EV_TAIL_DONE + ((n - 1) & 1)], 0) != hipSuccess) return -1;
+  g_tails_joined = n;
+  return pending;
+}
+extern "C" int64_t neosr_tblock_tails(void) { return g_tails; }
+extern "C" int neosr_set_tblock_tail(int on) {
+  const int prev = g_block_tail < 0 ? 1 : g_block_tail.load();
+  g_block_tail = on ? 1 : 0;
+  return prev;
+}
+

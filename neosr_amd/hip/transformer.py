@@ -608,10 +608,59 @@ class TBlock(torch.autograd.Function):
             meta["_G"] = (base, G)
         ws = _new((nws,), x)
         dx = torch.empty_like(x)
+        tails = lib.neosr_tblock_tails()
         _C.check(lib.neosr_tblock_backward(d, x.data_ptr(), g.data_ptr(), save.data_ptr(), dx.data_ptr(), G,
                                            ws.data_ptr(), _st()), "neosr_tblock_backward")
+        if lib.neosr_tblock_tails() != tails:
+            _tail_issued(ws, save, g, params)
         grads = [v if need else None for v, need in zip(views, ctx.needs_input_grad[4:])]
         return (dx if ctx.needs_input_grad[0] else None), None, None, None, *grads
+
+
+# ---- the backward plans' weight-gradient TAILS (csrc/blocks.hip, include/neosr_amd.h: neosr_tblock_tail_join).  A call of
+# neosr_tblock_backward may return with its tail in flight on the library's tail stream: the buffers it uses are kept alive
+# here for two more calls (the plan orders the caller's stream behind the tail of the call before the last), the caller's
+# stream is joined with the tails at the end of the backward pass, and at once where a gradient would be accumulated into
+# an existing `.grad` (autograd would add to it on the caller's stream before the tail has written it).
+_TAIL_KEEP: list = []
+_TAIL_CALLBACK = False
+_TAIL_STREAM = None
+
+
+def join_tails() -> int:
+    """the current stream waits for every tail issued so far; drops the kept buffers (they are only reused behind the wait)"""
+    n = int(_C.load().neosr_tblock_tail_join(_st()))
+    if n < 0:
+        _C.check(1, "neosr_tblock_tail_join")
+    _TAIL_KEEP.clear()
+    return n
+
+
+def _tails_end_of_backward() -> None:
+    # (an engine callback may run with another current stream than the backward nodes had: join on THEIR stream)
+    global _TAIL_CALLBACK, _TAIL_STREAM
+    _TAIL_CALLBACK = False
+    s, _TAIL_STREAM = _TAIL_STREAM, None
+    cur = torch.cuda.current_stream()
+    if s is None or s == cur:
+        join_tails()
+        return
+    with torch.cuda.stream(s):
+        join_tails()
+    cur.wait_stream(s)
+
+
+def _tail_issued(ws, save, g, params) -> None:
+    global _TAIL_CALLBACK, _TAIL_STREAM
+    _TAIL_STREAM = torch.cuda.current_stream()
+    _TAIL_KEEP.append((ws, save, g))
+    if len(_TAIL_KEEP) > 2:
+        del _TAIL_KEEP[0]
+    if not _TAIL_CALLBACK:
+        _TAIL_CALLBACK = True
+        torch.autograd.Variable._execution_engine.queue_callback(_tails_end_of_backward)  # noqa: SLF001
+    if any(p.grad is not None for p in params):   # (accumulation: AccumulateGrad adds on this stream right after we return)
+        join_tails()
 
 
 def tblock(x, rs, rs2, meta, params):

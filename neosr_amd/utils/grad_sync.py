@@ -197,6 +197,12 @@ class GradSync:
 
     def _send_bucket(self, b: int) -> None:
         lo, hi = self._bucket_range[b]
+        if self._arena.is_cuda:
+            # the transformer block plans finish their parameter gradients on a library stream (hip/transformer.py:
+            # join_tails): this stream waits for them before the bucket's gradients are copied / handed to the exchange
+            from neosr_amd.hip import transformer as _tr
+
+            _tr.join_tails()
         dst, src = [], []
         with torch.no_grad():
             for i in self._bucket_params[b]:

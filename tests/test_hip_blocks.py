@@ -216,3 +216,52 @@ def test_prelu_dslope_many_equals_single_calls_bitwise():
         assert torch.equal(a, b)
     ref = (dA[0].double() * z[0].double().clamp(max=0)).sum(0)
     assert (many[0].double() - ref).abs().max() < 1e-3 * ref.abs().max()
+
+
+def test_backward_tail_on_the_library_stream_is_bit_identical_and_joined():
+    """Round 6: a block's weight-gradient tail (grouped TN GEMMs + batched column sums) runs on a library stream and
+    `neosr_tblock_backward` returns with it in flight (include/neosr_amd.h: neosr_tblock_tail_join).  Same kernels on the
+    same operands: gradients bit-identical to the tail on the caller's stream — read WITHOUT a device synchronisation in
+    between (the end-of-backward join orders the caller's stream) —, also when a second backward accumulates into existing
+    gradients, and the buffers of a call survive the allocator's reuse (a churn of allocations right behind backward)."""
+    from neosr_amd import _C
+    from neosr_amd.archs import swinir_arch as A
+    from neosr_amd.archs.hat_arch import hat
+    from neosr_amd.hip import transformer as tr
+
+    lib = _C.load()
+    nets = []
+    torch.manual_seed(7)
+    nets.append((A.swinir_small(upscale=4, drop_path_rate=0.0).to(DEV).train(), 32, 48))
+    nets.append((hat(img_size=32, embed_dim=24, depths=(2, 2), num_heads=(2, 2), window_size=16, compress_ratio=3,
+                     squeeze_factor=6, mlp_ratio=2, drop_path_rate=0.0, upsampler="pixelshuffle", upscale=4).to(DEV).train(),
+                 32, 32))
+    for net, H, W in nets:
+        g = torch.Generator().manual_seed(3)
+        x = torch.rand(2, 3, H, W, generator=g).to(DEV)
+        gy = torch.randn(2, 3, 4 * H, 4 * W, generator=g).to(DEV)
+
+        def grads(tail: bool, passes: int):
+            prev = lib.neosr_set_tblock_tail(1 if tail else 0)
+            try:
+                net.zero_grad(set_to_none=True)
+                t0 = lib.neosr_tblock_tails()
+                for _ in range(passes):
+                    net(x).backward(gy)
+                    junk = [torch.full((1 << 20,), 3.0, device=DEV) for _ in range(8)]   # allocator churn on this stream
+                    del junk
+                issued = lib.neosr_tblock_tails() - t0
+                out = [p.grad.clone() for p in net.parameters()]   # (clone on the caller's stream: no synchronise before)
+                assert lib.neosr_tblock_tail_join(_C.stream_ptr()) == 0, "the backward pass must have joined its tails"
+                assert not tr._TAIL_KEEP
+                torch.cuda.synchronize()
+                return out, issued
+            finally:
+                lib.neosr_set_tblock_tail(prev)
+
+        for passes in (1, 2):
+            a, na = grads(True, passes)
+            b, nb = grads(False, passes)
+            assert na > 0 and nb == 0, (na, nb)
+            bad = [i for i, (u, v) in enumerate(zip(a, b)) if not torch.equal(u, v)]
+            assert not bad, (passes, bad[:6])
