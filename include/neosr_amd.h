@@ -903,15 +903,17 @@ int64_t neosr_tblock_side_forks(void);
  * it in flight (1 = default, env NEOSR_AMD_BLOCK_TAIL; only with neosr_set_tblock_streams(3), never under hipGraph capture).
  * Contract for the caller (neosr_amd/hip/transformer.py implements it; reference call sites: autograd of
  * neosr/archs/swinir_arch.py:231-392, hat_arch.py:218-515):
- *   - `workspace`, `save` and `dout` of a call must stay allocated and unwritten until TWO further calls of
- *     neosr_tblock_backward have returned (each call makes its stream wait for the tail of the call before the last) or
- *     until neosr_tblock_tail_join;
+ *   - `workspace`, `save` and `dout` of a call must stay allocated and unwritten until its tail has finished:
+ *     neosr_tblock_tail_done(n) (n = neosr_tblock_tails() before the call) is a host-side event query, 1 = finished;
+ *     individually answerable for the newest seven tails only — keep at most six calls' buffers, join beyond that — or
+ *     until neosr_tblock_tail_join has been enqueued on the stream that will reuse the memory;
  *   - the parameter gradients are complete behind neosr_tblock_tail_join(stream): `stream` waits for every tail issued so
  *     far; returns how many were outstanding (0: nothing to wait for, -1: error).
  * neosr_tblock_tails(): tails issued so far (callers compare it around a call to learn whether one was issued). */
 int neosr_set_tblock_tail(int on);
 int64_t neosr_tblock_tail_join(void* stream);
 int64_t neosr_tblock_tails(void);
+int neosr_tblock_tail_done(int64_t index);
 
 #ifdef __cplusplus
 }

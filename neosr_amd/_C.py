@@ -401,6 +401,7 @@ SIGNATURES: dict[str, tuple] = {
     "neosr_set_tblock_tail": (C.c_int, [C.c_int]),
     "neosr_tblock_tail_join": (C.c_int64, [_vp]),
     "neosr_tblock_tails": (C.c_int64, []),
+    "neosr_tblock_tail_done": (C.c_int, [C.c_int64]),
     "neosr_gemm_tn_group": (C.c_int, [C.POINTER(GemmDesc), _i32, C.POINTER(C.c_int32), _vp]),
     "neosr_prelu_dslope_many": (C.c_int, [C.POINTER(DslopeItem), _i32, _vp, _i64, _i32, _i32, _i32, _vp]),
     "neosr_pixel_shuffle_nhwc": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),

@@ -251,19 +251,20 @@ struct Side {
   int dev = -1;
   hipStream_t s = nullptr;
   hipStream_t tail = nullptr;   // stream of the backward plans' weight-gradient TAILS (below)
-  hipEvent_t ev[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev[16] = {};   // (EV_TAIL_DONE .. + 7: one per tail in flight, round robin)
 };
-enum { EV_FORK = 0, EV_GPRE, EV_DX2, EV_GT1, EV_GU0, EV_DQKV, EV_JOIN, EV_TAIL_FORK, EV_TAIL_DONE /* , EV_TAIL_DONE + 1 */ };
+enum { EV_FORK = 0, EV_GPRE, EV_DX2, EV_GT1, EV_GU0, EV_DQKV, EV_JOIN, EV_TAIL_FORK, EV_TAIL_DONE /* .. EV_TAIL_DONE + 7 */ };
+constexpr int TAIL_RING = 8;
 // The TAIL of a block's backward plan — the grouped weight-gradient GEMMs and the batched column sums that finish the
 // parameter gradients (~75 us per block at B = 8 / 64 x 64) — feeds nothing in the backward pass: only the optimizer (and
 // the gradient exchange) read what it writes, while the NEXT block's data-gradient chain waits behind it on the caller's
 // stream.  With NEOSR_AMD_BLOCK_TAIL (default on, modes 3 only) it runs on a second library stream and the call returns with
 // it in flight (round 6: swinir_medium +4.0 %, hat_l +3.3 %, same-box).  What that costs the caller:
 //   * everything the tail reads or writes — the workspace, the block's save buffer, the incoming gradient — must stay
-//     untouched until the tail is done.  The plan makes the caller's stream wait for the tail of the call BEFORE THE LAST
-//     at the end of every call (two alternating events), so a caller that keeps those three buffers alive for two more
-//     calls (hip/transformer.py: a two-entry ring) may then free them: whatever reuses the memory is enqueued behind
-//     that wait;
+//     untouched until the tail is done.  Nothing is put on the caller's stream for that (a wait per block on the critical
+//     chain cost two thirds of the gain): tail n records event n mod 8 on the tail stream and the caller asks
+//     neosr_tblock_tail_done(n) — a host-side event query — before it lets go of the buffers of call n (hip/transformer.py
+//     keeps them in a short ring and joins if the ring grows past six entries);
 //   * the parameter gradients are complete only behind neosr_tblock_tail_join(stream), which makes `stream` wait for every
 //     tail issued so far: the Python side calls it at the end of the backward pass (an autograd engine callback), before
 //     a data-parallel bucket leaves (utils/grad_sync.py), and at once when a gradient is going to be ACCUMULATED into an
@@ -629,12 +630,8 @@ extern "C" int neosr_tblock_backward(const neosr_tblock_desc* dp, const float* x
   NEOSR_CHECK(neosr_colsum_many_workspace_floats(jobs, nj) <= b.many_n, "tblock backward: column-sum workspace too small");
   TB_RUN(neosr_colsum_many(jobs, nj, b.many, ts));
   if (tail_side) {
-    // the caller's stream waits for the tail of the call before the last (same event slot, waited for BEFORE it is recorded
-    // again), then this call's tail is marked
     const long n = g_tails.fetch_add(1);
-    hipEvent_t done = side_any->ev[EV_TAIL_DONE + (n & 1)];
-    NEOSR_HIP(hipStreamWaitEvent((hipStream_t)stream, done, 0));
-    NEOSR_HIP(hipEventRecord(done, side_any->tail));
+    NEOSR_HIP(hipEventRecord(side_any->ev[EV_TAIL_DONE + (n % TAIL_RING)], side_any->tail));
   }
   return 0;
 }
@@ -647,11 +644,26 @@ extern "C" int64_t neosr_tblock_tail_join(void* stream) {
   Side* side = side_get();
   if (!side) return -1;
   // (in-order stream: the newest tail's event covers all of them)
-  if (hipStreamWaitEvent((hipStream_t)stream, side->ev[EV_TAIL_DONE + ((n - 1) & 1)], 0) != hipSuccess) return -1;
+  if (hipStreamWaitEvent((hipStream_t)stream, side->ev[EV_TAIL_DONE + ((n - 1) % TAIL_RING)], 0) != hipSuccess) return -1;
   g_tails_joined = n;
   return pending;
 }
 extern "C" int64_t neosr_tblock_tails(void) { return g_tails; }
+// 1: tail number `index` (0-based, in issue order) has finished; 0: still running; host-side query, no synchronisation.
+// Only the newest TAIL_RING - 1 tails can be asked about individually: an older index answers for the tail that took its
+// event slot since (callers keep at most six buffers: hip/transformer.py).
+extern "C" int neosr_tblock_tail_done(int64_t index) {
+  const long n = g_tails.load();
+  if (index < 0 || index >= n) return 1;
+  Side* side = side_get();
+  if (!side) return 1;
+  const hipError_t e = hipEventQuery(side->ev[EV_TAIL_DONE + (index % TAIL_RING)]);
+  if (e == hipErrorNotReady) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return 1;
+}
 extern "C" int neosr_set_tblock_tail(int on) {
   const int prev = g_block_tail < 0 ? 1 : g_block_tail.load();
   g_block_tail = on ? 1 : 0;

@@ -612,16 +612,16 @@ class TBlock(torch.autograd.Function):
         _C.check(lib.neosr_tblock_backward(d, x.data_ptr(), g.data_ptr(), save.data_ptr(), dx.data_ptr(), G,
                                            ws.data_ptr(), _st()), "neosr_tblock_backward")
         if lib.neosr_tblock_tails() != tails:
-            _tail_issued(ws, save, g, params)
+            _tail_issued(tails, ws, save, g, params)
         grads = [v if need else None for v, need in zip(views, ctx.needs_input_grad[4:])]
         return (dx if ctx.needs_input_grad[0] else None), None, None, None, *grads
 
 
 # ---- the backward plans' weight-gradient TAILS (csrc/blocks.hip, include/neosr_amd.h: neosr_tblock_tail_join).  A call of
 # neosr_tblock_backward may return with its tail in flight on the library's tail stream: the buffers it uses are kept alive
-# here for two more calls (the plan orders the caller's stream behind the tail of the call before the last), the caller's
-# stream is joined with the tails at the end of the backward pass, and at once where a gradient would be accumulated into
-# an existing `.grad` (autograd would add to it on the caller's stream before the tail has written it).
+# here until a host-side query says the tail has finished (neosr_tblock_tail_done: nothing waits on the compute stream),
+# the caller's stream is joined with the tails at the end of the backward pass, and at once where a gradient would be
+# accumulated into an existing `.grad` (autograd would add to it on the caller's stream before the tail has written it).
 _TAIL_KEEP: list = []
 _TAIL_CALLBACK = False
 _TAIL_STREAM = None
@@ -650,12 +650,15 @@ def _tails_end_of_backward() -> None:
     cur.wait_stream(s)
 
 
-def _tail_issued(ws, save, g, params) -> None:
+def _tail_issued(index, ws, save, g, params) -> None:
     global _TAIL_CALLBACK, _TAIL_STREAM
     _TAIL_STREAM = torch.cuda.current_stream()
-    _TAIL_KEEP.append((ws, save, g))
-    if len(_TAIL_KEEP) > 2:
+    lib = _C.load()
+    while _TAIL_KEEP and lib.neosr_tblock_tail_done(_TAIL_KEEP[0][0]):
         del _TAIL_KEEP[0]
+    _TAIL_KEEP.append((index, ws, save, g))
+    if len(_TAIL_KEEP) > 6:   # (the library answers for its newest seven tails only)
+        join_tails()
     if not _TAIL_CALLBACK:
         _TAIL_CALLBACK = True
         torch.autograd.Variable._execution_engine.queue_callback(_tails_end_of_backward)  # noqa: SLF001
