@@ -376,6 +376,10 @@ def run_config(args, config: str, world: int, rank: int, dev, steps: int, warmup
         # per-kernel durations are only meaningful without overlap: the trunk's launch chains are put
         # back on one stream for this pass (the timed region above ran the default, two chains)
         prev_streams = lib.neosr_set_num_streams(1)
+        # (likewise the side-by-side work of round 6: the block plans' weight-gradient tails and the discriminator phase go
+        # back onto the caller's stream for this pass)
+        prev_tail = lib.neosr_set_tblock_tail(0)
+        prev_ov, model._d_overlap = getattr(model, "_d_overlap", False), False
         lib.neosr_prof_enable(1)
         nprof = prof_steps
         for _ in range(nprof):
@@ -390,6 +394,8 @@ def run_config(args, config: str, world: int, rank: int, dev, steps: int, warmup
         _C.check(lib.neosr_prof_collect(ms, ln, fl, by), "neosr_prof_collect")
         lib.neosr_prof_enable(0)
         lib.neosr_set_num_streams(prev_streams)
+        lib.neosr_set_tblock_tail(prev_tail)
+        model._d_overlap = prev_ov
         ALGO = ("direct", "winograd F(2x2,3x3): 16 of the direct form's 36 multiplications",
                 "winograd F(4x4,3x3): 36 of the direct form's 144 multiplications")
         kern = {}
@@ -455,7 +461,8 @@ def run_config(args, config: str, world: int, rank: int, dev, steps: int, warmup
                     "kernels": kern,
                     "method": "HIP events around every launch of the class on the launch stream, separate "
                               "profiled pass after the timed region with the trunk on ONE stream "
-                              "(neosr_set_num_streams(1)); profiles/r06_<config>_kernel_stats.csv is rocprofv3 "
+                              "(neosr_set_num_streams(1)), the block plans' weight-gradient tails and the discriminator phase "
+                              "back on the caller's stream; profiles/r06_<config>_kernel_stats.csv is rocprofv3 "
                               "--kernel-trace --stats of `NEOSR_AMD_STREAMS=1 python bench.py --config <config>`"}
         if opt.get("fast_matmul") and dom in (0, 1) and dom_algo == 2:
             # the tier runs FOUR bf16 products per executed fp32-equivalent multiplication on the bf16 MFMA: priced against

@@ -10,11 +10,11 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_${ROUND}_${CFG}
 mkdir -p $OUT
 ARGS="--config $CFG --cpu-budget 0 --no-other-configs"
-NEOSR_AMD_STREAMS=1 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace --output-format csv -- python $R/bench.py $ARGS --steps 5 --warmup 2 > $OUT/trace.log 2>&1
+NEOSR_AMD_STREAMS=1 NEOSR_AMD_BLOCK_TAIL=0 NEOSR_AMD_D_OVERLAP=0 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace --output-format csv -- python $R/bench.py $ARGS --steps 5 --warmup 2 > $OUT/trace.log 2>&1
 rocprofv3 --kernel-trace --stats -d $OUT/trace2 -o trace --output-format csv -- python $R/bench.py $ARGS --steps 5 --warmup 2 > $OUT/trace2.log 2>&1
 cp $(find $OUT/trace -name '*kernel_stats.csv' | head -1) $OUT/kernel_stats.csv
 cp $(find $OUT/trace2 -name '*kernel_stats.csv' | head -1) $OUT/kernel_stats_chains.csv
-export NEOSR_AMD_STREAMS=1
+export NEOSR_AMD_STREAMS=1 NEOSR_AMD_BLOCK_TAIL=0 NEOSR_AMD_D_OVERLAP=0   # (serial per-kernel durations: no side-by-side work)
 BENCH="python $R/bench.py $ARGS --steps 2 --warmup 1 --no-roofline"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o fetch --output-format csv -- $BENCH > $OUT/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o write --output-format csv -- $BENCH > $OUT/write.log 2>&1

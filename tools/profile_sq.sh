@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_${ROUND}_${CFG}
 mkdir -p $OUT
-export NEOSR_AMD_STREAMS=1
+export NEOSR_AMD_STREAMS=1 NEOSR_AMD_BLOCK_TAIL=0 NEOSR_AMD_D_OVERLAP=0   # (serial per-kernel durations: no side-by-side work)
 BENCH="python $R/bench.py --config $CFG --cpu-budget 0 --no-other-configs --steps 2 --warmup 1 --no-roofline"
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 -d $OUT/sq1 -o sq1 --output-format csv -- $BENCH > $OUT/sq1.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_INSTS_VALU -d $OUT/sq2 -o sq2 --output-format csv -- $BENCH > $OUT/sq2.log 2>&1
@@ -51,7 +51,7 @@ for k, d in agg.items():
     if per.get("SQ_INSTS_VALU_MFMA_MOPS_F32", 0) > 0 and per.get("SQ_INSTS_VALU", 0) > 0:
         e["valu_insts_per_mfma_mop"] = round(per["SQ_INSTS_VALU"] / per["SQ_INSTS_VALU_MFMA_MOPS_F32"], 3)
     kern[k[:160]] = e
-json.dump({"command": "NEOSR_AMD_STREAMS=1 $BENCH", "definitions": {
+json.dump({"command": "NEOSR_AMD_STREAMS=1 NEOSR_AMD_BLOCK_TAIL=0 NEOSR_AMD_D_OVERLAP=0 $BENCH", "definitions": {
     "mfma_busy_frac": "SQ_VALU_MFMA_BUSY_CYCLES / (32 x SQ_BUSY_CYCLES): matrix-pipe busy cycles summed over the 1024 SIMDs against the kernel's busy cycles (summed over the 32 shader engines)",
     "executed_mfma_gflop_per_dispatch": "SQ_INSTS_VALU_MFMA_MOPS_F32 x 512 FLOP"}, "kernels": kern},
     open("$OUT/sq_summary.json", "w"), indent=1)
