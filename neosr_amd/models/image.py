@@ -175,6 +175,7 @@ class image(base):
         env_ov = os.environ.get("NEOSR_AMD_D_OVERLAP", "")
         self._d_overlap = env_ov == "1" or (env_ov != "0" and not isinstance(self.net_g, _HipNet))
         self._d_stream = None
+        self._vgg_prefetch = os.environ.get("NEOSR_AMD_VGG_PREFETCH", "1") != "0"
         self._sync_g = self._sync_d = None
         if self.opt["dist"]:
             self._sync_g = GradSync()
@@ -347,7 +348,8 @@ class image(base):
         if self._sync_g is not None:  # buckets may go during backward only if this backward is the one stepped
             self._sync_g.armed = step_now and self.accum_iters == 1 and not self._sam_now
         eco_now = self.eco and current_iter <= self.eco_iters and not (current_iter < self.eco_init and self.pretrain is None)
-        if self._d_overlap and self.cri_perceptual and not eco_now and hasattr(self.cri_perceptual, "prefetch_gt"):
+        if (self._d_overlap and self._vgg_prefetch and self.cri_perceptual and not eco_now
+                and hasattr(self.cri_perceptual, "prefetch_gt")):
             # the perceptual loss's target features beside the generator's forward (second stream; see `d_phase` below)
             main = torch.cuda.current_stream(self.device)
             if self._d_stream is None:
