@@ -156,18 +156,25 @@ __device__ __forceinline__ void chain_body(const W4ChainArgs& args) {
   }
   const auto rflag = __builtin_amdgcn_make_buffer_rsrc(args.flags, 0, 0x7ffffff0, 0x00020000);
   const auto rstat = __builtin_amdgcn_make_buffer_rsrc(args.status, 0, 4, 0x00020000);
-  auto poll_load = [&]() -> unsigned {  // (out-of-range offsets read 0)
-    unsigned v = __builtin_amdgcn_raw_buffer_load_b32(rflag, nb_flag >= 0 ? nb_flag * 4 : 0x7ffffff0, 0, AUX_SC1);
-    const unsigned s = __builtin_amdgcn_raw_buffer_load_b32(rstat, lane == 9 ? 0 : 0x7ffffff0, 0, AUX_SC1);
-    return lane == 9 ? s : v;
+  // (both words stay in their own registers until they are looked at: a select right here makes hipcc wait vmcnt(0) for the
+  // two loads it has just issued — the ISA of rounds 3-5 had that wait at the START of the polling chunk, in front of wave
+  // 0's MFMAs: one exposed L1-bypassing round trip per layer, which the other eleven waves then sat out at the barrier.
+  // Round 6: 639.7 -> 645.5 LR-patches/s on the headline, same box, three runs each)
+  struct PollWords { unsigned v, s; };
+  auto poll_load = [&]() -> PollWords {  // (out-of-range offsets read 0)
+    PollWords w;
+    w.v = __builtin_amdgcn_raw_buffer_load_b32(rflag, nb_flag >= 0 ? nb_flag * 4 : 0x7ffffff0, 0, AUX_SC1);
+    w.s = __builtin_amdgcn_raw_buffer_load_b32(rstat, lane == 9 ? 0 : 0x7ffffff0, 0, AUX_SC1);
+    return w;
   };
   // every neighbour has finished `need` layers (or the chain was aborted by a timeout somewhere)
-  auto poll_ok = [&](unsigned v, unsigned need) -> bool {
+  auto poll_ok = [&](PollWords w, unsigned need) -> bool {
+    const unsigned v = lane == 9 ? w.s : w.v;
     const bool ok = lane >= 9 || nb_flag < 0 || v >= need;
     const bool ab = lane == 9 && v != 0;
     return __builtin_amdgcn_ballot_w64(!ok) == 0 || __builtin_amdgcn_ballot_w64(ab) != 0;
   };
-  auto poll_wait = [&](unsigned v, unsigned need) {
+  auto poll_wait = [&](PollWords v, unsigned need) {
     if (!args.sync) return;
     unsigned spins = 0;
     while (!poll_ok(v, need)) {
@@ -368,7 +375,7 @@ __device__ __forceinline__ void chain_body(const W4ChainArgs& args) {
     for (int c = 0; c < nchunks; ++c) {
       const float* rb = c == 0 ? ldsC : ((c & 1) ? ldsA : ldsB);
       if (c < 6) CTL_MARK(l, 10 + c);
-      unsigned fv = 0;
+      PollWords fv = {0u, 0u};
       if (wave == 0 && c == pollc) fv = poll_load();
       if (c > 0) mac3(3, vhi, uhi);  // positions (ti, 3..5) of the previous (sub-)chunk
       __builtin_amdgcn_sched_barrier(0);
