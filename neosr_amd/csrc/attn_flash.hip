@@ -26,6 +26,13 @@
 
 namespace {
 
+#ifdef FATTN_TL   // debug timeline of the fused backward (tools/timeline_fattn.py): clocks of workgroup 0, thread 0
+__device__ unsigned long long g_fattn_tl[64];
+#define FTL(i, cond) do { if (blockIdx.x == 0 && threadIdx.x == 0 && (cond)) g_fattn_tl[i] = clock64(); } while (0)
+#else
+#define FTL(i, cond) do {} while (0)
+#endif
+
 constexpr int QB = 64;        // queries / keys per block
 constexpr int QS = 33;        // q/k/v LDS row stride
 constexpr int PS = 65;        // score tile row stride
@@ -120,31 +127,63 @@ struct Shared {
 
 constexpr int KEY_NONE = -2147483647 - 1;
 
-// 8 consecutive floats (cols part*8..) of one token row, zero beyond hd or when tok < 0
-__device__ __forceinline__ void load_row8(const float* src, int tok, int ld, int col0, int hd, int part,
-                                          float (&v)[8]) {
-  const float* row = src + (int64_t)(tok < 0 ? 0 : tok) * ld + col0;
-  if (((ld | col0 | hd) & 1) == 0 && (reinterpret_cast<uintptr_t>(src) & 7) == 0) {
+// Token rows of one (B*H*W, ld) matrix as a raw buffer over the workgroup's SAMPLE: a row is a 32-bit byte offset, a
+// padding token (tok < 0) an offset past the end — the hardware range check returns 0 for it, and for the two floats the
+// last head's 8-column group reads past the last row (hd = 30).  No branch, no 64-bit address arithmetic, no select for the
+// row; only the columns past hd of an in-range group (the next head's first values) are zeroed by a select.
+// (Round 6, found in the ISA: written as `cond ? *p : 0` on global pointers hipcc emits, per element, "v = 0; if (exec)
+// v = load" behind a branch, and its wait-count pass — which cannot tell at the join whether the 4-byte or the 8-byte
+// variant of the PREVIOUS row left loads in flight — puts s_waitcnt vmcnt(0) in front of the next row's zero moves: the
+// V row of a key block waited for its K row to come back, and q / dO / O of a query block for one another — one exposed
+// memory round trip per 64 x 64 tile, two more per query block.)
+typedef decltype(__builtin_amdgcn_make_buffer_rsrc((float*)nullptr, (short)0, 0, 0)) rows_rsrc_t;
+struct Rows {
+  rows_rsrc_t r;
+  int tok0, ld;   // first token of the sample; row stride (floats)
+  bool al8;       // 8-byte loads allowed (even stride, 8-byte aligned base)
+};
+constexpr unsigned ROW_DEAD = 0xC0000000u;   // > any sample's bytes (host check: H * W * ld * 4 <= ROW_DEAD)
+__device__ __forceinline__ Rows make_rows(const float* src, int b, int hw, int ld) {
+  Rows R;
+  R.r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src) + (int64_t)b * hw * ld, (short)0,
+                                            (int)((unsigned)hw * (unsigned)ld * 4u), 0x00020000);
+  R.tok0 = b * hw;
+  R.ld = ld;
+  R.al8 = (ld & 1) == 0 && (reinterpret_cast<uintptr_t>(src) & 7) == 0;
+  return R;
+}
+// 8 consecutive floats (cols col0 + part*8..) of one token row, zero when tok < 0.  Pure loads: the columns past hd (the
+// next head's first values) are zeroed where the row is CONSUMED (zero_tail8, store_row8) — a select next to the load makes
+// the wave wait for the load right there, and the rows are prefetched a whole tile ahead.
+__device__ __forceinline__ unsigned row_off(const Rows& R, int tok, int col0, int part) {
+  return tok >= 0 ? (unsigned)((tok - R.tok0) * R.ld + col0 + part * 8) * 4u : ROW_DEAD;
+}
+__device__ __forceinline__ bool row_al8(const Rows& R, int col0, int hd) { return R.al8 && ((col0 | hd) & 1) == 0; }
+__device__ __forceinline__ void load_row8_at(const Rows& R, unsigned off, bool al8, float (&v)[8]) {
+  if (al8) {
     // even row stride, head offset and head size (30-float head slices of a 180-channel row): 8-byte aligned -> four
     // 8-byte loads instead of eight 4-byte ones (the 8x8-window kernel gained 10 % from the same change)
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int c = part * 8 + 2 * e;
-      const float2 t = (tok >= 0 && c < hd) ? *reinterpret_cast<const float2*>(row + c) : make_float2(0.f, 0.f);
+      const float2 t = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(R.r, off + 8 * e, 0, 0));
       v[2 * e] = t.x;
       v[2 * e + 1] = t.y;
     }
     return;
   }
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const int c = part * 8 + e;
-    v[e] = (tok >= 0 && c < hd) ? row[c] : 0.f;
-  }
+  for (int e = 0; e < 8; ++e) v[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(R.r, off + 4 * e, 0, 0));
 }
-__device__ __forceinline__ void store_row8(float* dst, int n, int part, const float (&v)[8], float mul) {
+__device__ __forceinline__ void load_row8(const Rows& R, int tok, int col0, int hd, int part, float (&v)[8]) {
+  load_row8_at(R, row_off(R, tok, col0, part), row_al8(R, col0, hd), v);
+}
+__device__ __forceinline__ void zero_tail8(float (&v)[8], int hd, int part) {
 #pragma unroll
-  for (int e = 0; e < 8; ++e) dst[n * QS + part * 8 + e] = v[e] * mul;
+  for (int e = 0; e < 8; ++e) v[e] = part * 8 + e < hd ? v[e] : 0.f;
+}
+__device__ __forceinline__ void store_row8(float* dst, int n, int part, const float (&v)[8], float mul, int hd) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) dst[n * QS + part * 8 + e] = part * 8 + e < hd ? v[e] * mul : 0.f;
 }
 
 __device__ __forceinline__ f32x16 zero16() {
@@ -206,12 +245,12 @@ __device__ __forceinline__ f32x16 mm_atb(f32x16 acc, const float* A, int sa, con
 
 // S tile (MFMA layout: lane = key column, registers = query rows) + bias + mask -> P (raw scores, or
 // exp(s - lse[i]) when lse_row != nullptr); keys that do not exist get -inf / 0
-template <int NBINS, bool SELF>
+template <int NBINS, bool SELF, bool PARTIAL>
 __device__ __forceinline__ void scores_to_lds(const Shared& S, float* P, const f32x16& acc, int ti, int tj, int l31,
                                               int lh, const float* lse_row) {
   const int j = 32 * tj + l31;
   const int kp = S.kpk[j];
-  const bool none = kp == KEY_NONE;
+  const bool none = PARTIAL && kp == KEY_NONE;
   const int kterm = kp >> 4, kreg = kp & 15;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -250,38 +289,40 @@ __global__ __launch_bounds__(256) void flash_wattn_fwd_kernel(const neosr_fattn_
   const int bid = xcd_bid();
   const Win w = decode(d, bid, G::NQB);
   const int hd = d.C / d.heads, ld = 3 * d.C, kq = (hd + 1) & ~1;
+  const Rows Rqkv = make_rows(d.qkv, w.b, d.H * d.W, ld);
+  [[maybe_unused]] const Rows Rdo = make_rows(d.dout, w.b, d.H * d.W, d.C), Rout = make_rows(d.out, w.b, d.H * d.W, d.C);
   const int n = tid >> 2, part = tid & 3;
   setup_block<WS, KS>(d, w, S);
   __syncthreads();
   {
     float q[8];
-    load_row8(d.qkv, S.qtok[n], ld, w.head * hd, hd, part, q);
-    store_row8(S.Qs, n, part, q, d.scale);
+    load_row8(Rqkv, S.qtok[n], w.head * hd, hd, part, q);
+    store_row8(S.Qs, n, part, q, d.scale, hd);
   }
   // prefetch key block 0
   float kr[8], vr[8];
   int ktok, kreg, kterm;
   bool kex;
   key_geom<WS, KS>(d, w, n, ktok, kreg, kterm, kex);
-  load_row8(d.qkv, ktok, ld, d.C + w.head * hd, hd, part, kr);
-  load_row8(d.qkv, ktok, ld, 2 * d.C + w.head * hd, hd, part, vr);
+  load_row8(Rqkv, ktok, d.C + w.head * hd, hd, part, kr);
+  load_row8(Rqkv, ktok, 2 * d.C + w.head * hd, hd, part, vr);
   float m_run = -INFINITY, l_run = 0.f;  // row n, replicated in its 4 threads
   f32x16 o = zero16();                   // waves 0,1: rows 32 wave.., cols d
   for (int kb = 0; kb < G::NKB; ++kb) {
     __syncthreads();  // previous P.V finished with Ks / Vs / P
-    store_row8(S.Ks, n, part, kr, 1.f);
-    store_row8(S.Vs, n, part, vr, 1.f);
+    store_row8(S.Ks, n, part, kr, 1.f, hd);
+    store_row8(S.Vs, n, part, vr, 1.f, hd);
     if (part == 0) S.kpk[n] = kex ? kterm * 16 + kreg : KEY_NONE;
     __syncthreads();
     if (kb + 1 < G::NKB) {
       key_geom<WS, KS>(d, w, (kb + 1) * QB + n, ktok, kreg, kterm, kex);
-      load_row8(d.qkv, ktok, ld, d.C + w.head * hd, hd, part, kr);
-      load_row8(d.qkv, ktok, ld, 2 * d.C + w.head * hd, hd, part, vr);
+      load_row8(Rqkv, ktok, d.C + w.head * hd, hd, part, kr);
+      load_row8(Rqkv, ktok, 2 * d.C + w.head * hd, hd, part, vr);
     }
     {
       const int ti = wave >> 1, tj = wave & 1;
       const f32x16 acc = mm_abt(zero16(), S.Qs, QS, S.Ks, QS, ti, tj, kq, l31, lh);
-      scores_to_lds<G::NBINS, G::SELF>(S, S.P, acc, ti, tj, l31, lh, nullptr);
+      scores_to_lds<G::NBINS, G::SELF, G::NK % QB != 0>(S, S.P, acc, ti, tj, l31, lh, nullptr);
     }
     __syncthreads();
     {  // online softmax over this block's 64 columns: 4 threads per row, 16 columns each
@@ -330,11 +371,16 @@ __global__ __launch_bounds__(256) void flash_wattn_fwd_kernel(const neosr_fattn_
 }
 
 // ------------------------------------------------------------------------------------------ backward
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
 struct SharedBwd {
   float Qs[QB * QS], Ks[QB * QS], Vs[QB * QS], Gs[QB * QS], P[QB * PS], dS[QB * PS];
   float tab[TAB_MAX];
-  int qpk[QB], kpk[QB], qtok[QB], ktok[QB];
-  float lse[QB], dsum[QB];
+  alignas(16) int qpk[QB];
+  alignas(16) float lse[QB], dsum[QB];
+  int kpk[QB], qtok[QB], ktok[QB];
+#ifdef FATTN_TL
+  int tl_on;
+#endif
   float bins[31 * 31];  // self-attention dQ pass: this workgroup's share of the relative-position-bias gradient
                         // ((2 WS - 1)^2 bins, WS <= 16)
 };
@@ -357,16 +403,20 @@ __host__ __device__ inline BwdWs bwd_ws(const neosr_fattn_desc& d) {
 // shared by both backward kernels: P = exp(S - lse), dP = dO V^T, dS = P (dP - D) for the current
 // (query block in Qs/Gs, key block in Ks/Vs); leaves P and dS tiles in LDS
 // NEED_P = false (the dQ kernel only consumes dS): the P tile is not written
-template <int NBINS, bool SELF, bool NEED_P = true>
+// PARTIAL: the last key block has keys past the window's end (NK % 64 != 0: only the 8 / 12 windows) — without it `none`
+// is a compile-time false and the exponentials are straight-line code (hipcc puts `none ? 0 : exp(..)` behind a branch per
+// pair of scores)
+template <int NBINS, bool SELF, bool PARTIAL, bool NEED_P = true>
 __device__ __forceinline__ void recompute_p_ds(SharedBwd& S, int kq, int wave, int l31, int lh) {
   {
     const int ti = wave >> 1, tj = wave & 1;
     f32x16 s = zero16(), dp = zero16();
     mm_abt_pair(s, S.Qs, S.Ks, dp, S.Gs, S.Vs, QS, QS, ti, tj, kq, l31, lh);
+    FTL(30, S.tl_on);
     // scores_to_lds wants the forward Shared layout: replicate its body on SharedBwd fields
     const int j = 32 * tj + l31;
     const int kp = S.kpk[j];
-    const bool none = kp == KEY_NONE;
+    const bool none = PARTIAL && kp == KEY_NONE;
     const int kterm = kp >> 4, kreg = kp & 15;
     // (the per-row terms of 8 scores at a time — packed query geometry, LSE, D — in one batch of LDS reads, then the table
     // values they index in a second: written as one loop over the scores this is four dependent LDS round trips per score;
@@ -375,13 +425,19 @@ __device__ __forceinline__ void recompute_p_ds(SharedBwd& S, int kq, int wave, i
     for (int h = 0; h < 2; ++h) {
       int qp[8];
       float ls[8], dsu[8], tv[8];
+      // (the 16 rows of a lane are four runs of 4 consecutive queries: one 16-byte read per run and array — 6 LDS reads per
+      // half instead of 24)
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int r = 8 * h + q;
-        const int i = 32 * ti + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        qp[q] = S.qpk[i];
-        ls[q] = S.lse[i];
-        dsu[q] = S.dsum[i];
+      for (int g = 0; g < 2; ++g) {
+        const int i0 = 32 * ti + 8 * (2 * h + g) + 4 * lh;
+        const i32x4_t q4 = *reinterpret_cast<const i32x4_t*>(&S.qpk[i0]);
+        const f32x4 l4 = *reinterpret_cast<const f32x4*>(&S.lse[i0]), d4 = *reinterpret_cast<const f32x4*>(&S.dsum[i0]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          qp[4 * g + e] = q4[e];
+          ls[4 * g + e] = l4[e];
+          dsu[4 * g + e] = d4[e];
+        }
       }
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
@@ -402,8 +458,39 @@ __device__ __forceinline__ void recompute_p_ds(SharedBwd& S, int kq, int wave, i
         S.dS[i * PS + j] = p * (dp[r] - dsu[q]);
       }
     }
+    FTL(31, S.tl_on);
   }
   __syncthreads();
+}
+
+// Bias gradient of one 64-query x 64-key dS tile, owner-computes (kernel (A) explains the geometry): thread `tid` sums the
+// pairs of ITS bin (dyi, dx) of the tile in a fixed order.  The WS reads of a window-row pair go out as ONE batch in front
+// of their additions (sched_barrier): left to itself hipcc reuses one register pair for all of them — 32 LDS round trips in
+// a row, each waited for with lgkmcnt(0), ~1.5 us of a 7.5 us tile (round 6, found in the ISA).  Same additions, same order.
+template <int WS>
+__device__ __forceinline__ float tile_bin_sum(const float* dS, int tid, int& dyi, int& dx) {
+  constexpr int RQ = QB / WS, NB1 = 2 * WS - 1;
+  dyi = tid / NB1;
+  dx = tid % NB1 - (WS - 1);
+  const int xi0 = dx > 0 ? dx : 0, xj0 = dx < 0 ? -dx : 0, len = WS - (dx < 0 ? -dx : dx);
+  float s = 0.f;
+#pragma unroll
+  for (int a = 0; a < RQ; ++a) {
+    const int b = a - (dyi - (RQ - 1));  // key row of the tile paired with query row a
+    const bool oky = b >= 0 && b < RQ;
+    const int bc = b < 0 ? 0 : (b >= RQ ? RQ - 1 : b);
+    const float* base = dS + (a * WS + xi0) * PS + bc * WS + xj0;
+    float v[WS];
+#pragma unroll
+    for (int t = 0; t < WS; ++t) v[t] = base[t * (PS + 1)];
+    __builtin_amdgcn_sched_barrier(0);
+    float sa = 0.f;
+#pragma unroll
+    for (int t = 0; t < WS; ++t) sa += t < len ? v[t] : 0.f;  // (a select, not a 0 / 1 factor: past the diagonal the read may hit anything)
+    s += oky ? sa : 0.f;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  return s;
 }
 
 // (A) one workgroup per (window, head, query block): dQ, D = rowsum(dO * O), and the dS tiles
@@ -415,6 +502,8 @@ __global__ __launch_bounds__(256, KS > WS ? 2 : 1) void flash_wattn_bwd_dq_kerne
   const int bid = xcd_bid();
   const Win w = decode(d, bid, G::NQB);
   const int hd = d.C / d.heads, ld = 3 * d.C, kq = (hd + 1) & ~1;
+  const Rows Rqkv = make_rows(d.qkv, w.b, d.H * d.W, ld);
+  [[maybe_unused]] const Rows Rdo = make_rows(d.dout, w.b, d.H * d.W, d.C), Rout = make_rows(d.out, w.b, d.H * d.W, d.C);
   const int n = tid >> 2, part = tid & 3;
   if (tid < QB) {
     int tok, reg;
@@ -430,14 +519,14 @@ __global__ __launch_bounds__(256, KS > WS ? 2 : 1) void flash_wattn_bwd_dq_kerne
   {
     float q[8], g[8], o[8];
     const int tok = S.qtok[n];
-    load_row8(d.qkv, tok, ld, w.head * hd, hd, part, q);
-    load_row8(d.dout, tok, d.C, w.head * hd, hd, part, g);
-    load_row8(d.out, tok, d.C, w.head * hd, hd, part, o);
-    store_row8(S.Qs, n, part, q, d.scale);
-    store_row8(S.Gs, n, part, g, 1.f);
+    load_row8(Rqkv, tok, w.head * hd, hd, part, q);
+    load_row8(Rdo, tok, w.head * hd, hd, part, g);
+    load_row8(Rout, tok, w.head * hd, hd, part, o);
+    store_row8(S.Qs, n, part, q, d.scale, hd);
+    store_row8(S.Gs, n, part, g, 1.f, hd);
     float ds = 0.f;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) ds += g[e] * o[e];
+    for (int e = 0; e < 8; ++e) ds += part * 8 + e < hd ? g[e] * o[e] : 0.f;   // (columns past hd: the next head's values)
     ds += __shfl_xor(ds, 1, 64);
     ds += __shfl_xor(ds, 2, 64);
     if (part == 0) {
@@ -449,23 +538,23 @@ __global__ __launch_bounds__(256, KS > WS ? 2 : 1) void flash_wattn_bwd_dq_kerne
   int ktok, kreg, kterm;
   bool kex;
   key_geom<WS, KS>(d, w, n, ktok, kreg, kterm, kex);
-  load_row8(d.qkv, ktok, ld, d.C + w.head * hd, hd, part, kr);
-  load_row8(d.qkv, ktok, ld, 2 * d.C + w.head * hd, hd, part, vr);
+  load_row8(Rqkv, ktok, d.C + w.head * hd, hd, part, kr);
+  load_row8(Rqkv, ktok, 2 * d.C + w.head * hd, hd, part, vr);
   f32x16 dq = zero16();
   // dS dump: [(b, window, head)][query 256][key NK]
   float* dump = d.workspace + ws.ds_full + ((int64_t)(bid / G::NQB) * G::NQ + w.qb * QB) * G::NK;
   for (int kb = 0; kb < G::NKB; ++kb) {
     __syncthreads();
-    store_row8(S.Ks, n, part, kr, 1.f);
-    store_row8(S.Vs, n, part, vr, 1.f);
+    store_row8(S.Ks, n, part, kr, 1.f, hd);
+    store_row8(S.Vs, n, part, vr, 1.f, hd);
     if (part == 0) S.kpk[n] = kex ? kterm * 16 + kreg : KEY_NONE;
     __syncthreads();
     if (kb + 1 < G::NKB) {
       key_geom<WS, KS>(d, w, (kb + 1) * QB + n, ktok, kreg, kterm, kex);
-      load_row8(d.qkv, ktok, ld, d.C + w.head * hd, hd, part, kr);
-      load_row8(d.qkv, ktok, ld, 2 * d.C + w.head * hd, hd, part, vr);
+      load_row8(Rqkv, ktok, d.C + w.head * hd, hd, part, kr);
+      load_row8(Rqkv, ktok, 2 * d.C + w.head * hd, hd, part, vr);
     }
-    recompute_p_ds<G::NBINS, G::SELF, false>(S, kq, wave, l31, lh);
+    recompute_p_ds<G::NBINS, G::SELF, G::NK % QB != 0, false>(S, kq, wave, l31, lh);
     if (G::SELF) {
       // bias gradient of this 64-query x 64-key tile, owner-computes: the tile is RQ x RQ window rows of WS (4 x 4 rows of
       // 16, or the whole 8 x 8 window), so it touches (2 RQ - 1) x (2 WS - 1) bins (dy = yi - yj, dx = xi - xj) and thread
@@ -480,23 +569,8 @@ __global__ __launch_bounds__(256, KS > WS ? 2 : 1) void flash_wattn_bwd_dq_kerne
         // PS + 1, so the reads carry immediate offsets and validity is ONE predicate per t, shared by all a (t < len),
         // plus one per a — 16 + 4 masks instead of the 64 per-pair masks that spilled 170 SGPRs in this kernel; a key
         // row outside the tile is clamped for the address and its sum discarded.
-        const int dyi = tid / NB1, dx = tid % NB1 - (WS - 1);
-        const int xi0 = dx > 0 ? dx : 0, xj0 = dx < 0 ? -dx : 0, len = WS - (dx < 0 ? -dx : dx);
-        float s = 0.f;
-#pragma unroll
-        for (int a = 0; a < RQ; ++a) {
-          const int b = a - (dyi - (RQ - 1));  // key row of the tile paired with query row a
-          const bool oky = b >= 0 && b < RQ;
-          const int bc = b < 0 ? 0 : (b >= RQ ? RQ - 1 : b);
-          const float* base = S.dS + (a * WS + xi0) * PS + bc * WS + xj0;
-          float sa = 0.f;
-#pragma unroll
-          for (int t = 0; t < WS; ++t) {
-            const float v = base[t * (PS + 1)];
-            sa += t < len ? v : 0.f;  // (a select, not a 0 / 1 factor: past the diagonal the read may hit anything)
-          }
-          s += oky ? sa : 0.f;
-        }
+        int dyi, dx;
+        const float s = tile_bin_sum<WS>(S.dS, tid, dyi, dx);
         const int dy = RQ * (w.qb - kb) - (RQ - 1) + dyi;
         if (dy > -WS && dy < WS) S.bins[(dy + WS - 1) * NB1 + dx + WS - 1] += s;
       }
@@ -546,6 +620,8 @@ __global__ __launch_bounds__(256) void flash_wattn_bwd_dkv_kernel(const neosr_fa
   Win w = decode(d, bid, G::NKB);
   const int kb = w.qb;  // decode()'s innermost index is the key block here
   const int hd = d.C / d.heads, ld = 3 * d.C, kq = (hd + 1) & ~1;
+  const Rows Rqkv = make_rows(d.qkv, w.b, d.H * d.W, ld);
+  [[maybe_unused]] const Rows Rdo = make_rows(d.dout, w.b, d.H * d.W, d.C), Rout = make_rows(d.out, w.b, d.H * d.W, d.C);
   const int n = tid >> 2, part = tid & 3;
   const int64_t wh = bid / G::NKB;  // (b, window, head)
   if (tid < QB) {
@@ -559,10 +635,10 @@ __global__ __launch_bounds__(256) void flash_wattn_bwd_dkv_kernel(const neosr_fa
   __syncthreads();
   {
     float kr[8], vr[8];
-    load_row8(d.qkv, S.ktok[n], ld, d.C + w.head * hd, hd, part, kr);
-    load_row8(d.qkv, S.ktok[n], ld, 2 * d.C + w.head * hd, hd, part, vr);
-    store_row8(S.Ks, n, part, kr, 1.f);
-    store_row8(S.Vs, n, part, vr, 1.f);
+    load_row8(Rqkv, S.ktok[n], d.C + w.head * hd, hd, part, kr);
+    load_row8(Rqkv, S.ktok[n], 2 * d.C + w.head * hd, hd, part, vr);
+    store_row8(S.Ks, n, part, kr, 1.f, hd);
+    store_row8(S.Vs, n, part, vr, 1.f, hd);
   }
   f32x16 acc = zero16();  // waves 0,1: dV rows 32 wave..; waves 2,3: dK rows 32 (wave-2)..
   // the next query block's q / dO rows travel in registers while the current block is consumed (every thread works out
@@ -571,8 +647,8 @@ __global__ __launch_bounds__(256) void flash_wattn_bwd_dkv_kernel(const neosr_fa
   {
     int tok, reg;
     query_geom<WS>(d, w, n, tok, reg);
-    load_row8(d.qkv, tok, ld, w.head * hd, hd, part, qn);
-    load_row8(d.dout, tok, d.C, w.head * hd, hd, part, gn);
+    load_row8(Rqkv, tok, w.head * hd, hd, part, qn);
+    load_row8(Rdo, tok, w.head * hd, hd, part, gn);
   }
   for (int qb = 0; qb < G::NQB; ++qb) {
     __syncthreads();  // previous products finished with Qs / Gs / P / dS
@@ -585,16 +661,16 @@ __global__ __launch_bounds__(256) void flash_wattn_bwd_dkv_kernel(const neosr_fa
       S.lse[tid] = d.lse[(wh * G::NQB + qb) * QB + tid];
       S.dsum[tid] = d.workspace[ws.dsum + (wh * G::NQB + qb) * QB + tid];
     }
-    store_row8(S.Qs, n, part, qn, d.scale);
-    store_row8(S.Gs, n, part, gn, 1.f);
+    store_row8(S.Qs, n, part, qn, d.scale, hd);
+    store_row8(S.Gs, n, part, gn, 1.f, hd);
     __syncthreads();
     if (qb + 1 < G::NQB) {
       int tok, reg;
       query_geom<WS>(d, w, (qb + 1) * QB + n, tok, reg);
-      load_row8(d.qkv, tok, ld, w.head * hd, hd, part, qn);
-      load_row8(d.dout, tok, d.C, w.head * hd, hd, part, gn);
+      load_row8(Rqkv, tok, w.head * hd, hd, part, qn);
+      load_row8(Rdo, tok, w.head * hd, hd, part, gn);
     }
-    recompute_p_ds<G::NBINS, G::SELF>(S, kq, wave, l31, lh);
+    recompute_p_ds<G::NBINS, G::SELF, G::NK % QB != 0>(S, kq, wave, l31, lh);
     if (wave < 2)
       acc = mm_atb(acc, S.P, PS, S.Gs, QS, wave, 0, l31, lh);       // dV[j][d] += sum_i P[i][j] dO[i][d]
     else
@@ -634,8 +710,36 @@ __global__ __launch_bounds__(256, 2) void flash_wattn_bwd_fused_kernel(const neo
   const int bid = xcd_bid();            // (b, window, head)
   Win w = decode(d, bid, 1);
   const int hd = d.C / d.heads, ld = 3 * d.C, kq = (hd + 1) & ~1;
+  const Rows Rqkv = make_rows(d.qkv, w.b, d.H * d.W, ld);
+  [[maybe_unused]] const Rows Rdo = make_rows(d.dout, w.b, d.H * d.W, d.C), Rout = make_rows(d.out, w.b, d.H * d.W, d.C);
   const int n = tid >> 2, part = tid & 3;
+  FTL(0, true);
   for (int k = tid; k < G::NBINS; k += 256) S.tab[k] = d.rpb_table[k * d.heads + w.head];
+  // The key rows of the window are the same for every query block: this thread's row offset and the packed bias / mask
+  // term of its key in each key block are worked out ONCE (the geometry + address arithmetic of the next block's prefetch
+  // took ~700 of a tile's ~13 000 cycles; tools/timeline_fattn.py)
+  unsigned koff[G::NKB];
+  int kpkr[G::NKB];
+  const bool kal8 = row_al8(Rqkv, d.C + w.head * hd, hd) && (d.C & 1) == 0;
+#pragma unroll
+  for (int c = 0; c < G::NKB; ++c) {
+    int tok, reg, kterm;
+    bool ex;
+    key_geom<WS, KS>(d, w, c * QB + n, tok, reg, kterm, ex);
+    koff[c] = row_off(Rqkv, tok, d.C + w.head * hd, part);
+    kpkr[c] = ex ? kterm * 16 + reg : KEY_NONE;
+  }
+  auto key_rows = [&](int kb, float (&kr)[8], float (&vr)[8], int& kp) {   // (kb is a run-time index: selects, not scratch)
+    unsigned off = koff[0];
+    kp = kpkr[0];
+#pragma unroll
+    for (int c = 1; c < G::NKB; ++c) {
+      off = kb == c ? koff[c] : off;
+      kp = kb == c ? kpkr[c] : kp;
+    }
+    load_row8_at(Rqkv, off, kal8, kr);
+    load_row8_at(Rqkv, off + (unsigned)d.C * 4u, kal8, vr);
+  };
   f32x16 dkv[G::NKB];   // waves 0, 1: dV rows 32 wave..; waves 2, 3: dK rows 32 (wave - 2)..  of key block kb
 #pragma unroll
   for (int kb = 0; kb < G::NKB; ++kb) dkv[kb] = zero16();
@@ -654,65 +758,53 @@ __global__ __launch_bounds__(256, 2) void flash_wattn_bwd_fused_kernel(const neo
     {
       float q[8], g[8], o[8];
       const int tok = S.qtok[n];
-      load_row8(d.qkv, tok, ld, w.head * hd, hd, part, q);
-      load_row8(d.dout, tok, d.C, w.head * hd, hd, part, g);
-      load_row8(d.out, tok, d.C, w.head * hd, hd, part, o);
-      store_row8(S.Qs, n, part, q, d.scale);
-      store_row8(S.Gs, n, part, g, 1.f);
+      load_row8(Rqkv, tok, w.head * hd, hd, part, q);
+      load_row8(Rdo, tok, w.head * hd, hd, part, g);
+      load_row8(Rout, tok, w.head * hd, hd, part, o);
+      store_row8(S.Qs, n, part, q, d.scale, hd);
+      store_row8(S.Gs, n, part, g, 1.f, hd);
       float ds = 0.f;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) ds += g[e] * o[e];
+      for (int e = 0; e < 8; ++e) ds += part * 8 + e < hd ? g[e] * o[e] : 0.f;   // (columns past hd: the next head's values)
       ds += __shfl_xor(ds, 1, 64);
       ds += __shfl_xor(ds, 2, 64);
       if (part == 0) S.dsum[n] = ds;
     }
     float kr[8], vr[8];
-    int ktok, kreg, kterm;
-    bool kex;
-    key_geom<WS, KS>(d, w, n, ktok, kreg, kterm, kex);
-    load_row8(d.qkv, ktok, ld, d.C + w.head * hd, hd, part, kr);
-    load_row8(d.qkv, ktok, ld, 2 * d.C + w.head * hd, hd, part, vr);
+    int kp;
+    key_rows(0, kr, vr, kp);
     f32x16 dq = zero16();
     // (the loop stays rolled — unrolled, its four copies of the bias-bin walk spilled 29 VGPRs at the 256 a wave may hold
     // with two workgroups per CU; only the accumulation into the key block's own registers is spelled out per block)
 #pragma unroll 1
     for (int kb = 0; kb < G::NKB; ++kb) {
+#ifdef FATTN_TL
+      if (tid == 0) S.tl_on = qb == 1 && kb == 1;
+#endif
+      FTL(1, qb == 1 && kb == 1);
+      FTL(9, qb == 1 && kb == 2);
       __syncthreads();
-      store_row8(S.Ks, n, part, kr, 1.f);
-      store_row8(S.Vs, n, part, vr, 1.f);
-      if (part == 0) S.kpk[n] = kex ? kterm * 16 + kreg : KEY_NONE;
+      FTL(2, qb == 1 && kb == 1);
+      store_row8(S.Ks, n, part, kr, 1.f, hd);
+      store_row8(S.Vs, n, part, vr, 1.f, hd);
+      if (part == 0) S.kpk[n] = kp;
       __syncthreads();
-      if (kb + 1 < G::NKB) {
-        key_geom<WS, KS>(d, w, (kb + 1) * QB + n, ktok, kreg, kterm, kex);
-        load_row8(d.qkv, ktok, ld, d.C + w.head * hd, hd, part, kr);
-        load_row8(d.qkv, ktok, ld, 2 * d.C + w.head * hd, hd, part, vr);
-      }
-      recompute_p_ds<G::NBINS, G::SELF, true>(S, kq, wave, l31, lh);
+      FTL(3, qb == 1 && kb == 1);
+      if (kb + 1 < G::NKB) key_rows(kb + 1, kr, vr, kp);
+      FTL(4, qb == 1 && kb == 1);
+      recompute_p_ds<G::NBINS, G::SELF, G::NK % QB != 0, true>(S, kq, wave, l31, lh);
+      FTL(5, qb == 1 && kb == 1);
       {  // bias gradient of the tile (see kernel (A))
         constexpr int RQ = QB / WS, NB1 = 2 * WS - 1;
         static_assert((2 * RQ - 1) * NB1 <= 256, "one bin of the tile per thread");
         if (tid < (2 * RQ - 1) * NB1) {
-          const int dyi = tid / NB1, dx = tid % NB1 - (WS - 1);
-          const int xi0 = dx > 0 ? dx : 0, xj0 = dx < 0 ? -dx : 0, len = WS - (dx < 0 ? -dx : dx);
-          float s = 0.f;
-#pragma unroll
-          for (int a = 0; a < RQ; ++a) {
-            const int b = a - (dyi - (RQ - 1));
-            const bool oky = b >= 0 && b < RQ;
-            const int bc = b < 0 ? 0 : (b >= RQ ? RQ - 1 : b);
-            const float* base = S.dS + (a * WS + xi0) * PS + bc * WS + xj0;
-            float sa = 0.f;
-#pragma unroll
-            for (int t = 0; t < WS; ++t) {
-              const float v = base[t * (PS + 1)];
-              sa += t < len ? v : 0.f;
-            }
-            s += oky ? sa : 0.f;
-          }
+          int dyi, dx;
+          const float s = tile_bin_sum<WS>(S.dS, tid, dyi, dx);
           const int dy = RQ * (qb - kb) - (RQ - 1) + dyi;
           if (dy > -WS && dy < WS) S.bins[(dy + WS - 1) * NB1 + dx + WS - 1] += s;
         }
       }
+      FTL(6, qb == 1 && kb == 1);
       {
         // waves 0, 1: dV[j][d] += sum_i P[i][j] dO[i][d];  waves 2, 3: dK[j][d] += sum_i dS[i][j] (scale q)[i][d]
         const float* A = wave < 2 ? S.P : S.dS;
@@ -722,8 +814,11 @@ __global__ __launch_bounds__(256, 2) void flash_wattn_bwd_fused_kernel(const neo
         for (int c = 0; c < G::NKB; ++c)
           if (kb == c) dkv[c] = mm_atb(dkv[c], A, PS, Bm, QS, ti, 0, l31, lh);
       }
+      FTL(7, qb == 1 && kb == 1);
       dq = mm_ab_half(dq, S.dS, PS, S.Ks, QS, wave & 1, 0, l31, lh, 32 * (wave >> 1));
+      FTL(8, qb == 1 && kb == 1);
     }
+    FTL(10 + qb, true);
     __syncthreads();   // the last block's products have read P / dS
     {  // partial bins of (window, query block): row (bw index, qb) of a [rows][bin][head] matrix
       float* row = d.workspace + ws.ds_full + ((int64_t)(bid / d.heads) * G::NQB + qb) * G::NBINS * d.heads + w.head;
@@ -742,6 +837,7 @@ __global__ __launch_bounds__(256, 2) void flash_wattn_bwd_fused_kernel(const neo
             (dq[r] + S.P[wave * 1024 + r * 64 + lane]) * d.scale;
     }
   }
+  FTL(20, true);
   // dK / dV of every key block
   if (l31 < hd) {
     const int which = wave < 2 ? 2 : 1;  // v : k
@@ -823,6 +919,13 @@ __global__ __launch_bounds__(256) void rpb_bins_kernel(const float* __restrict__
   if (lane == 0) dtab[e] = accumulate ? dtab[e] + s : s;
 }
 
+#ifdef FATTN_TL
+}  // namespace
+extern "C" int neosr_debug_fattn_timeline(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fattn_tl), 64 * 8) == hipSuccess ? 0 : 1;
+}
+namespace {
+#endif
 int g_fattn_fused = -1;   // -1: read NEOSR_AMD_FATTN_FUSED on first use (default on)
 bool fattn_fused_on() {
   if (g_fattn_fused < 0) {
@@ -890,6 +993,8 @@ int check(const neosr_fattn_desc* d) {
               "(got %d / %d)", d->ws, d->ks);
   NEOSR_CHECK(d->H % d->ws == 0 && d->W % d->ws == 0, "flash_window_attention: H, W must be multiples of the window");
   NEOSR_CHECK(d->C % d->heads == 0 && d->C / d->heads <= 32, "flash_window_attention: head_dim must be <= 32");
+  NEOSR_CHECK((int64_t)d->H * d->W * 3 * d->C * 4 <= (int64_t)ROW_DEAD && d->C / d->heads >= 2,
+              "flash_window_attention: one sample's qkv rows must stay under 3 GiB (32-bit row offsets)");
   NEOSR_CHECK(d->shift >= 0 && d->shift < d->ws && (d->ks == d->ws || d->shift == 0),
               "flash_window_attention: bad shift");
   return 0;
