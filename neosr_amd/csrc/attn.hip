@@ -14,6 +14,7 @@
 #include "../../include/neosr_amd.h"
 #include "prof.h"
 #include "attn_wave.h"
+#include "attn_rows.h"
 
 namespace {
 
@@ -198,14 +199,19 @@ struct Tables {
   float tab[NB + 31];
 };
 
+// pixel row of window token n (the cyclic shift and window_partition as one index)
+__device__ __forceinline__ int window_token(const neosr_wattn_desc& d, const Win& w, int n) {
+  int y = w.Wy * WS + (n >> 3) + d.shift, x = w.Wx * WS + (n & 7) + d.shift;  // shift < WS <= H, W: one conditional subtract == modulo
+  if (y >= d.H) y -= d.H;
+  if (x >= d.W) x -= d.W;
+  return (w.b * d.H + y) * d.W + x;
+}
+
 __device__ __forceinline__ void build_tables(const neosr_wattn_desc& d, const Win& w, Tables& T) {
   const int n = threadIdx.x;
   if (n < NTOK) {
     const int ys = w.Wy * WS + (n >> 3), xs = w.Wx * WS + (n & 7);
-    int y = ys + d.shift, x = xs + d.shift;  // shift < WS <= H, W: one conditional subtract == modulo
-    if (y >= d.H) y -= d.H;
-    if (x >= d.W) x -= d.W;
-    T.tok[n] = (w.b * d.H + y) * d.W + x;
+    T.tok[n] = window_token(d, w, n);
     const int ry = ys < d.H - WS ? 0 : (ys < d.H - d.shift ? 1 : 2);
     const int rx = xs < d.W - WS ? 0 : (xs < d.W - d.shift ? 1 : 2);
     T.reg[n] = d.shift > 0 ? ry * 3 + rx : 0;
@@ -213,58 +219,19 @@ __device__ __forceinline__ void build_tables(const neosr_wattn_desc& d, const Wi
   if (n < NB) T.tab[n] = d.rpb_table[n * d.heads + w.head];
 }
 
-// stage one [64 x hd] slice of the fused qkv matrix (or of dout) into LDS, zero padded to 32 cols
-__device__ __forceinline__ void load_tile(const Tables& T, const float* src, int ld, int col0, int hd,
-                                          float mul, float* dst) {
-  const int n = threadIdx.x >> 2, part = threadIdx.x & 3;  // 64 tokens x 4 column groups of 8
-  const float* row = src + (int64_t)T.tok[n] * ld + col0;
-  if (((ld | col0 | hd) & 1) == 0 && (reinterpret_cast<uintptr_t>(src) & 7) == 0) {
-    // even row stride, head offset and head size: the slice is 8-byte aligned -> four 8-byte loads instead of eight 4-byte ones
-    float2 v[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int c = part * 8 + 2 * e;
-      v[e] = c < hd ? *reinterpret_cast<const float2*>(row + c) : make_float2(0.f, 0.f);
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      dst[n * QS + part * 8 + 2 * e] = v[e].x * mul;
-      dst[n * QS + part * 8 + 2 * e + 1] = v[e].y * mul;
-    }
-    return;
-  }
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const int c = part * 8 + e;
-    dst[n * QS + c] = c < hd ? row[c] * mul : 0.f;
-  }
+// One [64 x hd] slice of the fused qkv matrix (or of dout / out) in two halves — request (8 registers per thread: token
+// n = tid / 4, columns 8 (tid % 4)..) and store to LDS, zero padded to 32 columns — so that a kernel has the loads of ALL its
+// slices in flight before it waits for the first.  The rows are raw-buffer loads (attn_rows.h): written as conditional loads
+// from global pointers, hipcc put s_waitcnt vmcnt(0) between the slices (five dependent round trips in the backward's
+// prologue; round 6, found in the ISA).  The columns past hd are zeroed by put_tile.
+// (`tok` = window_token of the thread's own token n, worked out in registers: the requests do not wait for the tables)
+__device__ __forceinline__ void fetch_tile(int tok, const Rows& R, int col0, int hd, float (&v)[8]) {
+  load_row8_at(R, row_off(R, tok, col0, threadIdx.x & 3), row_al8(R, col0, hd), v);
 }
-
-// the same slice in two halves — request (into 8 registers) and store — so that a kernel can have the loads of all its
-// slices in flight before it waits for the first (three load_tile calls in a row are three dependent global round trips)
-__device__ __forceinline__ void fetch_tile(const Tables& T, const float* src, int ld, int col0, int hd, float (&v)[8]) {
-  const int n = threadIdx.x >> 2, part = threadIdx.x & 3;
-  const float* row = src + (int64_t)T.tok[n] * ld + col0;
-  if (((ld | col0 | hd) & 1) == 0 && (reinterpret_cast<uintptr_t>(src) & 7) == 0) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int c = part * 8 + 2 * e;
-      const float2 t = c < hd ? *reinterpret_cast<const float2*>(row + c) : make_float2(0.f, 0.f);
-      v[2 * e] = t.x;
-      v[2 * e + 1] = t.y;
-    }
-    return;
-  }
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const int c = part * 8 + e;
-    v[e] = c < hd ? row[c] : 0.f;
-  }
-}
-__device__ __forceinline__ void put_tile(const float (&v)[8], float mul, float* dst) {
+__device__ __forceinline__ void put_tile(const float (&v)[8], float mul, float* dst, int hd) {
   const int n = threadIdx.x >> 2, part = threadIdx.x & 3;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) dst[n * QS + part * 8 + e] = v[e] * mul;
+  for (int e = 0; e < 8; ++e) dst[n * QS + part * 8 + e] = part * 8 + e < hd ? v[e] * mul : 0.f;
 }
 
 // D[i][j] (one 32x32 tile: rows 32*ti.., cols 32*tj..) = sum_k A[i][k] * B[j][k], k < kdim (even)
@@ -348,11 +315,18 @@ __global__ __launch_bounds__(256) void window_attention_fwd_kernel(const neosr_w
   const int bid = xcd_bid();
   const Win w = decode(d, bid);
   const int hd = d.C / d.heads, ld = 3 * d.C;
-  build_tables(d, w, T);
-  __syncthreads();
-  load_tile(T, d.qkv, ld, w.head * hd, hd, d.scale, Qs);
-  load_tile(T, d.qkv, ld, d.C + w.head * hd, hd, 1.f, Ks);
-  load_tile(T, d.qkv, ld, 2 * d.C + w.head * hd, hd, 1.f, Vs);
+  {
+    const Rows Rqkv = make_rows(d.qkv, w.b, d.H * d.W, ld);
+    const int mytok = window_token(d, w, tid >> 2);
+    float rq[8], rk[8], rv[8];
+    fetch_tile(mytok, Rqkv, w.head * hd, hd, rq);
+    fetch_tile(mytok, Rqkv, d.C + w.head * hd, hd, rk);
+    fetch_tile(mytok, Rqkv, 2 * d.C + w.head * hd, hd, rv);
+    build_tables(d, w, T);   // (its table loads queue behind the row requests: one round trip for everything)
+    put_tile(rq, d.scale, Qs, hd);
+    put_tile(rk, 1.f, Ks, hd);
+    put_tile(rv, 1.f, Vs, hd);
+  }
   __syncthreads();
   {
     const int ti = wave >> 1, tj = wave & 1;
@@ -408,58 +382,50 @@ __global__ __launch_bounds__(256) void window_attention_bwd_kernel(const neosr_w
   const int bid = xcd_bid();
   const Win w = decode(d, bid);
   const int hd = d.C / d.heads, ld = 3 * d.C, kq = (hd + 1) & ~1;
-  build_tables(d, w, T);
-  if (tid < NTOK) lse_s[tid] = d.lse[(int64_t)bid * NTOK + tid];
-  __syncthreads();
-  // all five slices (q, k, v, and below dO, O) are requested before the first is waited for
+  // all five slices (q, k, v, and below dO, O) are requested before anything is waited for — the thread's own token is worked
+  // out in registers, the tables (and their loads) follow the requests
   float rq[8], rk[8], rv[8];
-  fetch_tile(T, d.qkv, ld, w.head * hd, hd, rq);
-  fetch_tile(T, d.qkv, ld, d.C + w.head * hd, hd, rk);
-  fetch_tile(T, d.qkv, ld, 2 * d.C + w.head * hd, hd, rv);
+  const Rows Rqkv = make_rows(d.qkv, w.b, d.H * d.W, ld), Rdo = make_rows(d.dout, w.b, d.H * d.W, d.C);
+  const int mytok = window_token(d, w, tid >> 2);
+  fetch_tile(mytok, Rqkv, w.head * hd, hd, rq);
+  fetch_tile(mytok, Rqkv, d.C + w.head * hd, hd, rk);
+  fetch_tile(mytok, Rqkv, 2 * d.C + w.head * hd, hd, rv);
   constexpr bool have_o = HAVE_O;
   if (!have_o) {
-    put_tile(rq, d.scale, Qs);
-    put_tile(rk, 1.f, Ks);
-    put_tile(rv, 1.f, Vs);
+    put_tile(rq, d.scale, Qs, hd);
+    put_tile(rk, 1.f, Ks, hd);
+    put_tile(rv, 1.f, Vs, hd);
   }
   if (have_o) {
     // delta[i] = sum_j P dP = sum_d dO[i][d] O[i][d]: with the forward output at hand the row sums come from two
     // 30-float rows instead of two 64 x 64 LDS tiles, and dS is finished in the score tile's registers.  The O row is
     // requested in the same batch as the dO row it multiplies (one round trip, no second pass over dO).
     const int n = tid >> 2, part = tid & 3;
-    const int64_t row = (int64_t)T.tok[n] * d.C + w.head * hd;
+    const Rows Rout = make_rows(d.out, w.b, d.H * d.W, d.C);
     float gv[8], ov[8];
-    if (((d.C | hd) & 1) == 0 && ((reinterpret_cast<uintptr_t>(d.dout) | reinterpret_cast<uintptr_t>(d.out)) & 7) == 0) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {  // 8-byte loads (see load_tile)
-        const int c = part * 8 + 2 * e;
-        const float2 a = c < hd ? *reinterpret_cast<const float2*>(d.dout + row + c) : make_float2(0.f, 0.f);
-        const float2 b = c < hd ? *reinterpret_cast<const float2*>(d.out + row + c) : make_float2(0.f, 0.f);
-        gv[2 * e] = a.x; gv[2 * e + 1] = a.y;
-        ov[2 * e] = b.x; ov[2 * e + 1] = b.y;
-      }
-    } else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int c = part * 8 + e;
-        gv[e] = c < hd ? d.dout[row + c] : 0.f;
-        ov[e] = c < hd ? d.out[row + c] : 0.f;
-      }
-    }
-    put_tile(rq, d.scale, Qs);
-    put_tile(rk, 1.f, Ks);
-    put_tile(rv, 1.f, Vs);
+    fetch_tile(mytok, Rdo, w.head * hd, hd, gv);
+    fetch_tile(mytok, Rout, w.head * hd, hd, ov);
+    build_tables(d, w, T);
+    if (tid < NTOK) lse_s[tid] = d.lse[(int64_t)bid * NTOK + tid];
+    put_tile(rq, d.scale, Qs, hd);
+    put_tile(rk, 1.f, Ks, hd);
+    put_tile(rv, 1.f, Vs, hd);
     float s = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      Gs[n * QS + part * 8 + e] = gv[e];
-      s += gv[e] * ov[e];
+      const bool in = part * 8 + e < hd;   // (columns past hd: the next head's values)
+      Gs[n * QS + part * 8 + e] = in ? gv[e] : 0.f;
+      s += in ? gv[e] * ov[e] : 0.f;
     }
     s += __shfl_xor(s, 1, 64);
     s += __shfl_xor(s, 2, 64);
     if (part == 0) delta_s[n] = s;
   } else {
-    load_tile(T, d.dout, d.C, w.head * hd, hd, 1.f, Gs);
+    float gv[8];
+    fetch_tile(mytok, Rdo, w.head * hd, hd, gv);
+    build_tables(d, w, T);
+    if (tid < NTOK) lse_s[tid] = d.lse[(int64_t)bid * NTOK + tid];
+    put_tile(gv, 1.f, Gs, hd);
   }
   __syncthreads();
   float* g = d.dqkv + w.head * hd + l31;
@@ -620,6 +586,8 @@ int wattn_check(const neosr_wattn_desc* d) {
   NEOSR_CHECK(d->H % WS == 0 && d->W % WS == 0, "window_attention: H, W must be multiples of the window size");
   NEOSR_CHECK(d->C % d->heads == 0 && d->C / d->heads <= HD_MAX, "window_attention: head_dim must be <= 32");
   NEOSR_CHECK(d->shift >= 0 && d->shift < WS, "window_attention: 0 <= shift < window size");
+  NEOSR_CHECK((int64_t)d->H * d->W * 3 * d->C * 4 <= (int64_t)ROW_DEAD && d->C / d->heads >= 2,
+              "window_attention: one sample's qkv rows must stay under 3 GiB (32-bit row offsets)");
   return 0;
 }
 

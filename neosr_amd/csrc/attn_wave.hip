@@ -15,6 +15,7 @@
 // in image order: torch.roll, window_partition / window_reverse and the head split are address arithmetic.
 // A wave loops over its (window, head) units and requests the next unit's rows as soon as the current scores
 // are formed.  Reference: neosr/archs/swinir_arch.py:150-212 (WindowAttention), :313-341 (mask), :343-392.
+#include <cstdlib>
 #include "common.h"
 #include "attn_wave.h"
 #include "prof.h"
@@ -282,18 +283,70 @@ __global__ __launch_bounds__(256, 2) void wattn16_wave_fwd_kernel(const neosr_fa
       const int Y = wrap(w.Wy * W16 + (n >> 4) + d.shift, d.H), X = wrap(w.Wx * W16 + (n & 15) + d.shift, d.W);
       return (w.b * d.H + Y) * d.W + X;
     };
-    float qf[NS];
+    // Every row / column fragment is requested TWO tiles ahead of the products that consume it (rings of three register
+    // buffers, the order pinned by sched_barrier).  Left to itself hipcc — with 128 accumulator registers live — places
+    // each 16-byte load right in front of the four MFMAs that read it and waits vmcnt(0) for it: ~32 exposed memory round
+    // trips per unit on the key side alone (round 6, found in the ISA; the products were 17 % of the unit's time).
+    // (the any-head-size variant — 16 conditional loads per fragment — has no registers for a ring: it loads in place, as before)
+    constexpr int RING = HALF ? 3 : 1, PF = RING - 1;
+    float qf[NS], kf[RING][NS];
     load_rows<HALF>(d.qkv, ld, pix(32 * ti + l31), w.head * hd, hd, lh, d.scale, qf);
-    for (int n = lane; n < NBIN16; n += 64) tab[(n / NB16) * TS16 + n % NB16] = d.rpb_table[n * d.heads + w.head];
+    load_rows<HALF>(d.qkv, ld, pix(l31), d.C + w.head * hd, hd, lh, 1.f, kf[0]);
+    if (RING > 2) load_rows<HALF>(d.qkv, ld, pix(32 + l31), d.C + w.head * hd, hd, lh, 1.f, kf[1]);
+    if (!PF) {
+      for (int n = lane; n < NBIN16; n += 64) tab[(n / NB16) * TS16 + n % NB16] = d.rpb_table[n * d.heads + w.head];
+    } else {  // the head's bias table: all 16 loads of a lane in one batch beside the row loads above, then the LDS writes
+      float tv[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int n = lane + 64 * i;
+        tv[i] = d.rpb_table[(n < NBIN16 ? n : NBIN16 - 1) * d.heads + w.head];
+      }
+      if (PF) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int n = lane + 64 * i;
+        if (n < NBIN16) tab[(n / NB16) * TS16 + n % NB16] = tv[i];
+      }
+    }
+    if (PF) __builtin_amdgcn_sched_barrier(0);
     // S^T tiles: rows (registers) = keys 32 tj + 8 g + 4 lh + r, column (lane) = query 32 ti + l31
     f32x16 st[NKT];
 #pragma unroll
     for (int tj = 0; tj < NKT; ++tj) {
-      float kf[NS];
-      load_rows<HALF>(d.qkv, ld, pix(32 * tj + l31), d.C + w.head * hd, hd, lh, 1.f, kf);
+      if (tj + PF < NKT)
+        load_rows<HALF>(d.qkv, ld, pix(32 * (tj + PF) + l31), d.C + w.head * hd, hd, lh, 1.f, kf[(tj + PF) % RING]);
+      if (PF) __builtin_amdgcn_sched_barrier(0);
       zero(st[tj]);
 #pragma unroll
-      for (int s = 0; s < KS; ++s) st[tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[s], qf[s], st[tj], 0, 0, 0);
+      for (int s = 0; s < KS; ++s) st[tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[tj % RING][s], qf[s], st[tj], 0, 0, 0);
+      if (PF) __builtin_amdgcn_sched_barrier(0);
+    }
+    // the first two V column tiles travel under the softmax.  (Raw-buffer loads: the image row is wave-uniform and rides in
+    // the scalar offset, the eight column offsets of a lane are loop-invariant — no 64-bit address pair per load, which
+    // is what the ring of three tiles has registers for.)
+    const auto rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.qkv) + (int64_t)w.b * d.H * d.W * ld, (short)0,
+                                                      (int)((unsigned)(d.H * d.W) * (unsigned)ld * 4u), 0x00020000);
+    int xoff[2][4];   // byte offsets inside an image row
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        xoff[h][r] = (wrap(w.Wx * W16 + 8 * h + 4 * lh + r + d.shift, d.W) * ld + 2 * d.C + w.head * hd + dl) * 4;
+    auto rowb = [&](int y) { return wrap(w.Wy * W16 + y + d.shift, d.H) * d.W; };   // first pixel of window row y in the sample
+    float vc[RING][4][4];
+    auto load_v = [&](int tj, float (&c)[4][4]) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int rb = __builtin_amdgcn_readfirstlane(rowb(2 * tj + (g >> 1)) * ld * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          c[g][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rv, xoff[g & 1][r], rb, 0));
+      }
+    };
+    if (PF) {
+      load_v(0, vc[0]);   // (one tile only: the softmax holds all 128 score registers + 16 bias values)
+      __builtin_amdgcn_sched_barrier(0);
     }
     // bias + mask, softmax over the 256 keys (registers + the other half-wave)
     const bool masked = d.shift > 0 && (w.Wy == w.nWy - 1 || w.Wx == w.nWx - 1);
@@ -340,37 +393,28 @@ __global__ __launch_bounds__(256, 2) void wattn16_wave_fwd_kernel(const neosr_fa
     if (d.lse && lh == 0) d.lse[(int64_t)w.wh * (W16 * W16) + 32 * ti + l31] = m + __logf(sum);
 
     // O[i][d] = sum_j P[i][j] V[j][d]; V column operand: key (yj, xj) = (2 tj + (g >> 1), 8 (g & 1) + 4 lh + r)
-    int64_t xoff[2][4];
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) xoff[h][r] = (int64_t)wrap(w.Wx * W16 + 8 * h + 4 * lh + r + d.shift, d.W);
-    auto rowb = [&](int y) { return ((int64_t)w.b * d.H + wrap(w.Wy * W16 + y + d.shift, d.H)) * d.W; };
-    const float* vb = d.qkv + 2 * d.C + w.head * hd + dl;
     f32x16 o;
     zero(o);
+    if (PF > 1) load_v(1, vc[1]);
 #pragma unroll
     for (int tj = 0; tj < NKT; ++tj) {
-      float vc[4][4];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int64_t row = rowb(2 * tj + (g >> 1));
-#pragma unroll
-        for (int r = 0; r < 4; ++r) vc[g][r] = vb[(row + xoff[g & 1][r]) * ld];
-      }
+      if (tj + PF < NKT) load_v(tj + PF, vc[(tj + PF) % RING]);
+      if (PF) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int g = 0; g < 4; ++g)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          o = __builtin_amdgcn_mfma_f32_32x32x2f32(st[tj][4 * g + r] * inv, vc[g][r], o, 0, 0, 0);
+          o = __builtin_amdgcn_mfma_f32_32x32x2f32(st[tj][4 * g + r] * inv, vc[tj % RING][g][r], o, 0, 0, 0);
+      if (PF) __builtin_amdgcn_sched_barrier(0);
     }
     if (l31 < hd) {
-      float* ob = d.out + w.head * hd + l31;
+      float* ob = d.out + (int64_t)w.b * d.H * d.W * d.C + w.head * hd + l31;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int64_t row = rowb(2 * ti + (g >> 1));
+        const int row = rowb(2 * ti + (g >> 1));
 #pragma unroll
-        for (int r = 0; r < 4; ++r) ob[(row + xoff[g & 1][r]) * d.C] = o[4 * g + r];
+        for (int r = 0; r < 4; ++r)
+          ob[(int64_t)(row + wrap(w.Wx * W16 + 8 * (g & 1) + 4 * lh + r + d.shift, d.W)) * d.C] = o[4 * g + r];
       }
     }
   }
@@ -399,7 +443,12 @@ bool wave16_ok(const neosr_fattn_desc& d) {
 void launch16_fwd(const neosr_fattn_desc& d, void* stream) {
   const int units = d.B * (d.H / W16) * (d.W / W16) * d.heads;  // (window, head); 8 query tiles each
   int nwg = (8 * units + 3) / 4;
-  if (nwg > 512) nwg = 512;
+  // Two workgroups fit a CU (255 VGPRs): 512 resident.  Up to two rounds' worth of workgroups are launched one unit per
+  // wave — the dispatcher hands a CU its next workgroup when one finishes, 3 units per SIMD at B = 4 instead of the 2 - 4 a
+  // fixed 512-workgroup walk gives (57 -> 49 us, same box) — beyond that the 512 walk the unit list (B = 8: 87 vs 89 us).
+  static const int cap = [] { const char* e = getenv("NEOSR_AMD_W16_NWG"); return e ? atoi(e) : 0; }();
+  if (cap > 0) { if (nwg > cap) nwg = cap; }
+  else if (nwg > 1024) nwg = 512;
   if (d.C / d.heads == 30)
     hipLaunchKernelGGL(wattn16_wave_fwd_kernel<15>, dim3(nwg), dim3(256), 0, (hipStream_t)stream, d, units);
   else
