@@ -148,6 +148,12 @@ __device__ __forceinline__ f32x16 mm_abt(f32x16 acc, const float* A, int sa, con
                                          int tj, int kdim, int l31, int lh) {
   const float* ap = A + (32 * ti + l31) * sa + lh;
   const float* bp = B + (32 * tj + l31) * sb + lh;
+  if (kdim == 30) {   // hat_m / hat_l heads: 15 steps straight-line (the rolled loop is read, wait, MFMA per step)
+#pragma unroll
+    for (int ks = 0; ks < 15; ++ks)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * ks], bp[2 * ks], acc, 0, 0, 0);
+    return acc;
+  }
   for (int ks = 0; ks < kdim / 2; ++ks)
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * ks], bp[2 * ks], acc, 0, 0, 0);
   return acc;
@@ -157,6 +163,15 @@ __device__ __forceinline__ f32x16 mm_abt(f32x16 acc, const float* A, int sa, con
 __device__ __forceinline__ void mm_abt_pair(f32x16& acc1, const float* A1, const float* B1, f32x16& acc2, const float* A2,
                                             const float* B2, int sa, int sb, int ti, int tj, int kdim, int l31, int lh) {
   const int ao = (32 * ti + l31) * sa + lh, bo = (32 * tj + l31) * sb + lh;
+  if (kdim == 30) {   // (see mm_abt: S, dP of a tile 2 650 -> 2 200 cycles, tools/timeline_fattn.py)
+#pragma unroll
+    for (int ks = 0; ks < 15; ++ks) {
+      const float a1 = A1[ao + 2 * ks], b1 = B1[bo + 2 * ks], a2 = A2[ao + 2 * ks], b2 = B2[bo + 2 * ks];
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc1, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2, acc2, 0, 0, 0);
+    }
+    return;
+  }
   for (int ks = 0; ks < kdim / 2; ++ks) {
     const float a1 = A1[ao + 2 * ks], b1 = B1[bo + 2 * ks], a2 = A2[ao + 2 * ks], b2 = B2[bo + 2 * ks];
     acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc1, 0, 0, 0);
