@@ -446,7 +446,7 @@ def test_residual_layer_norm_sums_the_shortcut_gradient_in_the_kernel():
 
 
 @pytest.mark.parametrize("shift", [0, 4])
-@pytest.mark.parametrize("B,H,W,C,heads", [(2, 16, 24, 60, 6), (1, 8, 8, 24, 2), (2, 32, 16, 180, 6), (1, 16, 16, 64, 2)])
+@pytest.mark.parametrize("B,H,W,C,heads", [(2, 16, 24, 60, 6), (1, 8, 8, 24, 2), (2, 32, 16, 180, 6), (1, 16, 16, 64, 2), (1, 16, 8, 54, 6)])
 def test_window_attention_fwd_bwd_vs_oracle(B, H, W, C, heads, shift):
     """kernel (addressing-folded roll / partition / head split, analytic index + mask) vs the oracle's
     roll -> window_partition -> softmax(qk^T + bias + mask) v -> window_reverse -> roll."""
