@@ -18,6 +18,13 @@
 
 namespace {
 
+#ifdef WATTN_TL   // debug timeline of the SwinIR attention backward (tools/timeline_fattn.py swin): clocks of workgroup 0, wave W
+__device__ unsigned long long g_wattn_tl[2][32];
+#define WTL(i) do { if (blockIdx.x == 0 && (threadIdx.x == 0 || threadIdx.x == 128)) g_wattn_tl[threadIdx.x >> 7][i] = clock64(); } while (0)
+#else
+#define WTL(i) do {} while (0)
+#endif
+
 inline int grid_for(int64_t work_items, int cap = 4096) {
   int64_t g = (work_items + 255) / 256;
   if (g < 1) g = 1;
@@ -243,8 +250,15 @@ __device__ __forceinline__ f32x16 tile_abt(const float* A, int sa, const float* 
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   const float* ap = A + (32 * ti + l31) * sa + lh;
   const float* bp = B + (32 * tj + l31) * sb + lh;
-  // (five steps' operands requested per batch — head_dim 30 is 15 steps: a rolled loop is a chain of read, wait, MFMA)
-#pragma unroll 5
+  // head_dim 30 (every SwinIR variant: 180 / 6, 60 / 6 is 10) is 15 steps, written straight-line: a rolled loop is a chain of
+  // read, wait, MFMA (`#pragma unroll 5` on the run-time trip count is refused by hipcc: "loop not unrolled") — 2 570 cycles per
+  // product against 960 of MFMA (tools/timeline_wattn.py)
+  if (kdim == 30) {
+#pragma unroll
+    for (int ks = 0; ks < 15; ++ks)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * ks], bp[2 * ks], acc, 0, 0, 0);
+    return acc;
+  }
   for (int ks = 0; ks < kdim / 2; ++ks)
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * ks], bp[2 * ks], acc, 0, 0, 0);
   return acc;
@@ -377,11 +391,14 @@ __global__ __launch_bounds__(256) void window_attention_bwd_kernel(const neosr_w
   __shared__ float dS2[HAVE_O ? 1 : NTOK * PS];
   float* dS = HAVE_O ? P : dS2;
   __shared__ float lse_s[NTOK], delta_s[NTOK];
+  __shared__ float zero_s[1];   // what the bias-bin walk reads for a pair outside the window
   __shared__ Tables T;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
   const int bid = xcd_bid();
   const Win w = decode(d, bid);
   const int hd = d.C / d.heads, ld = 3 * d.C, kq = (hd + 1) & ~1;
+  if (tid == 0) zero_s[0] = 0.f;
+  WTL(0);
   // all five slices (q, k, v, and below dO, O) are requested before anything is waited for — the thread's own token is worked
   // out in registers, the tables (and their loads) follow the requests
   float rq[8], rk[8], rv[8];
@@ -407,7 +424,9 @@ __global__ __launch_bounds__(256) void window_attention_bwd_kernel(const neosr_w
     fetch_tile(mytok, Rout, w.head * hd, hd, ov);
     build_tables(d, w, T);
     if (tid < NTOK) lse_s[tid] = d.lse[(int64_t)bid * NTOK + tid];
+    WTL(1);
     put_tile(rq, d.scale, Qs, hd);
+    WTL(2);
     put_tile(rk, 1.f, Ks, hd);
     put_tile(rv, 1.f, Vs, hd);
     float s = 0.f;
@@ -427,16 +446,22 @@ __global__ __launch_bounds__(256) void window_attention_bwd_kernel(const neosr_w
     if (tid < NTOK) lse_s[tid] = d.lse[(int64_t)bid * NTOK + tid];
     put_tile(gv, 1.f, Gs, hd);
   }
+  WTL(3);
   __syncthreads();
+  WTL(4);
   float* g = d.dqkv + w.head * hd + l31;
   {
     const int ti = wave >> 1, tj = wave & 1;
     const f32x16 s = tile_abt(Qs, QS, Ks, QS, ti, tj, kq, l31, lh);
+    WTL(5);
     scores_to_lds(T, s, ti, tj, l31, lh, lse_s, P);                   // P = softmax (recomputed)
+    WTL(6);
     const f32x16 dp = tile_abt(Gs, QS, Vs, QS, ti, tj, kq, l31, lh);  // dP = dO V^T
+    WTL(7);
     const int i0 = 32 * ti + 4 * lh, j = 32 * tj + l31;
     if (HAVE_O) {
       __syncthreads();   // P complete
+      WTL(8);
       if (wave >= 2) {   // dV[j][d] = sum_i P[i][j] dO[i][d]
         const f32x16 dv = tile_atb(P, PS, Gs, QS, wave - 2, 0, l31, lh);
         if (l31 < hd) {
@@ -445,7 +470,9 @@ __global__ __launch_bounds__(256) void window_attention_bwd_kernel(const neosr_w
             g[(int64_t)T.tok[32 * (wave - 2) + (r & 3) + 8 * (r >> 2) + 4 * lh] * ld + 2 * d.C] = dv[r];
         }
       }
+      WTL(9);
       __syncthreads();   // P has been read: dS over it, every lane on the elements it wrote
+      WTL(10);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int i = i0 + (r & 3) + 8 * (r >> 2);
@@ -459,7 +486,9 @@ __global__ __launch_bounds__(256) void window_attention_bwd_kernel(const neosr_w
       }
     }
   }
+  WTL(11);
   __syncthreads();
+  WTL(12);
   if (!have_o) {  // dS = P * (dP - sum_j P dP), 4 threads per row
     const int i = tid >> 2, q = tid & 3;
     const float* pr = P + i * PS + q * 16;
@@ -479,7 +508,9 @@ __global__ __launch_bounds__(256) void window_attention_bwd_kernel(const neosr_w
     // reads are independent (a loop over the valid range is a chain of dependent read + add latencies); same
     // summation order (yi, then xi)
     const int dy = tid / (2 * WS - 1) - (WS - 1), dx = tid % (2 * WS - 1) - (WS - 1);
-    float s = 0.f;
+    // (all 64 reads in ONE batch in front of the additions: hipcc groups them by eight and waits for every group —
+    // eight LDS round trips, 3 100 cycles of a 28 600-cycle workgroup; tools/timeline_wattn.py)
+    float v[WS * WS];
 #pragma unroll
     for (int yi = 0; yi < WS; ++yi) {
       const int yj = yi - dy;
@@ -488,12 +519,19 @@ __global__ __launch_bounds__(256) void window_attention_bwd_kernel(const neosr_w
       for (int xi = 0; xi < WS; ++xi) {
         const int xj = xi - dx;
         const bool ok = oky && xj >= 0 && xj < WS;
-        const float v = dS[ok ? (yi * WS + xi) * PS + yj * WS + xj : 0];
-        s += ok ? v : 0.f;
+        // (a pair that leaves the window reads a word that holds 0: no predicate at the addition — 64 of them lived in
+        // scalar register pairs across the batch and spilled)
+        const float* src = ok ? dS + (yi * WS + xi) * PS + yj * WS + xj : zero_s;
+        v[yi * WS + xi] = *src;
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < WS * WS; ++i) s += v[i];
     d.workspace[((int64_t)(bid / d.heads) * NB + tid) * d.heads + w.head] = s;
   }
+  WTL(13);
   if (wave < 2) {
     // dQ[i][d] = scale * sum_j dS[i][j] K[j][d]
     const f32x16 dq = tile_ab(dS, PS, Ks, QS, wave, 0, l31, lh);
@@ -516,8 +554,16 @@ __global__ __launch_bounds__(256) void window_attention_bwd_kernel(const neosr_w
         g[(int64_t)T.tok[32 * (wave - 2) + (r & 3) + 8 * (r >> 2) + 4 * lh] * ld + d.C] = dk[r];
     }
   }
+  WTL(14);
 }
 
+#ifdef WATTN_TL
+}  // namespace
+extern "C" int neosr_debug_wattn_timeline(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wattn_tl), 64 * 8) == hipSuccess ? 0 : 1;
+}
+namespace {
+#endif
 // ------------------------------------------------------------------------------ misc
 __global__ __launch_bounds__(256) void pixel_shuffle_nhwc_kernel(const float* __restrict__ in,
                                                                  float* __restrict__ out, int B, int H,
