@@ -370,7 +370,11 @@ __device__ __forceinline__ void gemm_nt_glds_body(const GemmArgs& args) {
   // the start instead of 8 exposed L2 round trips per lane at the end), the residual quads are requested under the
   // last chunk's MFMAs
   __shared__ __attribute__((aligned(16))) float bias_s[BN];
-  if (d.bias && tid < BN) bias_s[tid] = n0 + tid < d.N ? d.bias[n0 + tid] : 0.f;
+  // (requested here, stored to LDS behind the first chunk's loads: written `bias_s[tid] = d.bias[..]` in one statement the
+  // store waited vmcnt(0) for the load right here — one exposed L2 round trip per workgroup in front of the first DMA;
+  // round 6, found in the ISA)
+  float bias_v = 0.f;
+  if (d.bias && tid < BN) bias_v = n0 + tid < d.N ? d.bias[n0 + tid] : 0.f;
   // DMA addressing (round 4): a lane's source row and k quad never change — only the chunk does — so the byte offsets are
   // computed ONCE (rows past M / N: an out-of-range offset = zeros; a second set for the last chunk drops the quads past
   // K) and a chunk adds its 128-byte step as the SCALAR offset of `buffer_load ... lds`.  Rounds 2-3 rebuilt a 64-bit
@@ -466,6 +470,7 @@ __device__ __forceinline__ void gemm_nt_glds_body(const GemmArgs& args) {
     bstore(0);
   }
   __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
+  if (d.bias && tid < BN) bias_s[tid] = bias_v;
   __syncthreads();
   const int arow = wave * 32 + l31;
   // K = 180 / 360 end in a chunk with 20 / 8 valid columns: the last chunk runs only the 8-column steps it needs
@@ -590,7 +595,11 @@ __device__ __forceinline__ void gemm_nt_glds64_body(const GemmArgs& args) {
   const float* zp = gm_zero_page;
   asm volatile("" : "+s"(zp));
   __shared__ __attribute__((aligned(16))) float bias_s[BN];
-  if (d.bias && tid < BN) bias_s[tid] = n0 + tid < d.N ? d.bias[n0 + tid] : 0.f;
+  // (requested here, stored to LDS behind the first chunk's loads: written `bias_s[tid] = d.bias[..]` in one statement the
+  // store waited vmcnt(0) for the load right here — one exposed L2 round trip per workgroup in front of the first DMA;
+  // round 6, found in the ISA)
+  float bias_v = 0.f;
+  if (d.bias && tid < BN) bias_v = n0 + tid < d.N ? d.bias[n0 + tid] : 0.f;
   // (DMA addressing as in gemm_nt_glds_kernel: per-lane byte offsets once, the chunk as the scalar offset)
   const int kc_last = (K + BK - 1) / BK - 1;
   constexpr int OOB = 0x7ffffff0;
@@ -669,6 +678,7 @@ __device__ __forceinline__ void gemm_nt_glds64_body(const GemmArgs& args) {
     bstore(0);
   }
   __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
+  if (d.bias && tid < BN) bias_s[tid] = bias_v;
   __syncthreads();
   const int arow = wm * 32 + l31, brow = wn * 32 + l31;
   const int last_steps = (K - (nchunks - 1) * BK + 7) >> 3;
