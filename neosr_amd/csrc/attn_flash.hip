@@ -233,6 +233,25 @@ __device__ __forceinline__ void scores_to_lds(const Shared& S, float* P, const f
   }
 }
 
+// this head's column of the relative-position table -> LDS: every load of a thread in ONE batch (clamped index), then the
+// stores.  (The loop `tab[k] = table[k * heads + head]` compiles to load, wait, store per trip: four to six dependent memory
+// round trips at the start of every workgroup; round 6, found in the ISA.)
+template <int NBINS>
+__device__ __forceinline__ void stage_table(float* tab, const float* table, int heads, int head, int tid) {
+  constexpr int NT = (NBINS + 255) / 256;
+  float t[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    const int k = tid + 256 * i;
+    t[i] = table[(k < NBINS ? k : NBINS - 1) * heads + head];
+  }
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    const int k = tid + 256 * i;
+    if (k < NBINS) tab[k] = t[i];
+  }
+}
+
 template <int WS, int KS>
 __device__ __forceinline__ void setup_block(const neosr_fattn_desc& d, const Win& w, Shared& S) {
   using G = Geo<WS, KS>;
@@ -243,7 +262,7 @@ __device__ __forceinline__ void setup_block(const neosr_fattn_desc& d, const Win
     S.qtok[tid] = tok;
     S.qpk[tid] = query_term<WS, KS>(w.qb * QB + tid) * 16 + reg;
   }
-  for (int k = tid; k < G::NBINS; k += 256) S.tab[k] = d.rpb_table[k * d.heads + w.head];
+  stage_table<G::NBINS>(S.tab, d.rpb_table, d.heads, w.head, tid);
 }
 
 // ------------------------------------------------------------------------------------------ forward
@@ -258,20 +277,21 @@ __global__ __launch_bounds__(256) void flash_wattn_fwd_kernel(const neosr_fattn_
   const Rows Rqkv = make_rows(d.qkv, w.b, d.H * d.W, ld);
   [[maybe_unused]] const Rows Rdo = make_rows(d.dout, w.b, d.H * d.W, d.C), Rout = make_rows(d.out, w.b, d.H * d.W, d.C);
   const int n = tid >> 2, part = tid & 3;
-  setup_block<WS, KS>(d, w, S);
-  __syncthreads();
-  {
-    float q[8];
-    load_row8(Rqkv, S.qtok[n], w.head * hd, hd, part, q);
-    store_row8(S.Qs, n, part, q, d.scale, hd);
-  }
-  // prefetch key block 0
-  float kr[8], vr[8];
+  // the thread's query row and the rows of key block 0 are requested before the tables are built (their pixels worked out
+  // in registers): one memory round trip for rows and table together instead of two
+  float q[8], kr[8], vr[8];
   int ktok, kreg, kterm;
   bool kex;
+  {
+    int qtok, qreg;
+    query_geom<WS>(d, w, w.qb * QB + n, qtok, qreg);
+    load_row8(Rqkv, qtok, w.head * hd, hd, part, q);
+  }
   key_geom<WS, KS>(d, w, n, ktok, kreg, kterm, kex);
   load_row8(Rqkv, ktok, d.C + w.head * hd, hd, part, kr);
   load_row8(Rqkv, ktok, 2 * d.C + w.head * hd, hd, part, vr);
+  setup_block<WS, KS>(d, w, S);
+  store_row8(S.Qs, n, part, q, d.scale, hd);
   float m_run = -INFINITY, l_run = 0.f;  // row n, replicated in its 4 threads
   f32x16 o = zero16();                   // waves 0,1: rows 32 wave.., cols d
   for (int kb = 0; kb < G::NKB; ++kb) {
@@ -471,6 +491,21 @@ __global__ __launch_bounds__(256, KS > WS ? 2 : 1) void flash_wattn_bwd_dq_kerne
   const Rows Rqkv = make_rows(d.qkv, w.b, d.H * d.W, ld);
   [[maybe_unused]] const Rows Rdo = make_rows(d.dout, w.b, d.H * d.W, d.C), Rout = make_rows(d.out, w.b, d.H * d.W, d.C);
   const int n = tid >> 2, part = tid & 3;
+  // the thread's query rows (q, dO, O) and the rows of key block 0 are requested before the tables are built (their pixels
+  // worked out in registers): one memory round trip for rows, table and LSE together instead of two
+  float q[8], g[8], o[8], kr[8], vr[8];
+  int ktok, kreg, kterm;
+  bool kex;
+  {
+    int tok, reg;
+    query_geom<WS>(d, w, w.qb * QB + n, tok, reg);
+    load_row8(Rqkv, tok, w.head * hd, hd, part, q);
+    load_row8(Rdo, tok, w.head * hd, hd, part, g);
+    load_row8(Rout, tok, w.head * hd, hd, part, o);
+  }
+  key_geom<WS, KS>(d, w, n, ktok, kreg, kterm, kex);
+  load_row8(Rqkv, ktok, d.C + w.head * hd, hd, part, kr);
+  load_row8(Rqkv, ktok, 2 * d.C + w.head * hd, hd, part, vr);
   if (tid < QB) {
     int tok, reg;
     query_geom<WS>(d, w, w.qb * QB + tid, tok, reg);
@@ -478,16 +513,10 @@ __global__ __launch_bounds__(256, KS > WS ? 2 : 1) void flash_wattn_bwd_dq_kerne
     S.qpk[tid] = query_term<WS, KS>(w.qb * QB + tid) * 16 + reg;
     S.lse[tid] = d.lse[(int64_t)bid * QB + tid];
   }
-  for (int k = tid; k < G::NBINS; k += 256) S.tab[k] = d.rpb_table[k * d.heads + w.head];
+  stage_table<G::NBINS>(S.tab, d.rpb_table, d.heads, w.head, tid);
   if (G::SELF)
     for (int k = tid; k < G::NBINS; k += 256) S.bins[k] = 0.f;
-  __syncthreads();
   {
-    float q[8], g[8], o[8];
-    const int tok = S.qtok[n];
-    load_row8(Rqkv, tok, w.head * hd, hd, part, q);
-    load_row8(Rdo, tok, w.head * hd, hd, part, g);
-    load_row8(Rout, tok, w.head * hd, hd, part, o);
     store_row8(S.Qs, n, part, q, d.scale, hd);
     store_row8(S.Gs, n, part, g, 1.f, hd);
     float ds = 0.f;
@@ -500,12 +529,6 @@ __global__ __launch_bounds__(256, KS > WS ? 2 : 1) void flash_wattn_bwd_dq_kerne
       d.workspace[ws.dsum + (int64_t)bid * QB + n] = ds;
     }
   }
-  float kr[8], vr[8];
-  int ktok, kreg, kterm;
-  bool kex;
-  key_geom<WS, KS>(d, w, n, ktok, kreg, kterm, kex);
-  load_row8(Rqkv, ktok, d.C + w.head * hd, hd, part, kr);
-  load_row8(Rqkv, ktok, 2 * d.C + w.head * hd, hd, part, vr);
   f32x16 dq = zero16();
   // dS dump: [(b, window, head)][query 256][key NK]
   float* dump = d.workspace + ws.ds_full + ((int64_t)(bid / G::NQB) * G::NQ + w.qb * QB) * G::NK;
@@ -590,6 +613,19 @@ __global__ __launch_bounds__(256) void flash_wattn_bwd_dkv_kernel(const neosr_fa
   [[maybe_unused]] const Rows Rdo = make_rows(d.dout, w.b, d.H * d.W, d.C), Rout = make_rows(d.out, w.b, d.H * d.W, d.C);
   const int n = tid >> 2, part = tid & 3;
   const int64_t wh = bid / G::NKB;  // (b, window, head)
+  // the key block's rows and the first query block's q / dO rows are requested before the tables are built (every thread
+  // works out its own rows' pixels): one memory round trip for rows and table together
+  float kr[8], vr[8], qn[8], gn[8];
+  {
+    int tok, reg, kterm;
+    bool ex;
+    key_geom<WS, KS>(d, w, kb * QB + n, tok, reg, kterm, ex);
+    load_row8(Rqkv, tok, d.C + w.head * hd, hd, part, kr);
+    load_row8(Rqkv, tok, 2 * d.C + w.head * hd, hd, part, vr);
+    query_geom<WS>(d, w, n, tok, reg);
+    load_row8(Rqkv, tok, w.head * hd, hd, part, qn);
+    load_row8(Rdo, tok, w.head * hd, hd, part, gn);
+  }
   if (tid < QB) {
     int tok, reg, kterm;
     bool ex;
@@ -597,25 +633,11 @@ __global__ __launch_bounds__(256) void flash_wattn_bwd_dkv_kernel(const neosr_fa
     S.ktok[tid] = tok;
     S.kpk[tid] = ex ? kterm * 16 + reg : KEY_NONE;
   }
-  for (int k = tid; k < G::NBINS; k += 256) S.tab[k] = d.rpb_table[k * d.heads + w.head];
-  __syncthreads();
-  {
-    float kr[8], vr[8];
-    load_row8(Rqkv, S.ktok[n], d.C + w.head * hd, hd, part, kr);
-    load_row8(Rqkv, S.ktok[n], 2 * d.C + w.head * hd, hd, part, vr);
-    store_row8(S.Ks, n, part, kr, 1.f, hd);
-    store_row8(S.Vs, n, part, vr, 1.f, hd);
-  }
+  stage_table<G::NBINS>(S.tab, d.rpb_table, d.heads, w.head, tid);
+  store_row8(S.Ks, n, part, kr, 1.f, hd);
+  store_row8(S.Vs, n, part, vr, 1.f, hd);
   f32x16 acc = zero16();  // waves 0,1: dV rows 32 wave..; waves 2,3: dK rows 32 (wave-2)..
-  // the next query block's q / dO rows travel in registers while the current block is consumed (every thread works out
-  // its own row's pixel: no table, no barrier in front of the loads) — as the dQ kernel does with its key blocks
-  float qn[8], gn[8];
-  {
-    int tok, reg;
-    query_geom<WS>(d, w, n, tok, reg);
-    load_row8(Rqkv, tok, w.head * hd, hd, part, qn);
-    load_row8(Rdo, tok, w.head * hd, hd, part, gn);
-  }
+  // (the next query block's q / dO rows travel in registers while the current block is consumed)
   for (int qb = 0; qb < G::NQB; ++qb) {
     __syncthreads();  // previous products finished with Qs / Gs / P / dS
     w.qb = qb;
@@ -680,7 +702,7 @@ __global__ __launch_bounds__(256, 2) void flash_wattn_bwd_fused_kernel(const neo
   [[maybe_unused]] const Rows Rdo = make_rows(d.dout, w.b, d.H * d.W, d.C), Rout = make_rows(d.out, w.b, d.H * d.W, d.C);
   const int n = tid >> 2, part = tid & 3;
   FTL(0, true);
-  for (int k = tid; k < G::NBINS; k += 256) S.tab[k] = d.rpb_table[k * d.heads + w.head];
+  stage_table<G::NBINS>(S.tab, d.rpb_table, d.heads, w.head, tid);
   // The key rows of the window are the same for every query block: this thread's row offset and the packed bias / mask
   // term of its key in each key block are worked out ONCE (the geometry + address arithmetic of the next block's prefetch
   // took ~700 of a tile's ~13 000 cycles; tools/timeline_fattn.py)
