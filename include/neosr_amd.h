@@ -26,6 +26,7 @@ extern "C" {
 #define NEOSR_ACT_LRELU 1 /* slope given per call (0.2 esrgan/unet, 0.01 swinir) */
 #define NEOSR_ACT_RELU 2
 #define NEOSR_ACT_PRELU 3 /* per-channel learnable slope (compact) */
+#define NEOSR_ACT_GELU 4  /* nn.GELU() of HAT's CAB (hat_arch.py:62-66), F(4x4,3x3) kernel only: see out2 / out_mask_gelu */
 
 #define NEOSR_CONV_FWD 0
 #define NEOSR_CONV_DGRAD 1
@@ -104,7 +105,8 @@ typedef struct neosr_conv_desc {
                                    mask — the pre-activation a PReLU layer keeps for its backward pass (forward), the
                                    unmasked gradient its slope gradient needs (backward-data) */
   int32_t out2_cs;
-  int32_t reserved1;
+  int32_t out_mask_gelu;        /* 1: the out_mask derivative is GELU'(out_mask) instead of the leaky step (backward-data of the
+                                   convolution BEHIND a GELU: HAT's CAB, hat_arch.py:62-66) */
 } neosr_conv_desc;
 
 int neosr_conv3x3(const neosr_conv_desc* d, void* stream);

@@ -64,7 +64,7 @@ class ConvDesc(C.Structure):
         ("out_mask_slopes", C.c_void_p),
         ("out2", C.c_void_p),
         ("out2_cs", C.c_int32),
-        ("reserved1", C.c_int32),
+        ("out_mask_gelu", C.c_int32),
     ]
 
 
@@ -272,7 +272,7 @@ class MsssimDesc(C.Structure):
 
 
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
-ACT_NONE, ACT_LRELU, ACT_RELU, ACT_PRELU = 0, 1, 2, 3
+ACT_NONE, ACT_LRELU, ACT_RELU, ACT_PRELU, ACT_GELU = 0, 1, 2, 3, 4
 CONV_FWD, CONV_DGRAD = 0, 1
 
 # name -> (restype, argtypes); mirrors include/neosr_amd.h one to one

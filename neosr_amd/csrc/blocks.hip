@@ -100,9 +100,11 @@ neosr_gemm_desc gemm_desc(int mode, const float* A, const float* B, float* C, in
 }
 
 // plain 3x3 convolution launch as hip/ops.py:conv3x3 describes it (forward / backward-data of a CAB convolution)
+// (gelu_out2: forward with GELU in the epilogue, the pre-activation written to gelu_out2; gelu_mask: backward-data multiplied by
+// GELU'(gelu_mask) in the epilogue — both only on the F(4x4,3x3) kernel, i.e. when the launch carries a wino4 image)
 int conv_launch(const neosr_tblock_desc& d, int mode, const float* in, int in_cs, const float* w, int w_cout, int w_cin,
                 const float* bias, float* out, const float* res1, const float* pack, const float* wino, const float* wino4,
-                void* stream) {
+                void* stream, float* gelu_out2 = nullptr, const float* gelu_mask = nullptr) {
   neosr_conv_desc c;
   memset(&c, 0, sizeof(c));
   c.in = in; c.in_cs = in_cs; c.w = w; c.bias = bias; c.out = out;
@@ -115,6 +117,8 @@ int conv_launch(const neosr_tblock_desc& d, int mode, const float* in, int in_cs
   c.mask_slope = 1.f; c.alpha = 1.f; c.alpha2 = 1.f; c.out_mask_slope = 1.f;
   if (res1) { c.res1 = res1; c.res1_cs = c.N; c.res1_nch = c.N; }
   c.w_pack = pack; c.w_wino = wino; c.w_wino4 = wino4;
+  if (gelu_out2) { c.act = NEOSR_ACT_GELU; c.out2 = gelu_out2; c.out2_cs = c.N; }
+  if (gelu_mask) { c.out_mask = gelu_mask; c.out_mask_cs = c.N; c.out_mask_gelu = 1; }
   return neosr_conv3x3(&c, stream);
 }
 
@@ -305,6 +309,13 @@ struct SideJoin {
   }
 };
 
+// CAB: GELU / GELU' inside the epilogues of its two convolutions (only the F(4x4,3x3) kernel has them: launches that carry
+// its image); NEOSR_AMD_CAB_GELU_FUSED=0 keeps the elementwise passes.  Same expressions (gelu.h): bit-identical.
+bool cab_gelu_fused(const float* wino4_image) {
+  static const bool on = [] { const char* e = getenv("NEOSR_AMD_CAB_GELU_FUSED"); return !(e && e[0] == '0'); }();
+  return on && wino4_image != nullptr && neosr_get_winograd() == 2;
+}
+
 bool not_capturing(void* stream) {
   if (stream) {   // (the null stream cannot be captured; a stream under hipGraph capture keeps the block on itself)
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
@@ -397,9 +408,14 @@ extern "C" int neosr_tblock_forward(const neosr_tblock_desc* dp, const float* x,
       ++g_side_forks;
     }
     void* cs = cab_side ? (void*)side->s : stream;
-    TB_RUN(conv_launch(d, NEOSR_CONV_FWD, s.y1, C, d.c0_w, mid, C, d.c0_b, s.u0, nullptr, d.c0_pack_f, d.c0_wino_f,
-                       d.c0_wino4_f, cs));
-    TB_RUN(neosr_gelu(s.u0, nullptr, s.t0, (int64_t)M * mid, cs));
+    if (cab_gelu_fused(d.c0_wino4_f)) {   // GELU in the convolution's epilogue, the pre-activation as its second output
+      TB_RUN(conv_launch(d, NEOSR_CONV_FWD, s.y1, C, d.c0_w, mid, C, d.c0_b, s.t0, nullptr, d.c0_pack_f, d.c0_wino_f,
+                         d.c0_wino4_f, cs, s.u0));
+    } else {
+      TB_RUN(conv_launch(d, NEOSR_CONV_FWD, s.y1, C, d.c0_w, mid, C, d.c0_b, s.u0, nullptr, d.c0_pack_f, d.c0_wino_f,
+                         d.c0_wino4_f, cs));
+      TB_RUN(neosr_gelu(s.u0, nullptr, s.t0, (int64_t)M * mid, cs));
+    }
     TB_RUN(conv_launch(d, NEOSR_CONV_FWD, s.t0, mid, d.c2_w, C, mid, d.c2_b, s.t1, nullptr, d.c2_pack_f, d.c2_wino_f,
                        d.c2_wino4_f, cs));
     TB_RUN(neosr_batched_colsum(s.t1, nullptr, s.pooled, s.bcs, d.B, rps, C, 1.0f / rps, cs));
@@ -548,9 +564,14 @@ extern "C" int neosr_tblock_backward(const neosr_tblock_desc* dp, const float* x
     // second convolution: weight + bias gradient (side stream), data gradient (hip/layers.py: Conv3x3.backward)
     TB_RUN(after(EV_GT1));
     TB_RUN(wgrad_launch(d, s.t0, mid, b.gt1, C, G.c2_w, G.c2_b, b.wg2, cw));
-    TB_RUN(conv_launch(d, NEOSR_CONV_DGRAD, b.gt1, C, d.c2_w, C, mid, nullptr, b.gt0, nullptr, d.c2_pack_d, d.c2_wino_d,
-                       d.c2_wino4_d, cs));
-    TB_RUN(neosr_gelu(s.u0, b.gt0, b.gu0, (int64_t)M * mid, cs));
+    if (cab_gelu_fused(d.c2_wino4_d)) {   // GELU'(u0) in the data gradient's epilogue
+      TB_RUN(conv_launch(d, NEOSR_CONV_DGRAD, b.gt1, C, d.c2_w, C, mid, nullptr, b.gu0, nullptr, d.c2_pack_d, d.c2_wino_d,
+                         d.c2_wino4_d, cs, nullptr, s.u0));
+    } else {
+      TB_RUN(conv_launch(d, NEOSR_CONV_DGRAD, b.gt1, C, d.c2_w, C, mid, nullptr, b.gt0, nullptr, d.c2_pack_d, d.c2_wino_d,
+                         d.c2_wino4_d, cs));
+      TB_RUN(neosr_gelu(s.u0, b.gt0, b.gu0, (int64_t)M * mid, cs));
+    }
     // first convolution; its data gradient is one of the two contributions to norm1's output (the other comes from qkv,
     // whose GEMM adds this one in its epilogue below: a + b in either order, as autograd's accumulation would)
     TB_RUN(after(EV_GU0));

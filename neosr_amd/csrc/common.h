@@ -10,7 +10,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define NEOSR_WAVE 64
 
 // activation ids shared by host and device (see include/neosr_amd.h)
-enum : int { ACT_NONE = 0, ACT_LRELU = 1, ACT_RELU = 2, ACT_PRELU = 3 };
+enum : int { ACT_NONE = 0, ACT_LRELU = 1, ACT_RELU = 2, ACT_PRELU = 3, ACT_GELU = 4 };
 
 // error plumbing (api.hip owns the storage)
 void neosr_set_error(const char* fmt, ...);

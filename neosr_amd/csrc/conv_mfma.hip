@@ -424,8 +424,9 @@ extern "C" int neosr_conv3x3(const neosr_conv_desc* dp, void* stream) {
                          small(d.out2, d.out2_cs) && neosr_conv::wino_mode() == 2 &&
                          (w4_wgs >= NEOSR_WINO4_MIN_WGS || !use_wino) && small(d.out, d.out_cs) && small(d.res1, d.res1_cs) &&
                          small(d.res2, d.res2_cs) && small(d.out_mask, d.out_mask_cs) && small(d.in, d.in_cs);
-  NEOSR_CHECK(use_wino4 || (!d.out2 && !d.out_mask_slopes),
-              "conv3x3: out2 / out_mask_slopes need the F(4x4,3x3) kernel (w_wino4, winograd mode 2, aligned tensors)");
+  NEOSR_CHECK(use_wino4 || (!d.out2 && !d.out_mask_slopes && d.act != NEOSR_ACT_GELU && !d.out_mask_gelu),
+              "conv3x3: out2 / out_mask_slopes / GELU need the F(4x4,3x3) kernel (w_wino4, winograd mode 2, aligned tensors)");
+  NEOSR_CHECK(!d.out_mask_gelu || d.out_mask, "conv3x3: out_mask_gelu needs out_mask");
   const bool prof = neosr_prof_on();
   if (prof) {
     const double px = (double)d.B * d.H * d.W;

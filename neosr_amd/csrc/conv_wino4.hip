@@ -38,6 +38,7 @@
 #include <stdlib.h>
 #include <atomic>
 #include "conv_wino4.h"
+#include "gelu.h"
 
 using namespace neosr_conv;
 
@@ -298,6 +299,10 @@ void conv3x3_wino4_kernel(const ConvArgs args) {
   float s_uni = 1.f;
   if (d.act == ACT_LRELU) s_uni = d.slope;
   else if (d.act == ACT_RELU) s_uni = 0.f;
+  // HAT's CAB (conv -> GELU -> conv): GELU in the first convolution's epilogue (its pre-activation leaves as out2), GELU' of that
+  // pre-activation in the second convolution's backward-data epilogue (out_mask_gelu) — the expressions of cab.hip's
+  // elementwise pass (gelu.h): same bits, two launches per block and direction less on the CAB branch
+  const bool act_gelu = d.act == ACT_GELU, mask_gelu = d.out_mask_gelu != 0 && d.out_mask;
   // per-channel slopes (PReLU in the epilogue, PReLU' behind out_mask): uniform branches, a launch without them pays two
   // scalar tests
   f32x4 s_vec = splat(s_uni), m_vec = splat(d.out_mask_slope);
@@ -425,11 +430,11 @@ void conv3x3_wino4_kernel(const ConvArgs args) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float t = y[a][e] + bias[e];
-        t = t > 0.f ? t : t * s_vec[e];
+        t = act_gelu ? gelu_f(t) : (t > 0.f ? t : t * s_vec[e]);
         t = t * d.alpha + E.e1[a][e];
         t = t * d.alpha2 + E.e2[a][e];
         t += E.e0[a][e];
-        o[e] = E.mk[a][e] > 0.f ? t : t * m_vec[e];
+        o[e] = mask_gelu ? t * gelu_d(E.mk[a][e]) : (E.mk[a][e] > 0.f ? t : t * m_vec[e]);
       }
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(raw4_t, o), r_out, E.o_out[a], 0, 0);
     }

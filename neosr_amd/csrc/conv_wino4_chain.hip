@@ -687,8 +687,8 @@ int neosr_conv::launch_wino4_chain(const neosr_conv_desc* d, const int* dep, int
     const neosr_conv_desc& c = d[i];
     if (c.B != f.B || c.H != f.H || c.W != f.W || c.in_cs != f.in_cs) return -1;
     if (!c.w_wino4 || (uintptr_t)c.w_wino4 % 16 || c.ups || c.s2d_c || c.in_mask || c.in_prelu || c.accumulate ||
-        c.out2 || c.out_mask_slopes ||
-        c.act == NEOSR_ACT_PRELU || c.K % 32 || c.K < 64 || c.N > 64 || c.N % 4 || c.in_cs % 4 || c.out_cs % 4 ||
+        c.out2 || c.out_mask_slopes || c.out_mask_gelu ||
+        c.act == NEOSR_ACT_PRELU || c.act == NEOSR_ACT_GELU || c.K % 32 || c.K < 64 || c.N > 64 || c.N % 4 || c.in_cs % 4 || c.out_cs % 4 ||
         (uintptr_t)c.in % 16 || (uintptr_t)c.out % 16 || (uintptr_t)c.bias % 16 || (uintptr_t)c.res1 % 16 ||
         (uintptr_t)c.res2 % 16 || (uintptr_t)c.out_mask % 16 || c.res1_cs % 4 || c.res2_cs % 4 || c.out_mask_cs % 4 ||
         c.res1_nch % 4 || c.res2_nch % 4)
@@ -747,7 +747,7 @@ int neosr_conv::launch_wino4_strips(const neosr_conv_desc& d, void* stream) {
   const int tps = ceil_div(d.W, QT) * ceil_div(d.H, QT);
   const int cap = chain_max_tiles();
   if (d.ups || d.accumulate || d.N > 64 || d.K % 32 || d.K < 64 || tps > cap || (int64_t)tps * d.B < 2 * cap) return -1;
-  if (d.out2 || d.out_mask_slopes || d.act == NEOSR_ACT_PRELU) return -1;   // (epilogue features of the one-layer kernel only)
+  if (d.out2 || d.out_mask_slopes || d.out_mask_gelu || d.act == NEOSR_ACT_PRELU || d.act == NEOSR_ACT_GELU) return -1;   // (epilogue features of the one-layer kernel only)
   if (d.N > 32 && wino4_n64_mode() == 0) return -1;
   const int gs = cap / tps;                 // samples per layer
   if (gs < 1 || d.B % gs) return -1;

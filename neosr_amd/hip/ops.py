@@ -31,7 +31,7 @@ def conv3x3(x, w, bias=None, *, out=None, n_out=None, mode=CONV_FWD, ups=False, 
             slope=0.0, prelu=None, alpha=1.0, res1=None, res1_nch=None, alpha2=1.0, res2=None,
             res2_nch=None, accumulate=False, in_mask=None, mask_slope=1.0, mask_slopes=None,
             in_prelu=None, k_in=None, w_pack=None, out_mask=None, out_mask_slope=1.0, s2d_c=0, w_wino=None,
-            w_wino4=None):
+            w_wino4=None, out2=None, out_mask_gelu=False):
     """out = epilogue(conv3x3(x', w)).  See ``neosr_conv3x3`` in include/neosr_amd.h."""
     lib = _C.load()
     _C.require_device(x, "x")
@@ -82,6 +82,10 @@ def conv3x3(x, w, bias=None, *, out=None, n_out=None, mode=CONV_FWD, ups=False, 
         d.out_mask = out_mask.data_ptr()
         d.out_mask_cs = _cs(out_mask)
         d.out_mask_slope = out_mask_slope
+        d.out_mask_gelu = int(bool(out_mask_gelu))
+    if out2 is not None:   # (F(4x4,3x3) kernel only: conv + bias before the activation)
+        d.out2 = out2.data_ptr()
+        d.out2_cs = _cs(out2)
     _C.check(lib.neosr_conv3x3(C.byref(d), _C.stream_ptr()), "neosr_conv3x3")
     return out
 

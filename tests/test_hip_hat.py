@@ -322,3 +322,39 @@ def test_gelu_and_leaky_relu_vector_and_scalar_forms(n, off):
     assert rel_err(y, y_ref) < 1e-6 and rel_err(gx, gx_ref) < 1e-6
     lr = L.LeakyReLU.apply(x.detach(), 0.2)
     assert torch.equal(lr.cpu(), torch.nn.functional.leaky_relu(x.detach().cpu(), 0.2))
+
+
+@pytest.mark.parametrize("B,H,W,K,N", [(4, 64, 64, 180, 60), (2, 32, 48, 60, 180)])
+def test_conv_gelu_epilogues_are_bit_identical_to_the_elementwise_pass(B, H, W, K, N):
+    """HAT's CAB (hat_arch.py:62-66: conv -> GELU -> conv): GELU in the F(4x4,3x3) convolution's epilogue with the
+    pre-activation as second output (`act = NEOSR_ACT_GELU`, `out2`), and GELU'(pre-activation) in the backward-data epilogue of
+    the convolution behind it (`out_mask_gelu`) — the block plans use both (csrc/blocks.hip) — against the convolution followed by
+    `neosr_gelu`: the same expressions (csrc/gelu.h), so the results must agree bit for bit."""
+    from neosr_amd import _C
+    from neosr_amd.hip import ops
+
+    lib = _C.load()
+    g = torch.Generator().manual_seed(B + K)
+    x = torch.randn(B, H, W, K, generator=g).to(DEV)
+    w = (torch.randn(N, K, 3, 3, generator=g) * 0.05).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    w4 = ops.conv3x3_pack_wino4(w)
+    # forward
+    u_ref = ops.conv3x3(x, w, b, w_wino4=w4)
+    t_ref = torch.empty_like(u_ref)
+    _C.check(lib.neosr_gelu(u_ref.data_ptr(), None, t_ref.data_ptr(), u_ref.numel(), _C.stream_ptr()), "neosr_gelu")
+    u = torch.empty_like(u_ref)
+    t = ops.conv3x3(x, w, b, w_wino4=w4, act=_C.ACT_GELU, out2=u)
+    assert torch.equal(u, u_ref) and torch.equal(t, t_ref)
+    # backward-data of a convolution whose INPUT was gelu(z): gz = dgrad(gy) * gelu'(z)
+    z = torch.randn(B, H, W, K, generator=g).to(DEV)
+    gy = torch.randn(B, H, W, N, generator=g).to(DEV)
+    w4d = ops.conv3x3_pack_wino4(w, ops.CONV_DGRAD)
+    gt = ops.conv3x3(gy, w, None, mode=ops.CONV_DGRAD, w_wino4=w4d)
+    gz_ref = torch.empty_like(gt)
+    _C.check(lib.neosr_gelu(z.data_ptr(), gt.data_ptr(), gz_ref.data_ptr(), gt.numel(), _C.stream_ptr()), "neosr_gelu")
+    gz = ops.conv3x3(gy, w, None, mode=ops.CONV_DGRAD, w_wino4=w4d, out_mask=z, out_mask_gelu=True)
+    assert torch.equal(gz, gz_ref)
+    # a launch that cannot take the F(4x4,3x3) kernel refuses the GELU epilogue instead of ignoring it
+    with pytest.raises(_C.NeosrAmdError):
+        ops.conv3x3(x, w, b, w_pack=ops.conv3x3_pack_weights(w), act=_C.ACT_GELU, out2=u)
